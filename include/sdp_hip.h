@@ -1,0 +1,165 @@
+/*
+ * sdp_hip.h -- C ABI of libsdp_hip.so, the MI355X (gfx950) implementation of
+ * the stodynprog value-iteration hot path.
+ *
+ * The reference (pierre-haessig/stodynprog) is a Python library whose only
+ * native boundary is one Cython function; this header declares the C entry
+ * points a binding (ctypes, cffi, Cython `cdef extern`) uses instead.  Each
+ * entry cites the reference interface it replaces (paths relative to the
+ * reference checkout).  All functions return 0 on success and a negative
+ * SDP_E* code on failure; sdp_last_error() gives the message of the last
+ * failure on the calling thread.  No C++ exceptions cross this boundary.
+ * Host pointers are owned by the caller for the duration of a call; device
+ * memory is owned by the library and tied to the handle that allocated it.
+ */
+#ifndef SDP_HIP_H
+#define SDP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDP_OK          0
+#define SDP_EINVAL     -1   /* bad argument (maps to ValueError / AssertionError) */
+#define SDP_EDIM       -2   /* state dimension outside 1..4 (multilinear_cython.pyx:46-47 raises Exception) */
+#define SDP_EHIP       -3   /* HIP runtime error (RuntimeError) */
+#define SDP_ENOMEM     -4   /* device allocation failed (MemoryError) */
+#define SDP_ECOMM      -5   /* RCCL error or librccl not loadable */
+#define SDP_EMODULE    -6   /* model code object could not be loaded */
+
+#define SDP_F64 0
+#define SDP_F32 1
+
+const char *sdp_last_error(void);
+
+/* ---- device ------------------------------------------------------------- */
+int sdp_device_count(int *count);
+int sdp_set_device(int device);
+/* name buffer >= 256 bytes; any out pointer may be NULL */
+int sdp_device_info(int device, char *name, int *compute_units, int64_t *hbm_bytes,
+                    char *gcn_arch /* >= 64 bytes */);
+int sdp_synchronize(void);
+
+/* ---- multilinear interpolation ------------------------------------------- */
+/*
+ * Replaces  multilinear_interpolation(smin, smax, orders, values, s)
+ *   stodynprog/dolointerpolation/multilinear_cython.pyx:17-49
+ *   (called from stodynprog/stodynprog.py:285 and dolointerpolation/multilinear.py:87)
+ * smin,smax: [d]; orders: [d] int64 ('long[:]'); values: [n_v][S] C-contiguous
+ * with S = prod(orders), last axis fastest; s: [d][n_s] C-contiguous;
+ * out: [n_v][n_s].  All host pointers.  d must be 1..4 (else SDP_EDIM).
+ * Uniform grid, linear extrapolation outside [smin,smax].
+ */
+int sdp_mlinterp_f64(int d, const double *smin, const double *smax, const int64_t *orders,
+                     const double *values, int64_t n_v, const double *s, int64_t n_s,
+                     double *out);
+int sdp_mlinterp_f32(int d, const float *smin, const float *smax, const int64_t *orders,
+                     const float *values, int64_t n_v, const float *s, int64_t n_s,
+                     float *out);
+
+/* ---- value-iteration problem handle ---------------------------------------- */
+typedef struct sdp_problem sdp_problem;
+typedef struct sdp_comm sdp_comm;
+
+/*
+ * Discretised problem, i.e. what DPSolver holds after discretize_state /
+ * discretize_perturb / control_steps (stodynprog.py:335-389, 432-463).
+ */
+typedef struct sdp_problem_desc {
+    int32_t dtype;              /* SDP_F64 | SDP_F32: type of every real array below */
+    int32_t d;                  /* state variables, 1..4 */
+    int32_t nu;                 /* control variables, 1..4 */
+    int32_t W;                  /* perturbation points; 0 = deterministic system */
+    int64_t orders[4];          /* points per state axis (state_grid lengths) */
+    const void *axes[4];        /* state_grid[k]: orders[k] reals (np.linspace values) */
+    const void *wgrid;          /* perturb_grid[0]: W reals, NULL if W == 0 */
+    const void *proba;          /* perturb_proba[0]: W reals */
+    int32_t box_per_node;       /* 0: one box for all nodes, 1: arrays over nodes */
+    int32_t lanes_per_node;     /* SDP_LANES the code object was built with */
+    const void *box_lo;         /* control_grids() lower ends: [nu] or [nu][S] reals */
+    const void *box_hi;         /* upper ends */
+    const int32_t *box_n;       /* points per control: [nu] or [nu][S] */
+    int64_t node_begin;         /* slab of C-order node ids owned by this handle */
+    int64_t node_end;           /*   ([0,S) on a single GPU) */
+    const char *module_path;    /* gfx950 code object of the traced model (sdp_sweep, sdp_evalpol) */
+} sdp_problem_desc;
+
+int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **out);
+int sdp_problem_destroy(sdp_problem *p);
+
+/* J_next of value_iteration (stodynprog.py:466,498): S reals, C-order. */
+int sdp_problem_set_value(sdp_problem *p, const void *host_V);
+/* pol of eval_policy (stodynprog.py:693,723): [S][nu] reals (control values). */
+int sdp_problem_set_policy(sdp_problem *p, const void *host_pol);
+
+/*
+ * One Bellman backup over the handle's node slab -- DPSolver.value_iteration
+ * (stodynprog.py:466-534) fused with _value_at_state_vect (639-691) and the
+ * interpolation (multilinear_cython.pyx:51-300).  Reads the value buffer,
+ * writes J_k, the optimal control values and their flat lattice indices.
+ * With a communicator attached the J_k slabs are all-gathered (RCCL) so that
+ * every rank ends with the full J_k.  rel_dp != 0: J_ref = J_k[ref_index];
+ * J_k -= J_ref (stodynprog.py:523-525); *J_ref_out receives J_ref.
+ * t_k: time index passed to the model of a non-stationary system.
+ */
+int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int64_t ref_index,
+                         double *J_ref_out);
+
+/*
+ * n_iter fixed-policy backups -- DPSolver.eval_policy (stodynprog.py:693-775).
+ * Starts from the value buffer, leaves the result in the J buffer.
+ * J_ref_out: [n_iter] reference costs when rel_dp != 0 (may be NULL).
+ */
+int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_dp, int64_t ref_index,
+                            double *J_ref_out);
+
+/* Make the last J_k the next J_next without leaving the device. */
+int sdp_problem_swap(sdp_problem *p);
+
+int sdp_problem_get_value(sdp_problem *p, void *host_J);            /* S reals            */
+int sdp_problem_get_policy(sdp_problem *p, void *host_pol /* [S][nu] reals or NULL */,
+                           int32_t *host_idx /* [S] or NULL */);
+/* Policy rows of the handle's own slab only (no all-gather of policies). */
+
+/* HIP-event duration of the last sweep / eval kernel launch(es), milliseconds. */
+int sdp_problem_last_kernel_ms(sdp_problem *p, double *ms);
+/* Timed repetition for benchmarks: `reps` sweeps with ping-pong swap between
+ * them; returns the total HIP-event time of the whole loop and of the sweep
+ * kernels alone. */
+int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp, int64_t ref_index,
+                             double *loop_ms, double *kernel_ms);
+
+/* ---- tabulated backup (models that cannot be traced into device code) ------- */
+/*
+ * Replaces the numeric part of DPSolver._value_at_state_vect
+ * (stodynprog.py:677-690) for a batch of nodes whose dyn/cost callbacks were
+ * evaluated on the host exactly as stodynprog.py:674,676 does:
+ *   cell  = g[cell] + interp(V, x_next[:, cell])          (stodynprog.py:677)
+ *   J[c]  = sum_w cell(c,w) * proba[w]  (W == 0: no expectation; 679-683)
+ *   idx   = first-occurrence argmin over the node's controls (686)
+ * Node n owns cells [cell_off[n], cell_off[n+1]), laid out [control][w].
+ * The value array stays on the device between calls.
+ */
+typedef struct sdp_tab sdp_tab;
+int sdp_tab_create(int d, const double *smin, const double *smax, const int64_t *orders,
+                   const double *host_V, sdp_tab **out);
+int sdp_tab_destroy(sdp_tab *t);
+int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_off, int64_t W,
+                   const double *proba, const double *x_next /* [d][n_cells] */,
+                   const double *g /* [n_cells] */, double *J_out /* [n_nodes] */,
+                   int64_t *idx_out /* [n_nodes] */);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------- */
+int sdp_comm_unique_id(char id[128]);                       /* rank 0 */
+int sdp_comm_create(int rank, int nranks, const char id[128], sdp_comm **out);
+int sdp_comm_destroy(sdp_comm *c);
+int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, const int64_t *slab_bounds /* [nranks+1] */);
+int sdp_comm_allreduce_max(sdp_comm *c, double *inout);    /* host scalar, for timing */
+int sdp_comm_barrier(sdp_comm *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDP_HIP_H */

@@ -1,0 +1,182 @@
+// sdp_device.h -- device-side building blocks (gfx950, wave64) shared by the
+// built-in kernels and by generated-model code objects:
+//   * uniform-grid multilinear interpolation with linear extrapolation, op for
+//     op as reference multilinear_cython.pyx:51-300 (true division, truncating
+//     cast with x86 semantics, clamp of the cell index only, nested lerp with
+//     the last axis innermost);
+//   * numpy-semantics scalar helpers used by generated model code;
+//   * (value,index) first-occurrence argmin across the lanes of a wave segment.
+// Compiled with -ffp-contract=off: one IEEE operation per source operator.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include "sdp_kernel_args.h"
+
+#define SDP_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// <int>(p) of the Cython source is cvttsd2si / cvttss2si on the reference's
+// x86-64 build: NaN and out-of-range values give INT_MIN (then clamped to 0).
+// ---------------------------------------------------------------------------
+SDP_DEV int sdp_trunc_i32(double p) { return (fabs(p) < 2147483648.0) ? (int)p : INT_MIN; }
+SDP_DEV int sdp_trunc_i32(float p) { return (fabsf(p) < 2147483648.0f) ? (int)p : INT_MIN; }
+
+// Grid constants of one interpolation problem, kept in registers/SGPRs.
+template <typename real, int D>
+struct SdpGrid {
+    real smin[D];
+    real span[D];   // smax - smin              (pyx:75, denominator)
+    real nm1[D];    // (real)(order - 1)
+    int ordm2[D];   // order - 2
+    int M[D];       // C-order strides, M[D-1] = 1 (pyx:164-165)
+};
+
+// Per-point cell: integer offset of the lower corner along each axis and the
+// barycentric weights.  `wide` is the type the lerp tree is evaluated in:
+//   * the compiled reference evaluates `(1-lam)` with a C double literal
+//     (Cython emits `1.0`), so its float specialisation runs the whole tree in
+//     double except the innermost lam*v product, rounding to float once on the
+//     store -> wide = double reproduces it bit for bit for float AND double;
+//   * wide = real (pure float tree) is the fast variant of the fp32 sweep.
+template <typename real, int D, typename wide = double>
+struct SdpCell {
+    int off[D];     // M[k] * q[k]
+    real lam[D];
+    wide oml[D];    // 1 - lam[k]
+};
+
+template <typename real, int D, typename wide>
+SDP_DEV void sdp_locate_axis(const SdpGrid<real, D> &g, int k, real s, SdpCell<real, D, wide> &c)
+{
+    const real sn = (s - g.smin[k]) / g.span[k];                   // pyx:75
+    const real p = sn * g.nm1[k];
+    const int q = max(min(sdp_trunc_i32(p), g.ordm2[k]), 0);       // pyx:78
+    c.lam[k] = p - (real)q;                                        // pyx:81 (unclamped)
+    c.oml[k] = (wide)1 - (wide)c.lam[k];
+    c.off[k] = g.M[k] * q;
+}
+
+template <typename real, int D, typename wide, int K>
+struct SdpLerp {
+    static SDP_DEV wide eval(const real *__restrict__ V, const SdpGrid<real, D> &g,
+                             const SdpCell<real, D, wide> &c, int base)
+    {
+        const wide lo = SdpLerp<real, D, wide, K + 1>::eval(V, g, c, base + c.off[K]);
+        const wide hi = SdpLerp<real, D, wide, K + 1>::eval(V, g, c, base + c.off[K] + g.M[K]);
+        return c.oml[K] * lo + (wide)c.lam[K] * hi;                // pyx:88,140,208,300
+    }
+};
+// innermost axis: the two vertex loads; lam*v is a real x real product
+template <typename real, int D, typename wide>
+struct SdpLerp<real, D, wide, D - 1> {
+    static SDP_DEV wide eval(const real *__restrict__ V, const SdpGrid<real, D> &,
+                             const SdpCell<real, D, wide> &c, int base)
+    {
+        const real lo = V[base + c.off[D - 1]];
+        const real hi = V[base + c.off[D - 1] + 1];
+        return c.oml[D - 1] * (wide)lo + (wide)(c.lam[D - 1] * hi);
+    }
+};
+
+template <typename real, int D, typename wide = double>
+SDP_DEV real sdp_interp_point(const real *__restrict__ V, const SdpGrid<real, D> &g,
+                              const real *pt)
+{
+    SdpCell<real, D, wide> c;
+#pragma unroll
+    for (int k = 0; k < D; ++k) sdp_locate_axis<real, D, wide>(g, k, pt[k], c);
+    return (real)SdpLerp<real, D, wide, 0>::eval(V, g, c, 0);
+}
+
+template <typename real, int D>
+SDP_DEV void sdp_make_grid(SdpGrid<real, D> &g, const int32_t *orders, const real *smin,
+                           const real *smax)
+{
+    int m = 1;
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        g.smin[k] = smin[k];
+        g.span[k] = smax[k] - smin[k];
+        g.nm1[k] = (real)(orders[k] - 1);
+        g.ordm2[k] = orders[k] - 2;
+        g.M[k] = m;
+        m *= orders[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// numpy-semantics helpers for generated model code
+// ---------------------------------------------------------------------------
+template <typename real> SDP_DEV bool sdp_isnan(real a) { return a != a; }
+// np.minimum / np.maximum propagate NaN (first NaN operand is returned)
+template <typename real> SDP_DEV real sdp_npmin(real a, real b) { return (sdp_isnan(a) || a <= b) ? a : b; }
+template <typename real> SDP_DEV real sdp_npmax(real a, real b) { return (sdp_isnan(a) || a >= b) ? a : b; }
+// np.fmin / np.fmax ignore a NaN operand
+template <typename real> SDP_DEV real sdp_npfmin(real a, real b) { return (sdp_isnan(b) || a <= b) ? a : b; }
+template <typename real> SDP_DEV real sdp_npfmax(real a, real b) { return (sdp_isnan(b) || a >= b) ? a : b; }
+template <typename real> SDP_DEV real sdp_npsign(real a)
+{
+    return a > (real)0 ? (real)1 : (a < (real)0 ? (real)-1 : (a == (real)0 ? (real)0 : a));
+}
+SDP_DEV double sdp_nppymod(double a, double b)
+{
+    double m = fmod(a, b);
+    if (b != 0.0 && m != 0.0 && ((m < 0.0) != (b < 0.0))) m += b;
+    else if (m == 0.0) m = copysign(0.0, b);
+    return m;
+}
+SDP_DEV float sdp_nppymod(float a, float b)
+{
+    float m = fmodf(a, b);
+    if (b != 0.0f && m != 0.0f && ((m < 0.0f) != (b < 0.0f))) m += b;
+    else if (m == 0.0f) m = copysignf(0.0f, b);
+    return m;
+}
+template <typename real> SDP_DEV real sdp_npfloordiv(real a, real b)
+{
+    // numpy npy_divmod: floor of the quotient, consistent with the Python-style remainder
+    const real m0 = fmod(a, b);
+    real div = (a - m0) / b;
+    if (b != (real)0 && m0 != (real)0 && ((m0 < (real)0) != (b < (real)0))) div -= (real)1;
+    if (div != (real)0) {
+        real fl = floor(div);
+        if (div - fl > (real)0.5) fl += (real)1;
+        return fl;
+    }
+    return copysign((real)0, a / b);
+}
+
+// ---------------------------------------------------------------------------
+// first-occurrence argmin (numpy argmin, stodynprog.py:686): strictly smaller
+// wins, the first NaN wins over everything, equal values keep the lower index.
+// ---------------------------------------------------------------------------
+template <typename real>
+SDP_DEV bool sdp_better_seq(real cand, real best)          // candidate has the HIGHER index
+{
+    return (cand < best) || (sdp_isnan(cand) && !sdp_isnan(best));
+}
+template <typename real>
+SDP_DEV bool sdp_better_idx(real cv, int ci, real bv, int bi)
+{
+    const bool cn = sdp_isnan(cv), bn = sdp_isnan(bv);
+    if (cn != bn) return cn;
+    if (cn) return ci < bi;
+    return (cv < bv) || (cv == bv && ci < bi);
+}
+
+SDP_DEV double sdp_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+SDP_DEV float sdp_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// Butterfly over the L (power of two, <= 64) consecutive lanes of a segment;
+// every lane of the segment ends with the segment's (min value, first index).
+template <typename real, int L>
+SDP_DEV void sdp_seg_argmin(real &v, int &i)
+{
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) {
+        const real ov = sdp_shfl_xor(v, m);
+        const int oi = __shfl_xor(i, m, 64);
+        if (sdp_better_idx(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+}

@@ -1,0 +1,835 @@
+// sdp_hip.hip -- libsdp_hip.so: C ABI (include/sdp_hip.h) + built-in gfx950
+// kernels (stand-alone multilinear interpolation, tabulated backup,
+// relative-DP shift) + launch of the generated-model code objects + RCCL glue.
+// Plain HIP runtime; no PyTorch, no CUDA compatibility layer.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sdp_hip.h"
+#include "sdp_device.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess)                                                         \
+            return fail(e__ == hipErrorOutOfMemory ? SDP_ENOMEM : SDP_EHIP,            \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),        \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+extern "C" const char *sdp_last_error(void) { return g_err; }
+
+static size_t real_size(int dtype) { return dtype == SDP_F32 ? 4 : 8; }
+
+// ---------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------
+extern "C" int sdp_device_count(int *count)
+{
+    if (!count) return fail(SDP_EINVAL, "count is NULL");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return fail(SDP_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return SDP_OK;
+}
+
+extern "C" int sdp_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return SDP_OK;
+}
+
+extern "C" int sdp_device_info(int device, char *name, int *compute_units, int64_t *hbm_bytes,
+                               char *gcn_arch)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name) { strncpy(name, prop.name, 255); name[255] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (gcn_arch) { strncpy(gcn_arch, prop.gcnArchName, 63); gcn_arch[63] = 0; }
+    return SDP_OK;
+}
+
+extern "C" int sdp_synchronize(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    return SDP_OK;
+}
+
+static int device_cus()
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+
+// ---------------------------------------------------------------------------
+// built-in kernel: stand-alone multilinear interpolation
+// (multilinear_cython.pyx:17-49 dispatcher, 51-300 point kernels).
+// One lane per query point: the d coordinate rows s[k][i] are read coalesced,
+// the 2^d vertex gathers go through L1/L2, the value rows are looped in-lane
+// so the cell location is computed once per point.
+// ---------------------------------------------------------------------------
+template <typename real, int D>
+__global__ void __launch_bounds__(256) k_mlinterp(SdpInterpArgs a)
+{
+    SdpGrid<real, D> grid;
+    real smin[D], smax[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { smin[k] = (real)a.smin[k]; smax[k] = (real)a.smax[k]; }
+    sdp_make_grid<real, D>(grid, a.orders, smin, smax);
+    const real *__restrict__ s = (const real *)a.s;
+    const real *__restrict__ values = (const real *)a.values;
+    real *__restrict__ out = (real *)a.out;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_s; i += stride) {
+        SdpCell<real, D, double> c;
+#pragma unroll
+        for (int k = 0; k < D; ++k) sdp_locate_axis<real, D, double>(grid, k, s[k * a.n_s + i], c);
+        for (int v = 0; v < a.n_v; ++v)
+            out[v * a.n_s + i] = (real)SdpLerp<real, D, double, 0>::eval(values + v * a.S, grid, c, 0);
+    }
+}
+
+template <typename real>
+static int launch_mlinterp(const SdpInterpArgs &a, hipStream_t stream)
+{
+    if (a.n_s == 0 || a.n_v == 0) return SDP_OK;
+    int64_t blocks = (a.n_s + 255) / 256;
+    const int64_t cap = (int64_t)device_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    dim3 g((unsigned)blocks), b(256);
+    switch (a.d) {
+    case 1: hipLaunchKernelGGL((k_mlinterp<real, 1>), g, b, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((k_mlinterp<real, 2>), g, b, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((k_mlinterp<real, 3>), g, b, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((k_mlinterp<real, 4>), g, b, 0, stream, a); break;
+    default: return fail(SDP_EDIM, "Can't interpolate in dimension strictly greater than 5");
+    }
+    HIP_TRY(hipGetLastError());
+    return SDP_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        if (bytes == 0) bytes = 8;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(SDP_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+        return SDP_OK;
+    }
+};
+
+static int upload(DevBuf &b, const void *host, size_t bytes)
+{
+    int rc = b.alloc(bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return SDP_OK;
+}
+
+template <typename real>
+static int mlinterp_host(int d, const real *smin, const real *smax, const int64_t *orders,
+                         const real *values, int64_t n_v, const real *s, int64_t n_s, real *out)
+{
+    if (d < 1 || d > SDP_MAXD)                                    // pyx:46-47
+        return fail(SDP_EDIM, "Can't interpolate in dimension strictly greater than 5");
+    if (!smin || !smax || !orders || (!values && n_v) || (!s && n_s) || (!out && n_v && n_s))
+        return fail(SDP_EINVAL, "NULL argument");
+    if (n_v < 0 || n_s < 0) return fail(SDP_EINVAL, "negative size");
+    SdpInterpArgs a;
+    memset(&a, 0, sizeof(a));
+    int64_t S = 1;
+    for (int k = 0; k < d; ++k) {
+        if (orders[k] < 2) return fail(SDP_EINVAL, "orders[%d] = %lld: need at least 2 points per axis", k, (long long)orders[k]);
+        a.orders[k] = (int32_t)orders[k];
+        a.smin[k] = (double)smin[k];
+        a.smax[k] = (double)smax[k];
+        S *= orders[k];
+        if (S >= (int64_t)1 << 31) return fail(SDP_EINVAL, "grid too large: 32-bit vertex indices (pyx:164-165)");
+    }
+    if (n_v == 0 || n_s == 0) return SDP_OK;
+    DevBuf dv, ds, dout;
+    int rc;
+    if ((rc = dv.alloc(sizeof(real) * S * n_v))) return rc;
+    if ((rc = ds.alloc(sizeof(real) * d * n_s))) return rc;
+    if ((rc = dout.alloc(sizeof(real) * n_v * n_s))) return rc;
+    HIP_TRY(hipMemcpy(dv.p, values, sizeof(real) * S * n_v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ds.p, s, sizeof(real) * d * n_s, hipMemcpyHostToDevice));
+    a.values = dv.p; a.s = ds.p; a.out = dout.p;
+    a.n_s = n_s; a.S = S; a.n_v = (int32_t)n_v; a.d = d;
+    if ((rc = launch_mlinterp<real>(a, 0))) return rc;
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(real) * n_v * n_s, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+extern "C" int sdp_mlinterp_f64(int d, const double *smin, const double *smax,
+                                const int64_t *orders, const double *values, int64_t n_v,
+                                const double *s, int64_t n_s, double *out)
+{
+    return mlinterp_host<double>(d, smin, smax, orders, values, n_v, s, n_s, out);
+}
+
+extern "C" int sdp_mlinterp_f32(int d, const float *smin, const float *smax,
+                                const int64_t *orders, const float *values, int64_t n_v,
+                                const float *s, int64_t n_s, float *out)
+{
+    return mlinterp_host<float>(d, smin, smax, orders, values, n_v, s, n_s, out);
+}
+
+// ---------------------------------------------------------------------------
+// built-in kernels: relative-DP shift (stodynprog.py:523-525, 760-762)
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ void k_pick_ref(const real *__restrict__ J, int64_t ref, double *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (double)J[ref];
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256) k_shift(real *__restrict__ J, int64_t n,
+                                               const double *__restrict__ ref)
+{
+    const real r = (real)*ref;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        J[i] = J[i] - r;
+}
+
+// ---------------------------------------------------------------------------
+// built-in kernels: tabulated backup (stodynprog.py:677-690)
+//   k_tab_cells : one lane per lattice cell, coalesced x_next / g reads,
+//                 jc = g + interp(V, x_next)
+//   k_tab_reduce: one wavefront per node, lanes stride over controls, in-lane
+//                 sequential expectation over w, butterfly first-index argmin
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256) k_tab_cells(SdpTabArgs a, double *__restrict__ jc)
+{
+    SdpGrid<double, D> grid;
+    double smin[D], smax[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { smin[k] = a.smin[k]; smax[k] = a.smax[k]; }
+    sdp_make_grid<double, D>(grid, a.orders, smin, smax);
+    const double *__restrict__ xn = (const double *)a.x_next;
+    const double *__restrict__ g = (const double *)a.g;
+    const double *__restrict__ V = (const double *)a.V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_cells; i += stride) {
+        double pt[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) pt[k] = xn[k * a.n_cells + i];
+        jc[i] = g[i] + sdp_interp_point<double, D>(V, grid, pt);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tab_reduce(SdpTabArgs a, const double *__restrict__ jc,
+                                                    int64_t *__restrict__ idx_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const double *__restrict__ proba = (const double *)a.proba;
+    const int W = a.W > 0 ? a.W : 1;
+    for (int64_t n = wave; n < a.n_nodes; n += n_waves) {
+        const int64_t off = a.cell_off[n];
+        const int U = (int)((a.cell_off[n + 1] - off) / W);
+        double best = INFINITY;
+        int ibest = INT_MAX;
+        for (int c = lane; c < U; c += 64) {
+            double acc;
+            if (a.W > 0) {
+                acc = 0.0;
+                for (int w = 0; w < W; ++w) acc = acc + jc[off + (int64_t)c * W + w] * proba[w];
+            } else {
+                acc = jc[off + c];
+            }
+            if (ibest == INT_MAX || sdp_better_seq(acc, best)) { best = acc; ibest = c; }
+        }
+        sdp_seg_argmin<double, 64>(best, ibest);
+        if (lane == 0) { ((double *)a.J)[n] = best; idx_out[n] = ibest; }
+    }
+}
+
+struct sdp_tab {
+    int d = 0;
+    int64_t S = 0;
+    int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
+    double smin[SDP_MAXD], smax[SDP_MAXD];
+    DevBuf V;
+};
+
+extern "C" int sdp_tab_create(int d, const double *smin, const double *smax,
+                              const int64_t *orders, const double *host_V, sdp_tab **out)
+{
+    if (d < 1 || d > SDP_MAXD) return fail(SDP_EDIM, "Can't interpolate in dimension strictly greater than 5");
+    if (!smin || !smax || !orders || !host_V || !out) return fail(SDP_EINVAL, "NULL argument");
+    std::unique_ptr<sdp_tab> t(new sdp_tab());
+    t->d = d;
+    int64_t S = 1;
+    for (int k = 0; k < d; ++k) {
+        if (orders[k] < 2) return fail(SDP_EINVAL, "state axis %d has %lld points: at least 2 needed", k, (long long)orders[k]);
+        t->orders[k] = (int32_t)orders[k]; t->smin[k] = smin[k]; t->smax[k] = smax[k];
+        S *= orders[k];
+        if (S >= (int64_t)1 << 31) return fail(SDP_EINVAL, "state grid too large");
+    }
+    t->S = S;
+    int rc = upload(t->V, host_V, S * 8);
+    if (rc) return rc;
+    *out = t.release();
+    return SDP_OK;
+}
+
+extern "C" int sdp_tab_destroy(sdp_tab *t)
+{
+    delete t;
+    return SDP_OK;
+}
+
+extern "C" int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_off, int64_t W,
+                              const double *proba, const double *x_next, const double *g,
+                              double *J_out, int64_t *idx_out)
+{
+    if (!t || !cell_off || !J_out || !idx_out) return fail(SDP_EINVAL, "NULL argument");
+    if (n_nodes < 0 || W < 0) return fail(SDP_EINVAL, "negative size");
+    if (n_nodes == 0) return SDP_OK;
+    const int64_t n_cells = cell_off[n_nodes];
+    if (n_cells <= 0 || !x_next || !g) return fail(SDP_EINVAL, "empty lattice");
+    if (W > 0 && !proba) return fail(SDP_EINVAL, "perturbation weights missing");
+    DevBuf dx, dg, doff, dp, djc, dJ, didx;
+    int rc;
+    if ((rc = upload(dx, x_next, (size_t)t->d * n_cells * 8))) return rc;
+    if ((rc = upload(dg, g, (size_t)n_cells * 8))) return rc;
+    if ((rc = upload(doff, cell_off, (size_t)(n_nodes + 1) * 8))) return rc;
+    if (W > 0 && (rc = upload(dp, proba, (size_t)W * 8))) return rc;
+    if ((rc = djc.alloc((size_t)n_cells * 8))) return rc;
+    if ((rc = dJ.alloc((size_t)n_nodes * 8))) return rc;
+    if ((rc = didx.alloc((size_t)n_nodes * 8))) return rc;
+    SdpTabArgs a;
+    memset(&a, 0, sizeof(a));
+    a.V = t->V.p; a.x_next = dx.p; a.g = dg.p; a.cell_off = (const int64_t *)doff.p;
+    a.proba = dp.p; a.J = dJ.p; a.n_nodes = n_nodes; a.n_cells = n_cells;
+    a.W = (int32_t)W; a.d = t->d;
+    for (int k = 0; k < t->d; ++k) { a.orders[k] = t->orders[k]; a.smin[k] = t->smin[k]; a.smax[k] = t->smax[k]; }
+    const int cus = device_cus();
+    int64_t blocks = (n_cells + 255) / 256;
+    if (blocks > (int64_t)cus * 16) blocks = (int64_t)cus * 16;
+    dim3 gc((unsigned)blocks), b(256);
+    switch (t->d) {
+    case 1: hipLaunchKernelGGL(k_tab_cells<1>, gc, b, 0, 0, a, (double *)djc.p); break;
+    case 2: hipLaunchKernelGGL(k_tab_cells<2>, gc, b, 0, 0, a, (double *)djc.p); break;
+    case 3: hipLaunchKernelGGL(k_tab_cells<3>, gc, b, 0, 0, a, (double *)djc.p); break;
+    default: hipLaunchKernelGGL(k_tab_cells<4>, gc, b, 0, 0, a, (double *)djc.p); break;
+    }
+    HIP_TRY(hipGetLastError());
+    int64_t rblocks = (n_nodes + 3) / 4;
+    if (rblocks > (int64_t)cus * 8) rblocks = (int64_t)cus * 8;
+    hipLaunchKernelGGL(k_tab_reduce, dim3((unsigned)rblocks), b, 0, 0, a, (const double *)djc.p, (int64_t *)didx.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(J_out, dJ.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(idx_out, didx.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// RCCL, loaded lazily so single-GPU use never needs librccl
+// ---------------------------------------------------------------------------
+typedef struct { char internal[128]; } nccl_uid;
+typedef void *nccl_comm_t;
+enum { NCCL_INT8 = 0, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_MAX = 2 };
+
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(nccl_uid *) = nullptr;
+    int (*CommInitRank)(nccl_comm_t *, int, nccl_uid, int) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)(void) = nullptr;
+    int (*GroupEnd)(void) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load()
+{
+    if (g_rccl.h) return SDP_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(SDP_ECOMM, "cannot load librccl.so: %s", dlerror());
+#define SYM(field, name)                                                         \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                  \
+    if (!g_rccl.field) return fail(SDP_ECOMM, "librccl: missing symbol %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllGather, "ncclAllGather");
+    SYM(Broadcast, "ncclBroadcast");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.h = h;
+    return SDP_OK;
+}
+
+#define NCCL_TRY(expr)                                                                 \
+    do {                                                                               \
+        int r__ = (expr);                                                              \
+        if (r__ != 0) return fail(SDP_ECOMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r__)); \
+    } while (0)
+
+struct sdp_comm {
+    nccl_comm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;
+    double *d_scalar = nullptr;
+};
+
+extern "C" int sdp_comm_unique_id(char id[128])
+{
+    int rc = rccl_load();
+    if (rc) return rc;
+    nccl_uid uid;
+    NCCL_TRY(g_rccl.GetUniqueId(&uid));
+    memcpy(id, uid.internal, 128);
+    return SDP_OK;
+}
+
+extern "C" int sdp_comm_create(int rank, int nranks, const char id[128], sdp_comm **out)
+{
+    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(SDP_EINVAL, "bad communicator arguments");
+    int rc = rccl_load();
+    if (rc) return rc;
+    sdp_comm *c = new sdp_comm();
+    c->rank = rank; c->nranks = nranks;
+    nccl_uid uid;
+    memcpy(uid.internal, id, 128);
+    int r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
+    if (r != 0) { delete c; return fail(SDP_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void **)&c->d_scalar, 8) != hipSuccess) {
+        delete c; return fail(SDP_EHIP, "communicator stream/scratch allocation failed");
+    }
+    *out = c;
+    return SDP_OK;
+}
+
+extern "C" int sdp_comm_destroy(sdp_comm *c)
+{
+    if (!c) return SDP_OK;
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    delete c;
+    return SDP_OK;
+}
+
+extern "C" int sdp_comm_allreduce_max(sdp_comm *c, double *inout)
+{
+    if (!c || !inout) return fail(SDP_EINVAL, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(c->d_scalar, inout, 8, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(c->d_scalar, c->d_scalar, 1, NCCL_FLOAT64, NCCL_MAX, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(inout, c->d_scalar, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDP_OK;
+}
+
+extern "C" int sdp_comm_barrier(sdp_comm *c)
+{
+    double v = 0;
+    return sdp_comm_allreduce_max(c, &v);
+}
+
+// ---------------------------------------------------------------------------
+// problem handle
+// ---------------------------------------------------------------------------
+struct sdp_problem {
+    int dtype = SDP_F64, d = 0, nu = 0, W = 0, lanes = 64, box_per_node = 0;
+    int64_t S = 0, node_begin = 0, node_end = 0;
+    int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
+    int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
+    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs;
+    hipModule_t mod = nullptr;
+    hipFunction_t f_sweep = nullptr, f_evalpol = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    double last_kernel_ms = 0;
+    sdp_comm *comm = nullptr;
+    std::vector<int64_t> slabs;
+    int cus = 256;
+    int refs_cap = 0;
+    ~sdp_problem()
+    {
+        if (mod) (void)hipModuleUnload(mod);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (ev2) (void)hipEventDestroy(ev2);
+        if (ev3) (void)hipEventDestroy(ev3);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **out)
+{
+    if (!desc || !out) return fail(SDP_EINVAL, "NULL argument");
+    if (desc->dtype != SDP_F64 && desc->dtype != SDP_F32) return fail(SDP_EINVAL, "dtype must be SDP_F64 or SDP_F32");
+    if (desc->d < 1 || desc->d > SDP_MAXD)
+        return fail(SDP_EDIM, "state dimension %d: multilinear interpolation supports 1..4", desc->d);
+    if (desc->nu < 1 || desc->nu > SDP_MAXU) return fail(SDP_EINVAL, "number of controls %d outside 1..%d", desc->nu, SDP_MAXU);
+    if (desc->W < 0) return fail(SDP_EINVAL, "negative perturbation count");
+    if (!desc->module_path) return fail(SDP_EMODULE, "no model code object given");
+    if (!desc->box_lo || !desc->box_hi || !desc->box_n) return fail(SDP_EINVAL, "control box arrays missing");
+    sdp_problem *p = new sdp_problem();
+    std::unique_ptr<sdp_problem> guard(p);
+    p->dtype = desc->dtype; p->d = desc->d; p->nu = desc->nu; p->W = desc->W;
+    p->lanes = desc->lanes_per_node; p->box_per_node = desc->box_per_node;
+    if (p->lanes < 1 || p->lanes > 64 || (p->lanes & (p->lanes - 1))) return fail(SDP_EINVAL, "lanes_per_node must be a power of two in 1..64");
+    const size_t rs = real_size(p->dtype);
+    int64_t S = 1, total = 0;
+    for (int k = 0; k < p->d; ++k) {
+        if (desc->orders[k] < 2) return fail(SDP_EINVAL, "state axis %d has %lld points: at least 2 needed to interpolate", k, (long long)desc->orders[k]);
+        if (!desc->axes[k]) return fail(SDP_EINVAL, "state axis %d missing", k);
+        p->orders[k] = (int32_t)desc->orders[k];
+        p->axis_off[k] = (int32_t)total;
+        total += desc->orders[k];
+        S *= desc->orders[k];
+        if (S >= (int64_t)1 << 31) return fail(SDP_EINVAL, "state grid too large: 32-bit vertex indices (pyx:164-165)");
+    }
+    p->S = S;
+    p->node_begin = desc->node_begin;
+    p->node_end = desc->node_end;
+    if (p->node_begin < 0 || p->node_end > S || p->node_begin > p->node_end) return fail(SDP_EINVAL, "node slab [%lld,%lld) outside [0,%lld)", (long long)p->node_begin, (long long)p->node_end, (long long)S);
+    p->cus = device_cus();
+
+    // concatenated axes
+    std::vector<char> ax(total * rs);
+    for (int k = 0; k < p->d; ++k)
+        memcpy(ax.data() + (size_t)p->axis_off[k] * rs, desc->axes[k], (size_t)desc->orders[k] * rs);
+    int rc;
+    if ((rc = upload(p->axes, ax.data(), ax.size()))) return rc;
+    if (p->W > 0) {
+        if (!desc->wgrid || !desc->proba) return fail(SDP_EINVAL, "perturbation grid/weights missing");
+        if ((rc = upload(p->wgrid, desc->wgrid, p->W * rs))) return rc;
+        if ((rc = upload(p->proba, desc->proba, p->W * rs))) return rc;
+    }
+    const size_t nbox = (size_t)p->nu * (p->box_per_node ? (size_t)S : 1);
+    if ((rc = upload(p->box_lo, desc->box_lo, nbox * rs))) return rc;
+    if ((rc = upload(p->box_hi, desc->box_hi, nbox * rs))) return rc;
+    if ((rc = upload(p->box_n, desc->box_n, nbox * 4))) return rc;
+    if ((rc = p->V.alloc(S * rs))) return rc;
+    if ((rc = p->J.alloc(S * rs))) return rc;
+    if ((rc = p->pol.alloc((size_t)S * p->nu * rs))) return rc;
+    if ((rc = p->idx.alloc(S * 4))) return rc;
+    HIP_TRY(hipMemset(p->V.p, 0, S * rs));
+    HIP_TRY(hipMemset(p->J.p, 0, S * rs));
+    HIP_TRY(hipMemset(p->pol.p, 0, (size_t)S * p->nu * rs));
+    HIP_TRY(hipMemset(p->idx.p, 0, S * 4));
+
+    hipError_t e = hipModuleLoad(&p->mod, desc->module_path);
+    if (e != hipSuccess) { p->mod = nullptr; return fail(SDP_EMODULE, "hipModuleLoad(%s): %s", desc->module_path, hipGetErrorString(e)); }
+    e = hipModuleGetFunction(&p->f_sweep, p->mod, "sdp_sweep");
+    if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_sweep kernel: %s", desc->module_path, hipGetErrorString(e));
+    e = hipModuleGetFunction(&p->f_evalpol, p->mod, "sdp_evalpol");
+    if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_evalpol kernel: %s", desc->module_path, hipGetErrorString(e));
+    HIP_TRY(hipStreamCreate(&p->stream));
+    HIP_TRY(hipEventCreate(&p->ev0));
+    HIP_TRY(hipEventCreate(&p->ev1));
+    HIP_TRY(hipEventCreate(&p->ev2));
+    HIP_TRY(hipEventCreate(&p->ev3));
+    guard.release();
+    *out = p;
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_destroy(sdp_problem *p)
+{
+    if (p) { (void)hipDeviceSynchronize(); delete p; }
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_value(sdp_problem *p, const void *host_V)
+{
+    if (!p || !host_V) return fail(SDP_EINVAL, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(p->V.p, host_V, p->S * real_size(p->dtype), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_policy(sdp_problem *p, const void *host_pol)
+{
+    if (!p || !host_pol) return fail(SDP_EINVAL, "NULL argument");
+    const size_t bytes = (size_t)p->S * p->nu * real_size(p->dtype);
+    int rc;
+    if (!p->pol_in.p && (rc = p->pol_in.alloc(bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->pol_in.p, host_pol, bytes, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDP_OK;
+}
+
+static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k)
+{
+    memset(&a, 0, sizeof(a));
+    a.V = p->V.p; a.J = p->J.p; a.pol = p->pol.p; a.idx = (int32_t *)p->idx.p;
+    a.axes = p->axes.p; a.wgrid = p->wgrid.p; a.proba = p->proba.p;
+    a.box_lo = p->box_lo.p; a.box_hi = p->box_hi.p; a.box_n = (const int32_t *)p->box_n.p;
+    a.pol_in = p->pol_in.p;
+    a.node_begin = p->node_begin; a.node_end = p->node_end; a.S = p->S; a.t_k = t_k;
+    for (int k = 0; k < SDP_MAXD; ++k) { a.orders[k] = p->orders[k]; a.axis_off[k] = p->axis_off[k]; }
+    a.W = p->W; a.box_per_node = p->box_per_node;
+}
+
+static int launch_module(hipFunction_t f, SdpSweepArgs &a, unsigned blocks, hipStream_t stream)
+{
+    size_t size = sizeof(a);
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                     HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(f, blocks, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
+    return SDP_OK;
+}
+
+// workgroups for the sweep: a multiple of 8 (one share per XCD), enough to
+// fill every CU several times over, never more than there are node tiles
+static unsigned sweep_blocks(const sdp_problem *p)
+{
+    const int64_t nodes = p->node_end - p->node_begin;
+    const int64_t tile = (64 / p->lanes) * 4;
+    int64_t tiles = (nodes + tile - 1) / tile;
+    int64_t blocks = (int64_t)p->cus * 8;
+    if (blocks > tiles) blocks = tiles;
+    blocks = ((blocks + 7) / 8) * 8;
+    if (blocks < 8) blocks = 8;
+    return (unsigned)blocks;
+}
+
+static int launch_sweep(sdp_problem *p, double t_k)
+{
+    if (p->node_end == p->node_begin) return SDP_OK;
+    SdpSweepArgs a;
+    fill_args(p, a, t_k);
+    return launch_module(p->f_sweep, a, sweep_blocks(p), p->stream);
+}
+
+static int launch_evalpol(sdp_problem *p, double t_k)
+{
+    if (p->node_end == p->node_begin) return SDP_OK;
+    SdpSweepArgs a;
+    fill_args(p, a, t_k);
+    const int64_t nodes = p->node_end - p->node_begin;
+    int64_t blocks = (nodes + 255) / 256;
+    if (blocks > (int64_t)p->cus * 16) blocks = (int64_t)p->cus * 16;
+    return launch_module(p->f_evalpol, a, (unsigned)blocks, p->stream);
+}
+
+// all-gather of the J slabs (in place in the J buffer) on the problem's stream
+static int gather_slabs(sdp_problem *p)
+{
+    if (!p->comm || p->comm->nranks == 1) return SDP_OK;
+    const size_t rs = real_size(p->dtype);
+    const int dt = p->dtype == SDP_F32 ? NCCL_FLOAT32 : NCCL_FLOAT64;
+    const int n = p->comm->nranks;
+    bool even = true;
+    const int64_t len0 = p->slabs[1] - p->slabs[0];
+    for (int r = 0; r < n; ++r) even = even && (p->slabs[r + 1] - p->slabs[r] == len0);
+    char *base = (char *)p->J.p;
+    if (even) {
+        NCCL_TRY(g_rccl.AllGather(base + p->slabs[p->comm->rank] * rs, base + p->slabs[0] * rs,
+                                  (size_t)len0, dt, p->comm->comm, p->stream));
+    } else {
+        NCCL_TRY(g_rccl.GroupStart());
+        for (int r = 0; r < n; ++r) {
+            const int64_t cnt = p->slabs[r + 1] - p->slabs[r];
+            if (cnt == 0) continue;
+            void *ptr = base + p->slabs[r] * rs;
+            NCCL_TRY(g_rccl.Broadcast(ptr, ptr, (size_t)cnt, dt, r, p->comm->comm, p->stream));
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
+    }
+    return SDP_OK;
+}
+
+static int rel_shift(sdp_problem *p, int64_t ref_index, int slot)
+{
+    double *ref = (double *)p->refs.p + slot;
+    unsigned blocks = (unsigned)((p->S + 255) / 256);
+    if (blocks > (unsigned)p->cus * 16) blocks = p->cus * 16;
+    if (p->dtype == SDP_F32) {
+        hipLaunchKernelGGL(k_pick_ref<float>, dim3(1), dim3(64), 0, p->stream, (const float *)p->J.p, ref_index, ref);
+        hipLaunchKernelGGL(k_shift<float>, dim3(blocks), dim3(256), 0, p->stream, (float *)p->J.p, p->S, ref);
+    } else {
+        hipLaunchKernelGGL(k_pick_ref<double>, dim3(1), dim3(64), 0, p->stream, (const double *)p->J.p, ref_index, ref);
+        hipLaunchKernelGGL(k_shift<double>, dim3(blocks), dim3(256), 0, p->stream, (double *)p->J.p, p->S, ref);
+    }
+    HIP_TRY(hipGetLastError());
+    return SDP_OK;
+}
+
+static int ensure_refs(sdp_problem *p, int n)
+{
+    if (n < 16) n = 16;
+    if (p->refs_cap >= n) return SDP_OK;
+    int rc = p->refs.alloc((size_t)n * 8);
+    if (rc) return rc;
+    p->refs_cap = n;
+    return SDP_OK;
+}
+
+static int check_ref(const sdp_problem *p, int rel_dp, int64_t ref_index)
+{
+    if (rel_dp && (ref_index < 0 || ref_index >= p->S)) return fail(SDP_EINVAL, "reference node %lld outside the grid", (long long)ref_index);
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int64_t ref_index,
+                                    double *J_ref_out)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    int rc;
+    if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
+    if ((rc = ensure_refs(p, 1))) return rc;
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    if ((rc = launch_sweep(p, t_k))) return rc;
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    if ((rc = gather_slabs(p))) return rc;
+    if (rel_dp && (rc = rel_shift(p, ref_index, 0))) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->last_kernel_ms = ms;
+    if (rel_dp && J_ref_out) HIP_TRY(hipMemcpy(J_ref_out, p->refs.p, 8, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_swap(sdp_problem *p)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    std::swap(p->V.p, p->J.p);
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_dp,
+                                       int64_t ref_index, double *J_ref_out)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (n_iter < 0) return fail(SDP_EINVAL, "negative iteration count");
+    if (!p->pol_in.p) return fail(SDP_EINVAL, "no policy set (sdp_problem_set_policy)");
+    int rc;
+    if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
+    if ((rc = ensure_refs(p, n_iter))) return rc;
+    if (n_iter == 0) {                   // result = the starting value (stodynprog.py:714)
+        HIP_TRY(hipMemcpyAsync(p->J.p, p->V.p, p->S * real_size(p->dtype), hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return SDP_OK;
+    }
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    for (int k = 0; k < n_iter; ++k) {
+        if (k > 0) std::swap(p->V.p, p->J.p);
+        if ((rc = launch_evalpol(p, 0.0))) return rc;
+        if ((rc = gather_slabs(p))) return rc;
+        if (rel_dp && (rc = rel_shift(p, ref_index, k))) return rc;
+    }
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->last_kernel_ms = ms;
+    if (rel_dp && J_ref_out) HIP_TRY(hipMemcpy(J_ref_out, p->refs.p, (size_t)n_iter * 8, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_get_value(sdp_problem *p, void *host_J)
+{
+    if (!p || !host_J) return fail(SDP_EINVAL, "NULL argument");
+    HIP_TRY(hipMemcpy(host_J, p->J.p, p->S * real_size(p->dtype), hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_get_policy(sdp_problem *p, void *host_pol, int32_t *host_idx)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (host_pol) HIP_TRY(hipMemcpy(host_pol, p->pol.p, (size_t)p->S * p->nu * real_size(p->dtype), hipMemcpyDeviceToHost));
+    if (host_idx) HIP_TRY(hipMemcpy(host_idx, p->idx.p, p->S * 4, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_last_kernel_ms(sdp_problem *p, double *ms)
+{
+    if (!p || !ms) return fail(SDP_EINVAL, "NULL argument");
+    *ms = p->last_kernel_ms;
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp,
+                                        int64_t ref_index, double *loop_ms, double *kernel_ms)
+{
+    if (!p || reps < 1) return fail(SDP_EINVAL, "bad arguments");
+    int rc;
+    if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
+    if ((rc = ensure_refs(p, 1))) return rc;
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(p->ev2, p->stream));
+    for (int r = 0; r < reps; ++r) {
+        if (r > 0) std::swap(p->V.p, p->J.p);
+        HIP_TRY(hipEventRecord(ev[2 * r], p->stream));
+        if ((rc = launch_sweep(p, 0.0))) return rc;
+        HIP_TRY(hipEventRecord(ev[2 * r + 1], p->stream));
+        if ((rc = gather_slabs(p))) return rc;
+        if (rel_dp && (rc = rel_shift(p, ref_index, 0))) return rc;
+    }
+    HIP_TRY(hipEventRecord(p->ev3, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev2, p->ev3));
+    if (loop_ms) *loop_ms = ms;
+    double ksum = 0;
+    for (int r = 0; r < reps; ++r) {
+        HIP_TRY(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+        ksum += ms;
+    }
+    if (kernel_ms) *kernel_ms = ksum;
+    p->last_kernel_ms = ksum / reps;
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, const int64_t *slab_bounds)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (!c) { p->comm = nullptr; p->slabs.clear(); return SDP_OK; }
+    if (!slab_bounds) return fail(SDP_EINVAL, "slab bounds missing");
+    p->slabs.assign(slab_bounds, slab_bounds + c->nranks + 1);
+    if (p->slabs.front() != 0 || p->slabs.back() != p->S) return fail(SDP_EINVAL, "slab bounds must cover [0,S)");
+    for (int r = 0; r < c->nranks; ++r)
+        if (p->slabs[r] > p->slabs[r + 1]) return fail(SDP_EINVAL, "slab bounds must be non-decreasing");
+    if (p->slabs[c->rank] != p->node_begin || p->slabs[c->rank + 1] != p->node_end)
+        return fail(SDP_EINVAL, "this rank's slab does not match the handle's node range");
+    p->comm = c;
+    return SDP_OK;
+}

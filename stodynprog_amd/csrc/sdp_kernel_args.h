@@ -1,0 +1,65 @@
+// sdp_kernel_args.h -- plain-old-data argument blocks shared by the host
+// library (sdp_hip.hip) and the device kernels (built-in and generated-model
+// code objects).  Passed by value as the single kernel argument.
+#pragma once
+#include <stdint.h>
+
+#define SDP_MAXD 4   // multilinear_cython.pyx:33-47 dispatches d = 1..4 only
+#define SDP_MAXU 4   // control variables per system
+
+// One Bellman backup over a contiguous range of state nodes
+// (reference stodynprog.py:466-534 + 639-691).
+struct SdpSweepArgs {
+    const void *V;         // [S] cost-to-go J_next, C-order, last axis fastest
+    void *J;               // [S] output J_k (only nodes in [node_begin,node_end) written)
+    void *pol;             // [S*nu] output optimal control VALUES (may be null)
+    int32_t *idx;          // [S] output flat C-order index into the control lattice (may be null)
+    const void *axes;      // concatenated state-grid axes (reals); axis k at axis_off[k]
+    const void *wgrid;     // [W] perturbation grid (null when W == 0)
+    const void *proba;     // [W] perturbation weights
+    const void *box_lo;    // control box lower ends: [nu] or [nu][S] (per node)
+    const void *box_hi;    // control box upper ends
+    const int32_t *box_n;  // number of control points: [nu] or [nu][S]
+    const void *pol_in;    // [S*nu] prescribed policy (eval_policy kernel only)
+    int64_t node_begin;    // first node of this launch (flat C-order id)
+    int64_t node_end;      // one past the last node
+    int64_t S;             // total number of state nodes
+    double t_k;            // time index for non-stationary systems
+    int32_t orders[SDP_MAXD];
+    int32_t axis_off[SDP_MAXD];
+    int32_t W;             // perturbation points (0: deterministic system)
+    int32_t box_per_node;  // 0: constant box, 1: per-node arrays
+};
+
+// Stand-alone multilinear interpolation (multilinear_cython.pyx:17-49).
+struct SdpInterpArgs {
+    const void *values;    // [n_v][S]
+    const void *s;         // [d][n_s] query coordinates
+    void *out;             // [n_v][n_s]
+    int64_t n_s;
+    int64_t S;
+    int32_t n_v;
+    int32_t d;
+    int32_t orders[SDP_MAXD];
+    double smin[SDP_MAXD]; // converted to the kernel's real type on device
+    double smax[SDP_MAXD];
+};
+
+// Tabulated backup: the model callbacks were evaluated on the host
+// (stodynprog.py:674,676); the device does gather + expectation + argmin.
+struct SdpTabArgs {
+    const void *V;          // [S]
+    const void *x_next;     // [d][n_cells]
+    const void *g;          // [n_cells]
+    const int64_t *cell_off;// [n_nodes+1] first cell of each node
+    const void *proba;      // [W]
+    void *J;                // [n_nodes]
+    int32_t *idx;           // [n_nodes]
+    int64_t n_nodes;
+    int64_t n_cells;
+    int32_t W;
+    int32_t d;
+    int32_t orders[SDP_MAXD];
+    double smin[SDP_MAXD];
+    double smax[SDP_MAXD];
+};

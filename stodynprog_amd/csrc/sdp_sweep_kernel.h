@@ -1,0 +1,193 @@
+// sdp_sweep_kernel.h -- hand-written Bellman-backup kernels for gfx950.
+//
+// Included LAST by a generated-model translation unit, after it has defined
+//   SDP_REAL      double | float
+//   SDP_D         state dimension (1..4)
+//   SDP_NU        number of control variables (1..SDP_MAXU)
+//   SDP_HAS_W     1 when the system has one perturbation, 0 when deterministic
+//   SDP_LANES     lanes per state node (power of two, 1..64)
+//   sdp_model_cell(x, u, w, t, xn, g)   the traced dyn/cost of the user's model
+//
+// Kernel `sdp_sweep` is one value-iteration backup (reference
+// stodynprog.py:466-534 / 639-691):
+//     J_k(x) = min_u  sum_w p_w * ( g(x,u,w) + J_next( f(x,u,w) ) )
+// Mapping: a wavefront owns 64/SDP_LANES consecutive state nodes; the
+// SDP_LANES lanes of a node stride over its control lattice, each lane runs
+// the perturbation loop sequentially in registers (expectation accumulated in
+// w order), then a DPP/shuffle butterfly reduces (J, flat control index) with
+// first-occurrence tie-break (np.argmin semantics, stodynprog.py:686).
+// Workgroups walk contiguous chunks of the node range per XCD so that the
+// value-function neighbourhoods gathered by co-resident waves share one L2.
+//
+// Kernel `sdp_evalpol` is one fixed-policy backup (stodynprog.py:743-762): the
+// same cell evaluation with the control read from a policy array, one lane
+// per node.
+#pragma once
+#include "sdp_device.h"
+
+typedef SDP_REAL sdp_real;
+
+// Control lattice of one node: per control (lo, hi, n) and numpy.linspace
+// point generation (stodynprog.py:458): u_i = i*step + lo, last point == hi.
+struct SdpBox {
+    sdp_real lo[SDP_NU], hi[SDP_NU], step[SDP_NU], delta[SDP_NU];
+    int n[SDP_NU];
+    int total;
+};
+
+SDP_DEV void sdp_load_box(const SdpSweepArgs &a, int64_t node, SdpBox &b)
+{
+    const sdp_real *lo = (const sdp_real *)a.box_lo;
+    const sdp_real *hi = (const sdp_real *)a.box_hi;
+    b.total = 1;
+#pragma unroll
+    for (int c = 0; c < SDP_NU; ++c) {
+        const int64_t at = a.box_per_node ? (int64_t)c * a.S + node : (int64_t)c;
+        b.lo[c] = lo[at];
+        b.hi[c] = hi[at];
+        b.n[c] = a.box_n[at];
+        b.delta[c] = b.hi[c] - b.lo[c];
+        // numpy.linspace: step = delta / div with div = num - 1
+        b.step[c] = (b.n[c] > 1) ? b.delta[c] / (sdp_real)(b.n[c] - 1) : (sdp_real)0;
+        b.total *= b.n[c];
+    }
+}
+
+SDP_DEV sdp_real sdp_control_value(const SdpBox &b, int c, int k)
+{
+    if (b.n[c] == 1) return b.lo[c];                 // single point (host stores the centre)
+    if (k == b.n[c] - 1) return b.hi[c];             // y[-1] = stop
+    if (b.step[c] == (sdp_real)0)                    // linspace's denormal-step branch
+        return ((sdp_real)k / (sdp_real)(b.n[c] - 1)) * b.delta[c] + b.lo[c];
+    return (sdp_real)k * b.step[c] + b.lo[c];
+}
+
+// flat C-order lattice index (control 0 slowest) -> control values
+SDP_DEV void sdp_controls_at(const SdpBox &b, int flat, sdp_real *u)
+{
+#pragma unroll
+    for (int c = SDP_NU - 1; c >= 0; --c) {
+        const int k = flat % b.n[c];
+        flat /= b.n[c];
+        u[c] = sdp_control_value(b, c, k);
+    }
+}
+
+SDP_DEV void sdp_node_coords(const SdpSweepArgs &a, int64_t node, sdp_real *x)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    int64_t r = node;
+#pragma unroll
+    for (int k = SDP_D - 1; k >= 0; --k) {
+        const int i = (int)(r % a.orders[k]);
+        r /= a.orders[k];
+        x[k] = axes[a.axis_off[k] + i];
+    }
+}
+
+SDP_DEV void sdp_grid_from_args(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_D> &g)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    sdp_real smin[SDP_D], smax[SDP_D];
+#pragma unroll
+    for (int k = 0; k < SDP_D; ++k) {
+        smin[k] = axes[a.axis_off[k]];                       // x[0]   stodynprog.py:263
+        smax[k] = axes[a.axis_off[k] + a.orders[k] - 1];     // x[-1]  stodynprog.py:264
+    }
+    sdp_make_grid<sdp_real, SDP_D>(g, a.orders, smin, smax);
+}
+
+// expected cost of one (node, control): sum_w p_w * (g + J_next(f))
+SDP_DEV sdp_real sdp_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_D> &grid,
+                                   const sdp_real *__restrict__ V, const sdp_real *x,
+                                   const sdp_real *u, sdp_real t)
+{
+    sdp_real xn[SDP_D], g;
+#if SDP_HAS_W
+    const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
+    const sdp_real *__restrict__ proba = (const sdp_real *)a.proba;
+    sdp_real acc = (sdp_real)0;
+    for (int wi = 0; wi < a.W; ++wi) {
+        sdp_model_cell(x, u, wgrid[wi], t, xn, g);
+        const sdp_real jc = g + sdp_interp_point<sdp_real, SDP_D, sdp_real>(V, grid, xn);   // stodynprog.py:677
+        acc = acc + jc * proba[wi];                                               // stodynprog.py:681
+    }
+    return acc;
+#else
+    sdp_model_cell(x, u, (sdp_real)0, t, xn, g);
+    return g + sdp_interp_point<sdp_real, SDP_D, sdp_real>(V, grid, xn);                    // stodynprog.py:679-680
+#endif
+}
+
+extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
+{
+    constexpr int L = SDP_LANES;
+    constexpr int NPW = 64 / L;                       // nodes per wavefront
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (L - 1);
+    const int slot = lane / L;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int64_t tile_nodes = (int64_t)NPW * waves;  // nodes per workgroup step
+
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+    SdpGrid<sdp_real, SDP_D> grid;
+    sdp_grid_from_args(a, grid);
+    const sdp_real t = (sdp_real)a.t_k;
+
+    // XCD-aware walk: workgroups b and b+8 share an XCD (round-robin dispatch),
+    // so XCD x takes the x-th contiguous eighth of the tiles.
+    const int64_t n_nodes = a.node_end - a.node_begin;
+    const int64_t n_tiles = (n_nodes + tile_nodes - 1) / tile_nodes;
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_xcd = (n_tiles + 7) / 8;
+    const int64_t t_end = min((int64_t)(xcd + 1) * per_xcd, n_tiles);
+    const int64_t stride = gridDim.x >> 3;
+
+    for (int64_t tile = (int64_t)xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += stride) {
+        const int64_t node = a.node_begin + tile * tile_nodes + (int64_t)wave * NPW + slot;
+        const bool live = node < a.node_end;
+        sdp_real best = INFINITY;
+        int ibest = INT_MAX;
+        SdpBox box;
+        sdp_real x[SDP_D];
+        if (live) {
+            sdp_node_coords(a, node, x);
+            sdp_load_box(a, node, box);
+            for (int ci = sub; ci < box.total; ci += L) {
+                sdp_real u[SDP_NU];
+                sdp_controls_at(box, ci, u);
+                const sdp_real jc = sdp_expected_cost(a, grid, V, x, u, t);
+                if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
+            }
+        }
+        sdp_seg_argmin<sdp_real, L>(best, ibest);
+        if (live && sub == 0) {
+            ((sdp_real *)a.J)[node] = best;
+            if (a.idx) a.idx[node] = ibest;
+            if (a.pol) {
+                sdp_real u[SDP_NU];
+                sdp_controls_at(box, ibest, u);
+#pragma unroll
+                for (int c = 0; c < SDP_NU; ++c) ((sdp_real *)a.pol)[node * SDP_NU + c] = u[c];
+            }
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256) sdp_evalpol(SdpSweepArgs a)
+{
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+    SdpGrid<sdp_real, SDP_D> grid;
+    sdp_grid_from_args(a, grid);
+    const sdp_real t = (sdp_real)a.t_k;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t node = a.node_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+         node < a.node_end; node += stride) {
+        sdp_real x[SDP_D], u[SDP_NU];
+        sdp_node_coords(a, node, x);
+#pragma unroll
+        for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+        ((sdp_real *)a.J)[node] = sdp_expected_cost(a, grid, V, x, u, t);
+    }
+}

@@ -1,0 +1,691 @@
+"""Dynamic-programming solver: the drop-in `DPSolver` class.
+
+Host-side mirror of the reference's solver API (reference
+stodynprog/stodynprog.py:317-876).  The discretisation helpers stay in numpy
+(same operators as the reference, so grids and weights are bit-identical); the
+sweeps run on the GPU:
+
+  value_iteration / bellman_recursion
+      -> sdp_problem_vi_sweep   (fused node x control x perturbation backup)
+  eval_policy / policy_iteration
+      -> sdp_problem_eval_policy (device-resident fixed-policy backups)
+  interp_on_state(...)(coords)
+      -> sdp_mlinterp_f64 / _f32
+
+The user's `dyn` and `cost` callables are traced once (trace.py) and compiled
+into the sweep kernel (codegen.py).  Callables that cannot be traced are
+evaluated on the host exactly as the reference does and only the gather /
+expectation / argmin runs on the device (sdp_tab_backup, "tabulated mode").
+There is no CPU compute fallback: without the HIP library and a GPU every
+sweep raises.
+"""
+from __future__ import division, print_function
+import ctypes as C
+import itertools
+from datetime import datetime
+
+import numpy as np
+
+from . import _native as nat
+from . import codegen
+from .interp import MlinInterpolator
+from .trace import TraceError, trace_model
+
+__all__ = ['DPSolver']
+
+
+class _DeviceProblem(object):
+    """Owner of one sdp_problem handle (include/sdp_hip.h)."""
+
+    def __init__(self, desc_arrays, module_path, dtype, shape, nu, W, lanes, box_per_node,
+                 node_range, comm=None, slab_bounds=None):
+        self._keep = desc_arrays            # host arrays referenced by the descriptor
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(shape)
+        self.S = int(np.prod(shape))
+        self.nu = nu
+        d = nat.sdp_problem_desc()
+        d.dtype = nat.np_real(dtype)
+        d.d, d.nu, d.W = len(shape), nu, W
+        for k, n in enumerate(shape):
+            d.orders[k] = n
+            d.axes[k] = desc_arrays['axes'][k].ctypes.data
+        if W > 0:
+            d.wgrid = desc_arrays['wgrid'].ctypes.data
+            d.proba = desc_arrays['proba'].ctypes.data
+        d.box_per_node = int(box_per_node)
+        d.lanes_per_node = int(lanes)
+        d.box_lo = desc_arrays['box_lo'].ctypes.data
+        d.box_hi = desc_arrays['box_hi'].ctypes.data
+        d.box_n = desc_arrays['box_n'].ctypes.data
+        d.node_begin, d.node_end = node_range
+        d.module_path = module_path.encode()
+        h = C.c_void_p()
+        nat.check(nat.lib().sdp_problem_create(C.byref(d), C.byref(h)))
+        self.h = h
+        self.node_range = tuple(node_range)
+        if comm is not None:
+            bounds = np.ascontiguousarray(slab_bounds, dtype=np.int64)
+            nat.check(nat.lib().sdp_problem_attach_comm(self.h, comm.handle, nat.ptr(bounds)))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            nat.lib().sdp_problem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_value(self, V):
+        V = np.ascontiguousarray(V, dtype=self.dtype)
+        assert V.size == self.S
+        nat.check(nat.lib().sdp_problem_set_value(self.h, nat.ptr(V)))
+
+    def set_policy(self, pol):
+        pol = np.ascontiguousarray(pol, dtype=self.dtype)
+        assert pol.size == self.S * self.nu
+        nat.check(nat.lib().sdp_problem_set_policy(self.h, nat.ptr(pol)))
+
+    def sweep(self, t_k=0.0, rel_dp=False, ref_index=0):
+        ref = C.c_double(0.0)
+        nat.check(nat.lib().sdp_problem_vi_sweep(self.h, float(t_k), int(bool(rel_dp)),
+                                                 int(ref_index), C.byref(ref)))
+        return ref.value
+
+    def eval_policy(self, n_iter, rel_dp=False, ref_index=0):
+        refs = np.zeros(max(int(n_iter), 1))
+        nat.check(nat.lib().sdp_problem_eval_policy(self.h, int(n_iter), int(bool(rel_dp)),
+                                                    int(ref_index), nat.ptr(refs)))
+        return refs[:int(n_iter)]
+
+    def swap(self):
+        nat.check(nat.lib().sdp_problem_swap(self.h))
+
+    def get_value(self):
+        J = np.zeros(self.shape, dtype=self.dtype)
+        nat.check(nat.lib().sdp_problem_get_value(self.h, nat.ptr(J)))
+        return J
+
+    def get_policy(self):
+        pol = np.zeros(self.shape + (self.nu,), dtype=self.dtype)
+        idx = np.zeros(self.shape, dtype=np.int32)
+        nat.check(nat.lib().sdp_problem_get_policy(self.h, nat.ptr(pol), nat.ptr(idx)))
+        return pol, idx
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0.0)
+        nat.check(nat.lib().sdp_problem_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def bench_sweeps(self, reps, rel_dp=False, ref_index=0):
+        loop, kern = C.c_double(0.0), C.c_double(0.0)
+        nat.check(nat.lib().sdp_problem_bench_sweeps(self.h, int(reps), int(bool(rel_dp)),
+                                                     int(ref_index), C.byref(loop),
+                                                     C.byref(kern)))
+        return loop.value, kern.value
+
+
+class DPSolver(object):
+    def __init__(self, sys, dtype=np.float64, comm=None):
+        """Dynamic Programming solver for stochastic dynamic control of `sys`
+        (a `SysDescription`).  Implements value iteration, policy evaluation,
+        policy iteration and finite-horizon Bellman recursion on an AMD GPU.
+
+        New (optional) arguments, absent from the reference:
+        dtype : arithmetic type of the sweep, float64 (default) or float32
+        comm  : a `stodynprog_amd.dist.Communicator` to shard the outer state
+                axis over several GPUs (one process per GPU)
+        """
+        self.sys = sys
+        self.state_grid = [[0.] for s in self.sys.state]
+        self.perturb_grid = [[0.] for p in self.sys.perturb]
+        self.perturb_proba = [[1.] for p in self.sys.perturb]
+        self.control_steps = (1.,) * len(self.sys.control)
+        self.dtype = np.dtype(dtype)
+        self.comm = comm
+        self._cache = {}
+        self.last_policy_index = None      # flat control-lattice index of the last sweep
+        self.backend_info = {}
+
+    # ------------------------------------------------------------------ grids
+    def discretize_perturb(self, *linspace_args):
+        """create a regular discrete grid for each perturbation variable;
+        grids go to `self.perturb_grid` (may also be set manually), the
+        probability weights to `self.perturb_proba` (reference sdp.py:335-362)."""
+        assert len(linspace_args) == len(self.sys.perturb) * 3
+        self.perturb_grid = []
+        self.perturb_proba = []
+        for i in range(len(self.sys.perturb)):
+            grid_wi = np.linspace(*linspace_args[i * 3:i * 3 + 3])
+            law = self.sys.perturb_laws[i]
+            if self.sys.perturb_types[i] == 'continuous':
+                proba_wi = law.pdf(grid_wi)
+                proba_wi /= proba_wi.sum()
+            else:
+                proba_wi = law.pmf(grid_wi)
+                assert np.allclose(proba_wi.sum(), 1.)
+            self.perturb_grid.append(grid_wi)
+            self.perturb_proba.append(proba_wi)
+        return self.perturb_grid, self.perturb_proba
+
+    def discretize_state(self, *linspace_args):
+        """create a regular discrete grid for each state variable, stored in
+        `self.state_grid` (reference sdp.py:364-389)."""
+        assert len(linspace_args) == len(self.sys.state) * 3
+        self.state_grid = [np.linspace(*linspace_args[i * 3:i * 3 + 3])
+                           for i in range(len(self.sys.state))]
+        shape = tuple(len(g) for g in self.state_grid)
+        self._state_grid_shape = shape
+        # reference state of the relative DP algorithm: the middle of the grid
+        self._state_ref_ind = tuple(n // 2 for n in shape)
+        self._state_ref = tuple(g[i] for g, i in zip(self.state_grid, self._state_ref_ind))
+        return self.state_grid
+
+    @property
+    def state_grid_full(self):
+        """broadcasted state grid (self.state_grid is flat)"""
+        d = len(self.state_grid)
+        parts = []
+        for i, g in enumerate(self.state_grid):
+            shape = [1] * d
+            shape[i] = -1
+            parts.append(np.asarray(g).reshape(shape))
+        return np.broadcast_arrays(*parts)
+
+    def interp_on_state(self, A):
+        """returns an interpolating function of array A, assumed to be given
+        on the state grid (reference sdp.py:405-430)."""
+        expect_shape = self._state_grid_shape
+        if A.shape != expect_shape:
+            raise ValueError('array `A` should be of shape {:s}, not {:s}'.format(
+                str(expect_shape), str(A.shape)))
+        if len(expect_shape) <= 5:
+            A_interp = MlinInterpolator(*self.state_grid)
+            A_interp.set_values(A)
+            return A_interp
+        raise NotImplementedError('interpolation for state dimension >5'
+                                  ' is not implemented.')
+
+    def control_grids(self, state_k, t_k=None):
+        """grid on the box of admissible controls at state `state_k`, using
+        self.control_steps as hints (reference sdp.py:432-463).
+        Returns (list of 1-D arrays, tuple of their lengths)."""
+        if t_k is not None:
+            state_k = (t_k,) + tuple(state_k)
+        intervals = self.sys.control_box(*state_k, **self.sys.params)
+        grids, dims = [], []
+        for (u_min, u_max), step in zip(intervals, self.control_steps):
+            n_interv = (u_max - u_min) / step
+            if n_interv < 0.1:
+                npts = 1
+                u_grid = np.array([(u_min + u_max) / 2])
+            else:
+                npts = int(np.ceil(n_interv) + 1)
+                u_grid = np.linspace(u_min, u_max, npts)
+            grids.append(u_grid)
+            dims.append(npts)
+        return grids, tuple(dims)
+
+    # ------------------------------------------------- host-side preparation
+    def _shape(self):
+        return tuple(len(g) for g in self.state_grid)
+
+    def _box_table(self, t_k=None):
+        """control_grids() for every node at once: (lo, hi, n) arrays of shape
+        (nu, S), with the same numpy operators as control_grids.  The box
+        callback is first tried on whole-grid arrays and checked against
+        scalar calls on sample nodes; callbacks that only work on scalars
+        (np.max((a, b)) style) are evaluated node by node."""
+        shape = self._shape()
+        S = int(np.prod(shape))
+        nu = len(self.sys.control)
+        params = self.sys.params
+        lead = () if t_k is None else (t_k,)
+
+        def scalar_box(flat):
+            ind = np.unravel_index(flat, shape)
+            x = tuple(g[i] for g, i in zip(self.state_grid, ind))
+            return self.sys.control_box(*(lead + x), **params)
+
+        lo = hi = None
+        try:
+            full = [np.ascontiguousarray(a, dtype=float) for a in self.state_grid_full]
+            with np.errstate(all='ignore'):
+                box = self.sys.control_box(*(lead + tuple(full)), **params)
+            if len(box) != nu:
+                raise ValueError
+            lo_v = np.empty((nu, S))
+            hi_v = np.empty((nu, S))
+            for c, (a, b) in enumerate(box):
+                lo_v[c] = np.broadcast_to(np.asarray(a, dtype=float), shape).ravel()
+                hi_v[c] = np.broadcast_to(np.asarray(b, dtype=float), shape).ravel()
+            rng = np.random.default_rng(12345)
+            probe = set(rng.integers(0, S, size=min(S, 48)).tolist())
+            probe.update([0, S - 1, S // 2])
+            ok = True
+            for flat in probe:
+                sb = scalar_box(flat)
+                for c, (a, b) in enumerate(sb):
+                    if not (_same(lo_v[c, flat], a) and _same(hi_v[c, flat], b)):
+                        ok = False
+            if ok:
+                lo, hi = lo_v, hi_v
+        except Exception:
+            lo = hi = None
+        if lo is None:
+            lo = np.empty((nu, S))
+            hi = np.empty((nu, S))
+            for flat, x in enumerate(itertools.product(*self.state_grid)):
+                box = self.sys.control_box(*(lead + x), **params)
+                for c, (a, b) in enumerate(box):
+                    lo[c, flat] = a
+                    hi[c, flat] = b
+        n = np.empty((nu, S), dtype=np.int32)
+        with np.errstate(all='ignore'):
+            for c in range(nu):
+                step = self.control_steps[c]
+                n_interv = (hi[c] - lo[c]) / step                   # sdp.py:446-447
+                single = n_interv < 0.1                              # sdp.py:449
+                npts = np.where(single, 1, np.ceil(np.where(single, 0., n_interv)) + 1)
+                n[c] = npts.astype(np.int32)
+                mid = (lo[c] + hi[c]) / 2                            # sdp.py:453
+                lo[c] = np.where(single, mid, lo[c])
+                hi[c] = np.where(single, mid, hi[c])
+        return lo, hi, n
+
+    def _fingerprint(self, t_k):
+        s = self.sys
+        parts = [id(s.dyn), id(s.cost), id(s.control_box), repr(sorted(s.params.items())),
+                 tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
+                 id(self.comm)]
+        for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
+            parts.append(np.asarray(g, dtype=float).tobytes())
+        return hash(tuple(parts))
+
+    def _traced(self):
+        key = ('trace', id(self.sys.dyn), id(self.sys.cost), repr(sorted(self.sys.params.items())))
+        if key not in self._cache:
+            s = self.sys
+            try:
+                model = trace_model(s.dyn, s.cost, len(s.state), len(s.control),
+                                    len(s.perturb), s.params, s.stationnary)
+            except TraceError as e:
+                model = e
+            self._cache[key] = model
+        return self._cache[key]
+
+    def _check_supported(self):
+        if len(self.perturb_grid) > 1:
+            raise NotImplementedError('only one perturbation variable is supported '
+                                      '(as in the reference, sdp.py:664-666)')
+        d = len(self.state_grid)
+        if d > 5:
+            raise NotImplementedError('interpolation for state dimension >5'
+                                      ' is not implemented.')
+        if d > 4:
+            raise Exception("Can't interpolate in dimension strictly greater than 5")
+
+    def _problem(self, t_k=None):
+        """Device problem for the current discretisation (cached)."""
+        self._check_supported()
+        box_t = None if self.sys.stationnary else t_k
+        fp = ('problem', self._fingerprint(box_t))
+        prob = self._cache.get(fp)
+        if prob is not None:
+            return prob
+        nat.require_gpu()
+        model = self._traced()
+        if isinstance(model, TraceError):
+            raise model
+        shape = self._shape()
+        S = int(np.prod(shape))
+        dt = self.dtype
+        lo, hi, n = self._box_table(box_t)
+        per_node = not (np.all(lo == lo[:, :1]) and np.all(hi == hi[:, :1])
+                        and np.all(n == n[:, :1]))
+        max_u = int(np.prod(n.astype(np.int64), axis=0).max())
+        if max_u >= 2 ** 31:
+            raise ValueError('control lattice too large')
+        lanes = codegen.lanes_for(max_u)
+        if not per_node:
+            lo, hi, n = lo[:, :1], hi[:, :1], n[:, :1]
+        W = len(self.perturb_grid[0]) if self.perturb_grid else 0
+        arrays = dict(
+            axes=[np.ascontiguousarray(g, dtype=dt) for g in self.state_grid],
+            box_lo=np.ascontiguousarray(lo, dtype=dt),
+            box_hi=np.ascontiguousarray(hi, dtype=dt),
+            box_n=np.ascontiguousarray(n, dtype=np.int32))
+        if W:
+            arrays['wgrid'] = np.ascontiguousarray(self.perturb_grid[0], dtype=dt)
+            arrays['proba'] = np.ascontiguousarray(self.perturb_proba[0], dtype=dt)
+        source = codegen.translation_unit(model, dt, lanes)
+        module = nat.compile_model(source)
+        if self.comm is not None:
+            bounds = self.comm.slab_bounds(shape)
+            node_range = (int(bounds[self.comm.rank]), int(bounds[self.comm.rank + 1]))
+        else:
+            bounds, node_range = None, (0, S)
+        # drop other cached problems: they hold large device buffers
+        for k in [k for k in self._cache if k[0] == 'problem']:
+            self._cache.pop(k).close()
+        prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
+                              per_node, node_range, self.comm, bounds)
+        self._cache[fp] = prob
+        self.backend_info = dict(mode='fused', module=module, lanes_per_node=lanes,
+                                 max_controls=max_u, box_per_node=bool(per_node),
+                                 bit_exact_model=model.bit_exact,
+                                 inexact_ops=model.inexact_ops())
+        return prob
+
+    def _ref_flat(self):
+        return int(np.ravel_multi_index(self._state_ref_ind, self._shape()))
+
+    # ------------------------------------------------------------ value iteration
+    def value_iteration(self, J_next, rel_dp=False, report_time=True):
+        """solve one DP step on the entire state space grid, given the
+        cost-to-go array `J_next` discretized over the state space grid
+        (reference sdp.py:466-534).
+
+        If rel_dp is True, J_next should be a (J_next, J_ref) tuple.
+
+        Returns (J_k, pol_k); J_k is a tuple (J_diff, J_ref) if `rel_dp` is True.
+        pol_k holds the optimal control VALUES, shape state_dims + (nb_control,).
+        """
+        t_start = datetime.now()
+        ref_ind = self._state_ref_ind if rel_dp else None
+        if rel_dp:
+            J_next, J_ref = J_next
+            # the cost-to-go must be a *differential* cost, zero at the reference state
+            assert J_next[ref_ind] == 0.
+        J_next = np.asarray(J_next)
+        self.interp_on_state(J_next)            # shape check (ValueError) as the reference
+        if report_time:
+            print('value iteration...', end='')
+        J_k, pol_k, J_ref = self._backup(J_next, None, rel_dp)
+        exec_time = (datetime.now() - t_start).total_seconds()
+        if report_time:
+            print('\rvalue iteration run in {:.2f} s'.format(exec_time))
+        if rel_dp:
+            J_k = J_k, J_ref
+        return J_k, pol_k
+
+    def _backup(self, J_next, t_k, rel_dp):
+        """One sweep: fused kernel when the model is traceable, else tabulated."""
+        model = self._traced()
+        if isinstance(model, TraceError):
+            return self._backup_tabulated(J_next, t_k, rel_dp)
+        prob = self._problem(t_k)
+        prob.set_value(J_next)
+        J_ref = prob.sweep(0.0 if t_k is None else t_k, rel_dp,
+                           self._ref_flat() if rel_dp else 0)
+        J_k = prob.get_value()
+        pol_k, idx = prob.get_policy()
+        self.last_policy_index = idx
+        return J_k, pol_k, J_ref
+
+    def _backup_tabulated(self, J_next, t_k, rel_dp, chunk_cells=4_000_000):
+        """Tabulated mode: callbacks evaluated on the host node by node exactly
+        like reference sdp.py:651-676; gather + expectation + argmin on the
+        device (sdp_tab_backup)."""
+        nat.require_gpu()
+        self._check_supported()
+        shape = self._shape()
+        S = int(np.prod(shape))
+        nu = len(self.sys.control)
+        W = len(self.perturb_grid[0]) if self.perturb_grid else 0
+        d = len(shape)
+        smin = np.array([g[0] for g in self.state_grid], dtype=float)
+        smax = np.array([g[-1] for g in self.state_grid], dtype=float)
+        orders = np.array(shape, dtype=np.int64)
+        V = np.ascontiguousarray(J_next, dtype=float)
+        h = C.c_void_p()
+        nat.check(nat.lib().sdp_tab_create(d, nat.ptr(smin), nat.ptr(smax), nat.ptr(orders),
+                                           nat.ptr(V), C.byref(h)))
+        self.backend_info = dict(mode='tabulated', reason=str(self._traced()))
+        J_k = np.zeros(S)
+        idx_k = np.zeros(S, dtype=np.int64)
+        pol_k = np.zeros((S, nu))
+        proba = np.ascontiguousarray(self.perturb_proba[0], dtype=float) if W else None
+        try:
+            batch = []          # (flat, u_grids, dims, x_next[d, cells], g[cells])
+            cells = 0
+
+            def flush():
+                nonlocal batch, cells
+                if not batch:
+                    return
+                off = np.zeros(len(batch) + 1, dtype=np.int64)
+                for i, b in enumerate(batch):
+                    off[i + 1] = off[i] + b[4].size
+                xn = np.ascontiguousarray(np.concatenate([b[3] for b in batch], axis=1))
+                g = np.ascontiguousarray(np.concatenate([b[4] for b in batch]))
+                Jb = np.zeros(len(batch))
+                ib = np.zeros(len(batch), dtype=np.int64)
+                nat.check(nat.lib().sdp_tab_backup(h, len(batch), nat.ptr(off), W,
+                                                   nat.ptr(proba), nat.ptr(xn), nat.ptr(g),
+                                                   nat.ptr(Jb), nat.ptr(ib)))
+                for (flat, u_grids, dims, _, _), Jv, iv in zip(batch, Jb, ib):
+                    J_k[flat] = Jv
+                    idx_k[flat] = iv
+                    ind = np.unravel_index(iv, dims)
+                    pol_k[flat] = [u_grids[c].ravel()[ind[c]] for c in range(nu)]
+                batch, cells = [], 0
+
+            for flat, x_k in enumerate(itertools.product(*self.state_grid)):
+                u_grids, dims = self.control_grids(x_k, t_k)
+                lattice = dims + ((W,) if W else ())
+                for i in range(nu):
+                    u_grids[i] = u_grids[i].reshape((1,) * i + (-1,) + (1,) * (nu - i))
+                args = tuple(x_k) + tuple(u_grids) + tuple(self.perturb_grid)
+                if t_k is not None:
+                    args = (t_k,) + args
+                x_next = self.sys.dyn(*args, **self.sys.params)
+                g_grid = self.sys.cost(*args, **self.sys.params)
+                xn = np.vstack([np.broadcast_to(np.asarray(x, dtype=float), lattice).ravel()
+                                for x in x_next])
+                gg = np.broadcast_to(np.asarray(g_grid, dtype=float), lattice).ravel()
+                batch.append((flat, u_grids, dims, xn, gg))
+                cells += gg.size
+                if cells >= chunk_cells:
+                    flush()
+            flush()
+        finally:
+            nat.lib().sdp_tab_destroy(h)
+        J_k = J_k.reshape(shape)
+        J_ref = 0.0
+        if rel_dp:
+            J_ref = J_k[self._state_ref_ind]
+            J_k -= J_ref
+        self.last_policy_index = idx_k.reshape(shape).astype(np.int32)
+        return J_k, pol_k.reshape(shape + (nu,)), J_ref
+
+    def bellman_recursion(self, t_fin, J_fin, t_ini=0, report_time=True):
+        """solve the Bellman backward recursion of a *finite horizon problem*
+        from `t_fin` (positive int) down to `t_ini` (reference sdp.py:536-591).
+        Supports non-stationnary problems.  Returns (J, pol) with a leading
+        time axis."""
+        t_start = datetime.now()
+        state_dims = tuple(len(grid) for grid in self.state_grid)
+        nb_control = len(self.sys.control)
+        stationnary = self.sys.stationnary
+        print('time-dependent problem: {:s}'.format('no' if stationnary else 'yes'))
+        assert t_ini == 0       # t_ini > 0 not tested (as in the reference)
+        J = np.zeros((t_fin - t_ini,) + state_dims)
+        pol = np.zeros((t_fin - t_ini,) + state_dims + (nb_control,))
+        if report_time:
+            print('bellman recursion...', end='')
+        for t_k in range(t_ini, t_fin)[::-1]:
+            print('\rtk = {:3d}...'.format(t_k), end='')
+            k = t_k - t_ini
+            J_next = J_fin if t_k == (t_fin - 1) else J[k + 1]
+            self.interp_on_state(np.asarray(J_next))
+            # the reference always passes t_k to the callbacks here (sdp.py:582)
+            J[k], pol[k], _ = self._backup(np.asarray(J_next), t_k, False)
+        exec_time = (datetime.now() - t_start).total_seconds()
+        if report_time:
+            print('\rvalue iteration run in {:.2f} s'.format(exec_time))
+        return J, pol
+
+    # ----------------------------------------------------- per-node entry points
+    def _node_lattice(self, x_k, t_k):
+        u_grids, dims = self.control_grids(x_k, t_k)
+        nu = len(u_grids)
+        for i in range(nu):
+            u_grids[i] = u_grids[i].reshape((1,) * i + (-1,) + (1,) * (nu - i))
+        args = tuple(x_k) + tuple(u_grids) + tuple(self.perturb_grid)
+        if t_k is not None:
+            args = (t_k,) + args
+        return u_grids, dims, args
+
+    def _value_at_state_vect(self, x_k, J_next_interp, t_k=None):
+        """optimal cost and control at one state point `x_k` (reference
+        sdp.py:639-691): callbacks on the host, gather / expectation / argmin
+        on the device.  Returns (J_xk_opt, u_xk_opt)."""
+        u_grids, dims, args = self._node_lattice(x_k, t_k)
+        nu = len(u_grids)
+        W = len(self.perturb_grid[0]) if self.perturb_grid else 0
+        lattice = dims + ((W,) if W else ())
+        x_next = self.sys.dyn(*args, **self.sys.params)
+        g_grid = self.sys.cost(*args, **self.sys.params)
+        xn = np.ascontiguousarray(np.vstack(
+            [np.broadcast_to(np.asarray(x, dtype=float), lattice).ravel() for x in x_next]))
+        gg = np.ascontiguousarray(np.broadcast_to(np.asarray(g_grid, dtype=float), lattice).ravel())
+        it = J_next_interp
+        h = C.c_void_p()
+        V = np.ascontiguousarray(it.values, dtype=float).ravel()
+        smin = np.ascontiguousarray(it._xmin, dtype=float)
+        smax = np.ascontiguousarray(it._xmax, dtype=float)
+        orders = np.ascontiguousarray(it._xshape, dtype=np.int64)
+        nat.check(nat.lib().sdp_tab_create(it.ndim, nat.ptr(smin), nat.ptr(smax),
+                                           nat.ptr(orders), nat.ptr(V), C.byref(h)))
+        try:
+            off = np.array([0, gg.size], dtype=np.int64)
+            Jb = np.zeros(1)
+            ib = np.zeros(1, dtype=np.int64)
+            proba = np.ascontiguousarray(self.perturb_proba[0], dtype=float) if W else None
+            nat.check(nat.lib().sdp_tab_backup(h, 1, nat.ptr(off), W, nat.ptr(proba),
+                                               nat.ptr(xn), nat.ptr(gg), nat.ptr(Jb),
+                                               nat.ptr(ib)))
+        finally:
+            nat.lib().sdp_tab_destroy(h)
+        ind_opt = np.unravel_index(int(ib[0]), dims)
+        u_opt = [u_grids[i].flatten()[ind_opt[i]] for i in range(nu)]
+        return (Jb[0], u_opt)
+
+    def _value_at_state_loop(self, x_k, J_next_interp):
+        """same result as `_value_at_state_vect` (the reference's iterative
+        variant, sdp.py:594-636, keeps the first minimum as well)."""
+        J, u = self._value_at_state_vect(x_k, J_next_interp)
+        return (J, tuple(u))
+
+    # ------------------------------------------------------------ policy evaluation
+    def eval_policy(self, pol, n_iter, rel_dp=False, J_zero=None,
+                    report_time=True, J_ref_full=False):
+        """evaluate the policy `pol`: cost of each state after `n_iter` steps
+        (reference sdp.py:693-775).  If rel_dp is True the relative DP
+        algorithm is used.
+
+        Returns J_pol (array of shape self._state_grid_shape), or
+        (J_pol, J_ref) if `rel_dp` is True (J_ref: the last reference cost,
+        or all of them when J_ref_full).
+        """
+        t_start = datetime.now()
+        state_dims = self._state_grid_shape
+        if J_zero is None:
+            J_zero = np.zeros(state_dims)
+        assert J_zero.shape == state_dims
+        nb_control = len(self.sys.control)
+        assert pol.shape == state_dims + (nb_control,)
+        model = self._traced()
+        if isinstance(model, TraceError):
+            raise NotImplementedError('eval_policy needs a traceable model: {}'.format(model))
+        prob = self._problem(None if self.sys.stationnary else 0)
+        prob.set_value(J_zero)
+        prob.set_policy(pol)
+        for k in range(n_iter):
+            # progress line of the reference; the iterations themselves run in one device call
+            print('\rpolicy evaluation: iter. {:d}/{:d}'.format(k, n_iter), end='')
+        J_ref = prob.eval_policy(n_iter, rel_dp, self._ref_flat() if rel_dp else 0)
+        J_pol = prob.get_value()
+        exec_time = (datetime.now() - t_start).total_seconds()
+        if report_time:
+            print('\rpolicy evaluation run in {:.2f} s     '.format(exec_time))
+        if rel_dp:
+            if not J_ref_full:
+                J_ref = J_ref[-1]
+            return J_pol, J_ref
+        return J_pol
+
+    def policy_iteration(self, pol_init, n_val, n_pol=1, rel_dp=False):
+        """policy iteration algorithm (reference sdp.py:777-812).
+
+        pol_init : initial policy to evaluate
+        n_val : number of value iterations to evaluate the policy
+        n_pol : number of policy iterations (default to 1)
+
+        Returns (J_pol, pol); J_pol is a tuple (J_diff, J_ref) if rel_dp.
+        """
+        pol = pol_init
+        J_pol = self.eval_policy(pol, n_val, rel_dp)
+        if rel_dp:
+            J_diff, J_ref = J_pol
+            print('ref policy cost: {:g}'.format(J_ref))
+        for k in range(n_pol):
+            print('policy iteration {:d}/{:d}'.format(k + 1, n_pol))
+            _, pol = self.value_iteration(J_pol, rel_dp=rel_dp)
+            J_pol = self.eval_policy(pol, n_val, rel_dp)
+            if rel_dp:
+                J_ref = J_pol[1]
+                print('ref policy cost: {:g}'.format(J_ref))
+        return J_pol, pol
+
+    # ------------------------------------------------------------------ reporting
+    def print_summary(self):
+        """summary information about the state of the SDP solver
+        (reference sdp.py:814-875)"""
+        print('SDP solver for system "{}"'.format(self.sys.name))
+
+        def describe(names, grids):
+            for name, grid in zip(names, grids):
+                if len(grid) > 1:
+                    print('  - Δ{:s} = {:g}'.format(name, grid[1] - grid[0]))
+                else:
+                    print('  - {:s} fixed at {:g}'.format(name, grid[0]))
+
+        size = 'x'.join(str(len(g)) for g in self.state_grid)
+        print('* state space discretized on a {:s} points grid'.format(size))
+        describe(self.sys.state, self.state_grid)
+        if self.sys.stochastic:
+            size = 'x'.join(str(len(g)) for g in self.perturb_grid)
+            print('* perturbation discretized on a {:s} points grid'.format(size))
+            describe(self.sys.perturb, self.perturb_grid)
+        cdim = None
+        if self.sys.control_box is not None:
+            t_k = None if self.sys.stationnary else 0
+            _, _, n = self._box_table(t_k)
+            cdim = n.T.astype(np.int64)             # (S, nu)
+        else:
+            print('Warning: sys.control_box is still to be defined!')
+        print('* control discretization steps:')
+        for i in range(len(self.sys.control)):
+            print('  - Δ{:s} = {:g}'.format(self.sys.control[i], self.control_steps[i]))
+            if cdim is not None:
+                lo_n, hi_n = cdim[:, i].min(), cdim[:, i].max()
+                if lo_n != hi_n:
+                    print(('    yields [{:,d} to {:,d}] possible values'
+                           ' ({:,.1f} on average)').format(lo_n, hi_n, cdim[:, i].mean()))
+                else:
+                    print('    yields {:,d} possible values'.format(cdim[0, i]))
+        if cdim is not None and len(self.sys.control) >= 2:
+            tot = np.prod(cdim, axis=1)
+            print('  control combinations:'
+                  ' [{:,d} to {:,d}] possible values ({:,.1f} on average)'.format(
+                      tot.min(), tot.max(), tot.mean()))
+
+
+def _same(a, b):
+    a, b = float(a), float(b)
+    return a == b or (a != a and b != b)

@@ -1,0 +1,501 @@
+"""Symbolic tracing of the user's model callables.
+
+The reference evaluates `dyn`, `cost` (numpy expressions written by the user)
+inside its hot loop (reference stodynprog/stodynprog.py:674,676).  Device code
+cannot call Python, so `DPSolver` calls each callable ONCE with `Sym` proxies
+for x, u, w (and t_k); the proxies record every arithmetic operator and numpy
+ufunc into an expression DAG, which codegen.py turns into a HIP device
+function with one IEEE operation per recorded operator, in the recorded order
+(contraction off), so results match numpy bit for bit for + - * / sqrt abs,
+comparisons and selects.
+
+Anything that needs a concrete value (`if x > 0:`, `float(x)`, `max(a, b)`,
+indexing a table with x) raises TraceError; the solver then reports the model
+as not traceable (tabulated mode evaluates such callables on the host).
+"""
+import math
+import numbers
+
+import numpy as np
+
+__all__ = ['TraceError', 'Graph', 'Sym', 'trace_model']
+
+
+class TraceError(Exception):
+    """The callable cannot be expressed as a straight-line expression DAG."""
+
+
+# dependency bits
+DEP_X, DEP_U, DEP_W, DEP_T = 1, 2, 4, 8
+
+# op -> (arity, result kind)   kind: 'r' real, 'b' bool
+_OPS = {
+    'add': (2, 'r'), 'sub': (2, 'r'), 'mul': (2, 'r'), 'div': (2, 'r'),
+    'neg': (1, 'r'), 'abs': (1, 'r'), 'sqrt': (1, 'r'), 'square': (1, 'r'),
+    'recip': (1, 'r'),
+    'pow': (2, 'r'), 'min': (2, 'r'), 'max': (2, 'r'), 'fmin': (2, 'r'), 'fmax': (2, 'r'),
+    'floor': (1, 'r'), 'ceil': (1, 'r'), 'trunc': (1, 'r'), 'rint': (1, 'r'),
+    'sign': (1, 'r'), 'exp': (1, 'r'), 'exp2': (1, 'r'), 'expm1': (1, 'r'),
+    'log': (1, 'r'), 'log2': (1, 'r'), 'log10': (1, 'r'), 'log1p': (1, 'r'),
+    'sin': (1, 'r'), 'cos': (1, 'r'), 'tan': (1, 'r'), 'asin': (1, 'r'),
+    'acos': (1, 'r'), 'atan': (1, 'r'), 'sinh': (1, 'r'), 'cosh': (1, 'r'),
+    'tanh': (1, 'r'), 'atan2': (2, 'r'), 'hypot': (2, 'r'), 'fmod': (2, 'r'),
+    'pymod': (2, 'r'), 'floordiv': (2, 'r'), 'cbrt': (1, 'r'),
+    'lt': (2, 'b'), 'le': (2, 'b'), 'gt': (2, 'b'), 'ge': (2, 'b'),
+    'eq': (2, 'b'), 'ne': (2, 'b'),
+    'and': (2, 'b'), 'or': (2, 'b'), 'xor': (2, 'b'), 'not': (1, 'b'),
+    'isnan': (1, 'b'), 'isfinite': (1, 'b'), 'isinf': (1, 'b'),
+    'select': (3, 'r'), 'bselect': (3, 'b'), 'b2r': (1, 'r'),
+}
+
+# ops whose device result is the correctly rounded IEEE result (bit-exact vs numpy)
+EXACT_OPS = {'add', 'sub', 'mul', 'div', 'neg', 'abs', 'sqrt', 'square', 'recip',
+             'min', 'max', 'fmin', 'fmax', 'floor', 'ceil', 'trunc', 'rint', 'sign',
+             'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'and', 'or', 'xor', 'not', 'isnan',
+             'isfinite', 'isinf', 'select', 'bselect', 'b2r', 'var', 'const', 'bconst'}
+
+
+class Node(object):
+    __slots__ = ('id', 'op', 'args', 'value', 'kind', 'deps')
+
+    def __init__(self, id, op, args, value, kind, deps):
+        self.id, self.op, self.args, self.value = id, op, args, value
+        self.kind, self.deps = kind, deps
+
+
+class Graph(object):
+    """Hash-consed expression DAG (common sub-expressions are shared)."""
+
+    def __init__(self):
+        self.nodes = []
+        self._memo = {}
+
+    def _intern(self, key, op, args, value, kind, deps):
+        n = self._memo.get(key)
+        if n is None:
+            n = Node(len(self.nodes), op, args, value, kind, deps)
+            self.nodes.append(n)
+            self._memo[key] = n
+        return n
+
+    def var(self, name, dep):
+        return self._intern(('var', name), 'var', (), name, 'r', dep)
+
+    def const(self, value):
+        value = float(value)
+        # key on the bit pattern: -0.0 and 0.0, and NaN payloads, stay distinct
+        key = ('const', np.float64(value).tobytes())
+        return self._intern(key, 'const', (), value, 'r', 0)
+
+    def bconst(self, value):
+        return self._intern(('bconst', bool(value)), 'bconst', (), bool(value), 'b', 0)
+
+    def op(self, op, *args):
+        arity, kind = _OPS[op]
+        assert len(args) == arity, op
+        deps = 0
+        for a in args:
+            deps |= a.deps
+        return self._intern((op,) + tuple(a.id for a in args), op, tuple(args), None,
+                            kind, deps)
+
+
+def _is_plain_number(v):
+    if isinstance(v, (bool, np.bool_)):
+        return False
+    if isinstance(v, numbers.Real):
+        return True
+    if isinstance(v, np.ndarray) and v.ndim == 0 and v.dtype.kind in 'fiu':
+        return True
+    return False
+
+
+class Sym(object):
+    """Proxy standing for a real (or boolean) array of lattice shape."""
+    __array_priority__ = 1000.
+    __slots__ = ('g', 'n')
+
+    def __init__(self, graph, node):
+        self.g, self.n = graph, node
+
+    # ---- lifting ------------------------------------------------------------
+    def _lift(self, other):
+        if isinstance(other, Sym):
+            if other.g is not self.g:
+                raise TraceError('mixing symbols of two different traces')
+            return other.n
+        if isinstance(other, (bool, np.bool_)):
+            return self.g.bconst(other)
+        if _is_plain_number(other):
+            return self.g.const(float(other))
+        if isinstance(other, np.ndarray) and other.size == 1 and other.dtype.kind in 'fiu':
+            return self.g.const(float(other.reshape(())))
+        if isinstance(other, np.ndarray) and other.size == 1 and other.dtype.kind == 'b':
+            return self.g.bconst(bool(other.reshape(())))
+        raise TraceError('cannot trace operand of type {}'.format(type(other).__name__))
+
+    def _real(self, node):
+        """coerce a bool node to real (numpy: True -> 1.0 in arithmetic)"""
+        return self.g.op('b2r', node) if node.kind == 'b' else node
+
+    def _bin(self, op, a, b):
+        a, b = self._lift(a), self._lift(b)
+        if op in ('and', 'or', 'xor'):
+            if a.kind != 'b' or b.kind != 'b':
+                raise TraceError('bitwise operator on non-boolean operands')
+        elif op in ('eq', 'ne') and a.kind == 'b' and b.kind == 'b':
+            x = self.g.op('xor', a, b)
+            return Sym(self.g, x if op == 'ne' else self.g.op('not', x))
+        else:
+            a, b = self._real(a), self._real(b)
+        return Sym(self.g, self.g.op(op, a, b))
+
+    def _un(self, op, a):
+        a = self._lift(a)
+        if op == 'not':
+            if a.kind != 'b':
+                raise TraceError('logical not of a non-boolean')
+        elif op not in ('isnan', 'isfinite', 'isinf') or a.kind == 'b':
+            a = self._real(a)
+        return Sym(self.g, self.g.op(op, a))
+
+    # ---- arithmetic ------------------------------------------------------------
+    def __add__(self, o): return self._bin('add', self, o)
+    def __radd__(self, o): return self._bin('add', o, self)
+    def __sub__(self, o): return self._bin('sub', self, o)
+    def __rsub__(self, o): return self._bin('sub', o, self)
+    def __mul__(self, o): return self._bin('mul', self, o)
+    def __rmul__(self, o): return self._bin('mul', o, self)
+    def __truediv__(self, o): return self._bin('div', self, o)
+    def __rtruediv__(self, o): return self._bin('div', o, self)
+    def __floordiv__(self, o): return self._bin('floordiv', self, o)
+    def __rfloordiv__(self, o): return self._bin('floordiv', o, self)
+    def __mod__(self, o): return self._bin('pymod', self, o)
+    def __rmod__(self, o): return self._bin('pymod', o, self)
+    def __neg__(self): return self._un('neg', self)
+    def __pos__(self): return self
+    def __abs__(self): return self._un('abs', self)
+
+    def __pow__(self, o):
+        return _power(self, o)
+
+    def __rpow__(self, o):
+        return _power(o, self)
+
+    # ---- comparisons / logic ------------------------------------------------------
+    def __lt__(self, o): return self._bin('lt', self, o)
+    def __le__(self, o): return self._bin('le', self, o)
+    def __gt__(self, o): return self._bin('gt', self, o)
+    def __ge__(self, o): return self._bin('ge', self, o)
+    def __eq__(self, o): return self._bin('eq', self, o)
+    def __ne__(self, o): return self._bin('ne', self, o)
+    __hash__ = None
+    def __and__(self, o): return self._bin('and', self, o)
+    def __rand__(self, o): return self._bin('and', o, self)
+    def __or__(self, o): return self._bin('or', self, o)
+    def __ror__(self, o): return self._bin('or', o, self)
+    def __xor__(self, o): return self._bin('xor', self, o)
+    def __rxor__(self, o): return self._bin('xor', o, self)
+    def __invert__(self): return self._un('not', self)
+
+    # ---- things that need a concrete value -------------------------------------------
+    def __bool__(self):
+        raise TraceError('the truth value of a symbolic expression is needed '
+                         '(Python `if`/`max`/`min` on state, control or perturbation)')
+    __nonzero__ = __bool__
+
+    def __float__(self):
+        raise TraceError('float() of a symbolic expression')
+
+    def __int__(self):
+        raise TraceError('int() of a symbolic expression')
+
+    def __index__(self):
+        raise TraceError('symbolic expression used as an index')
+
+    def __len__(self):
+        raise TraceError('len() of a symbolic expression')
+
+    def __iter__(self):
+        raise TraceError('iteration over a symbolic expression')
+
+    def __getitem__(self, key):
+        if key is Ellipsis or key == ():
+            return self
+        raise TraceError('indexing a symbolic expression')
+
+    # ---- ndarray-like conveniences used in model code --------------------------------------
+    @property
+    def shape(self):
+        raise TraceError('.shape of a symbolic expression')
+
+    def astype(self, dtype, **kw):
+        dt = np.dtype(dtype)
+        if dt.kind == 'f':
+            return Sym(self.g, self._real(self.n))
+        if dt.kind == 'b' and self.n.kind == 'b':
+            return self
+        raise TraceError('astype({}) is not traceable'.format(dt))
+
+    def clip(self, a_min=None, a_max=None, **kw):
+        return _clip(self, a_min, a_max)
+
+    def copy(self):
+        return self
+
+    # ---- numpy protocols --------------------------------------------------------------------
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != '__call__' or kwargs.get('out') is not None:
+            raise TraceError('ufunc method {}.{} is not traceable'.format(ufunc.__name__, method))
+        extra = set(kwargs) - {'dtype', 'casting', 'order', 'subok', 'where'}
+        if extra or kwargs.get('where', True) is not True:
+            raise TraceError('ufunc keyword(s) {} not traceable'.format(sorted(extra)))
+        name = ufunc.__name__
+        sym = next(i for i in inputs if isinstance(i, Sym))
+        if name in _UFUNC_BIN:
+            return sym._bin(_UFUNC_BIN[name], inputs[0], inputs[1])
+        if name in _UFUNC_UN:
+            return sym._un(_UFUNC_UN[name], inputs[0])
+        if name in ('power', 'float_power'):
+            return _power(inputs[0], inputs[1])
+        if name == 'positive':
+            return sym
+        if name == 'reciprocal':
+            return sym._bin('div', 1.0, inputs[0])
+        if name in ('logical_and', 'logical_or', 'logical_xor', 'bitwise_and',
+                    'bitwise_or', 'bitwise_xor'):
+            op = name.split('_')[1]
+            a, b = (_as_bool(sym, i) for i in inputs)
+            return Sym(sym.g, sym.g.op(op, a, b))
+        if name in ('logical_not', 'invert'):
+            return Sym(sym.g, sym.g.op('not', _as_bool(sym, inputs[0])))
+        raise TraceError('numpy ufunc `{}` is not traceable'.format(name))
+
+    def __array_function__(self, func, types, args, kwargs):
+        name = func.__name__
+        if name == 'where' and len(args) == 3 and not kwargs:
+            return _where(*args)
+        if name == 'clip':
+            a = args[0]
+            lo = args[1] if len(args) > 1 else kwargs.get('a_min', kwargs.get('min'))
+            hi = args[2] if len(args) > 2 else kwargs.get('a_max', kwargs.get('max'))
+            return _clip(a, lo, hi)
+        if name in ('asarray', 'asanyarray', 'ascontiguousarray', 'array', 'copy',
+                    'squeeze', 'ravel', 'atleast_1d', 'real'):
+            a = args[0]
+            if isinstance(a, Sym):
+                return a
+        if name in ('abs', 'absolute'):
+            return abs(args[0])
+        if name in ('zeros_like', 'ones_like', 'full_like') and isinstance(args[0], Sym):
+            fill = {'zeros_like': 0., 'ones_like': 1.}.get(name)
+            if fill is None:
+                fill = args[1] if len(args) > 1 else kwargs['fill_value']
+            return Sym(args[0].g, args[0]._lift(fill))
+        if name in ('isnan', 'isfinite', 'isinf'):
+            return args[0]._un(name, args[0])
+        raise TraceError('numpy function `{}` is not traceable'.format(name))
+
+
+_UFUNC_BIN = {
+    'add': 'add', 'subtract': 'sub', 'multiply': 'mul', 'divide': 'div',
+    'true_divide': 'div', 'minimum': 'min', 'maximum': 'max', 'fmin': 'fmin',
+    'fmax': 'fmax', 'less': 'lt', 'less_equal': 'le', 'greater': 'gt',
+    'greater_equal': 'ge', 'equal': 'eq', 'not_equal': 'ne', 'arctan2': 'atan2',
+    'hypot': 'hypot', 'fmod': 'fmod', 'remainder': 'pymod', 'mod': 'pymod',
+    'floor_divide': 'floordiv',
+}
+_UFUNC_UN = {
+    'negative': 'neg', 'absolute': 'abs', 'fabs': 'abs', 'sqrt': 'sqrt', 'square': 'square',
+    'floor': 'floor', 'ceil': 'ceil', 'trunc': 'trunc', 'rint': 'rint', 'sign': 'sign',
+    'exp': 'exp', 'exp2': 'exp2', 'expm1': 'expm1', 'log': 'log', 'log2': 'log2',
+    'log10': 'log10', 'log1p': 'log1p', 'sin': 'sin', 'cos': 'cos', 'tan': 'tan',
+    'arcsin': 'asin', 'arccos': 'acos', 'arctan': 'atan', 'sinh': 'sinh', 'cosh': 'cosh',
+    'tanh': 'tanh', 'cbrt': 'cbrt', 'isnan': 'isnan', 'isfinite': 'isfinite',
+    'isinf': 'isinf',
+}
+
+
+def _any_sym(*vals):
+    for v in vals:
+        if isinstance(v, Sym):
+            return v
+    raise TraceError('no symbolic operand')
+
+
+def _as_bool(sym, v):
+    n = sym._lift(v)
+    if n.kind == 'b':
+        return n
+    return sym.g.op('ne', n, sym.g.const(0.0))      # numpy truthiness of a real
+
+
+def _power(base, expo):
+    sym = _any_sym(base, expo)
+    if _is_plain_number(expo):
+        e = float(expo)
+        b = sym._real(sym._lift(base))
+        # numpy's fast paths for scalar exponents (array_power / fast_scalar_power):
+        # 2 -> square, 1 -> positive, 0.5 -> sqrt, -1 -> reciprocal, 0 -> ones
+        if e == 2.0:
+            return Sym(sym.g, sym.g.op('square', b))
+        if e == 1.0:
+            return Sym(sym.g, b)
+        if e == 0.5:
+            return Sym(sym.g, sym.g.op('sqrt', b))
+        if e == -1.0:
+            return Sym(sym.g, sym.g.op('recip', b))
+        if e == 0.0:
+            return Sym(sym.g, sym.g.const(1.0))
+    return sym._bin('pow', base, expo)
+
+
+def _where(cond, a, b):
+    sym = _any_sym(cond, a, b)
+    g = sym.g
+    if isinstance(cond, (bool, np.bool_)):
+        pick = a if cond else b
+        return pick if isinstance(pick, Sym) else Sym(g, sym._lift(pick))
+    c = _as_bool(sym, cond)
+    an, bn = sym._lift(a), sym._lift(b)
+    if an.kind == 'b' and bn.kind == 'b':
+        return Sym(g, g.op('bselect', c, an, bn))
+    return Sym(g, g.op('select', c, sym._real(an), sym._real(bn)))
+
+
+def _clip(a, lo, hi):
+    # np.clip(a, lo, hi) == minimum(maximum(a, lo), hi)
+    sym = _any_sym(a, lo, hi)
+    out = a
+    if lo is not None:
+        out = sym._bin('max', out, lo)
+    if hi is not None:
+        out = sym._bin('min', out, hi)
+    return out
+
+
+class TracedModel(object):
+    """Result of tracing one (dyn, cost) pair."""
+
+    def __init__(self, graph, x_next, cost, n_state, n_control, n_perturb, time_dep):
+        self.graph = graph
+        self.x_next = x_next          # list of Node (real), one per state axis
+        self.cost = cost              # Node (real)
+        self.n_state, self.n_control, self.n_perturb = n_state, n_control, n_perturb
+        self.time_dep = time_dep
+
+    def live_nodes(self):
+        """Nodes reachable from the outputs, in topological (creation) order."""
+        seen = set()
+        stack = list(self.x_next) + [self.cost]
+        while stack:
+            n = stack.pop()
+            if n.id in seen:
+                continue
+            seen.add(n.id)
+            stack.extend(n.args)
+        return [n for n in self.graph.nodes if n.id in seen]
+
+    @property
+    def bit_exact(self):
+        """True when every op is correctly rounded on the device (so the model
+        evaluates bit-identically to numpy on the host)."""
+        return all(n.op in EXACT_OPS for n in self.live_nodes())
+
+    def inexact_ops(self):
+        return sorted({n.op for n in self.live_nodes() if n.op not in EXACT_OPS})
+
+
+def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True):
+    """Trace `dyn` and `cost` with symbolic x, u, w (and t_k first when the
+    system is time dependent), in the argument order of sdp.py:668-672."""
+    params = params or {}
+    g = Graph()
+    xs = [Sym(g, g.var('x%d' % i, DEP_X)) for i in range(n_state)]
+    us = [Sym(g, g.var('u%d' % i, DEP_U)) for i in range(n_control)]
+    ws = [Sym(g, g.var('w%d' % i, DEP_W)) for i in range(n_perturb)]
+    args = xs + us + ws
+    if not stationnary:
+        args = [Sym(g, g.var('t', DEP_T))] + args
+    some = xs[0] if xs else Sym(g, g.const(0.0))
+
+    def as_real_node(v, what):
+        if isinstance(v, Sym):
+            return some._real(v.n)
+        try:
+            return some._real(some._lift(v))
+        except TraceError:
+            raise TraceError('{} returned a value of type {} that does not depend '
+                             'symbolically on its arguments'.format(what, type(v).__name__))
+
+    try:
+        out = dyn(*args, **params)
+    except TraceError:
+        raise
+    except Exception as e:      # e.g. numpy failing on an object array
+        raise TraceError('dynamics function not traceable: {}: {}'.format(type(e).__name__, e))
+    if isinstance(out, Sym) or _is_plain_number(out):
+        out = (out,)
+    try:
+        out = tuple(out)
+    except TypeError:
+        raise TraceError('dynamics function should return a tuple of next-state values')
+    if len(out) != n_state:
+        raise TraceError('dynamics function returned {} values for {} state variables'
+                         .format(len(out), n_state))
+    x_next = [as_real_node(v, 'dynamics function') for v in out]
+    try:
+        c = cost(*args, **params)
+    except TraceError:
+        raise
+    except Exception as e:
+        raise TraceError('cost function not traceable: {}: {}'.format(type(e).__name__, e))
+    cnode = as_real_node(c, 'cost function')
+    return TracedModel(g, x_next, cnode, n_state, n_control, n_perturb, not stationnary)
+
+
+def evaluate(model, x, u, w, t=None):
+    """Reference interpreter of a traced model with numpy (host).  Used by the
+    tests to check that tracing preserved the callable's semantics."""
+    env = {}
+    vals = {}
+    for i, v in enumerate(x):
+        vals['x%d' % i] = v
+    for i, v in enumerate(u):
+        vals['u%d' % i] = v
+    for i, v in enumerate(w):
+        vals['w%d' % i] = v
+    vals['t'] = t
+    f = _NP_EVAL
+    with np.errstate(all='ignore'):
+        for n in model.live_nodes():
+            if n.op == 'var':
+                env[n.id] = np.asarray(vals[n.value], dtype=float)
+            elif n.op == 'const':
+                env[n.id] = np.float64(n.value)
+            elif n.op == 'bconst':
+                env[n.id] = np.bool_(n.value)
+            else:
+                env[n.id] = f[n.op](*[env[a.id] for a in n.args])
+    return [env[n.id] for n in model.x_next], env[model.cost.id]
+
+
+_NP_EVAL = {
+    'add': np.add, 'sub': np.subtract, 'mul': np.multiply, 'div': np.divide,
+    'neg': np.negative, 'abs': np.abs, 'sqrt': np.sqrt, 'square': np.square,
+    'recip': lambda a: 1.0 / a, 'pow': np.power, 'min': np.minimum, 'max': np.maximum,
+    'fmin': np.fmin, 'fmax': np.fmax, 'floor': np.floor, 'ceil': np.ceil,
+    'trunc': np.trunc, 'rint': np.rint, 'sign': np.sign, 'exp': np.exp, 'exp2': np.exp2,
+    'expm1': np.expm1, 'log': np.log, 'log2': np.log2, 'log10': np.log10,
+    'log1p': np.log1p, 'sin': np.sin, 'cos': np.cos, 'tan': np.tan, 'asin': np.arcsin,
+    'acos': np.arccos, 'atan': np.arctan, 'sinh': np.sinh, 'cosh': np.cosh,
+    'tanh': np.tanh, 'atan2': np.arctan2, 'hypot': np.hypot, 'fmod': np.fmod,
+    'pymod': np.mod, 'floordiv': np.floor_divide, 'cbrt': np.cbrt,
+    'lt': np.less, 'le': np.less_equal, 'gt': np.greater, 'ge': np.greater_equal,
+    'eq': np.equal, 'ne': np.not_equal, 'and': np.logical_and, 'or': np.logical_or,
+    'xor': np.logical_xor, 'not': np.logical_not, 'isnan': np.isnan,
+    'isfinite': np.isfinite, 'isinf': np.isinf,
+    'select': np.where, 'bselect': np.where,
+    'b2r': lambda a: np.asarray(a, dtype=float),
+}
+assert not math.isnan(0.0)
