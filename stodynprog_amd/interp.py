@@ -77,8 +77,8 @@ def mlinspace(smin, smax, orders):
     """(d, S) array enumerating the nodes of the Cartesian grid, last axis
     fastest (reference multilinear.py:15-21)."""
     if len(orders) == 1:
-        return np.atleast_2d(np.linspace(np.array(smin), np.array(smax),
-                                         np.array(orders))).copy()
+        return np.atleast_2d(np.linspace(np.ravel(smin)[0], np.ravel(smax)[0],
+                                         int(np.ravel(orders)[0]))).copy()
     axes = [np.linspace(smin[i], smax[i], orders[i]) for i in range(len(orders))]
     meshes = np.meshgrid(*axes, indexing='ij')
     return np.vstack([m.flatten() for m in meshes])

@@ -372,7 +372,9 @@ class DPSolver(object):
         for k in [k for k in self._cache if k[0] == 'problem']:
             self._cache.pop(k).close()
         prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
-                              per_node, node_range, self.comm, bounds)
+                              per_node, node_range,
+                              self.comm if (self.comm is not None and self.comm.is_device) else None,
+                              bounds)
         self._cache[fp] = prob
         self.backend_info = dict(mode='fused', module=module, lanes_per_node=lanes,
                                  max_controls=max_u, box_per_node=bool(per_node),
@@ -419,9 +421,17 @@ class DPSolver(object):
             return self._backup_tabulated(J_next, t_k, rel_dp)
         prob = self._problem(t_k)
         prob.set_value(J_next)
-        J_ref = prob.sweep(0.0 if t_k is None else t_k, rel_dp,
+        # with a host-side (gloo) communicator the slabs are exchanged through
+        # host memory after the sweep; with RCCL the library does it on device
+        host_comm = self.comm is not None and not self.comm.is_device
+        J_ref = prob.sweep(0.0 if t_k is None else t_k, rel_dp and not host_comm,
                            self._ref_flat() if rel_dp else 0)
         J_k = prob.get_value()
+        if host_comm:
+            self.comm.all_gather_slabs(J_k, self.comm.slab_bounds(self._shape()))
+            if rel_dp:
+                J_ref = J_k[self._state_ref_ind]              # sdp.py:523-525
+                J_k -= J_ref
         pol_k, idx = prob.get_policy()
         self.last_policy_index = idx
         return J_k, pol_k, J_ref

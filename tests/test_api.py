@@ -1,0 +1,243 @@
+"""Host-side drop-in API: same behaviour as the reference's description layer
+and discretisation helpers.  The first block restates the reference's own unit
+tests (stodynprog/tests/test_stodynprog.py) against this package.  No GPU."""
+import io
+import contextlib
+import pickle
+
+import numpy as np
+import pytest
+
+import stodynprog_amd
+from stodynprog_amd import SysDescription, DPSolver, models
+from stodynprog_amd.sysdesc import _zero_cost, _enforce_sig_len
+from conftest import golden
+
+
+# ---- reference tests/test_stodynprog.py:15-65 --------------------------------
+def test_zero_cost():
+    assert _zero_cost() == 0.
+    assert _zero_cost(1) == 0.
+    assert _zero_cost(1, 2, 3) == 0.
+
+
+def test_enforce_sig_len():
+    def f0():
+        pass
+
+    def f1(x):
+        pass
+
+    def f2(x, y):
+        pass
+    arg0, arg1, arg2 = [], ['x'], ['x', 'y']
+    assert _enforce_sig_len(f0, arg0, False)
+    assert _enforce_sig_len(f1, arg1, False)
+    assert _enforce_sig_len(f2, arg2, False)
+    for f, a in ((f0, arg1), (f0, arg2), (f1, arg0), (f1, arg2), (f2, arg1)):
+        with pytest.raises(ValueError):
+            _enforce_sig_len(f, a, False)
+    with pytest.raises(ValueError) as e:
+        _enforce_sig_len(f1, arg2, False)
+    assert e.value.args[0] == "'f1' should accept 2 args (x, y), not 1"   # :58
+
+    def f1p(x, **params):
+        pass
+    assert _enforce_sig_len(f1p, arg1, with_params=True)
+    with pytest.raises(ValueError):
+        _enforce_sig_len(f1p, arg1, with_params=False)
+    with pytest.raises(ValueError):
+        _enforce_sig_len(f1, arg1, with_params=True)
+    with pytest.raises(ValueError) as e:
+        _enforce_sig_len(f1, arg2, False, 'dynamics function')
+    assert e.value.args[0].startswith("dynamics function'f1' should accept")
+
+
+# ---- reference tests/test_stodynprog.py:69-107 ---------------------------------
+def test_sysdescription_attributes_and_names():
+    sys110 = SysDescription((1, 1, 0), stationnary=True, name='sys110')
+    sys111 = SysDescription((1, 1, 1), stationnary=True, name='sys111')
+    assert sys111.stationnary and sys111.stochastic and not sys110.stochastic
+    assert sys111.name == 'sys111'
+    assert sys111.state == ['x1'] and sys111.control == ['u1'] and sys111.perturb == ['w1']
+
+    def dyn3(my_state, my_control, my_perturb):
+        pass
+    sys111.dyn = dyn3
+    assert sys111.state == ['my_state']
+    assert sys111.control == ['my_control']
+    assert sys111.perturb == ['my_perturb']
+
+    def dyn2(x, u):
+        pass
+
+    def dyn4(x, y, u, w):
+        pass
+    with pytest.raises(ValueError):
+        sys111.dyn = dyn2
+    with pytest.raises(ValueError):
+        sys111.dyn = dyn4
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        sys111.print_summary()
+    assert 'Dynamical system "sys111" description' in buf.getvalue()
+    assert repr(sys111).startswith('<SysDescription "sys111" at 0x')
+
+
+def test_sysdescription_dims_and_laws():
+    with pytest.raises(ValueError) as e:
+        SysDescription((1,))
+    assert e.value.args[0] == 'dims tuple should be of len 2 or 3'
+    s = SysDescription((2, 1))
+    assert s.perturb == [] and not s.stochastic
+    s = SysDescription((1, 1, 1))
+    with pytest.raises(ValueError):
+        s.perturb_laws = []
+    with pytest.raises(ValueError):
+        s.perturb_laws = [object()]
+    s.perturb_laws = [models.NormalLaw(0, 1)]
+    assert s.perturb_types == ['continuous']
+    s.perturb_laws = [models.DiscreteLaw([0, 1], [.5, .5])]
+    assert s.perturb_types == ['discrete']
+
+    def tc(a, b):
+        return 0
+    with pytest.raises(ValueError):
+        s.terminal_cost = tc
+    # non-stationnary systems take the time index first (sdp.py:89-91)
+    ns = SysDescription((1, 1, 0), stationnary=False)
+
+    def dyn_t(k, x, u):
+        return (x + u,)
+    ns.dyn = dyn_t
+    assert ns.state == ['x'] and ns.control == ['u']
+
+    def box_t(k, x):
+        return ((0, 1),)
+    ns.control_box = box_t
+    # parameters are forwarded as keyword arguments and must be accepted
+    ps = SysDescription((1, 1, 0), params={'a': 2.})
+
+    def dyn_np(x, u):
+        return (x + u,)
+    with pytest.raises(ValueError):
+        ps.dyn = dyn_np
+
+
+def test_scipy_laws_give_the_same_weights():
+    stats = pytest.importorskip('scipy.stats')
+    _, solver = models.searev()
+    grid = solver.perturb_grid[0]
+    p = stats.norm(loc=0, scale=models.SEAREV['innov_std']).pdf(grid)
+    p /= p.sum()
+    assert np.array_equal(p, solver.perturb_proba[0])
+    law = stats.rv_discrete(values=([0, 1, 2, 3], [0.2, 0.4, 0.3, 0.1])).freeze()
+    assert np.allclose(law.pmf(np.linspace(0, 3, 4)), models.inventory()[1].perturb_proba[0])
+
+
+# ---- discretisation helpers ------------------------------------------------------
+def test_inventory_discretisation_matches_the_tutorial():
+    # doc/example_inventory.rst:182,188
+    _, solver = models.inventory()
+    assert np.array_equal(solver.state_grid[0], np.arange(-3., 7.))
+    assert np.array_equal(solver.perturb_grid[0], [0., 1., 2., 3.])
+    assert np.allclose(solver.perturb_proba[0], [0.2, 0.4, 0.3, 0.1])
+    assert solver._state_grid_shape == (10,)
+    assert solver._state_ref_ind == (5,) and solver._state_ref == (2.0,)
+    grids, dims = solver.control_grids((0.,))
+    assert dims == (11,) and np.array_equal(grids[0], np.arange(0., 11.))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        solver.print_summary()
+    out = buf.getvalue()
+    assert '* state space discretized on a 10 points grid' in out
+    assert 'yields 11 possible values' in out
+
+
+def test_control_grids_rules():
+    _, solver = models.storage_ar1()
+    # width/step < 0.1 -> one point at the centre (sdp.py:449-453)
+    grids, dims = solver.control_grids((0., 0.))
+    assert dims == (4001, 1)
+    assert grids[1][0] == 0.0
+    assert grids[0][0] == 0.0 and grids[0][-1] == 4.0
+    grids, dims = solver.control_grids((5., 1.))
+    assert dims == (8001, 1)
+    # the vectorised box table agrees with control_grids on every node
+    lo, hi, n = solver._box_table()
+    g = golden('g3_ar1_ref')
+    assert np.array_equal(n.T.reshape(41, 61, 2), g['npts'])
+    import itertools
+    for flat, x in enumerate(itertools.product(*solver.state_grid)):
+        if flat % 97:
+            continue
+        grids, dims = solver.control_grids(x)
+        assert tuple(n[:, flat]) == dims
+        assert lo[0, flat] == grids[0][0] and hi[0, flat] == grids[0][-1]
+        assert lo[1, flat] == grids[1][0]
+
+
+def test_box_table_falls_back_to_scalar_calls():
+    calls = []
+    s = SysDescription((1, 1, 0))
+
+    def dyn(x, u):
+        return (x + u,)
+    s.dyn = dyn
+
+    def box(x):
+        calls.append(x)
+        if x > 0.5:                       # only works on scalars
+            return ((0., 1.),)
+        return ((0., 2.),)
+    s.control_box = box
+    solver = DPSolver(s)
+    solver.discretize_state(0, 1, 5)
+    solver.control_steps = (0.5,)
+    lo, hi, n = solver._box_table()
+    assert list(n[0]) == [5, 5, 5, 3, 3]
+    assert list(hi[0]) == [2., 2., 2., 1., 1.]
+
+
+def test_interp_on_state_errors_and_state_grid_full():
+    _, solver = models.nas_demo()
+    with pytest.raises(ValueError) as e:
+        solver.interp_on_state(np.zeros((3, 3)))
+    assert e.value.args[0] == 'array `A` should be of shape (51, 41), not (3, 3)'
+    full = solver.state_grid_full
+    assert full[0].shape == (51, 41) and full[1].shape == (51, 41)
+    assert np.array_equal(full[0][:, 0], solver.state_grid[0])
+    it = solver.interp_on_state(np.zeros((51, 41)))
+    assert it.ndim == 2 and it.values.shape == (1, 51 * 41)
+    # pickles with the reference's attribute names (searev/P_sto_law.dat format)
+    it2 = pickle.loads(pickle.dumps(it))
+    assert set(vars(it2)) == {'ndim', '_xmin', '_xmax', '_xshape', 'values'}
+    assert np.array_equal(it2._xshape, [51, 41])
+
+
+def test_value_iteration_argument_checks_need_no_gpu():
+    _, solver = models.inventory()
+    with pytest.raises(ValueError):
+        solver.value_iteration(np.zeros(9), report_time=False)
+    with pytest.raises(AssertionError):       # rel_dp needs a differential cost (sdp.py:488)
+        solver.value_iteration((np.ones(10), 0.), rel_dp=True, report_time=False)
+    with pytest.raises(AssertionError):
+        solver.discretize_state(0, 1)
+    with pytest.raises(AssertionError):
+        solver.eval_policy(np.zeros((10, 2)), 1)
+
+
+def test_package_surface():
+    assert stodynprog_amd.SysDescription is SysDescription
+    from stodynprog_amd.dolointerpolation import (MultilinearInterpolator,
+                                                  multilinear_interpolation, mlinspace)
+    g = mlinspace([0, 0], [1, 2], [2, 3])
+    assert g.shape == (2, 6) and np.array_equal(g[1], [0, 1, 2, 0, 1, 2])
+    assert mlinspace([0.], [1.], [3]).shape == (1, 3)
+    mli = MultilinearInterpolator([0, 0], [1, 2], [2, 3])
+    assert mli.d == 2 and mli.grid.shape == (2, 6)
+    assert callable(multilinear_interpolation)
+    for name in ('discretize_perturb', 'discretize_state', 'state_grid_full', 'interp_on_state',
+                 'control_grids', 'value_iteration', 'bellman_recursion', '_value_at_state_loop',
+                 '_value_at_state_vect', 'eval_policy', 'policy_iteration', 'print_summary'):
+        assert hasattr(DPSolver, name), name

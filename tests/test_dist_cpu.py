@@ -1,0 +1,114 @@
+"""Multi-rank slab logic on CPU: world_size-2 gloo processes exchange J slabs
+exactly as the RCCL path does on GPUs.  The per-rank sweep is played by the
+CPU oracle (no GPU here); what is under test is the partition, the all-gather
+assembly (uneven slabs included) and the relative-DP shift after the gather."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from stodynprog_amd import dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_slab_bounds():
+    b = dist.slab_bounds((256, 256, 256), 8)
+    assert list(np.diff(b)) == [32 * 65536] * 8 and b[-1] == 256 ** 3
+    b = dist.slab_bounds((10, 3), 4)
+    assert list(b) == [0, 9, 18, 24, 30]
+    b = dist.slab_bounds((2, 5), 4)                 # more ranks than planes: empty slabs
+    assert list(b) == [0, 5, 10, 10, 10]
+    assert list(dist.slab_bounds((7,), 1)) == [0, 7]
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch.distributed as dist_t
+from stodynprog_amd import dist, models, solver as solver_mod
+from oracle import vi_numpy
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist_t.init_process_group('gloo', rank=rank, world_size=world)
+comm = dist.GlooCommunicator()
+assert comm.nranks == world and not comm.is_device
+
+sysd, ref = models.nas_demo(n_E=7, n_P=5, n_w=5)       # 7 planes over 2 ranks: uneven slabs
+spec = vi_numpy.Spec.from_solver(ref)
+bounds = comm.slab_bounds(spec.shape)
+lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+
+
+class FakeProblem(object):
+    """stands for _DeviceProblem: computes this rank's slab with the oracle"""
+    def set_value(self, V):
+        self.V = np.array(V, dtype=float)
+    def sweep(self, t_k, rel_dp, ref_index):
+        assert not rel_dp                     # the shift must happen after the gather
+        nodes = np.arange(lo, hi)
+        self.J = np.full(spec.shape, np.nan)
+        self.pol = np.zeros(spec.shape + (1,)); self.idx = np.zeros(spec.shape, dtype=np.int32)
+        J, pol, idx, _ = vi_numpy.value_iteration(spec, self.V, nodes=nodes)
+        self.J.reshape(-1)[lo:hi] = J
+        self.pol.reshape(-1, 1)[lo:hi] = pol
+        self.idx.reshape(-1)[lo:hi] = idx
+        return 0.0
+    def get_value(self):
+        return self.J.copy()
+    def get_policy(self):
+        return self.pol, self.idx
+
+s = solver_mod.DPSolver(sysd, comm=comm)
+s.state_grid, s.perturb_grid, s.perturb_proba = ref.state_grid, ref.perturb_grid, ref.perturb_proba
+s._state_grid_shape, s._state_ref_ind = ref._state_grid_shape, ref._state_ref_ind
+s.control_steps = ref.control_steps
+s._problem = lambda t_k=None: FakeProblem()
+
+V0 = np.zeros(spec.shape)
+J1, pol1 = s.value_iteration(V0, report_time=False)
+Jd = J1 - J1[s._state_ref_ind]
+(J2, J2ref), pol2 = s.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
+
+# single-process oracle
+E1, _, _, _ = vi_numpy.value_iteration(spec, V0)
+(E2, E2ref), _, _, _ = vi_numpy.value_iteration(spec, (E1 - E1[spec.ref_ind], 0.), rel_dp=True)
+assert np.array_equal(J1, E1), 'gathered J differs from the single-process sweep'
+assert np.array_equal(J2, E2) and J2ref == E2ref
+assert J2[s._state_ref_ind] == 0.0
+assert comm.allreduce_max(float(rank)) == world - 1
+payload = comm.broadcast_bytes(b'id-from-rank0' if rank == 0 else None)
+assert payload == b'id-from-rank0'
+comm.barrier()
+print('rank', rank, 'ok', flush=True)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_sweep_matches_single_process(tmp_path):
+    pytest.importorskip('torch')
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=280)[0].decode() for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, out)
+        assert 'rank {} ok'.format(rank) in out

@@ -1,0 +1,393 @@
+"""Parity of the HIP value-iteration path (through DPSolver -> C ABI) with the
+reference: golden vectors produced by the real reference for every BASELINE
+config, the CPU oracle on the same inputs, and size-independent properties at
+full benchmark size.  Bars: fp64 |dJ|/|J| < 1e-10, argmin indices exact outside
+near-ties, control values bit-identical where the index agrees."""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from conftest import golden, assert_sweep_parity
+from oracle import c_oracle, vi_numpy
+from stodynprog_amd import SysDescription, DPSolver, models
+from stodynprog_amd.trace import TraceError
+
+pytestmark = pytest.mark.gpu
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def check_policy_values(pol, idx, pol_ref, idx_ref):
+    same = np.asarray(idx).astype(np.int64) == np.asarray(idx_ref).astype(np.int64)
+    assert np.array_equal(np.asarray(pol)[same], np.asarray(pol_ref)[same])
+
+
+# ---------------------------------------------------------------- config 1
+def test_inventory_tutorial(gpu):
+    g = golden('g2_inventory')
+    _, solver = models.inventory()
+    J = np.zeros(10)
+    for k in range(6):
+        J, u = solver.value_iteration(J, report_time=False)
+        assert solver.backend_info['mode'] == 'fused'
+        assert_sweep_parity(J, solver.last_policy_index, g['J'][k], g['idx'][k], g['margin'][k],
+                            'inventory sweep %d' % k)
+        assert np.array_equal(u, g['pol'][k])
+        if k == 0:      # doc/example_inventory.rst:220-222
+            assert np.allclose(J, [9, 6, 3, 0, 0.5, 1, 1.5, 2, 2.5, 3], rtol=0, atol=1e-14)
+            assert np.array_equal(u[..., 0], np.zeros(10))
+        if k == 1:      # :231
+            assert np.array_equal(u[..., 0], [4, 3, 2, 1, 0, 0, 0, 0, 0, 0])
+        if k in (2, 3):  # :235, :239
+            assert np.array_equal(u[..., 0], [5, 4, 3, 2, 1, 0, 0, 0, 0, 0])
+
+
+def test_value_iteration_prints_like_the_reference(gpu, capsys):
+    _, solver = models.inventory()
+    solver.value_iteration(np.zeros(10))
+    out = capsys.readouterr().out
+    assert out.startswith('value iteration...')
+    assert '\rvalue iteration run in 0.' in out
+
+
+# ---------------------------------------------------------------- NaS demo
+def test_nas_demo_two_sweeps(gpu):
+    g = golden('g7_nas')
+    _, solver = models.nas_demo()
+    J1, u1 = solver.value_iteration(np.zeros((51, 41)), report_time=False)
+    assert solver.backend_info['box_per_node']
+    assert_sweep_parity(J1, solver.last_policy_index, g['J1'], g['idx1'], g['margin1'], 'nas 1')
+    check_policy_values(u1, solver.last_policy_index, g['pol1'], g['idx1'])
+    J2, u2 = solver.value_iteration(g['J1'], report_time=False)
+    assert_sweep_parity(J2, solver.last_policy_index, g['J2'], g['idx2'], g['margin2'], 'nas 2')
+    check_policy_values(u2, solver.last_policy_index, g['pol2'], g['idx2'])
+
+
+# ---------------------------------------------------------------- config 2
+def test_storage_ar1_reference_size(gpu):
+    """41 x 61 nodes, 4001..8001 x 1 controls, 9 perturbations: the notebook problem"""
+    g = golden('g3_ar1_ref')
+    _, solver = models.storage_ar1()
+    J1, u1 = solver.value_iteration(np.zeros((41, 61)), report_time=False)
+    assert solver.backend_info['max_controls'] == 8001
+    assert_sweep_parity(J1, solver.last_policy_index, g['J1'], g['idx1'], g['margin1'], 'ar1 1')
+    check_policy_values(u1, solver.last_policy_index, g['pol1'], g['idx1'])
+    J2, u2 = solver.value_iteration(g['J1'], report_time=False)
+    _, ndiff = assert_sweep_parity(J2, solver.last_policy_index, g['J2'], g['idx2'],
+                                   g['margin2'], 'ar1 2')
+    assert ndiff <= 25           # dead-band cost: a few exact ties may resolve differently
+    check_policy_values(u2, solver.last_policy_index, g['pol2'], g['idx2'])
+    (J3, J3ref), u3 = solver.value_iteration((g['Jd'], 0.), rel_dp=True, report_time=False)
+    assert_sweep_parity(J3, solver.last_policy_index, g['J3'], g['idx3'], g['margin3'], 'ar1 3')
+    assert abs(J3ref - float(g['J3ref'])) <= 1e-12 * abs(float(g['J3ref']))
+    assert J3[solver._state_ref_ind] == 0.0
+
+
+def test_storage_ar1_config2_200x200(gpu):
+    g = golden('g3_ar1_c2')
+    _, solver = models.storage_ar1(n_E=200, n_P=200, steps=(8. / 49, 0.1))
+    x0 = solver.state_grid[0].reshape(-1, 1)
+    x1 = solver.state_grid[1].reshape(1, -1)
+    V0 = 0.05 * (x0 - 4.) * (x0 - 4.) + 0.3 * (x1 * x1) + 0.02 * x0 * x1
+    J, u = solver.value_iteration(V0, report_time=False)
+    assert solver.backend_info['max_controls'] == 51      # 8/(8/49) rounds just above 49
+    assert_sweep_parity(J, solver.last_policy_index, g['J'], g['idx'], g['margin'], 'ar1 c2')
+    check_policy_values(u[..., 0], solver.last_policy_index, g['pol0'], g['idx'])
+
+
+# ---------------------------------------------------------------- config 3
+def _searev_V0(solver):
+    E, S, A = solver.state_grid_full
+    return np.ascontiguousarray(0.02 * (E - 5.) * (E - 5.) + 1.5 * (S * S) + 0.7 * (A * A)
+                                + 0.1 * S * A - 0.01 * E)
+
+
+def test_searev_config3_128cubed(gpu):
+    g = golden('g4_searev')
+    _, solver = models.searev(n_E=128, n_S=128, n_A=128, step=2.2 / 31)
+    J, u = solver.value_iteration(_searev_V0(solver), report_time=False)
+    assert solver.backend_info['max_controls'] == int(g['npts'].max())
+    nodes = g['nodes']
+    idx = solver.last_policy_index.ravel()[nodes]
+    assert_sweep_parity(J.ravel()[nodes], idx, g['J'], g['idx'], g['margin'], 'searev c3')
+    check_policy_values(u.reshape(-1, 1)[nodes], idx, g['pol'], g['idx'])
+
+
+def test_searev_reference_size(gpu):
+    """31 x 61 x 61 nodes with 1101 / 2201 controls (control_steps = 0.001)"""
+    g = golden('g4_searev')
+    _, solver = models.searev()
+    J, u = solver.value_iteration(_searev_V0(solver), report_time=False)
+    assert solver.backend_info['max_controls'] == 2201
+    nodes = g['nodes_s']
+    idx = solver.last_policy_index.ravel()[nodes]
+    assert_sweep_parity(J.ravel()[nodes], idx, g['J_s'], g['idx_s'], g['margin_s'], 'searev ref')
+    check_policy_values(u.reshape(-1, 1)[nodes], idx, g['pol_s'], g['idx_s'])
+    lo, hi, n = solver._box_table()
+    assert np.array_equal(n[0][nodes], g['npts_s'][:, 0])
+
+
+# ---------------------------------------------------------------- config 4
+def test_synthetic_benchmark_problem_full_size(gpu):
+    """256^3 x 64 x 32 fp64 (the bench.py workload): 4099 nodes against the
+    reference, 20000 more against the C oracle, plus determinism."""
+    g = golden('g5_synth')
+    _, solver = models.synthetic3d()
+    V0 = models.synthetic3d_V0(solver.state_grid)
+    J, u = solver.value_iteration(V0, report_time=False)
+    idx = solver.last_policy_index
+    info = solver.backend_info
+    assert info['mode'] == 'fused' and info['lanes_per_node'] == 64 and not info['box_per_node']
+    nodes = g['nodes']
+    _, ndiff = assert_sweep_parity(J.ravel()[nodes], idx.ravel()[nodes], g['J'], g['idx'],
+                                   g['margin'], 'synthetic c4 vs reference')
+    assert ndiff == 0
+    assert np.array_equal(u.reshape(-1, 1)[nodes], g['pol'])
+    more = np.random.default_rng(7).integers(0, V0.size, 20000)
+    Jo, io, _ = c_oracle.vi_synth3d(solver.state_grid, V0, models.SYNTH_PAR, -1., 1., 64,
+                                    solver.perturb_grid[0], solver.perturb_proba[0],
+                                    node_ids=more, n_threads=8)
+    assert np.array_equal(J.ravel()[more], Jo)           # same summation order: bit-exact
+    assert np.array_equal(idx.ravel()[more], io)
+    # size-independent properties: every index valid, controls on the lattice, rerun identical
+    assert idx.min() >= 0 and idx.max() <= 63
+    ugrid = np.linspace(-1., 1., 64)
+    assert np.array_equal(u[..., 0], ugrid[idx])
+    J_again, _ = solver.value_iteration(V0, report_time=False)
+    assert np.array_equal(J, J_again)
+
+
+def test_synthetic_small_full_grid_two_sweeps_and_slabs(gpu):
+    g = golden('g5_synth')
+    _, solver = models.synthetic3d(N=20)
+    V0 = models.synthetic3d_V0(solver.state_grid)
+    J1, u1 = solver.value_iteration(V0, report_time=False)
+    assert_sweep_parity(J1, solver.last_policy_index, g['s_J1'], g['s_idx1'], g['s_margin1'], 's1')
+    assert np.array_equal(u1, g['s_pol1'])
+    J2, u2 = solver.value_iteration(g['s_J1'], report_time=False)
+    assert_sweep_parity(J2, solver.last_policy_index, g['s_J2'], g['s_idx2'], g['s_margin2'], 's2')
+    # slab invariance: sweeping two node ranges separately gives the same bits
+    # (this is what each rank does in the multi-GPU sweep)
+    from stodynprog_amd.solver import _DeviceProblem
+    prob = solver._problem()
+    full = prob.get_value().ravel()
+    parts = np.zeros_like(full)
+    for lo, hi in ((0, 3333), (3333, 8000)):
+        sub = _DeviceProblem(prob._keep, solver.backend_info['module'], np.float64, (20, 20, 20),
+                             1, 32, 64, False, (lo, hi))
+        sub.set_value(g['s_J1'])
+        sub.sweep()
+        parts[lo:hi] = sub.get_value().ravel()[lo:hi]
+        sub.close()
+    assert np.array_equal(parts, full)
+
+
+# ---------------------------------------------------------------- config 5 (fp32)
+def test_fp32_sweep_against_fp64(gpu):
+    _, s64 = models.synthetic3d(N=48)
+    V0 = models.synthetic3d_V0(s64.state_grid)
+    J64, u64 = s64.value_iteration(V0, report_time=False)
+    idx64 = s64.last_policy_index
+    sysd, ref = models.synthetic3d(N=48)
+    s32 = DPSolver(sysd, dtype=np.float32)
+    s32.discretize_state(0, 1, 48, 0, 1, 48, 0, 1, 48)
+    s32.perturb_grid, s32.perturb_proba = ref.perturb_grid, ref.perturb_proba
+    s32.control_steps = ref.control_steps
+    J32, u32 = s32.value_iteration(V0.astype(np.float32), report_time=False)
+    assert J32.dtype == np.float32
+    assert np.abs(J32 - J64).max() / np.abs(J64).max() < 1e-5       # BASELINE config 5 bar
+    assert (s32.last_policy_index != idx64).mean() < 0.02            # fp32 near-ties only
+    assert np.abs(u32[..., 0] - u64[..., 0]).max() <= 2.01 * (2. / 63)
+
+
+# ---------------------------------------------------------------- generic shapes
+def _small_problem(d, nu, with_w):
+    dims = (d, nu, 1) if with_w else (d, nu)
+    s = SysDescription(dims)
+    a = [0.9, 0.8, 0.7, 0.6][:d]
+
+    def dyn(*args):
+        x, u = args[:d], args[d:d + nu]
+        w = args[d + nu] if with_w else 0.
+        return tuple(a[k] * x[k] + 0.3 * u[k % nu] + (w if k == d - 1 else 0. * u[0])
+                     for k in range(d))
+
+    def cost(*args):
+        x, u = args[:d], args[d:d + nu]
+        c = sum((x[k] - 0.2) * (x[k] - 0.2) for k in range(d)) + sum(0.1 * abs(ui) for ui in u)
+        if nu > 1:
+            c = c + 0.05 * u[0] * u[1]
+        return c + 0. * u[0]
+
+    def box(*x):
+        return tuple((-1., 1. + 0.25 * c) for c in range(nu))
+    # wrap in functions with explicit signatures (the API inspects them)
+    names = ['x%d' % i for i in range(d)] + ['u%d' % i for i in range(nu)] + (['w'] if with_w else [])
+    ns = {}
+    exec('def dyn_f({0}): return _dyn({0})\ndef cost_f({0}): return _cost({0})\n'
+         'def box_f({1}): return _box({1})'.format(', '.join(names), ', '.join(names[:d])),
+         dict(_dyn=dyn, _cost=cost, _box=box), ns)
+    s.dyn, s.cost, s.control_box = ns['dyn_f'], ns['cost_f'], ns['box_f']
+    if with_w:
+        s.perturb_laws = [models.NormalLaw(0, 0.2)]
+    solver = DPSolver(s)
+    solver.discretize_state(*sum(([-1., 1., 5 + k] for k in range(d)), []))
+    if with_w:
+        solver.discretize_perturb(-0.5, 0.5, 5)
+    solver.control_steps = tuple(0.4 + 0.1 * c for c in range(nu))
+    return solver
+
+
+@pytest.mark.parametrize('d,nu,with_w', [(1, 1, True), (2, 2, True), (3, 1, False),
+                                         (4, 1, True), (2, 3, False), (4, 2, True)])
+def test_generic_dimensions_against_numpy_oracle(gpu, d, nu, with_w):
+    solver = _small_problem(d, nu, with_w)
+    rng = np.random.default_rng(d * 10 + nu)
+    V = rng.standard_normal(solver._state_grid_shape)
+    J, u = solver.value_iteration(V, report_time=False)
+    Jo, uo, io, mo = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+    assert np.array_equal(J, Jo)            # same operators, same order: bit-exact
+    assert np.array_equal(solver.last_policy_index, io)
+    assert np.array_equal(u, uo)
+
+
+def test_nan_and_inf_costs_follow_numpy_argmin(gpu):
+    s = SysDescription((1, 1, 1))
+
+    def dyn(x, u, w):
+        return (x + u + w,)
+
+    def cost(x, u, w):
+        bad = np.where(u > 0.5, np.nan, np.where(u < -0.5, np.inf, u * u))
+        return np.where(x > 0.4, bad, np.where(x < -0.4, np.inf + 0. * u, u * u))
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda x: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.1)]
+    solver = DPSolver(s)
+    solver.discretize_state(-1, 1, 9)
+    solver.discretize_perturb(-0.2, 0.2, 3)
+    solver.control_steps = (0.25,)
+    V = np.linspace(0, 1, 9)
+    with np.errstate(all='ignore'):
+        J, u = solver.value_iteration(V, report_time=False)
+        Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+    assert np.array_equal(J, Jo, equal_nan=True)
+    assert np.array_equal(solver.last_policy_index, io)
+    assert np.isnan(J[-1]) and np.isinf(J[0])         # first NaN wins; all-inf keeps index 0
+    assert io[0] == 0
+
+
+def test_tabulated_mode_for_untraceable_callables(gpu):
+    _, ref = models.nas_demo(n_E=11, n_P=9, n_w=5)
+    sysd = SysDescription((2, 1, 1), name='untraceable')
+
+    def dyn(E, P_req, P_sto, innov):
+        shape = np.shape(P_sto)                     # needs a concrete array
+        return ref.sys.dyn(E, P_req, np.asarray(P_sto).reshape(shape), innov)
+    sysd.dyn = dyn
+    sysd.cost = ref.sys.cost
+    sysd.control_box = ref.sys.control_box
+    sysd.perturb_laws = ref.sys.perturb_laws
+    solver = DPSolver(sysd)
+    solver.discretize_state(0, 7.2, 11, -6, 6, 9)
+    solver.perturb_grid, solver.perturb_proba = ref.perturb_grid, ref.perturb_proba
+    solver.control_steps = (.1,)
+    assert isinstance(solver._traced(), TraceError)
+    V = np.random.default_rng(0).standard_normal((11, 9))
+    J, u = solver.value_iteration(V, report_time=False)
+    assert solver.backend_info['mode'] == 'tabulated'
+    Jf, uf = ref.value_iteration(V, report_time=False)
+    assert ref.backend_info['mode'] == 'fused'
+    assert np.array_equal(J, Jf) and np.array_equal(u, uf)
+    assert np.array_equal(solver.last_policy_index, ref.last_policy_index)
+    (Jr, r), _ = solver.value_iteration((V - V[5, 4], 0.), rel_dp=True, report_time=False)
+    assert Jr[5, 4] == 0.0
+
+
+def test_value_at_state_entry_points(gpu):
+    g = golden('g7_nas')
+    _, solver = models.nas_demo()
+    interp = solver.interp_on_state(g['J1'])
+    for ind in ((0, 0), (25, 20), (50, 40), (13, 7)):
+        x_k = (solver.state_grid[0][ind[0]], solver.state_grid[1][ind[1]])
+        J_opt, u_opt = solver._value_at_state_vect(x_k, interp)
+        assert abs(J_opt - g['J2'][ind]) <= 1e-12 * max(1, abs(g['J2'][ind]))
+        if g['margin2'][ind] > 1e-12:
+            assert u_opt[0] == g['pol2'][ind][0]
+        J_loop, u_loop = solver._value_at_state_loop(x_k, interp)
+        assert J_loop == J_opt and tuple(u_loop) == tuple(u_opt)
+
+
+def test_bellman_recursion_time_dependent(gpu):
+    s = SysDescription((1, 1, 1), stationnary=False)
+
+    def dyn(k, x, u, w):
+        return (0.9 * x + u + w + 0.05 * k,)
+
+    def cost(k, x, u, w):
+        return (x - 0.1 * k) ** 2 + 0.1 * u * u
+
+    def box(k, x):
+        return ((-1., 1. + 0.5 * k),)
+    s.dyn, s.cost, s.control_box = dyn, cost, box
+    s.perturb_laws = [models.NormalLaw(0, 0.1)]
+    solver = DPSolver(s)
+    solver.discretize_state(-2, 2, 17)
+    solver.discretize_perturb(-0.3, 0.3, 5)
+    solver.control_steps = (0.125,)
+    J_fin = solver.state_grid[0] ** 2
+    J, pol = quiet(solver.bellman_recursion, 4, J_fin)
+    assert J.shape == (4, 17) and pol.shape == (4, 17, 1)
+    spec = vi_numpy.Spec.from_solver(solver)
+    nxt = J_fin
+    for t in (3, 2, 1, 0):
+        Jo, po, _, _ = vi_numpy.value_iteration(spec, nxt, t_k=t)
+        assert np.array_equal(J[t], Jo) and np.array_equal(pol[t], po)
+        nxt = Jo
+
+
+# ---------------------------------------------------------------- next rows (8f)
+def test_eval_policy_against_reference(gpu):
+    g = golden('g6_policy')
+    _, solver = models.storage_ar1()
+    pol = models.storage_ar1_empirical_policy(solver)
+    J, J_ref = quiet(solver.eval_policy, pol, 50, rel_dp=True, J_ref_full=True)
+    assert J_ref.shape == (50,)
+    assert np.allclose(J_ref, g['ar1_J_ref'], rtol=1e-12, atol=1e-15)
+    assert np.abs(J - g['ar1_J']).max() < 1e-12
+    assert '{:g}'.format(J_ref[-1]) == '0.105724'            # AR1.ipynb:594
+    J7 = quiet(solver.eval_policy, pol, 7)
+    assert np.abs(J7 - g['ar1_J7']).max() < 1e-12
+    Jl, last = quiet(solver.eval_policy, pol, 50, rel_dp=True)
+    assert last == J_ref[-1] and np.array_equal(Jl, J)
+    # bit-exact against the sequential-order oracle
+    Jo, Jo_ref = vi_numpy.eval_policy(vi_numpy.Spec.from_solver(solver), pol, 50, True,
+                                      J_ref_full=True)
+    assert np.array_equal(J, Jo) and np.array_equal(J_ref, Jo_ref)
+    _, sea = models.searev()
+    Js, Js_ref = quiet(sea.eval_policy, models.searev_linear_policy(sea), 20, True,
+                       J_ref_full=True)
+    assert np.allclose(Js_ref, g['searev_J_ref'], rtol=1e-12, atol=1e-16)
+    assert np.abs(Js - g['searev_J']).max() < 1e-12
+
+
+def test_policy_iteration_reproduces_published_costs(gpu, capsys):
+    """AR1.ipynb:594-602: ref policy cost 0.105724 -> 0.0486519 -> 0.0468464"""
+    g = golden('g6_policy')
+    _, solver = models.storage_ar1()
+    pol_ini = models.storage_ar1_empirical_policy(solver)
+    (J, J_ref), pol = solver.policy_iteration(pol_ini, 50, 2, rel_dp=True)
+    out = capsys.readouterr().out.replace('\r', '\n')
+    costs = [l.split(':')[1].strip() for l in out.split('\n') if l.startswith('ref policy cost')]
+    assert costs == ['0.105724', '0.0486519', '0.0468464']
+    assert 'policy iteration 1/2' in out and 'policy iteration 2/2' in out
+    assert abs(J_ref - float(g['ar1_pi_Jref'])) < 1e-12
+    assert np.abs(J - g['ar1_pi_J']).max() < 1e-10
+    frac_same = (pol[..., 0] == g['ar1_pi_pol0']).mean()
+    assert frac_same > 0.97                      # dead-band cost: ties may resolve differently
+    assert np.abs(pol[..., 0] - g['ar1_pi_pol0']).max() < 0.9 + 1e-9

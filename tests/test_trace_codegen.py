@@ -1,0 +1,130 @@
+"""Tracing of model callables and HIP source generation.  No GPU: the traced
+DAG is interpreted with numpy and compared bit for bit with the callable; the
+generated translation units are cross-compiled for gfx950 with hipcc."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from stodynprog_amd import models, codegen, _native as nat
+from stodynprog_amd.trace import trace_model, evaluate, TraceError, Sym
+from stodynprog_amd import SysDescription, DPSolver
+
+ALL = ['inventory', 'storage_ar1', 'searev', 'nas_demo', 'synthetic3d']
+
+
+def _random_args(sysd, rng, n=257):
+    x = [rng.uniform(-3, 6) for _ in sysd.state]
+    u = [rng.uniform(-2, 2, n) for _ in sysd.control]
+    w = [rng.uniform(-1, 1, n) for _ in sysd.perturb]
+    return x, u, w
+
+
+@pytest.mark.parametrize('name', ALL)
+def test_trace_preserves_semantics_bitwise(name):
+    sysd, solver = getattr(models, name)()
+    model = solver._traced()
+    assert not isinstance(model, TraceError)
+    assert model.bit_exact, model.inexact_ops()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        x, u, w = _random_args(sysd, rng)
+        xn_t, g_t = evaluate(model, x, u, w)
+        xn = sysd.dyn(*(x + u + w))
+        g = sysd.cost(*(x + u + w))
+        for a, b in zip(xn_t, xn):
+            assert np.array_equal(np.broadcast_to(a, (257,)), np.broadcast_to(b, (257,)))
+        assert np.array_equal(np.broadcast_to(g_t, (257,)), np.broadcast_to(g, (257,)))
+
+
+def test_trace_operator_coverage():
+    def dyn(x, u, w):
+        a = np.where((x > 0) & ~(u < 0) | (w == 0), np.abs(u) ** 2, np.sqrt(np.abs(w)))
+        b = np.clip(x + u, -1, 1) + np.minimum(u, w) - np.maximum(u, 2 * w)
+        c = np.sign(u) * np.floor(w * 3) + np.ceil(u) / (1 + u * u) + (-u) ** 0.5 * 0
+        return (a + b + np.where(np.isnan(c), 0., c),)
+
+    def cost(x, u, w):
+        return (x - u) ** 2 + abs(w) + 1.0 / (1 + w ** 2) + (u > w) * 0.5
+
+    m = trace_model(dyn, cost, 1, 1, 1)
+    rng = np.random.default_rng(1)
+    x, u, w = [0.3], [rng.uniform(-2, 2, 100)], [rng.uniform(-1, 1, 100)]
+    with np.errstate(all='ignore'):
+        xn_t, g_t = evaluate(m, x, u, w)
+        assert np.array_equal(xn_t[0], dyn(x[0], u[0], w[0])[0], equal_nan=True)
+        assert np.array_equal(g_t, cost(x[0], u[0], w[0]))
+    assert m.bit_exact
+    src = codegen.model_function_source(m)
+    assert 'sdp_npmin' in src and 'sqrt(' in src
+
+
+def test_inexact_ops_are_flagged():
+    m = trace_model(lambda x, u, w: (x + np.sin(u) * np.exp(w),), lambda x, u, w: u ** 3, 1, 1, 1)
+    assert not m.bit_exact and m.inexact_ops() == ['exp', 'pow', 'sin']
+
+
+@pytest.mark.parametrize('bad', [
+    lambda x, u, w: (x + u if u > 0 else x,),          # truth value of a symbol
+    lambda x, u, w: (max(x, u),),                        # builtin max
+    lambda x, u, w: (float(u) + x,),                     # float()
+    lambda x, u, w: (np.max((x, u)),),                   # np.max on a tuple of symbols
+    lambda x, u, w: (np.array([1., 2.])[0] * x + np.arange(3.) * u,),   # table operand
+    lambda x, u, w: (x, u),                              # wrong number of outputs
+])
+def test_untraceable_callables_raise_trace_error(bad):
+    with pytest.raises(TraceError):
+        trace_model(bad, lambda x, u, w: 0. * u, 1, 1, 1)
+
+
+def test_constants_and_params_and_time():
+    def dyn(k, x, u, **p):
+        return (p['a'] * x + u + k,)
+
+    def cost(k, x, u, **p):
+        return 0.
+
+    m = trace_model(dyn, cost, 1, 1, 0, params={'a': 0.5}, stationnary=False)
+    assert m.time_dep
+    xn, g = evaluate(m, [2.0], [np.array([1., 2.])], [], t=3)
+    assert np.array_equal(xn[0], [5., 6.]) and g == 0.0
+    src = codegen.model_function_source(m)
+    assert '0x1.0000000000000p-1' in src and ' t)' in src or 't;' in src
+    assert codegen.real_literal(float('inf')) == '(sdp_real)INFINITY'
+    assert 'NAN' in codegen.real_literal(float('nan'))
+    assert codegen.real_literal(-0.0) == '(sdp_real)(-0x0.0p+0)'
+
+
+def test_lanes_for():
+    assert [codegen.lanes_for(n) for n in (1, 2, 3, 11, 32, 33, 64, 65, 8001)] == \
+        [1, 2, 4, 16, 32, 64, 64, 64, 64]
+
+
+@pytest.mark.skipif(not os.path.exists(nat.HIPCC), reason='hipcc not installed')
+@pytest.mark.parametrize('name,dtype,lanes', [('inventory', np.float64, 16),
+                                              ('storage_ar1', np.float64, 64),
+                                              ('searev', np.float32, 32)])
+def test_generated_units_compile_for_gfx950(name, dtype, lanes, tmp_path, monkeypatch):
+    _, solver = getattr(models, name)()
+    src = codegen.translation_unit(solver._traced(), dtype, lanes)
+    assert '#define SDP_LANES {}'.format(lanes) in src
+    monkeypatch.setattr(nat, 'KCACHE', str(tmp_path))
+    path = nat.compile_model(src)
+    assert os.path.getsize(path) > 1000
+    assert nat.compile_model(src) == path                  # cache hit
+    with pytest.raises(nat.NativeError):
+        nat.compile_model(src + '\n#error broken\n')
+
+
+def test_solver_reports_untraceable_model_without_gpu():
+    s = SysDescription((1, 1, 0))
+
+    def dyn(x, u):
+        return (x + (u if u > 0 else 0.),)
+    s.dyn = dyn
+    s.cost = lambda x, u: u * 0.
+    s.control_box = lambda x: ((0., 1.),)
+    solver = DPSolver(s)
+    solver.discretize_state(0, 1, 3)
+    assert isinstance(solver._traced(), TraceError)
