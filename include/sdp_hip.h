@@ -32,6 +32,19 @@ extern "C" {
 #define SDP_F64 0
 #define SDP_F32 1
 
+/*
+ * Order of every per-node array of a problem handle (value, policy, index,
+ * per-node control boxes):
+ *   SDP_LAYOUT_NODES    C order of the state grid, last axis fastest -- the
+ *                       order of the reference's arrays (stodynprog.py:272,478);
+ *   SDP_LAYOUT_COLUMNS  axis 0 moved last (numpy.moveaxis(A, 0, -1), then C
+ *                       order): used by the column kernels for storage-separable
+ *                       models, whose table build reads axis-0 pencils coalesced.
+ *                       node_begin/node_end must then be multiples of orders[0].
+ */
+#define SDP_LAYOUT_NODES   0
+#define SDP_LAYOUT_COLUMNS 1
+
 const char *sdp_last_error(void);
 
 /* ---- device ------------------------------------------------------------- */
@@ -78,6 +91,8 @@ typedef struct sdp_problem_desc {
     const void *proba;          /* perturb_proba[0]: W reals */
     int32_t box_per_node;       /* 0: one box for all nodes, 1: arrays over nodes */
     int32_t lanes_per_node;     /* SDP_LANES the code object was built with */
+    int32_t layout;             /* SDP_LAYOUT_NODES | SDP_LAYOUT_COLUMNS (see below) */
+    int32_t reserved;           /* must be 0 */
     const void *box_lo;         /* control_grids() lower ends: [nu] or [nu][S] reals */
     const void *box_hi;         /* upper ends */
     const int32_t *box_n;       /* points per control: [nu] or [nu][S] */

@@ -82,22 +82,14 @@ def _emit_node(n, name):
     raise NotImplementedError(op)
 
 
-def model_function_source(model):
-    """C++ text of sdp_model_cell for a TracedModel."""
-    assert isinstance(model, TracedModel)
-    if model.n_perturb > 1:
-        raise NotImplementedError('only 0 or 1 perturbation variable is supported '
-                                  '(as reference stodynprog.py:679-683)')
-    lines = ['SDP_DEV void sdp_model_cell(const sdp_real *x, const sdp_real *u, sdp_real w,',
-             '                            sdp_real t, sdp_real *xn, sdp_real &g)',
-             '{',
-             '    (void)x; (void)u; (void)w; (void)t;']
+def _emit_body(model, nodes, lines):
+    """statements for `nodes` (topological order); returns the name map"""
     names = {}
 
     def name(n):
         return names[n.id]
 
-    for n in model.live_nodes():
+    for n in nodes:
         expr = _emit_node(n, name)
         if n.op in ('const', 'bconst', 'var'):
             names[n.id] = expr              # inline leaves
@@ -106,11 +98,51 @@ def model_function_source(model):
         ctype = 'bool' if n.kind == 'b' else 'sdp_real'
         lines.append('    const {} {} = {};'.format(ctype, var, expr))
         names[n.id] = var
+    return names
+
+
+def model_function_source(model):
+    """C++ text of sdp_model_cell for a TracedModel: the whole dyn + cost."""
+    assert isinstance(model, TracedModel)
+    if model.n_perturb > 1:
+        raise NotImplementedError('only 0 or 1 perturbation variable is supported '
+                                  '(as reference stodynprog.py:679-683)')
+    lines = ['SDP_DEV void sdp_model_cell(const sdp_real *x, const sdp_real *u, sdp_real w,',
+             '                            sdp_real t, sdp_real *xn, sdp_real &g)',
+             '{',
+             '    (void)x; (void)u; (void)w; (void)t;']
+    names = _emit_body(model, model.live_nodes(), lines)
     for k, n in enumerate(model.x_next):
-        lines.append('    xn[{}] = {};'.format(k, name(n)))
-    lines.append('    g = {};'.format(name(model.cost)))
+        lines.append('    xn[{}] = {};'.format(k, names[n.id]))
+    lines.append('    g = {};'.format(names[model.cost.id]))
     lines.append('}')
     return '\n'.join(lines)
+
+
+def separable_functions_source(model):
+    """C++ text of the three slices used by the column kernel
+    (csrc/sdp_column_kernel.h) for a storage-separable model."""
+    assert model.storage_separable
+    out = []
+    lines = ['SDP_DEV sdp_real sdp_model_lead(const sdp_real *x, const sdp_real *u, sdp_real t)',
+             '{', '    (void)x; (void)u; (void)t;']
+    names = _emit_body(model, model.slice_nodes([model.x_next[0]]), lines)
+    lines += ['    return {};'.format(names[model.x_next[0].id]), '}']
+    out.append('\n'.join(lines))
+    lines = ['SDP_DEV void sdp_model_trail(const sdp_real *x, sdp_real w, sdp_real t, sdp_real *xn)',
+             '{', '    (void)x; (void)w; (void)t;']
+    names = _emit_body(model, model.slice_nodes(model.x_next[1:]), lines)
+    for k, n in enumerate(model.x_next[1:]):
+        lines.append('    xn[{}] = {};'.format(k + 1, names[n.id]))
+    lines.append('}')
+    out.append('\n'.join(lines))
+    lines = ['SDP_DEV sdp_real sdp_model_cost(const sdp_real *x, const sdp_real *u, sdp_real w,',
+             '                                sdp_real t)',
+             '{', '    (void)x; (void)u; (void)w; (void)t;']
+    names = _emit_body(model, model.slice_nodes([model.cost]), lines)
+    lines += ['    return {};'.format(names[model.cost.id]), '}']
+    out.append('\n'.join(lines))
+    return '\n\n'.join(out)
 
 
 def lanes_for(max_controls):
@@ -122,7 +154,10 @@ def lanes_for(max_controls):
     return lanes
 
 
-def translation_unit(model, dtype, lanes):
+def translation_unit(model, dtype, lanes, column=None):
+    """column: None for the generic node-order kernels, or (N0, W) to also
+    build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
+    model on a grid with N0 points along axis 0 and W perturbation points."""
     real = {'float64': 'double', 'float32': 'float'}[np.dtype(dtype).name]
     head = [
         '// generated by stodynprog_amd.codegen -- do not edit',
@@ -136,10 +171,29 @@ def translation_unit(model, dtype, lanes):
         '',
         model_function_source(model),
         '',
-        '#include "sdp_sweep_kernel.h"',
-        '',
     ]
+    if column is not None:
+        assert model.storage_separable
+        head += [
+            '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
+            '#define SDP_COL_N0 {}'.format(int(column[0])),
+            '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
+            separable_functions_source(model),
+            '',
+            '#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h',
+            '',
+        ]
+    else:
+        head += ['#include "sdp_sweep_kernel.h"', '']
     return '\n'.join(head)
+
+
+def column_lds_bytes(n0, w, n_state, dtype):
+    """LDS bytes of the column kernel's table (struct SdpColLds)."""
+    rs = np.dtype(dtype).itemsize
+    w = max(int(w), 1)
+    raw = w * n0 * rs + w * (n_state - 1) * (2 * rs + 4)
+    return (raw + 15) // 16 * 16
 
 
 HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
@@ -148,7 +202,8 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
 
 def _headers_digest():
     h = hashlib.sha256()
-    for fn in ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h'):
+    for fn in ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h',
+               'sdp_column_kernel.h'):
         with open(os.path.join(CSRC, fn), 'rb') as f:
             h.update(f.read())
     return h

@@ -1,0 +1,310 @@
+// sdp_column_kernel.h -- Bellman backup for "storage-separable" models:
+//
+//     x0' = f0(x, u)            leading axis: driven by the control
+//     xk' = fk(x1.., w), k>=1   trailing axes: an exogenous process driven by w
+//
+// (inventory-free storage problems: every storage-control example of the
+// reference has this shape).  The reference interpolates J_next at every
+// lattice cell with the nested lerp of multilinear_cython.pyx:88-300, axis 0
+// OUTERMOST:
+//     out = (1-lam0) * inner(q0) + lam0 * inner(q0+1)
+//     inner(r) = lerp over axes 1..d-1 of V[r, ...] at the cell of (x1'..)
+// For a separable model inner(r) depends on (r, w) only -- not on the control
+// and not on the node's position along axis 0.  So one workgroup takes a whole
+// COLUMN of nodes (fixed x1.., all x0) and
+//   phase W  locates the trailing cell of each perturbation point      (W items)
+//   phase A  tabulates T[w][r] = inner(r) for every row r of axis 0 in LDS
+//            (W x N0 reals, e.g. 32 x 256 x 8 B = 64 KiB of the CU's 160 KiB);
+//            with the value array stored axis-0-fastest the 2^(d-1) vertex
+//            reads of a (w, r..r+255) strip are fully coalesced
+//   phase B  runs the node x control x perturbation loop out of LDS: per cell
+//            two ds_read_b64 (rows q0, q0+1; conflict-free: bank = row), one
+//            lerp, the cost add and the weighted accumulation in w order;
+//            then the (J, index) butterfly argmin over the node's lanes.
+// Every floating-point operation of the reference is executed with the same
+// operands in the same order (the table only removes repeats), so results are
+// bit-identical to the generic kernel and to the oracle.
+//
+// Needs from the generated unit (besides what sdp_sweep_kernel.h needs):
+//   sdp_model_lead(x, u, t)          -> x0'
+//   sdp_model_trail(x, w, t, xn)     fills xn[1..SDP_D-1]  (x[0] is not read)
+//   sdp_model_cost(x, u, w, t)       -> g
+//   SDP_COST_HAS_W                   0: g is hoisted out of the w loop
+//   SDP_COL_N0, SDP_COL_W            points of axis 0 / perturbation points (1 if
+//                                    deterministic): compile-time, they size the
+//                                    statically allocated LDS table
+#pragma once
+#include "sdp_sweep_kernel.h"
+
+#if SDP_D >= 2
+
+#define SDP_COL_THREADS 512
+constexpr int SDP_DT = SDP_D - 1;
+
+struct SdpColShared {
+    sdp_real *T;        // [Wn][N0]
+    int *w_off;         // [Wn][SDP_DT]   M[k]*q[k] of the trailing cell (x N0)
+    sdp_real *w_lam;    // [Wn][SDP_DT]
+    sdp_real *w_oml;    // [Wn][SDP_DT]
+};
+
+// statically sized LDS image (a single workgroup may use up to 160 KiB)
+struct __attribute__((aligned(16))) SdpColLds {
+    sdp_real T[SDP_COL_W * SDP_COL_N0];
+    sdp_real w_lam[SDP_COL_W * SDP_DT];
+    sdp_real w_oml[SDP_COL_W * SDP_DT];
+    int w_off[SDP_COL_W * SDP_DT];
+};
+static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
+
+SDP_DEV void sdp_col_carve(SdpColLds &m, SdpColShared &s)
+{
+    s.T = m.T;
+    s.w_lam = m.w_lam;
+    s.w_oml = m.w_oml;
+    s.w_off = m.w_off;
+}
+
+// grid of the trailing axes over the axis-0-fastest array: strides in elements
+SDP_DEV void sdp_col_trailing_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_DT> &g)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    int m = SDP_COL_N0;
+#pragma unroll
+    for (int k = SDP_DT - 1; k >= 0; --k) {
+        const int ax = k + 1;
+        g.smin[k] = axes[a.axis_off[ax]];
+        g.span[k] = axes[a.axis_off[ax] + a.orders[ax] - 1] - g.smin[k];
+        g.nm1[k] = (sdp_real)(a.orders[ax] - 1);
+        g.ordm2[k] = a.orders[ax] - 2;
+        g.M[k] = m;
+        m *= a.orders[ax];
+    }
+}
+
+// phases W and A for column `c`: fills s.T.  All threads of the workgroup call it.
+SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                                 const SdpColShared &s, const sdp_real *x, sdp_real t)
+{
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+#if SDP_HAS_W
+    const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
+#endif
+    // ---- phase W: trailing cell of every perturbation point
+    for (int w = threadIdx.x; w < Wn; w += blockDim.x) {
+        sdp_real xn[SDP_D];
+#if SDP_HAS_W
+        sdp_model_trail(x, wgrid[w], t, xn);
+#else
+        sdp_model_trail(x, (sdp_real)0, t, xn);
+#endif
+        SdpCell<sdp_real, SDP_DT, sdp_real> c;
+#pragma unroll
+        for (int k = 0; k < SDP_DT; ++k) {
+            sdp_locate_axis<sdp_real, SDP_DT, sdp_real>(tg, k, xn[k + 1], c);
+            s.w_off[w * SDP_DT + k] = c.off[k];
+            s.w_lam[w * SDP_DT + k] = c.lam[k];
+            s.w_oml[w * SDP_DT + k] = c.oml[k];
+        }
+    }
+    __syncthreads();
+    // ---- phase A: T[w][r] = lerp over the trailing axes of V[r, .] (coalesced in r)
+    for (int w = 0; w < Wn; ++w) {
+        SdpCell<sdp_real, SDP_DT, sdp_real> c;
+#pragma unroll
+        for (int k = 0; k < SDP_DT; ++k) {
+            c.off[k] = s.w_off[w * SDP_DT + k];
+            c.lam[k] = s.w_lam[w * SDP_DT + k];
+            c.oml[k] = s.w_oml[w * SDP_DT + k];
+        }
+        for (int r = threadIdx.x; r < N0; r += blockDim.x)
+            s.T[w * N0 + r] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r, tg, c, 0);
+    }
+    __syncthreads();
+}
+
+struct SdpLeadAxis {
+    sdp_real smin, span, nm1;
+    int ordm2;
+};
+
+SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    l.smin = axes[a.axis_off[0]];
+    l.span = axes[a.axis_off[0] + a.orders[0] - 1] - l.smin;
+    l.nm1 = (sdp_real)(a.orders[0] - 1);
+    l.ordm2 = a.orders[0] - 2;
+}
+
+// expected cost of one (node, control) out of the table
+SDP_DEV sdp_real sdp_col_expected_cost(const SdpSweepArgs &a, const SdpLeadAxis &l,
+                                       const sdp_real *__restrict__ T,
+                                       const sdp_real *x, const sdp_real *u, sdp_real t)
+{
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    const sdp_real xn0 = sdp_model_lead(x, u, t);
+    const sdp_real sn = (xn0 - l.smin) / l.span;                      // pyx:75
+    const sdp_real p = sn * l.nm1;
+    const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);            // pyx:78
+    const sdp_real lam0 = p - (sdp_real)q0;                           // pyx:81
+    const sdp_real oml0 = (sdp_real)1 - lam0;
+    const sdp_real *__restrict__ row = T + q0;
+#if SDP_HAS_W
+    const sdp_real *__restrict__ proba = (const sdp_real *)a.proba;
+#if SDP_COST_HAS_W
+    const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
+#else
+    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+#endif
+    sdp_real acc = (sdp_real)0;
+#pragma unroll 4
+    for (int w = 0; w < Wn; ++w) {
+        const sdp_real lo = row[w * N0];
+        const sdp_real hi = row[w * N0 + 1];
+        const sdp_real val = oml0 * lo + lam0 * hi;                   // outermost lerp, pyx:88-300
+#if SDP_COST_HAS_W
+        const sdp_real g = sdp_model_cost(x, u, wgrid[w], t);
+#endif
+        const sdp_real jc = g + val;                                  // stodynprog.py:677
+        acc = acc + jc * proba[w];                                    // stodynprog.py:681
+    }
+    return acc;
+#else
+    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    return g + (oml0 * row[0] + lam0 * row[1]);
+#endif
+}
+
+// unit = (column, split); XCD-aware walk like sdp_sweep
+struct SdpColWalk {
+    int64_t unit, end, stride;
+};
+SDP_DEV void sdp_col_walk(const SdpSweepArgs &a, SdpColWalk &w)
+{
+    const int64_t n_units = (a.col_end - a.col_begin) * a.col_splits;
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_xcd = (n_units + 7) / 8;
+    w.unit = (int64_t)xcd * per_xcd + (blockIdx.x >> 3);
+    w.end = min((int64_t)(xcd + 1) * per_xcd, n_units);
+    w.stride = gridDim.x >> 3;
+}
+
+SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    int64_t r = col;
+#pragma unroll
+    for (int k = SDP_D - 1; k >= 1; --k) {
+        const int i = (int)(r % a.orders[k]);
+        r /= a.orders[k];
+        x[k] = axes[a.axis_off[k] + i];
+    }
+    x[0] = (sdp_real)0;
+}
+
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_sweep_col(SdpSweepArgs a)
+{
+    __shared__ SdpColLds sdp_lds;
+    constexpr int L = SDP_LANES;
+    constexpr int NPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (L - 1);
+    const int slot = lane / L;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    const sdp_real t = (sdp_real)a.t_k;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+
+    SdpColShared s;
+    sdp_col_carve(sdp_lds, s);
+    SdpGrid<sdp_real, SDP_DT> tg;
+    sdp_col_trailing_grid(a, tg);
+    SdpLeadAxis lead;
+    sdp_col_lead_axis(a, lead);
+    SdpColWalk walk;
+    sdp_col_walk(a, walk);
+
+    for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
+        const int64_t col = a.col_begin + unit / a.col_splits;
+        const int part = (int)(unit % a.col_splits);
+        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
+        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        sdp_real x[SDP_D];
+        sdp_col_coords(a, col, x);
+        __syncthreads();                       // readers of the previous table are done
+        sdp_col_build_table(a, tg, s, x, t);
+
+        for (int ib = i_lo + wave * NPW; ib < i_hi; ib += waves * NPW) {
+            const int i = ib + slot;
+            const bool live = i < i_hi;
+            const int64_t node = col * N0 + i;        // axis-0-fastest index
+            sdp_real best = INFINITY;
+            int ibest = INT_MAX;
+            SdpBox box;
+            if (live) {
+                x[0] = axis0[i];
+                sdp_load_box(a, node, box);
+                for (int ci = sub; ci < box.total; ci += L) {
+                    sdp_real u[SDP_NU];
+                    sdp_controls_at(box, ci, u);
+                    const sdp_real jc = sdp_col_expected_cost(a, lead, s.T, x, u, t);
+                    if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
+                }
+            }
+            sdp_seg_argmin<sdp_real, L>(best, ibest);
+            if (live && sub == 0) {
+                ((sdp_real *)a.J)[node] = best;
+                if (a.idx) a.idx[node] = ibest;
+                if (a.pol) {
+                    sdp_real u[SDP_NU];
+                    sdp_controls_at(box, ibest, u);
+#pragma unroll
+                    for (int c = 0; c < SDP_NU; ++c) ((sdp_real *)a.pol)[node * SDP_NU + c] = u[c];
+                }
+            }
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)
+{
+    __shared__ SdpColLds sdp_lds;
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    const sdp_real t = (sdp_real)a.t_k;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+    SdpColShared s;
+    sdp_col_carve(sdp_lds, s);
+    SdpGrid<sdp_real, SDP_DT> tg;
+    sdp_col_trailing_grid(a, tg);
+    SdpLeadAxis lead;
+    sdp_col_lead_axis(a, lead);
+    SdpColWalk walk;
+    sdp_col_walk(a, walk);
+    for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
+        const int64_t col = a.col_begin + unit / a.col_splits;
+        const int part = (int)(unit % a.col_splits);
+        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
+        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        sdp_real x[SDP_D];
+        sdp_col_coords(a, col, x);
+        __syncthreads();
+        sdp_col_build_table(a, tg, s, x, t);
+        for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {
+            const int64_t node = col * N0 + i;
+            sdp_real u[SDP_NU];
+            x[0] = axis0[i];
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+            ((sdp_real *)a.J)[node] = sdp_col_expected_cost(a, lead, s.T, x, u, t);
+        }
+    }
+}
+
+#endif  // SDP_D >= 2

@@ -70,11 +70,11 @@ struct SdpLerp {
 // innermost axis: the two vertex loads; lam*v is a real x real product
 template <typename real, int D, typename wide>
 struct SdpLerp<real, D, wide, D - 1> {
-    static SDP_DEV wide eval(const real *__restrict__ V, const SdpGrid<real, D> &,
+    static SDP_DEV wide eval(const real *__restrict__ V, const SdpGrid<real, D> &g,
                              const SdpCell<real, D, wide> &c, int base)
     {
         const real lo = V[base + c.off[D - 1]];
-        const real hi = V[base + c.off[D - 1] + 1];
+        const real hi = V[base + c.off[D - 1] + g.M[D - 1]];
         return c.oml[D - 1] * (wide)lo + (wide)(c.lam[D - 1] * hi);
     }
 };

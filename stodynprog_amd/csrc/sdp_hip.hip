@@ -471,7 +471,7 @@ extern "C" int sdp_comm_barrier(sdp_comm *c)
 // problem handle
 // ---------------------------------------------------------------------------
 struct sdp_problem {
-    int dtype = SDP_F64, d = 0, nu = 0, W = 0, lanes = 64, box_per_node = 0;
+    int dtype = SDP_F64, d = 0, nu = 0, W = 0, lanes = 64, box_per_node = 0, layout = 0;
     int64_t S = 0, node_begin = 0, node_end = 0;
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
@@ -554,10 +554,19 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
 
     hipError_t e = hipModuleLoad(&p->mod, desc->module_path);
     if (e != hipSuccess) { p->mod = nullptr; return fail(SDP_EMODULE, "hipModuleLoad(%s): %s", desc->module_path, hipGetErrorString(e)); }
-    e = hipModuleGetFunction(&p->f_sweep, p->mod, "sdp_sweep");
-    if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_sweep kernel: %s", desc->module_path, hipGetErrorString(e));
-    e = hipModuleGetFunction(&p->f_evalpol, p->mod, "sdp_evalpol");
-    if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_evalpol kernel: %s", desc->module_path, hipGetErrorString(e));
+    p->layout = desc->layout;
+    if (p->layout != SDP_LAYOUT_NODES && p->layout != SDP_LAYOUT_COLUMNS) return fail(SDP_EINVAL, "unknown layout %d", p->layout);
+    if (p->layout == SDP_LAYOUT_COLUMNS) {
+        if (p->d < 2) return fail(SDP_EINVAL, "column layout needs at least two state axes");
+        if (p->node_begin % p->orders[0] || p->node_end % p->orders[0])
+            return fail(SDP_EINVAL, "column layout: the node slab must consist of whole columns");
+    }
+    const char *k_sweep = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_sweep_col" : "sdp_sweep";
+    const char *k_eval = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_evalpol_col" : "sdp_evalpol";
+    e = hipModuleGetFunction(&p->f_sweep, p->mod, k_sweep);
+    if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_sweep, hipGetErrorString(e));
+    e = hipModuleGetFunction(&p->f_evalpol, p->mod, k_eval);
+    if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_eval, hipGetErrorString(e));
     HIP_TRY(hipStreamCreate(&p->stream));
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
@@ -603,15 +612,44 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k)
     a.node_begin = p->node_begin; a.node_end = p->node_end; a.S = p->S; a.t_k = t_k;
     for (int k = 0; k < SDP_MAXD; ++k) { a.orders[k] = p->orders[k]; a.axis_off[k] = p->axis_off[k]; }
     a.W = p->W; a.box_per_node = p->box_per_node;
+    if (p->layout == SDP_LAYOUT_COLUMNS) {
+        a.n_lead = p->orders[0];
+        a.col_begin = p->node_begin / p->orders[0];
+        a.col_end = p->node_end / p->orders[0];
+        a.col_splits = 1;
+    }
 }
 
-static int launch_module(hipFunction_t f, SdpSweepArgs &a, unsigned blocks, hipStream_t stream)
+static int launch_module(hipFunction_t f, SdpSweepArgs &a, unsigned blocks, unsigned threads,
+                         hipStream_t stream)
 {
     size_t size = sizeof(a);
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
                      HIP_LAUNCH_PARAM_END};
-    HIP_TRY(hipModuleLaunchKernel(f, blocks, 1, 1, 256, 1, 1, 0, stream, nullptr, extra));
+    HIP_TRY(hipModuleLaunchKernel(f, blocks, 1, 1, threads, 1, 1, 0, stream, nullptr, extra));
     return SDP_OK;
+}
+
+// Column kernels: a unit of work is (column, split).  Splitting a column over
+// several workgroups repeats its table build, so split only as far as needed
+// to give every CU a few workgroups; `min_nodes` nodes per split at least.
+static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes)
+{
+    const int64_t cols = a.col_end - a.col_begin;
+    const int n0 = p->orders[0];
+    int64_t want = (int64_t)p->cus * 4;
+    int splits = (int)((want + cols - 1) / cols);
+    int max_splits = n0 / (min_nodes > 0 ? min_nodes : 1);
+    if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.col_splits = splits;
+    int64_t units = cols * splits;
+    int64_t blocks = (int64_t)p->cus * 8;
+    if (blocks > units) blocks = units;
+    blocks = ((blocks + 7) / 8) * 8;
+    if (blocks < 8) blocks = 8;
+    return (unsigned)blocks;
 }
 
 // workgroups for the sweep: a multiple of 8 (one share per XCD), enough to
@@ -633,7 +671,13 @@ static int launch_sweep(sdp_problem *p, double t_k)
     if (p->node_end == p->node_begin) return SDP_OK;
     SdpSweepArgs a;
     fill_args(p, a, t_k);
-    return launch_module(p->f_sweep, a, sweep_blocks(p), p->stream);
+    if (p->layout == SDP_LAYOUT_COLUMNS) {
+        // 512-thread workgroups (8 waves share one LDS table); a wave backs up
+        // 64/lanes nodes at a time
+        const unsigned blocks = column_grid(p, a, (64 / p->lanes) * 8);
+        return launch_module(p->f_sweep, a, blocks, 512, p->stream);
+    }
+    return launch_module(p->f_sweep, a, sweep_blocks(p), 256, p->stream);
 }
 
 static int launch_evalpol(sdp_problem *p, double t_k)
@@ -641,10 +685,17 @@ static int launch_evalpol(sdp_problem *p, double t_k)
     if (p->node_end == p->node_begin) return SDP_OK;
     SdpSweepArgs a;
     fill_args(p, a, t_k);
+    if (p->layout == SDP_LAYOUT_COLUMNS) {
+        const unsigned blocks = column_grid(p, a, 64);       // one lane per node
+        const int per_split = (p->orders[0] + a.col_splits - 1) / a.col_splits;
+        unsigned threads = (unsigned)((per_split + 63) / 64) * 64;
+        if (threads > 512) threads = 512;
+        return launch_module(p->f_evalpol, a, blocks, threads, p->stream);
+    }
     const int64_t nodes = p->node_end - p->node_begin;
     int64_t blocks = (nodes + 255) / 256;
     if (blocks > (int64_t)p->cus * 16) blocks = (int64_t)p->cus * 16;
-    return launch_module(p->f_evalpol, a, (unsigned)blocks, p->stream);
+    return launch_module(p->f_evalpol, a, (unsigned)blocks, 256, p->stream);
 }
 
 // all-gather of the J slabs (in place in the J buffer) on the problem's stream

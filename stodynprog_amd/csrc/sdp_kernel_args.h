@@ -29,6 +29,14 @@ struct SdpSweepArgs {
     int32_t axis_off[SDP_MAXD];
     int32_t W;             // perturbation points (0: deterministic system)
     int32_t box_per_node;  // 0: constant box, 1: per-node arrays
+    // ---- column layout only (sdp_column_kernel.h) ----------------------------
+    // Arrays over nodes (V, J, pol, idx, box_*, pol_in) are then stored with the
+    // LEADING state axis fastest: element (c, i) at c*n_lead + i, c = C-order
+    // index over axes 1..d-1 ("column"), i = index along axis 0.
+    int64_t col_begin;     // first column of this launch
+    int64_t col_end;       // one past the last column
+    int32_t n_lead;        // orders[0]
+    int32_t col_splits;    // workgroups sharing one column (each redoes the table)
 };
 
 // Stand-alone multilinear interpolation (multilinear_cython.pyx:17-49).

@@ -38,12 +38,16 @@ class _DeviceProblem(object):
     """Owner of one sdp_problem handle (include/sdp_hip.h)."""
 
     def __init__(self, desc_arrays, module_path, dtype, shape, nu, W, lanes, box_per_node,
-                 node_range, comm=None, slab_bounds=None):
+                 node_range, comm=None, slab_bounds=None, layout=0):
         self._keep = desc_arrays            # host arrays referenced by the descriptor
+        self.layout = int(layout)
         self.dtype = np.dtype(dtype)
         self.shape = tuple(shape)
         self.S = int(np.prod(shape))
         self.nu = nu
+        # shape of the per-node arrays as the device stores them
+        self.dev_shape = (self.shape[1:] + self.shape[:1]
+                          if self.layout == nat.LAYOUT_COLUMNS else self.shape)
         d = nat.sdp_problem_desc()
         d.dtype = nat.np_real(dtype)
         d.d, d.nu, d.W = len(shape), nu, W
@@ -55,6 +59,7 @@ class _DeviceProblem(object):
             d.proba = desc_arrays['proba'].ctypes.data
         d.box_per_node = int(box_per_node)
         d.lanes_per_node = int(lanes)
+        d.layout = int(layout)
         d.box_lo = desc_arrays['box_lo'].ctypes.data
         d.box_hi = desc_arrays['box_hi'].ctypes.data
         d.box_n = desc_arrays['box_n'].ctypes.data
@@ -79,14 +84,28 @@ class _DeviceProblem(object):
         except Exception:
             pass
 
+    # per-node arrays cross the API in the reference's C order; the device
+    # keeps them axis-0-fastest when the column kernels are used
+    def _to_device_order(self, A, extra=()):
+        A = np.asarray(A, dtype=self.dtype).reshape(self.shape + extra)
+        if self.layout == nat.LAYOUT_COLUMNS:
+            A = np.moveaxis(A, 0, len(self.shape) - 1)
+        return np.ascontiguousarray(A)
+
+    def _from_device_order(self, A, extra=()):
+        if self.layout == nat.LAYOUT_COLUMNS:
+            A = A.reshape(self.shape[1:] + self.shape[:1] + extra)
+            A = np.moveaxis(A, len(self.shape) - 1, 0)
+        return np.ascontiguousarray(A).reshape(self.shape + extra)
+
     def set_value(self, V):
-        V = np.ascontiguousarray(V, dtype=self.dtype)
-        assert V.size == self.S
+        assert np.size(V) == self.S
+        V = self._to_device_order(V)
         nat.check(nat.lib().sdp_problem_set_value(self.h, nat.ptr(V)))
 
     def set_policy(self, pol):
-        pol = np.ascontiguousarray(pol, dtype=self.dtype)
-        assert pol.size == self.S * self.nu
+        assert np.size(pol) == self.S * self.nu
+        pol = self._to_device_order(pol, (self.nu,))
         nat.check(nat.lib().sdp_problem_set_policy(self.h, nat.ptr(pol)))
 
     def sweep(self, t_k=0.0, rel_dp=False, ref_index=0):
@@ -105,15 +124,15 @@ class _DeviceProblem(object):
         nat.check(nat.lib().sdp_problem_swap(self.h))
 
     def get_value(self):
-        J = np.zeros(self.shape, dtype=self.dtype)
+        J = np.zeros(self.S, dtype=self.dtype)
         nat.check(nat.lib().sdp_problem_get_value(self.h, nat.ptr(J)))
-        return J
+        return self._from_device_order(J)
 
     def get_policy(self):
-        pol = np.zeros(self.shape + (self.nu,), dtype=self.dtype)
-        idx = np.zeros(self.shape, dtype=np.int32)
+        pol = np.zeros(self.S * self.nu, dtype=self.dtype)
+        idx = np.zeros(self.S, dtype=np.int32)
         nat.check(nat.lib().sdp_problem_get_policy(self.h, nat.ptr(pol), nat.ptr(idx)))
-        return pol, idx
+        return self._from_device_order(pol, (self.nu,)), self._from_device_order(idx)
 
     def last_kernel_ms(self):
         ms = C.c_double(0.0)
@@ -129,6 +148,8 @@ class _DeviceProblem(object):
 
 
 class DPSolver(object):
+    COLUMN_LDS_LIMIT = 160 * 1024          # LDS of one gfx950 CU
+
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
         (a `SysDescription`).  Implements value iteration, policy evaluation,
@@ -146,6 +167,7 @@ class DPSolver(object):
         self.control_steps = (1.,) * len(self.sys.control)
         self.dtype = np.dtype(dtype)
         self.comm = comm
+        self.kernel = 'auto'               # 'auto' | 'generic' | 'column' (see _problem)
         self._cache = {}
         self.last_policy_index = None      # flat control-lattice index of the last sweep
         self.backend_info = {}
@@ -300,7 +322,7 @@ class DPSolver(object):
         s = self.sys
         parts = [id(s.dyn), id(s.cost), id(s.control_box), repr(sorted(s.params.items())),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
-                 id(self.comm)]
+                 id(self.comm), self.kernel]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         return hash(tuple(parts))
@@ -328,20 +350,14 @@ class DPSolver(object):
         if d > 4:
             raise Exception("Can't interpolate in dimension strictly greater than 5")
 
-    def _problem(self, t_k=None):
-        """Device problem for the current discretisation (cached)."""
-        self._check_supported()
-        box_t = None if self.sys.stationnary else t_k
-        fp = ('problem', self._fingerprint(box_t))
-        prob = self._cache.get(fp)
-        if prob is not None:
-            return prob
-        nat.require_gpu()
+    def _kernel_plan(self, box_t=None):
+        """Everything that determines the model code object of the current
+        discretisation (no GPU needed): control-box table, lanes per node,
+        kernel family, generated source."""
         model = self._traced()
         if isinstance(model, TraceError):
             raise model
         shape = self._shape()
-        S = int(np.prod(shape))
         dt = self.dtype
         lo, hi, n = self._box_table(box_t)
         per_node = not (np.all(lo == lo[:, :1]) and np.all(hi == hi[:, :1])
@@ -353,6 +369,38 @@ class DPSolver(object):
         if not per_node:
             lo, hi, n = lo[:, :1], hi[:, :1], n[:, :1]
         W = len(self.perturb_grid[0]) if self.perturb_grid else 0
+        # storage-separable models on a grid whose (W x N0) table fits the LDS of
+        # a CU run the column kernels, with per-node arrays stored axis-0-fastest
+        column = (self.kernel != 'generic' and model.storage_separable and
+                  codegen.column_lds_bytes(shape[0], W, len(shape), dt) <= self.COLUMN_LDS_LIMIT)
+        if self.kernel == 'column' and not column:
+            raise ValueError('the column kernel needs a storage-separable model whose '
+                             'table fits in LDS')
+        source = codegen.translation_unit(model, dt, lanes,
+                                          column=(shape[0], W) if column else None)
+        return dict(model=model, source=source, column=column, lanes=lanes, per_node=per_node,
+                    lo=lo, hi=hi, n=n, max_u=max_u, W=W)
+
+    def _problem(self, t_k=None):
+        """Device problem for the current discretisation (cached)."""
+        self._check_supported()
+        box_t = None if self.sys.stationnary else t_k
+        fp = ('problem', self._fingerprint(box_t))
+        prob = self._cache.get(fp)
+        if prob is not None:
+            return prob
+        nat.require_gpu()
+        plan = self._kernel_plan(box_t)
+        model, source, column, lanes = plan['model'], plan['source'], plan['column'], plan['lanes']
+        per_node, lo, hi, n, max_u, W = (plan[k] for k in ('per_node', 'lo', 'hi', 'n', 'max_u', 'W'))
+        shape = self._shape()
+        S = int(np.prod(shape))
+        dt = self.dtype
+        layout = nat.LAYOUT_COLUMNS if column else nat.LAYOUT_NODES
+        if column and per_node:
+            nu_, n0 = lo.shape[0], shape[0]
+            lo, hi, n = (np.ascontiguousarray(a.reshape(nu_, n0, -1).transpose(0, 2, 1))
+                         .reshape(nu_, -1) for a in (lo, hi, n))
         arrays = dict(
             axes=[np.ascontiguousarray(g, dtype=dt) for g in self.state_grid],
             box_lo=np.ascontiguousarray(lo, dtype=dt),
@@ -361,10 +409,11 @@ class DPSolver(object):
         if W:
             arrays['wgrid'] = np.ascontiguousarray(self.perturb_grid[0], dtype=dt)
             arrays['proba'] = np.ascontiguousarray(self.perturb_proba[0], dtype=dt)
-        source = codegen.translation_unit(model, dt, lanes)
         module = nat.compile_model(source)
+        # slabs: whole hyperplanes of the outermost axis of the device layout
+        dev_shape = (shape[1:] + shape[:1]) if column else shape
         if self.comm is not None:
-            bounds = self.comm.slab_bounds(shape)
+            bounds = self.comm.slab_bounds(dev_shape)
             node_range = (int(bounds[self.comm.rank]), int(bounds[self.comm.rank + 1]))
         else:
             bounds, node_range = None, (0, S)
@@ -374,16 +423,21 @@ class DPSolver(object):
         prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
                               per_node, node_range,
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
-                              bounds)
+                              bounds, layout)
         self._cache[fp] = prob
-        self.backend_info = dict(mode='fused', module=module, lanes_per_node=lanes,
+        self.backend_info = dict(mode='fused', kernel='column' if column else 'generic',
+                                 module=module, lanes_per_node=lanes,
                                  max_controls=max_u, box_per_node=bool(per_node),
                                  bit_exact_model=model.bit_exact,
                                  inexact_ops=model.inexact_ops())
         return prob
 
-    def _ref_flat(self):
-        return int(np.ravel_multi_index(self._state_ref_ind, self._shape()))
+    def _ref_flat(self, prob=None):
+        """flat index of the relative-DP reference node in the device layout"""
+        ind, shape = self._state_ref_ind, self._shape()
+        if prob is not None and prob.layout == nat.LAYOUT_COLUMNS:
+            ind, shape = ind[1:] + ind[:1], shape[1:] + shape[:1]
+        return int(np.ravel_multi_index(ind, shape))
 
     # ------------------------------------------------------------ value iteration
     def value_iteration(self, J_next, rel_dp=False, report_time=True):
@@ -425,10 +479,12 @@ class DPSolver(object):
         # host memory after the sweep; with RCCL the library does it on device
         host_comm = self.comm is not None and not self.comm.is_device
         J_ref = prob.sweep(0.0 if t_k is None else t_k, rel_dp and not host_comm,
-                           self._ref_flat() if rel_dp else 0)
+                           self._ref_flat(prob) if rel_dp else 0)
         J_k = prob.get_value()
         if host_comm:
-            self.comm.all_gather_slabs(J_k, self.comm.slab_bounds(self._shape()))
+            Jd = prob._to_device_order(J_k).reshape(-1)
+            self.comm.all_gather_slabs(Jd, self.comm.slab_bounds(prob.dev_shape))
+            J_k = prob._from_device_order(Jd)
             if rel_dp:
                 J_ref = J_k[self._state_ref_ind]              # sdp.py:523-525
                 J_k -= J_ref
@@ -618,7 +674,7 @@ class DPSolver(object):
         for k in range(n_iter):
             # progress line of the reference; the iterations themselves run in one device call
             print('\rpolicy evaluation: iter. {:d}/{:d}'.format(k, n_iter), end='')
-        J_ref = prob.eval_policy(n_iter, rel_dp, self._ref_flat() if rel_dp else 0)
+        J_ref = prob.eval_policy(n_iter, rel_dp, self._ref_flat(prob) if rel_dp else 0)
         J_pol = prob.get_value()
         exec_time = (datetime.now() - t_start).total_seconds()
         if report_time:

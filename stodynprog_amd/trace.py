@@ -26,7 +26,8 @@ class TraceError(Exception):
 
 
 # dependency bits
-DEP_X, DEP_U, DEP_W, DEP_T = 1, 2, 4, 8
+# x0 (the leading state axis) is tracked apart from the other state variables
+DEP_X, DEP_U, DEP_W, DEP_T, DEP_XR = 1, 2, 4, 8, 16
 
 # op -> (arity, result kind)   kind: 'r' real, 'b' bool
 _OPS = {
@@ -405,13 +406,48 @@ class TracedModel(object):
     def inexact_ops(self):
         return sorted({n.op for n in self.live_nodes() if n.op not in EXACT_OPS})
 
+    def slice_nodes(self, outputs):
+        """Nodes reachable from `outputs` only, in topological order."""
+        seen = set()
+        stack = list(outputs)
+        while stack:
+            n = stack.pop()
+            if n.id in seen:
+                continue
+            seen.add(n.id)
+            stack.extend(n.args)
+        return [n for n in self.graph.nodes if n.id in seen]
+
+    @property
+    def storage_separable(self):
+        """True when the next value of the LEADING state axis does not depend
+        on the perturbation, and the next values of all other axes depend
+        neither on the control nor on the leading state variable:
+            x0' = f0(x, u[, t])       x_k' = f_k(x_1.., w[, t])  for k >= 1
+        (the shape of every storage-control example of the reference: a stock
+        driven by the control next to an exogenous process driven by the
+        noise).  The partial interpolation over axes 1.. is then a function of
+        (row of axis 0, w) only and is shared by all controls and by all nodes
+        of a column along axis 0 -- see csrc/sdp_column_kernel.h."""
+        if self.n_state < 2:
+            return False
+        lead = self.x_next[0].deps
+        trail = 0
+        for n in self.x_next[1:]:
+            trail |= n.deps
+        return (lead & DEP_W) == 0 and (trail & (DEP_U | DEP_X)) == 0
+
+    @property
+    def cost_depends_on_w(self):
+        return bool(self.cost.deps & DEP_W)
+
 
 def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True):
     """Trace `dyn` and `cost` with symbolic x, u, w (and t_k first when the
     system is time dependent), in the argument order of sdp.py:668-672."""
     params = params or {}
     g = Graph()
-    xs = [Sym(g, g.var('x%d' % i, DEP_X)) for i in range(n_state)]
+    xs = [Sym(g, g.var('x%d' % i, DEP_X if i == 0 else DEP_XR)) for i in range(n_state)]
     us = [Sym(g, g.var('u%d' % i, DEP_U)) for i in range(n_control)]
     ws = [Sym(g, g.var('w%d' % i, DEP_W)) for i in range(n_perturb)]
     args = xs + us + ws

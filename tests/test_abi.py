@@ -53,8 +53,8 @@ def test_error_convention_without_gpu():
 
 
 def test_descriptor_layout_matches_the_header():
-    # 4*int32 + 4*int64 + 4 ptr + 2 ptr + 2*int32 + 3 ptr + 2*int64 + ptr
-    assert C.sizeof(nat.sdp_problem_desc) == 16 + 32 + 32 + 16 + 8 + 24 + 16 + 8
+    # 4*int32 + 4*int64 + 4 ptr + 2 ptr + 4*int32 + 3 ptr + 2*int64 + ptr
+    assert C.sizeof(nat.sdp_problem_desc) == 16 + 32 + 32 + 16 + 16 + 24 + 16 + 8
 
 
 def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):

@@ -46,6 +46,12 @@ lo, hi = int(bounds[rank]), int(bounds[rank + 1])
 
 class FakeProblem(object):
     """stands for _DeviceProblem: computes this rank's slab with the oracle"""
+    layout = 0
+    dev_shape = spec.shape
+    def _to_device_order(self, A):
+        return np.ascontiguousarray(A)
+    def _from_device_order(self, A):
+        return A.reshape(spec.shape)
     def set_value(self, V):
         self.V = np.array(V, dtype=float)
     def sweep(self, t_k, rel_dp, ref_index):

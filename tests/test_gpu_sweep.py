@@ -391,3 +391,60 @@ def test_policy_iteration_reproduces_published_costs(gpu, capsys):
     frac_same = (pol[..., 0] == g['ar1_pi_pol0']).mean()
     assert frac_same > 0.97                      # dead-band cost: ties may resolve differently
     assert np.abs(pol[..., 0] - g['ar1_pi_pol0']).max() < 0.9 + 1e-9
+
+
+# ---------------------------------------------------------------- kernel families
+def _clone_with_kernel(sysd, ref, kernel, dtype=np.float64):
+    s = DPSolver(sysd, dtype=dtype)
+    s.state_grid, s._state_grid_shape = ref.state_grid, ref._state_grid_shape
+    s._state_ref_ind, s._state_ref = ref._state_ref_ind, ref._state_ref
+    s.perturb_grid, s.perturb_proba = ref.perturb_grid, ref.perturb_proba
+    s.control_steps = ref.control_steps
+    s.kernel = kernel
+    return s
+
+
+@pytest.mark.parametrize('name,kw', [
+    ('nas_demo', {}),
+    ('storage_ar1', dict(n_E=33, n_P=20, steps=(0.05, 0.1))),
+    ('searev', dict(n_E=17, n_S=12, n_A=9, step=0.01)),
+    ('synthetic3d', dict(N=24)),
+])
+def test_column_and_generic_kernels_agree_bitwise(gpu, name, kw):
+    """the LDS-table column kernel only removes repeated work: same bits as the
+    generic per-cell kernel for J, index, control values, relative DP and
+    policy evaluation"""
+    sysd, ref = getattr(models, name)(**kw)
+    assert ref._traced().storage_separable
+    col = _clone_with_kernel(sysd, ref, 'column')
+    gen = _clone_with_kernel(sysd, ref, 'generic')
+    V = np.random.default_rng(11).standard_normal(ref._state_grid_shape)
+    Jc, uc = col.value_iteration(V, report_time=False)
+    Jg, ug = gen.value_iteration(V, report_time=False)
+    assert col.backend_info['kernel'] == 'column' and gen.backend_info['kernel'] == 'generic'
+    assert np.array_equal(Jc, Jg) and np.array_equal(uc, ug)
+    assert np.array_equal(col.last_policy_index, gen.last_policy_index)
+    Vd = V - V[ref._state_ref_ind]
+    (Jc2, rc), _ = col.value_iteration((Vd, 0.), rel_dp=True, report_time=False)
+    (Jg2, rg), _ = gen.value_iteration((Vd, 0.), rel_dp=True, report_time=False)
+    assert rc == rg and np.array_equal(Jc2, Jg2)
+    Ec, refs_c = quiet(col.eval_policy, ug, 6, True, V * 0.1, J_ref_full=True)
+    Eg, refs_g = quiet(gen.eval_policy, ug, 6, True, V * 0.1, J_ref_full=True)
+    assert np.array_equal(Ec, Eg) and np.array_equal(refs_c, refs_g)
+
+
+def test_column_kernel_is_the_default_for_storage_problems(gpu):
+    for name in ('nas_demo', 'storage_ar1', 'searev', 'synthetic3d'):
+        _, s = getattr(models, name)()
+        plan = s._kernel_plan()
+        assert plan['column'], name
+    _, inv = models.inventory()
+    assert not inv._kernel_plan()['column']          # x' = x + u - w is not separable
+    # a table that does not fit the 160 KiB LDS falls back to the generic kernel
+    _, big = models.synthetic3d(N=20)
+    big.state_grid[0] = np.linspace(0, 1, 1000)
+    big._state_grid_shape = (1000, 20, 20)
+    assert not big._kernel_plan()['column']
+    big.kernel = 'column'
+    with pytest.raises(ValueError):
+        big._kernel_plan()
