@@ -145,12 +145,14 @@ def main():
         'config': {'workload': 'synthetic3d {0}^3 state x {1} controls x {2} perturbations '
                                '(BASELINE.json configs[3])'.format(N, U, W),
                    'state_nodes': S, 'controls': U, 'perturbations': W,
-                   'sharding': 'outer state axis over {} rank(s), RCCL all-gather of J'.format(world)},
+                   'kernel_family': solver.backend_info.get('kernel'),
+                   'sharding': 'outer axis of the device layout over {} rank(s), RCCL all-gather of J'.format(world)},
         'state_cells_per_sec': S * sweeps_per_s,
         'lattice_cells_per_sec': S * U * W * sweeps_per_s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'kernel': 'sdp_sweep', 'kernel_ms': k_ms,
+                     'kernel': 'sdp_sweep_col' if solver.backend_info.get('kernel') == 'column' else 'sdp_sweep',
+                     'kernel_ms': k_ms,
                      'algorithmic_bytes_per_launch': bytes_launch,
                      'note': 'gather accounting (SURVEY 8d): 2^d*T bytes per lattice cell; V '
                              'is reused from L2/Infinity Cache so frac may exceed 1'},

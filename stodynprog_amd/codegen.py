@@ -178,6 +178,10 @@ def translation_unit(model, dtype, lanes, column=None):
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
             '#define SDP_COL_N0 {}'.format(int(column[0])),
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
+        ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
+             for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_THREADS',
+                       'SDP_COL_W_REGS_MAX')
+             if os.environ.get(k)] + [
             separable_functions_source(model),
             '',
             '#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h',
@@ -192,7 +196,8 @@ def column_lds_bytes(n0, w, n_state, dtype):
     """LDS bytes of the column kernel's table (struct SdpColLds)."""
     rs = np.dtype(dtype).itemsize
     w = max(int(w), 1)
-    raw = w * n0 * rs + w * (n_state - 1) * (2 * rs + 4)
+    threads = 512                                   # SDP_COL_THREADS
+    raw = w * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4)
     return (raw + 15) // 16 * 16
 
 

@@ -38,7 +38,15 @@
 
 #if SDP_D >= 2
 
+#ifndef SDP_COL_THREADS
 #define SDP_COL_THREADS 512
+#endif
+#ifndef SDP_COL_BATCH
+#define SDP_COL_BATCH 1          // perturbation points whose LDS reads are issued together (A/B: 1 is fastest)
+#endif
+#ifndef SDP_COL_MIN_WAVES
+#define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
+#endif
 constexpr int SDP_DT = SDP_D - 1;
 
 struct SdpColShared {
@@ -46,6 +54,8 @@ struct SdpColShared {
     int *w_off;         // [Wn][SDP_DT]   M[k]*q[k] of the trailing cell (x N0)
     sdp_real *w_lam;    // [Wn][SDP_DT]
     sdp_real *w_oml;    // [Wn][SDP_DT]
+    sdp_real *part_J;   // [chunks][nodes of the unit], chunks*nodes <= SDP_COL_THREADS
+    int *part_i;
 };
 
 // statically sized LDS image (a single workgroup may use up to 160 KiB)
@@ -53,6 +63,8 @@ struct __attribute__((aligned(16))) SdpColLds {
     sdp_real T[SDP_COL_W * SDP_COL_N0];
     sdp_real w_lam[SDP_COL_W * SDP_DT];
     sdp_real w_oml[SDP_COL_W * SDP_DT];
+    sdp_real part_J[SDP_COL_THREADS];      // partial minima of the control chunks
+    int part_i[SDP_COL_THREADS];
     int w_off[SDP_COL_W * SDP_DT];
 };
 static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
@@ -63,6 +75,8 @@ SDP_DEV void sdp_col_carve(SdpColLds &m, SdpColShared &s)
     s.w_lam = m.w_lam;
     s.w_oml = m.w_oml;
     s.w_off = m.w_off;
+    s.part_J = m.part_J;
+    s.part_i = m.part_i;
 }
 
 // grid of the trailing axes over the axis-0-fastest array: strides in elements
@@ -139,9 +153,54 @@ SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
     l.ordm2 = a.orders[0] - 2;
 }
 
+// Perturbation weights (and points, when the cost depends on w) live in
+// registers for the whole kernel when there are few of them: every lane holds
+// the same W values, the w loop is fully unrolled so the array is never
+// indexed dynamically, and the inner loop issues no memory instruction besides
+// its two LDS reads per cell.  Larger W falls back to (cached) global loads.
+#ifndef SDP_COL_W_REGS_MAX
+#define SDP_COL_W_REGS_MAX 32
+#endif
+#if SDP_COL_W <= SDP_COL_W_REGS_MAX
+#define SDP_COL_W_IN_REGS 1
+#else
+#define SDP_COL_W_IN_REGS 0
+#endif
+
+struct SdpColWeights {
+#if SDP_COL_W_IN_REGS && SDP_HAS_W
+    sdp_real p[SDP_COL_W];
+#if SDP_COST_HAS_W
+    sdp_real w[SDP_COL_W];
+#endif
+#endif
+    const sdp_real *gp, *gw;
+};
+
+SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k)
+{
+    k.gp = (const sdp_real *)a.proba;
+    k.gw = (const sdp_real *)a.wgrid;
+#if SDP_COL_W_IN_REGS && SDP_HAS_W
+#pragma unroll
+    for (int w = 0; w < SDP_COL_W; ++w) {
+        // the empty asm pins each (wave-uniform) value in a VGPR: left to
+        // itself the compiler keeps them in SGPRs, runs out and spills
+        sdp_real v = k.gp[w];
+        asm volatile("" : "+v"(v));
+        k.p[w] = v;
+#if SDP_COST_HAS_W
+        v = k.gw[w];
+        asm volatile("" : "+v"(v));
+        k.w[w] = v;
+#endif
+    }
+#endif
+}
+
 // expected cost of one (node, control) out of the table
-SDP_DEV sdp_real sdp_col_expected_cost(const SdpSweepArgs &a, const SdpLeadAxis &l,
-                                       const sdp_real *__restrict__ T,
+SDP_DEV sdp_real sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
+                                       const sdp_real *T,
                                        const sdp_real *x, const sdp_real *u, sdp_real t)
 {
     constexpr int N0 = SDP_COL_N0;
@@ -152,31 +211,78 @@ SDP_DEV sdp_real sdp_col_expected_cost(const SdpSweepArgs &a, const SdpLeadAxis 
     const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);            // pyx:78
     const sdp_real lam0 = p - (sdp_real)q0;                           // pyx:81
     const sdp_real oml0 = (sdp_real)1 - lam0;
-    const sdp_real *__restrict__ row = T + q0;
+    // two separate 8-byte LDS reads per cell (rows q0 and q0+1 of T[w]): as
+    // ds_read_b64 they cost 2 LDS cycles each, conflict-free (bank = row);
+    // `volatile` keeps the compiler from fusing them into ds_read2_b64, which
+    // runs at half the LDS rate (MI355X_MICROARCH.md, LDS table)
+    typedef __attribute__((address_space(3))) sdp_real lds_real;
+    const volatile lds_real *row = (const volatile lds_real *)(T + q0);
 #if SDP_HAS_W
-    const sdp_real *__restrict__ proba = (const sdp_real *)a.proba;
-#if SDP_COST_HAS_W
-    const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
-#else
+#if !SDP_COST_HAS_W
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
 #endif
     sdp_real acc = (sdp_real)0;
-#pragma unroll 4
-    for (int w = 0; w < Wn; ++w) {
-        const sdp_real lo = row[w * N0];
-        const sdp_real hi = row[w * N0 + 1];
-        const sdp_real val = oml0 * lo + lam0 * hi;                   // outermost lerp, pyx:88-300
-#if SDP_COST_HAS_W
-        const sdp_real g = sdp_model_cost(x, u, wgrid[w], t);
+    // The LDS reads are issued in batches of SDP_COL_BATCH perturbation points
+    // (volatile keeps their order, so a batch goes out back to back and the
+    // arithmetic of the previous batch overlaps its latency); the expectation
+    // is still accumulated strictly in w order.
+    constexpr int B = SDP_COL_BATCH;
+#if SDP_COL_W_IN_REGS
+#pragma unroll
+#else
+#pragma unroll
 #endif
-        const sdp_real jc = g + val;                                  // stodynprog.py:677
-        acc = acc + jc * proba[w];                                    // stodynprog.py:681
+    for (int w0 = 0; w0 < Wn; w0 += B) {
+        sdp_real lo[B], hi[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            if (w0 + b < Wn) {
+                lo[b] = row[(w0 + b) * N0];
+                hi[b] = row[(w0 + b) * N0 + 1];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int w = w0 + b;
+            if (w < Wn) {
+                const sdp_real val = oml0 * lo[b] + lam0 * hi[b];     // outermost lerp, pyx:88-300
+#if SDP_COL_W_IN_REGS
+                const sdp_real pw = k.p[w];
+#else
+                const sdp_real pw = k.gp[w];
+#endif
+#if SDP_COST_HAS_W
+#if SDP_COL_W_IN_REGS
+                const sdp_real g = sdp_model_cost(x, u, k.w[w], t);
+#else
+                const sdp_real g = sdp_model_cost(x, u, k.gw[w], t);
+#endif
+#endif
+                const sdp_real jc = g + val;                          // stodynprog.py:677
+                acc = acc + jc * pw;                                  // stodynprog.py:681
+            }
+        }
     }
     return acc;
 #else
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
-    return g + (oml0 * row[0] + lam0 * row[1]);
+    const sdp_real lo = row[0];
+    const sdp_real hi = row[1];
+    return g + (oml0 * lo + lam0 * hi);
 #endif
+}
+
+SDP_DEV void sdp_col_store(const SdpSweepArgs &a, int64_t node, const SdpBox &box,
+                           sdp_real best, int ibest)
+{
+    ((sdp_real *)a.J)[node] = best;
+    if (a.idx) a.idx[node] = ibest;
+    if (a.pol) {
+        sdp_real u[SDP_NU];
+        sdp_controls_at(box, ibest, u);
+#pragma unroll
+        for (int c = 0; c < SDP_NU; ++c) ((sdp_real *)a.pol)[node * SDP_NU + c] = u[c];
+    }
 }
 
 // unit = (column, split); XCD-aware walk like sdp_sweep
@@ -206,14 +312,10 @@ SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
     x[0] = (sdp_real)0;
 }
 
-extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_sweep_col(SdpSweepArgs a)
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
-    constexpr int L = SDP_LANES;
-    constexpr int NPW = 64 / L;
     const int lane = threadIdx.x & 63;
-    const int sub = lane & (L - 1);
-    const int slot = lane / L;
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     constexpr int N0 = SDP_COL_N0;
@@ -229,6 +331,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_sweep_col(SdpS
     sdp_col_lead_axis(a, lead);
     SdpColWalk walk;
     sdp_col_walk(a, walk);
+    SdpColWeights wts;
+    sdp_col_load_weights(a, wts);
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
@@ -240,33 +344,61 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_sweep_col(SdpS
         __syncthreads();                       // readers of the previous table are done
         sdp_col_build_table(a, tg, s, x, t);
 
-        for (int ib = i_lo + wave * NPW; ib < i_hi; ib += waves * NPW) {
-            const int i = ib + slot;
-            const bool live = i < i_hi;
-            const int64_t node = col * N0 + i;        // axis-0-fastest index
-            sdp_real best = INFINITY;
-            int ibest = INT_MAX;
-            SdpBox box;
-            if (live) {
+        // ---- phase B.  One LANE per node (64 consecutive nodes of the column
+        // per wavefront: their rows q0 are consecutive, so the LDS reads are
+        // conflict-free), the control loop and the argmin run in-lane with no
+        // cross-lane traffic.  With fewer 64-node groups than waves the
+        // control lattice is cut into `chunks` consecutive ranges, one wave
+        // each; the partial minima meet in LDS and are merged in chunk order
+        // (first occurrence wins, stodynprog.py:686).
+        const int n_nodes = i_hi - i_lo;
+        const int groups = (n_nodes + 63) >> 6;
+        const int chunks = groups < waves ? waves / groups : 1;
+        for (int item = wave; item < groups * chunks; item += waves) {
+            const int grp = item / chunks;
+            const int chunk = item - grp * chunks;
+            const int i = i_lo + (grp << 6) + lane;
+            if (i < i_hi) {
+                const int64_t node = col * N0 + i;            // axis-0-fastest index
+                SdpBox box;
                 x[0] = axis0[i];
                 sdp_load_box(a, node, box);
-                for (int ci = sub; ci < box.total; ci += L) {
+                const int c_lo = (int)((int64_t)box.total * chunk / chunks);
+                const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
+                sdp_real best = INFINITY;
+                int ibest = INT_MAX;
+                for (int ci = c_lo; ci < c_hi; ++ci) {
                     sdp_real u[SDP_NU];
                     sdp_controls_at(box, ci, u);
-                    const sdp_real jc = sdp_col_expected_cost(a, lead, s.T, x, u, t);
+                    const sdp_real jc = sdp_col_expected_cost(wts, lead, s.T, x, u, t);
                     if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
                 }
-            }
-            sdp_seg_argmin<sdp_real, L>(best, ibest);
-            if (live && sub == 0) {
-                ((sdp_real *)a.J)[node] = best;
-                if (a.idx) a.idx[node] = ibest;
-                if (a.pol) {
-                    sdp_real u[SDP_NU];
-                    sdp_controls_at(box, ibest, u);
-#pragma unroll
-                    for (int c = 0; c < SDP_NU; ++c) ((sdp_real *)a.pol)[node * SDP_NU + c] = u[c];
+                if (chunks == 1) {
+                    sdp_col_store(a, node, box, best, ibest);
+                } else {
+                    s.part_J[chunk * n_nodes + (i - i_lo)] = best;
+                    s.part_i[chunk * n_nodes + (i - i_lo)] = ibest;
                 }
+            }
+        }
+        if (chunks > 1) {
+            __syncthreads();
+            for (int n = threadIdx.x; n < n_nodes; n += blockDim.x) {
+                sdp_real best = s.part_J[n];
+                int ibest = s.part_i[n];
+                for (int k = 1; k < chunks; ++k) {
+                    const sdp_real cj = s.part_J[k * n_nodes + n];
+                    const int cidx = s.part_i[k * n_nodes + n];
+                    // an empty chunk (fewer controls than chunks) carries INT_MAX
+                    if (cidx != INT_MAX && (ibest == INT_MAX || sdp_better_seq(cj, best))) {
+                        best = cj;
+                        ibest = cidx;
+                    }
+                }
+                const int64_t node = col * N0 + i_lo + n;
+                SdpBox box;
+                sdp_load_box(a, node, box);
+                sdp_col_store(a, node, box, best, ibest);
             }
         }
     }
@@ -287,6 +419,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     sdp_col_lead_axis(a, lead);
     SdpColWalk walk;
     sdp_col_walk(a, walk);
+    SdpColWeights wts;
+    sdp_col_load_weights(a, wts);
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
         const int part = (int)(unit % a.col_splits);
@@ -302,7 +436,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
             x[0] = axis0[i];
 #pragma unroll
             for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-            ((sdp_real *)a.J)[node] = sdp_col_expected_cost(a, lead, s.T, x, u, t);
+            ((sdp_real *)a.J)[node] = sdp_col_expected_cost(wts, lead, s.T, x, u, t);
         }
     }
 }

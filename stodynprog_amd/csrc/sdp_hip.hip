@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <memory>
 #include <string>
@@ -674,8 +675,10 @@ static int launch_sweep(sdp_problem *p, double t_k)
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         // 512-thread workgroups (8 waves share one LDS table); a wave backs up
         // 64/lanes nodes at a time
-        const unsigned blocks = column_grid(p, a, (64 / p->lanes) * 8);
-        return launch_module(p->f_sweep, a, blocks, 512, p->stream);
+        unsigned threads = 512;
+        if (const char *e = getenv("SDP_COL_THREADS")) threads = (unsigned)atoi(e);   // tuning only
+        const unsigned blocks = column_grid(p, a, 64);          // one lane per node
+        return launch_module(p->f_sweep, a, blocks, threads, p->stream);
     }
     return launch_module(p->f_sweep, a, sweep_blocks(p), 256, p->stream);
 }

@@ -65,6 +65,10 @@ SDP_DEV sdp_real sdp_control_value(const SdpBox &b, int c, int k)
 // flat C-order lattice index (control 0 slowest) -> control values
 SDP_DEV void sdp_controls_at(const SdpBox &b, int flat, sdp_real *u)
 {
+#if SDP_NU == 1
+    u[0] = sdp_control_value(b, 0, flat);
+    return;
+#endif
 #pragma unroll
     for (int c = SDP_NU - 1; c >= 0; --c) {
         const int k = flat % b.n[c];
