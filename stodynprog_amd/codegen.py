@@ -180,7 +180,7 @@ def translation_unit(model, dtype, lanes, column=None):
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
         ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_THREADS',
-                       'SDP_COL_W_REGS_MAX')
+                       'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             '',
@@ -197,7 +197,7 @@ def column_lds_bytes(n0, w, n_state, dtype):
     rs = np.dtype(dtype).itemsize
     w = max(int(w), 1)
     threads = 512                                   # SDP_COL_THREADS
-    raw = w * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4)
+    raw = w * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs
     return (raw + 15) // 16 * 16
 
 

@@ -42,7 +42,13 @@
 #define SDP_COL_THREADS 512
 #endif
 #ifndef SDP_COL_BATCH
-#define SDP_COL_BATCH 1          // perturbation points whose LDS reads are issued together (A/B: 1 is fastest)
+#define SDP_COL_BATCH 2          // perturbation points whose LDS reads are issued together
+#endif
+#ifndef SDP_COL_UNROLL_U
+#define SDP_COL_UNROLL_U 2       // controls evaluated together per lane (independent chains)
+#endif
+#ifndef SDP_COL_UNROLL_W
+#define SDP_COL_UNROLL_W 4       // unroll factor of the perturbation loop (in batches)
 #endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
@@ -63,6 +69,8 @@ struct __attribute__((aligned(16))) SdpColLds {
     sdp_real T[SDP_COL_W * SDP_COL_N0];
     sdp_real w_lam[SDP_COL_W * SDP_DT];
     sdp_real w_oml[SDP_COL_W * SDP_DT];
+    sdp_real pw[SDP_COL_W];                // weight / point copies (SDP_COL_WMODE 2)
+    sdp_real gw[SDP_COL_W];
     sdp_real part_J[SDP_COL_THREADS];      // partial minima of the control chunks
     int part_i[SDP_COL_THREADS];
     int w_off[SDP_COL_W * SDP_DT];
@@ -153,122 +161,164 @@ SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
     l.ordm2 = a.orders[0] - 2;
 }
 
-// Perturbation weights (and points, when the cost depends on w) live in
-// registers for the whole kernel when there are few of them: every lane holds
-// the same W values, the w loop is fully unrolled so the array is never
-// indexed dynamically, and the inner loop issues no memory instruction besides
-// its two LDS reads per cell.  Larger W falls back to (cached) global loads.
-#ifndef SDP_COL_W_REGS_MAX
-#define SDP_COL_W_REGS_MAX 32
-#endif
-#if SDP_COL_W <= SDP_COL_W_REGS_MAX
-#define SDP_COL_W_IN_REGS 1
-#else
-#define SDP_COL_W_IN_REGS 0
+// Where the inner loop takes the perturbation weights p_w (and points w, when
+// the cost depends on w) from -- SDP_COL_WMODE:
+//   0  VGPRs: every lane holds the same W values for the whole kernel (the w
+//      loop is fully unrolled, so the arrays are never indexed dynamically);
+//      2*W registers, no memory instruction besides the two LDS reads per cell
+//   1  scalar loads (s_load_*) from the constant address space into SGPRs,
+//      used directly as VALU operands: no VGPR cost
+//   2  LDS broadcast reads of a copy made at kernel start
+// Default: scalar loads (A/B on MI355X: as fast as VGPRs, and no register cost).
+#ifndef SDP_COL_WMODE
+#define SDP_COL_WMODE 1
 #endif
 
+typedef const __attribute__((address_space(4))) sdp_real sdp_cst_real;
+typedef __attribute__((address_space(3))) sdp_real sdp_lds_real;
+
 struct SdpColWeights {
-#if SDP_COL_W_IN_REGS && SDP_HAS_W
+#if SDP_COL_WMODE == 0 && SDP_HAS_W
     sdp_real p[SDP_COL_W];
 #if SDP_COST_HAS_W
     sdp_real w[SDP_COL_W];
 #endif
 #endif
-    const sdp_real *gp, *gw;
+    const volatile sdp_cst_real *cp, *cw;  // mode 1 (volatile: stay inside the loop)
+    const volatile sdp_lds_real *lp, *lw;  // mode 2
 };
 
-SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k)
+#if SDP_COL_WMODE == 0
+#define SDP_COL_PW(k, w) ((k).p[w])
+#define SDP_COL_GW(k, w) ((k).w[w])
+#elif SDP_COL_WMODE == 1
+#define SDP_COL_PW(k, w) ((k).cp[w])
+#define SDP_COL_GW(k, w) ((k).cw[w])
+#else
+#define SDP_COL_PW(k, w) ((k).lp[w])
+#define SDP_COL_GW(k, w) ((k).lw[w])
+#endif
+
+SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k, sdp_real *lds_p,
+                                  sdp_real *lds_w)
 {
-    k.gp = (const sdp_real *)a.proba;
-    k.gw = (const sdp_real *)a.wgrid;
-#if SDP_COL_W_IN_REGS && SDP_HAS_W
+    const sdp_real *gp = (const sdp_real *)a.proba;
+    const sdp_real *gw = (const sdp_real *)a.wgrid;
+    k.cp = (const volatile sdp_cst_real *)a.proba;
+    k.cw = (const volatile sdp_cst_real *)a.wgrid;
+    k.lp = (const volatile sdp_lds_real *)lds_p;
+    k.lw = (const volatile sdp_lds_real *)lds_w;
+    (void)gp; (void)gw;
+#if SDP_HAS_W
+#if SDP_COL_WMODE == 0
 #pragma unroll
     for (int w = 0; w < SDP_COL_W; ++w) {
         // the empty asm pins each (wave-uniform) value in a VGPR: left to
         // itself the compiler keeps them in SGPRs, runs out and spills
-        sdp_real v = k.gp[w];
+        sdp_real v = gp[w];
         asm volatile("" : "+v"(v));
         k.p[w] = v;
 #if SDP_COST_HAS_W
-        v = k.gw[w];
+        v = gw[w];
         asm volatile("" : "+v"(v));
         k.w[w] = v;
 #endif
     }
+#elif SDP_COL_WMODE == 2
+    for (int w = threadIdx.x; w < SDP_COL_W; w += blockDim.x) {
+        lds_p[w] = gp[w];
+        lds_w[w] = gw[w];
+    }
+    __syncthreads();
+#endif
 #endif
 }
 
-// expected cost of one (node, control) out of the table
-SDP_DEV sdp_real sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
-                                       const sdp_real *T,
-                                       const sdp_real *x, const sdp_real *u, sdp_real t)
+// Expected cost of K controls of one node out of the table.  The K cost
+// chains are independent, so interleaving them gives the in-order wave K times
+// the instruction-level parallelism per LDS round trip (and one scalar load of
+// p_w serves K cells); each chain is evaluated exactly as for K = 1.
+template <int K>
+SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
+                                   const sdp_real *T, const sdp_real *x,
+                                   const sdp_real (*u)[SDP_NU], sdp_real t, sdp_real *out)
 {
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
-    const sdp_real xn0 = sdp_model_lead(x, u, t);
-    const sdp_real sn = (xn0 - l.smin) / l.span;                      // pyx:75
-    const sdp_real p = sn * l.nm1;
-    const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);            // pyx:78
-    const sdp_real lam0 = p - (sdp_real)q0;                           // pyx:81
-    const sdp_real oml0 = (sdp_real)1 - lam0;
+    sdp_real lam0[K], oml0[K], acc[K], g[K];
     // two separate 8-byte LDS reads per cell (rows q0 and q0+1 of T[w]): as
     // ds_read_b64 they cost 2 LDS cycles each, conflict-free (bank = row);
     // `volatile` keeps the compiler from fusing them into ds_read2_b64, which
     // runs at half the LDS rate (MI355X_MICROARCH.md, LDS table)
-    typedef __attribute__((address_space(3))) sdp_real lds_real;
-    const volatile lds_real *row = (const volatile lds_real *)(T + q0);
-#if SDP_HAS_W
-#if !SDP_COST_HAS_W
-    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    const volatile sdp_lds_real *row[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const sdp_real xn0 = sdp_model_lead(x, u[j], t);
+        const sdp_real sn = (xn0 - l.smin) / l.span;                  // pyx:75
+        const sdp_real p = sn * l.nm1;
+        const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);        // pyx:78
+        lam0[j] = p - (sdp_real)q0;                                   // pyx:81
+        oml0[j] = (sdp_real)1 - lam0[j];
+        row[j] = (const volatile sdp_lds_real *)(T + q0);
+        acc[j] = (sdp_real)0;
+#if !SDP_COST_HAS_W || !SDP_HAS_W
+        g[j] = sdp_model_cost(x, u[j], (sdp_real)0, t);
 #endif
-    sdp_real acc = (sdp_real)0;
+    }
+#if SDP_HAS_W
     // The LDS reads are issued in batches of SDP_COL_BATCH perturbation points
-    // (volatile keeps their order, so a batch goes out back to back and the
-    // arithmetic of the previous batch overlaps its latency); the expectation
-    // is still accumulated strictly in w order.
+    // (volatile keeps their order); the expectation is accumulated strictly in
+    // w order.
     constexpr int B = SDP_COL_BATCH;
-#if SDP_COL_W_IN_REGS
+    // a partially unrolled loop bounds the region the instruction scheduler sees
+    // (fully unrolled it tends to hoist every read and spill); mode-0 weights
+    // live in registers and need static indices, hence the full unroll there
+#if SDP_COL_WMODE == 0
 #pragma unroll
 #else
-#pragma unroll
+#pragma unroll SDP_COL_UNROLL_W
 #endif
     for (int w0 = 0; w0 < Wn; w0 += B) {
-        sdp_real lo[B], hi[B];
+        sdp_real lo[B][K], hi[B][K];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             if (w0 + b < Wn) {
-                lo[b] = row[(w0 + b) * N0];
-                hi[b] = row[(w0 + b) * N0 + 1];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    lo[b][j] = row[j][(w0 + b) * N0];
+                    hi[b][j] = row[j][(w0 + b) * N0 + 1];
+                }
             }
         }
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const int w = w0 + b;
             if (w < Wn) {
-                const sdp_real val = oml0 * lo[b] + lam0 * hi[b];     // outermost lerp, pyx:88-300
-#if SDP_COL_W_IN_REGS
-                const sdp_real pw = k.p[w];
-#else
-                const sdp_real pw = k.gp[w];
-#endif
+                const sdp_real pw = SDP_COL_PW(k, w);
 #if SDP_COST_HAS_W
-#if SDP_COL_W_IN_REGS
-                const sdp_real g = sdp_model_cost(x, u, k.w[w], t);
-#else
-                const sdp_real g = sdp_model_cost(x, u, k.gw[w], t);
+                const sdp_real gw = SDP_COL_GW(k, w);
 #endif
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const sdp_real val = oml0[j] * lo[b][j] + lam0[j] * hi[b][j];   // pyx:88-300
+#if SDP_COST_HAS_W
+                    g[j] = sdp_model_cost(x, u[j], gw, t);
 #endif
-                const sdp_real jc = g + val;                          // stodynprog.py:677
-                acc = acc + jc * pw;                                  // stodynprog.py:681
+                    const sdp_real jc = g[j] + val;                   // stodynprog.py:677
+                    acc[j] = acc[j] + jc * pw;                        // stodynprog.py:681
+                }
             }
         }
     }
-    return acc;
+#pragma unroll
+    for (int j = 0; j < K; ++j) out[j] = acc[j];
 #else
-    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
-    const sdp_real lo = row[0];
-    const sdp_real hi = row[1];
-    return g + (oml0 * lo + lam0 * hi);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const sdp_real lo = row[j][0];
+        const sdp_real hi = row[j][1];
+        out[j] = g[j] + (oml0[j] * lo + lam0[j] * hi);
+    }
 #endif
 }
 
@@ -332,7 +382,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     SdpColWalk walk;
     sdp_col_walk(a, walk);
     SdpColWeights wts;
-    sdp_col_load_weights(a, wts);
+    sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
@@ -367,11 +417,22 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
                 sdp_real best = INFINITY;
                 int ibest = INT_MAX;
-                for (int ci = c_lo; ci < c_hi; ++ci) {
-                    sdp_real u[SDP_NU];
-                    sdp_controls_at(box, ci, u);
-                    const sdp_real jc = sdp_col_expected_cost(wts, lead, s.T, x, u, t);
-                    if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
+                constexpr int K = SDP_COL_UNROLL_U;
+                int ci = c_lo;
+                for (; ci + K <= c_hi; ci += K) {             // K controls at a time
+                    sdp_real u[K][SDP_NU], jc[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) sdp_controls_at(box, ci + j, u[j]);
+                    sdp_col_expected_cost<K>(wts, lead, s.T, x, u, t, jc);
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+                        if (ibest == INT_MAX || sdp_better_seq(jc[j], best)) { best = jc[j]; ibest = ci + j; }
+                }
+                for (; ci < c_hi; ++ci) {                     // remainder
+                    sdp_real u[1][SDP_NU], jc[1];
+                    sdp_controls_at(box, ci, u[0]);
+                    sdp_col_expected_cost<1>(wts, lead, s.T, x, u, t, jc);
+                    if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
                 }
                 if (chunks == 1) {
                     sdp_col_store(a, node, box, best, ibest);
@@ -420,7 +481,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     SdpColWalk walk;
     sdp_col_walk(a, walk);
     SdpColWeights wts;
-    sdp_col_load_weights(a, wts);
+    sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
         const int part = (int)(unit % a.col_splits);
@@ -432,11 +493,12 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
         sdp_col_build_table(a, tg, s, x, t);
         for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {
             const int64_t node = col * N0 + i;
-            sdp_real u[SDP_NU];
+            sdp_real u[1][SDP_NU], jc[1];
             x[0] = axis0[i];
 #pragma unroll
-            for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-            ((sdp_real *)a.J)[node] = sdp_col_expected_cost(wts, lead, s.T, x, u, t);
+            for (int c = 0; c < SDP_NU; ++c) u[0][c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+            sdp_col_expected_cost<1>(wts, lead, s.T, x, u, t, jc);
+            ((sdp_real *)a.J)[node] = jc[0];
         }
     }
 }
