@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_ISSUE_PEAK = 4.85e11      # fp64 VALU wave-instructions/s, measured (profiles/ubench_fp64_rate.txt)
 
 
 def algorithmic_bytes(S, U, W, d, real_bytes, nu):
@@ -137,6 +138,16 @@ def main():
     bytes_launch = algorithmic_bytes(nodes_per_launch, U, W, d, rb, nu)
     k_ms = kernel_ms / args.steps
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+    # HBM-side traffic of one launch from the committed rocprofv3 PMC passes of
+    # this same command (profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) KiB
+    traffic = None
+    if (N, rb, world, solver.backend_info.get('kernel')) == (256, 8, 1, 'column'):
+        traffic = (2 * 1.1873e6 + 327680.0) * 1024
+    # the column kernel's real ceiling: 6 fp64 operations per lattice cell that
+    # bit-exactness does not allow to fuse, against the measured fp64 VALU
+    # issue rate of the chip (profiles/ubench_fp64_rate.txt)
+    fp64_wave_instr = nodes_per_launch * U * W * 6 / 64.0
+    fp64_rate = fp64_wave_instr / (k_ms * 1e-3)
     out = {
         'metric': 'vi_sweeps_per_sec', 'value': sweeps_per_s, 'unit': 'sweeps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -150,7 +161,11 @@ def main():
         'state_cells_per_sec': S * sweeps_per_s,
         'lattice_cells_per_sec': S * U * W * sweeps_per_s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'traffic_source': 'profiles/r01_col_v4_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
+                                       'WRITE_SIZE, FETCH x2 per the gfx950 correction)' if traffic else None,
+                     'fp64_valu_wave_instr_per_s': fp64_rate, 'fp64_valu_peak_measured': FP64_ISSUE_PEAK,
+                     'fp64_valu_frac': fp64_rate / FP64_ISSUE_PEAK,
                      'kernel': 'sdp_sweep_col' if solver.backend_info.get('kernel') == 'column' else 'sdp_sweep',
                      'kernel_ms': k_ms,
                      'algorithmic_bytes_per_launch': bytes_launch,

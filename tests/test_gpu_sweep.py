@@ -448,3 +448,32 @@ def test_column_kernel_is_the_default_for_storage_problems(gpu):
     big.kernel = 'column'
     with pytest.raises(ValueError):
         big._kernel_plan()
+
+
+# ---------------------------------------------------------------- RCCL plumbing
+def test_rccl_communicator_single_rank(gpu):
+    """librccl loads, a 1-rank communicator initialises, attaches to a problem
+    handle, and the device collectives used by bench.py work (the N > 1 data
+    path is the same code with more ranks; its slab logic is covered on CPU in
+    test_dist_cpu.py)."""
+    from stodynprog_amd import dist
+    uid = dist.RcclCommunicator.new_unique_id()
+    assert len(uid) == 128
+    comm = dist.RcclCommunicator(0, 1, uid)
+    try:
+        assert comm.allreduce_max(3.5) == 3.5
+        comm.barrier()
+        sysd, ref = models.synthetic3d(N=20)
+        s = DPSolver(sysd, comm=comm)
+        s.discretize_state(0, 1, 20, 0, 1, 20, 0, 1, 20)
+        s.perturb_grid, s.perturb_proba = ref.perturb_grid, ref.perturb_proba
+        s.control_steps = ref.control_steps
+        V0 = models.synthetic3d_V0(s.state_grid)
+        J, u = s.value_iteration(V0, report_time=False)
+        Jr, ur = ref.value_iteration(V0, report_time=False)
+        assert np.array_equal(J, Jr) and np.array_equal(u, ur)
+        (Jd, r), _ = s.value_iteration((J - J[10, 10, 10], 0.), rel_dp=True, report_time=False)
+        assert Jd[10, 10, 10] == 0.0
+    finally:
+        s._cache.clear()
+        comm.close()
