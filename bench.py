@@ -134,7 +134,10 @@ def main():
     # roofline of the dominant kernel (sdp_sweep): algorithmic bytes of the
     # nodes ONE launch processes / its average duration (HIP events on the
     # kernel's stream, measured above inside the timed region)
-    nodes_per_launch = prob.node_range[1] - prob.node_range[0]
+    if prob.parts is not None:       # sharded: this rank's nodes, summed over its phase launches
+        nodes_per_launch = int((prob.parts[:, rank + 1] - prob.parts[:, rank]).sum())
+    else:
+        nodes_per_launch = prob.node_range[1] - prob.node_range[0]
     bytes_launch = algorithmic_bytes(nodes_per_launch, U, W, d, rb, nu)
     k_ms = kernel_ms / args.steps
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9

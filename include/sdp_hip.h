@@ -170,7 +170,16 @@ int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_off, int64_t
 int sdp_comm_unique_id(char id[128]);                       /* rank 0 */
 int sdp_comm_create(int rank, int nranks, const char id[128], sdp_comm **out);
 int sdp_comm_destroy(sdp_comm *c);
-int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, const int64_t *slab_bounds /* [nranks+1] */);
+/*
+ * Shard the handle's backups over the ranks of `c`.  The node range (device
+ * order) is cut into n_phases contiguous phases and every phase into one part
+ * per rank: part_bounds[ph*(nranks+1) + r] .. [.. + r + 1] are rank r's nodes of
+ * phase ph (whole columns in SDP_LAYOUT_COLUMNS).  Each backup then runs phase by
+ * phase; the RCCL all-gather of a phase overlaps the kernel of the next one.
+ * The handle must have been created with node range [0, S).
+ */
+int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
+                            const int64_t *part_bounds /* [n_phases][nranks+1] */);
 int sdp_comm_allreduce_max(sdp_comm *c, double *inout);    /* host scalar, for timing */
 int sdp_comm_barrier(sdp_comm *c);
 

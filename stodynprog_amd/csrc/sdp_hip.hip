@@ -483,7 +483,11 @@ struct sdp_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double last_kernel_ms = 0;
     sdp_comm *comm = nullptr;
-    std::vector<int64_t> slabs;
+    std::vector<int64_t> parts;            // [n_phases][nranks+1] node bounds (device order)
+    std::vector<hipEvent_t> ev_phase;
+    hipEvent_t ev_comm = nullptr;
+    int n_phases = 0;
+    bool comm_pending = false;
     int cus = 256;
     int refs_cap = 0;
     ~sdp_problem()
@@ -493,6 +497,8 @@ struct sdp_problem {
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
         if (ev3) (void)hipEventDestroy(ev3);
+        if (ev_comm) (void)hipEventDestroy(ev_comm);
+        for (auto &e : ev_phase) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -603,20 +609,20 @@ extern "C" int sdp_problem_set_policy(sdp_problem *p, const void *host_pol)
     return SDP_OK;
 }
 
-static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k)
+static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t nb, int64_t ne)
 {
     memset(&a, 0, sizeof(a));
     a.V = p->V.p; a.J = p->J.p; a.pol = p->pol.p; a.idx = (int32_t *)p->idx.p;
     a.axes = p->axes.p; a.wgrid = p->wgrid.p; a.proba = p->proba.p;
     a.box_lo = p->box_lo.p; a.box_hi = p->box_hi.p; a.box_n = (const int32_t *)p->box_n.p;
     a.pol_in = p->pol_in.p;
-    a.node_begin = p->node_begin; a.node_end = p->node_end; a.S = p->S; a.t_k = t_k;
+    a.node_begin = nb; a.node_end = ne; a.S = p->S; a.t_k = t_k;
     for (int k = 0; k < SDP_MAXD; ++k) { a.orders[k] = p->orders[k]; a.axis_off[k] = p->axis_off[k]; }
     a.W = p->W; a.box_per_node = p->box_per_node;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
-        a.col_begin = p->node_begin / p->orders[0];
-        a.col_end = p->node_end / p->orders[0];
+        a.col_begin = nb / p->orders[0];
+        a.col_end = ne / p->orders[0];
         a.col_splits = 1;
     }
 }
@@ -655,9 +661,8 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
 
 // workgroups for the sweep: a multiple of 8 (one share per XCD), enough to
 // fill every CU several times over, never more than there are node tiles
-static unsigned sweep_blocks(const sdp_problem *p)
+static unsigned sweep_blocks(const sdp_problem *p, int64_t nodes)
 {
-    const int64_t nodes = p->node_end - p->node_begin;
     const int64_t tile = (64 / p->lanes) * 4;
     int64_t tiles = (nodes + tile - 1) / tile;
     int64_t blocks = (int64_t)p->cus * 8;
@@ -667,27 +672,26 @@ static unsigned sweep_blocks(const sdp_problem *p)
     return (unsigned)blocks;
 }
 
-static int launch_sweep(sdp_problem *p, double t_k)
+static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
 {
-    if (p->node_end == p->node_begin) return SDP_OK;
+    if (ne <= nb) return SDP_OK;
     SdpSweepArgs a;
-    fill_args(p, a, t_k);
+    fill_args(p, a, t_k, nb, ne);
     if (p->layout == SDP_LAYOUT_COLUMNS) {
-        // 512-thread workgroups (8 waves share one LDS table); a wave backs up
-        // 64/lanes nodes at a time
+        // 512-thread workgroups: 8 waves share one LDS table, one lane per node
         unsigned threads = 512;
         if (const char *e = getenv("SDP_COL_THREADS")) threads = (unsigned)atoi(e);   // tuning only
-        const unsigned blocks = column_grid(p, a, 64);          // one lane per node
+        const unsigned blocks = column_grid(p, a, 64);
         return launch_module(p->f_sweep, a, blocks, threads, p->stream);
     }
-    return launch_module(p->f_sweep, a, sweep_blocks(p), 256, p->stream);
+    return launch_module(p->f_sweep, a, sweep_blocks(p, ne - nb), 256, p->stream);
 }
 
-static int launch_evalpol(sdp_problem *p, double t_k)
+static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
 {
-    if (p->node_end == p->node_begin) return SDP_OK;
+    if (ne <= nb) return SDP_OK;
     SdpSweepArgs a;
-    fill_args(p, a, t_k);
+    fill_args(p, a, t_k, nb, ne);
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         const unsigned blocks = column_grid(p, a, 64);       // one lane per node
         const int per_split = (p->orders[0] + a.col_splits - 1) / a.col_splits;
@@ -695,35 +699,81 @@ static int launch_evalpol(sdp_problem *p, double t_k)
         if (threads > 512) threads = 512;
         return launch_module(p->f_evalpol, a, blocks, threads, p->stream);
     }
-    const int64_t nodes = p->node_end - p->node_begin;
+    const int64_t nodes = ne - nb;
     int64_t blocks = (nodes + 255) / 256;
     if (blocks > (int64_t)p->cus * 16) blocks = (int64_t)p->cus * 16;
     return launch_module(p->f_evalpol, a, (unsigned)blocks, 256, p->stream);
 }
 
-// all-gather of the J slabs (in place in the J buffer) on the problem's stream
-static int gather_slabs(sdp_problem *p)
+// Exchange of one phase of J (in place in the J buffer) on the communicator's
+// stream: rank r owns [b[r], b[r+1]) of the phase; equal parts go through one
+// ncclAllGather, uneven ones through grouped broadcasts.
+static int gather_phase(sdp_problem *p, int phase)
 {
-    if (!p->comm || p->comm->nranks == 1) return SDP_OK;
     const size_t rs = real_size(p->dtype);
     const int dt = p->dtype == SDP_F32 ? NCCL_FLOAT32 : NCCL_FLOAT64;
     const int n = p->comm->nranks;
+    const int64_t *b = p->parts.data() + (size_t)phase * (n + 1);
     bool even = true;
-    const int64_t len0 = p->slabs[1] - p->slabs[0];
-    for (int r = 0; r < n; ++r) even = even && (p->slabs[r + 1] - p->slabs[r] == len0);
+    const int64_t len0 = b[1] - b[0];
+    for (int r = 0; r < n; ++r) even = even && (b[r + 1] - b[r] == len0);
+    if (b[n] == b[0]) return SDP_OK;
     char *base = (char *)p->J.p;
+    hipStream_t cs = p->comm->stream;
     if (even) {
-        NCCL_TRY(g_rccl.AllGather(base + p->slabs[p->comm->rank] * rs, base + p->slabs[0] * rs,
-                                  (size_t)len0, dt, p->comm->comm, p->stream));
+        NCCL_TRY(g_rccl.AllGather(base + b[p->comm->rank] * rs, base + b[0] * rs, (size_t)len0, dt,
+                                  p->comm->comm, cs));
     } else {
         NCCL_TRY(g_rccl.GroupStart());
         for (int r = 0; r < n; ++r) {
-            const int64_t cnt = p->slabs[r + 1] - p->slabs[r];
+            const int64_t cnt = b[r + 1] - b[r];
             if (cnt == 0) continue;
-            void *ptr = base + p->slabs[r] * rs;
-            NCCL_TRY(g_rccl.Broadcast(ptr, ptr, (size_t)cnt, dt, r, p->comm->comm, p->stream));
+            void *ptr = base + b[r] * rs;
+            NCCL_TRY(g_rccl.Broadcast(ptr, ptr, (size_t)cnt, dt, r, p->comm->comm, cs));
         }
         NCCL_TRY(g_rccl.GroupEnd());
+    }
+    return SDP_OK;
+}
+
+// One backup (Bellman sweep or fixed-policy evaluation) over the nodes this
+// handle owns, V -> J.  Single GPU: one launch.  With a communicator the node
+// range is cut into phases, every phase is shared out over the ranks, and the
+// all-gather of phase k (communicator stream) overlaps the kernel of phase k+1
+// (problem stream); the problem stream then waits for the last gather, so
+// whatever follows (relative-DP shift, next sweep) sees the complete J.
+static int run_backup(sdp_problem *p, bool evalpol, double t_k)
+{
+    int rc;
+    if (!p->comm) {
+        return evalpol ? launch_evalpol(p, t_k, p->node_begin, p->node_end)
+                       : launch_sweep(p, t_k, p->node_begin, p->node_end);
+    }
+    const int n = p->comm->nranks, rank = p->comm->rank;
+    for (int ph = 0; ph < p->n_phases; ++ph) {
+        const int64_t *b = p->parts.data() + (size_t)ph * (n + 1);
+        rc = evalpol ? launch_evalpol(p, t_k, b[rank], b[rank + 1])
+                     : launch_sweep(p, t_k, b[rank], b[rank + 1]);
+        if (rc) return rc;
+        if (n > 1) {
+            HIP_TRY(hipEventRecord(p->ev_phase[ph], p->stream));
+            HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
+            if ((rc = gather_phase(p, ph))) return rc;
+        }
+    }
+    if (n > 1) {
+        HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
+        p->comm_pending = true;
+    }
+    return SDP_OK;
+}
+
+// make the problem stream wait for the exchange of the last backup
+static int join_comm(sdp_problem *p)
+{
+    if (p->comm_pending) {
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_comm, 0));
+        p->comm_pending = false;
     }
     return SDP_OK;
 }
@@ -768,9 +818,9 @@ extern "C" int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int6
     if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
     if ((rc = ensure_refs(p, 1))) return rc;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
-    if ((rc = launch_sweep(p, t_k))) return rc;
+    if ((rc = run_backup(p, false, t_k))) return rc;
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
-    if ((rc = gather_slabs(p))) return rc;
+    if ((rc = join_comm(p))) return rc;
     if (rel_dp && (rc = rel_shift(p, ref_index, 0))) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
     float ms = 0;
@@ -804,8 +854,8 @@ extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_d
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     for (int k = 0; k < n_iter; ++k) {
         if (k > 0) std::swap(p->V.p, p->J.p);
-        if ((rc = launch_evalpol(p, 0.0))) return rc;
-        if ((rc = gather_slabs(p))) return rc;
+        if ((rc = run_backup(p, true, 0.0))) return rc;
+        if ((rc = join_comm(p))) return rc;
         if (rel_dp && (rc = rel_shift(p, ref_index, k))) return rc;
     }
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
@@ -852,9 +902,9 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
     for (int r = 0; r < reps; ++r) {
         if (r > 0) std::swap(p->V.p, p->J.p);
         HIP_TRY(hipEventRecord(ev[2 * r], p->stream));
-        if ((rc = launch_sweep(p, 0.0))) return rc;
+        if ((rc = run_backup(p, false, 0.0))) return rc;
         HIP_TRY(hipEventRecord(ev[2 * r + 1], p->stream));
-        if ((rc = gather_slabs(p))) return rc;
+        if ((rc = join_comm(p))) return rc;
         if (rel_dp && (rc = rel_shift(p, ref_index, 0))) return rc;
     }
     HIP_TRY(hipEventRecord(p->ev3, p->stream));
@@ -873,17 +923,33 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
     return SDP_OK;
 }
 
-extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, const int64_t *slab_bounds)
+extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
+                                       const int64_t *part_bounds)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
-    if (!c) { p->comm = nullptr; p->slabs.clear(); return SDP_OK; }
-    if (!slab_bounds) return fail(SDP_EINVAL, "slab bounds missing");
-    p->slabs.assign(slab_bounds, slab_bounds + c->nranks + 1);
-    if (p->slabs.front() != 0 || p->slabs.back() != p->S) return fail(SDP_EINVAL, "slab bounds must cover [0,S)");
-    for (int r = 0; r < c->nranks; ++r)
-        if (p->slabs[r] > p->slabs[r + 1]) return fail(SDP_EINVAL, "slab bounds must be non-decreasing");
-    if (p->slabs[c->rank] != p->node_begin || p->slabs[c->rank + 1] != p->node_end)
-        return fail(SDP_EINVAL, "this rank's slab does not match the handle's node range");
+    if (!c) { p->comm = nullptr; p->parts.clear(); p->n_phases = 0; return SDP_OK; }
+    if (!part_bounds || n_phases < 1) return fail(SDP_EINVAL, "phase partition missing");
+    const int n = c->nranks;
+    std::vector<int64_t> parts(part_bounds, part_bounds + (size_t)n_phases * (n + 1));
+    int64_t at = 0;
+    const int64_t unit = p->layout == SDP_LAYOUT_COLUMNS ? p->orders[0] : 1;
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int64_t *b = parts.data() + (size_t)ph * (n + 1);
+        if (b[0] != at) return fail(SDP_EINVAL, "phases must be contiguous and start at node 0");
+        for (int r = 0; r < n; ++r) {
+            if (b[r] > b[r + 1]) return fail(SDP_EINVAL, "phase partition must be non-decreasing");
+            if (b[r] % unit) return fail(SDP_EINVAL, "column layout: parts must consist of whole columns");
+        }
+        at = b[n];
+    }
+    if (at != p->S) return fail(SDP_EINVAL, "phases must cover all %lld nodes", (long long)p->S);
+    for (auto &e : p->ev_phase) (void)hipEventDestroy(e);
+    p->ev_phase.assign((size_t)n_phases, nullptr);
+    for (auto &e : p->ev_phase) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!p->ev_comm) HIP_TRY(hipEventCreateWithFlags(&p->ev_comm, hipEventDisableTiming));
+    p->parts.swap(parts);
+    p->n_phases = n_phases;
     p->comm = c;
+    p->comm_pending = false;
     return SDP_OK;
 }

@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-__all__ = ['slab_bounds', 'RcclCommunicator', 'GlooCommunicator', 'from_env']
+__all__ = ['slab_bounds', 'phase_partition', 'RcclCommunicator', 'GlooCommunicator', 'from_env']
 
 
 def slab_bounds(shape, nranks):
@@ -33,6 +33,22 @@ def slab_bounds(shape, nranks):
     bounds = np.zeros(nranks + 1, dtype=np.int64)
     for r in range(nranks):
         bounds[r + 1] = bounds[r] + (base + (1 if r < extra else 0)) * plane
+    return bounds
+
+
+def phase_partition(n_units, unit, nranks, n_phases):
+    """Node bounds [n_phases][nranks+1] for the overlapped multi-GPU backup:
+    `n_units` work units of `unit` nodes each (columns of the column layout, or
+    single nodes) are cut into `n_phases` contiguous phases and every phase
+    into one contiguous part per rank, all as even as possible.  Phases let
+    the all-gather of one phase run under the kernel of the next."""
+    n_phases = max(1, min(int(n_phases), max(1, n_units // max(nranks, 1))))
+    bounds = np.zeros((n_phases, nranks + 1), dtype=np.int64)
+    for ph in range(n_phases):
+        lo = n_units * ph // n_phases
+        hi = n_units * (ph + 1) // n_phases
+        for r in range(nranks + 1):
+            bounds[ph, r] = (lo + (hi - lo) * r // nranks) * unit
     return bounds
 
 
@@ -144,7 +160,27 @@ def from_env():
     if not dist.is_initialized():
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
     host = GlooCommunicator()
-    uid = RcclCommunicator.new_unique_id() if rank == 0 else None
-    uid = host.broadcast_bytes(uid, src=0)
-    dev = RcclCommunicator(rank, world, uid)
+    with _stdout_to_stderr():          # RCCL prints a version banner on stdout at init
+        uid = RcclCommunicator.new_unique_id() if rank == 0 else None
+        uid = host.broadcast_bytes(uid, src=0)
+        dev = RcclCommunicator(rank, world, uid)
+        dev.barrier()
     return dev, host
+
+
+class _stdout_to_stderr(object):
+    """Send file descriptor 1 to stderr for the duration of the block, so that
+    banners printed by native libraries cannot land in a program's stdout
+    (bench.py promises exactly one JSON line there)."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)

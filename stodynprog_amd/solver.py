@@ -69,9 +69,13 @@ class _DeviceProblem(object):
         nat.check(nat.lib().sdp_problem_create(C.byref(d), C.byref(h)))
         self.h = h
         self.node_range = tuple(node_range)
+        self.parts = None
         if comm is not None:
-            bounds = np.ascontiguousarray(slab_bounds, dtype=np.int64)
-            nat.check(nat.lib().sdp_problem_attach_comm(self.h, comm.handle, nat.ptr(bounds)))
+            # slab_bounds: [n_phases][nranks+1] partition (dist.phase_partition)
+            self.parts = np.ascontiguousarray(slab_bounds, dtype=np.int64)
+            nat.check(nat.lib().sdp_problem_attach_comm(self.h, comm.handle,
+                                                        int(self.parts.shape[0]),
+                                                        nat.ptr(self.parts)))
 
     def close(self):
         if getattr(self, 'h', None):
@@ -168,6 +172,7 @@ class DPSolver(object):
         self.dtype = np.dtype(dtype)
         self.comm = comm
         self.kernel = 'auto'               # 'auto' | 'generic' | 'column' (see _problem)
+        self.comm_phases = 4               # multi-GPU: phases per backup (comm/compute overlap)
         self._cache = {}
         self.last_policy_index = None      # flat control-lattice index of the last sweep
         self.backend_info = {}
@@ -274,24 +279,35 @@ class DPSolver(object):
 
         lo = hi = None
         try:
-            full = [np.ascontiguousarray(a, dtype=float) for a in self.state_grid_full]
+            # open (sparse) grids: axis k has shape (1,..,N_k,..,1), so a box that
+            # ignores the state, or depends on one axis only, stays small
+            d = len(shape)
+            open_grid = [np.asarray(g, dtype=float).reshape((1,) * k + (-1,) + (1,) * (d - k - 1))
+                         for k, g in enumerate(self.state_grid)]
             with np.errstate(all='ignore'):
-                box = self.sys.control_box(*(lead + tuple(full)), **params)
+                box = self.sys.control_box(*(lead + tuple(open_grid)), **params)
             if len(box) != nu:
                 raise ValueError
-            lo_v = np.empty((nu, S))
-            hi_v = np.empty((nu, S))
-            for c, (a, b) in enumerate(box):
-                lo_v[c] = np.broadcast_to(np.asarray(a, dtype=float), shape).ravel()
-                hi_v[c] = np.broadcast_to(np.asarray(b, dtype=float), shape).ravel()
+            ends = [(np.asarray(a, dtype=float), np.asarray(b, dtype=float)) for a, b in box]
+            constant = all(a.size == 1 and b.size == 1 for a, b in ends)
+            cols = 1 if constant else S
+            lo_v = np.empty((nu, cols))
+            hi_v = np.empty((nu, cols))
+            for c, (a, b) in enumerate(ends):
+                if constant:
+                    lo_v[c, 0], hi_v[c, 0] = a.reshape(()), b.reshape(())
+                else:
+                    lo_v[c] = np.broadcast_to(a, shape).ravel()
+                    hi_v[c] = np.broadcast_to(b, shape).ravel()
             rng = np.random.default_rng(12345)
             probe = set(rng.integers(0, S, size=min(S, 48)).tolist())
             probe.update([0, S - 1, S // 2])
             ok = True
             for flat in probe:
                 sb = scalar_box(flat)
+                col = 0 if constant else flat
                 for c, (a, b) in enumerate(sb):
-                    if not (_same(lo_v[c, flat], a) and _same(hi_v[c, flat], b)):
+                    if not (_same(lo_v[c, col], a) and _same(hi_v[c, col], b)):
                         ok = False
             if ok:
                 lo, hi = lo_v, hi_v
@@ -305,7 +321,7 @@ class DPSolver(object):
                 for c, (a, b) in enumerate(box):
                     lo[c, flat] = a
                     hi[c, flat] = b
-        n = np.empty((nu, S), dtype=np.int32)
+        n = np.empty(lo.shape, dtype=np.int32)
         with np.errstate(all='ignore'):
             for c in range(nu):
                 step = self.control_steps[c]
@@ -412,7 +428,14 @@ class DPSolver(object):
         module = nat.compile_model(source)
         # slabs: whole hyperplanes of the outermost axis of the device layout
         dev_shape = (shape[1:] + shape[:1]) if column else shape
-        if self.comm is not None:
+        if self.comm is not None and self.comm.is_device:
+            # RCCL: the library shares out phases of the node range and overlaps
+            # each phase's all-gather with the next phase's kernel
+            from .dist import phase_partition
+            unit = shape[0] if column else 1
+            bounds = phase_partition(S // unit, unit, self.comm.nranks, self.comm_phases)
+            node_range = (0, S)
+        elif self.comm is not None:
             bounds = self.comm.slab_bounds(dev_shape)
             node_range = (int(bounds[self.comm.rank]), int(bounds[self.comm.rank + 1]))
         else:

@@ -25,6 +25,19 @@ def test_slab_bounds():
     assert list(dist.slab_bounds((7,), 1)) == [0, 7]
 
 
+def test_phase_partition():
+    b = dist.phase_partition(65536, 256, 8, 4)           # 256^3 column layout on 8 GPUs
+    assert b.shape == (4, 9) and b[0, 0] == 0 and b[-1, -1] == 256 ** 3
+    assert (np.diff(b, axis=1) == 2048 * 256).all()      # equal parts -> one ncclAllGather each
+    assert (b[1:, 0] == b[:-1, -1]).all()                # phases are contiguous
+    b = dist.phase_partition(10, 1, 3, 4)                 # uneven: 10 nodes, 3 ranks
+    assert b[0, 0] == 0 and b[-1, -1] == 10 and (np.diff(b, axis=1) >= 0).all()
+    assert (b[1:, 0] == b[:-1, -1]).all()
+    assert dist.phase_partition(5, 7, 8, 4).shape[0] == 1   # fewer units than ranks: one phase
+    b = dist.phase_partition(61, 41, 2, 4)
+    assert (b % 41 == 0).all() and b[-1, -1] == 61 * 41
+
+
 WORKER = r'''
 import os, sys
 import numpy as np

@@ -474,6 +474,42 @@ def test_rccl_communicator_single_rank(gpu):
         assert np.array_equal(J, Jr) and np.array_equal(u, ur)
         (Jd, r), _ = s.value_iteration((J - J[10, 10, 10], 0.), rel_dp=True, report_time=False)
         assert Jd[10, 10, 10] == 0.0
+        # the communicator path runs every backup phase by phase (4 launches here)
+        prob = s._problem()
+        assert prob.parts is not None and prob.parts.shape == (4, 2)
+        assert prob.parts[0, 0] == 0 and prob.parts[-1, -1] == 8000
+        E, refs = quiet(s.eval_policy, u, 5, True, J * 0.5, J_ref_full=True)
+        Er, refs_r = quiet(ref.eval_policy, u, 5, True, J * 0.5, J_ref_full=True)
+        assert np.array_equal(E, Er) and np.array_equal(refs, refs_r)
     finally:
         s._cache.clear()
         comm.close()
+
+
+def test_column_kernel_partial_ranges_match_full_sweep(gpu):
+    """what each rank computes in the multi-GPU sweep: the column kernel over
+    sub-ranges of columns (the parts of dist.phase_partition) gives the same
+    bits as one launch over everything"""
+    from stodynprog_amd import dist, _native as nat
+    from stodynprog_amd.solver import _DeviceProblem
+    _, solver = models.synthetic3d(N=24)
+    V = np.random.default_rng(5).standard_normal((24, 24, 24))
+    J, u = solver.value_iteration(V, report_time=False)
+    full = solver._problem()
+    assert full.layout == nat.LAYOUT_COLUMNS
+    Jd = full._to_device_order(J).ravel()
+    parts = dist.phase_partition(24 * 24, 24, 3, 4)        # 3 ranks, 4 phases
+    merged = np.full(Jd.shape, np.nan)
+    for rank in range(3):
+        for ph in range(parts.shape[0]):
+            lo, hi = int(parts[ph, rank]), int(parts[ph, rank + 1])
+            if hi == lo:
+                continue
+            sub = _DeviceProblem(full._keep, solver.backend_info['module'], np.float64,
+                                 (24, 24, 24), 1, 32, solver.backend_info['lanes_per_node'],
+                                 False, (lo, hi), layout=nat.LAYOUT_COLUMNS)
+            sub.set_value(V)
+            sub.sweep()
+            merged[lo:hi] = sub._to_device_order(sub.get_value()).ravel()[lo:hi]
+            sub.close()
+    assert np.array_equal(merged, Jd)
