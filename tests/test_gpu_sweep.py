@@ -513,3 +513,54 @@ def test_column_kernel_partial_ranges_match_full_sweep(gpu):
             merged[lo:hi] = sub._to_device_order(sub.get_value()).ravel()[lo:hi]
             sub.close()
     assert np.array_equal(merged, Jd)
+
+
+# ---------------------------------------------------------------- end-to-end known answers
+def test_searev_policy_iteration_reproduces_the_committed_policy(gpu, capsys):
+    """The reference example ships the optimal storage policy computed by
+    policy_iteration(pol_lin, n_val=1000, n_pol=5, rel_dp=True)
+    (examples/20 Searev storage control/storage_control.py:137-160; 773 s on one
+    CPU core).  Same call here: 6000 policy evaluations + 5 sweeps of
+    31x61x61 nodes x up to 2201 controls x 9 perturbations."""
+    g = golden('g4_searev')
+    committed = g['committed_policy']
+    assert committed.shape == (31, 61, 61, 1)
+    _, solver = models.searev()
+    pol_lin = models.searev_linear_policy(solver)
+    (J, J_ref), pol = solver.policy_iteration(pol_lin, 1000, 5, rel_dp=True)
+    out = capsys.readouterr().out.replace('\r', '\n')
+    costs = [float(l.split(':')[1]) for l in out.split('\n') if l.startswith('ref policy cost')]
+    assert len(costs) == 6
+    assert '{:g}'.format(costs[-1]) == '0.0746743'          # BASELINE.md section 2
+    same = pol == committed
+    # control step is 0.001: entries that differ (near-ties of the argmin) may
+    # only move by a few steps
+    assert same.mean() > 0.999, same.mean()
+    assert np.abs(pol - committed).max() < 0.02
+
+
+# ---------------------------------------------------------------- config 5
+def test_fp32_512cubed_against_fp64_oracle(gpu):
+    """BASELINE config 5: 512^3 fp32 sweep with policy-index extraction,
+    tolerance 1e-5 against the fp64 oracle on the same grid (sampled nodes)."""
+    sysd, ref = models.synthetic3d(N=512)
+    s32 = DPSolver(sysd, dtype=np.float32)
+    s32.state_grid, s32._state_grid_shape = ref.state_grid, ref._state_grid_shape
+    s32._state_ref_ind = ref._state_ref_ind
+    s32.perturb_grid, s32.perturb_proba = ref.perturb_grid, ref.perturb_proba
+    s32.control_steps = ref.control_steps
+    V0 = models.synthetic3d_V0(ref.state_grid)                # fp64, 1.07 GB
+    J32, u32 = s32.value_iteration(V0.astype(np.float32), report_time=False)
+    assert s32.backend_info['kernel'] == 'column' and J32.dtype == np.float32
+    idx32 = s32.last_policy_index
+    nodes = np.random.default_rng(9).integers(0, V0.size, 20000)
+    Jo, io, mo = c_oracle.vi_synth3d(ref.state_grid, V0, models.SYNTH_PAR, -1., 1., 64,
+                                     ref.perturb_grid[0], ref.perturb_proba[0],
+                                     node_ids=nodes, n_threads=8)
+    rel = np.abs(J32.ravel()[nodes] - Jo).max() / np.abs(Jo).max()
+    assert rel < 1e-5, rel
+    # indices: exact wherever the fp64 margin is above fp32 resolution
+    clear = mo > 1e-5 * np.maximum(1.0, np.abs(Jo))
+    assert (idx32.ravel()[nodes][clear] == io[clear]).all()
+    assert clear.mean() > 0.5
+    assert idx32.min() >= 0 and idx32.max() <= 63
