@@ -33,14 +33,16 @@ extern "C" {
 #define SDP_F32 1
 
 /*
- * Order of every per-node array of a problem handle (value, policy, index,
- * per-node control boxes):
- *   SDP_LAYOUT_NODES    C order of the state grid, last axis fastest -- the
- *                       order of the reference's arrays (stodynprog.py:272,478);
- *   SDP_LAYOUT_COLUMNS  axis 0 moved last (numpy.moveaxis(A, 0, -1), then C
- *                       order): used by the column kernels for storage-separable
- *                       models, whose table build reads axis-0 pencils coalesced.
- *                       node_begin/node_end must then be multiples of orders[0].
+ * How a problem handle stores its per-node arrays ON THE DEVICE.  Host arrays
+ * passed to / returned by this API (value, policy, index, per-node control
+ * boxes) are ALWAYS in the reference's order: C order of the state grid, last
+ * axis fastest (stodynprog.py:272,478); the library converts on the device.
+ *   SDP_LAYOUT_NODES    device order = host order (generic kernels);
+ *   SDP_LAYOUT_COLUMNS  axis 0 fastest (numpy.moveaxis(A, 0, -1)): the column
+ *                       kernels for storage-separable models read axis-0
+ *                       pencils coalesced.  node_begin/node_end and the parts of
+ *                       sdp_problem_attach_comm are indices in DEVICE order and
+ *                       must then be multiples of orders[0] (whole columns).
  */
 #define SDP_LAYOUT_NODES   0
 #define SDP_LAYOUT_COLUMNS 1

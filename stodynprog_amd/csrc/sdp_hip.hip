@@ -357,6 +357,60 @@ extern "C" int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_o
 }
 
 // ---------------------------------------------------------------------------
+// built-in kernel: layout conversion at the API boundary.  Host arrays are
+// always in the reference's C order (last state axis fastest); a handle in
+// SDP_LAYOUT_COLUMNS keeps its per-node arrays with axis 0 fastest.  Both
+// directions are the transpose of an [R][C] matrix of elements of WORDS 32-bit
+// words, done through a 32x33 LDS tile so reads and writes are both coalesced.
+// ---------------------------------------------------------------------------
+template <int WORDS>
+__global__ void __launch_bounds__(256) k_transpose(const uint32_t *__restrict__ in,
+                                                   uint32_t *__restrict__ out, int64_t R, int64_t C)
+{
+    __shared__ uint32_t tile[WORDS][32][33];
+    const int64_t tiles_c = (C + 31) / 32, tiles_r = (R + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
+    for (int64_t t = blockIdx.x; t < tiles_r * tiles_c; t += gridDim.x) {
+        const int64_t r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t r = r0 + j, c = c0 + tx;
+            if (r < R && c < C)
+#pragma unroll
+                for (int k = 0; k < WORDS; ++k) tile[k][j][tx] = in[(r * C + c) * WORDS + k];
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int64_t c = c0 + j, r = r0 + tx;
+            if (r < R && c < C)
+#pragma unroll
+                for (int k = 0; k < WORDS; ++k) out[(c * R + r) * WORDS + k] = tile[k][tx][j];
+        }
+    }
+}
+
+static int launch_transpose(const void *in, void *out, int64_t R, int64_t C, int words,
+                            hipStream_t stream)
+{
+    if (R == 0 || C == 0) return SDP_OK;
+    int64_t tiles = ((R + 31) / 32) * ((C + 31) / 32);
+    unsigned blocks = (unsigned)(tiles < 65536 ? tiles : 65536);
+    const uint32_t *i = (const uint32_t *)in;
+    uint32_t *o = (uint32_t *)out;
+    switch (words) {
+    case 1: hipLaunchKernelGGL(k_transpose<1>, dim3(blocks), dim3(256), 0, stream, i, o, R, C); break;
+    case 2: hipLaunchKernelGGL(k_transpose<2>, dim3(blocks), dim3(256), 0, stream, i, o, R, C); break;
+    case 3: hipLaunchKernelGGL(k_transpose<3>, dim3(blocks), dim3(256), 0, stream, i, o, R, C); break;
+    case 4: hipLaunchKernelGGL(k_transpose<4>, dim3(blocks), dim3(256), 0, stream, i, o, R, C); break;
+    case 6: hipLaunchKernelGGL(k_transpose<6>, dim3(blocks), dim3(256), 0, stream, i, o, R, C); break;
+    case 8: hipLaunchKernelGGL(k_transpose<8>, dim3(blocks), dim3(256), 0, stream, i, o, R, C); break;
+    default: return fail(SDP_EINVAL, "unsupported element size for the layout conversion");
+    }
+    HIP_TRY(hipGetLastError());
+    return SDP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // RCCL, loaded lazily so single-GPU use never needs librccl
 // ---------------------------------------------------------------------------
 typedef struct { char internal[128]; } nccl_uid;
@@ -476,7 +530,8 @@ struct sdp_problem {
     int64_t S = 0, node_begin = 0, node_end = 0;
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
-    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs;
+    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch;
+    size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
     hipFunction_t f_sweep = nullptr, f_evalpol = nullptr;
     hipStream_t stream = nullptr;
@@ -547,9 +602,26 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         if ((rc = upload(p->proba, desc->proba, p->W * rs))) return rc;
     }
     const size_t nbox = (size_t)p->nu * (p->box_per_node ? (size_t)S : 1);
-    if ((rc = upload(p->box_lo, desc->box_lo, nbox * rs))) return rc;
-    if ((rc = upload(p->box_hi, desc->box_hi, nbox * rs))) return rc;
-    if ((rc = upload(p->box_n, desc->box_n, nbox * 4))) return rc;
+    if (p->box_per_node && desc->layout == SDP_LAYOUT_COLUMNS) {
+        // [nu][N0][P] (reference order) -> [nu][P][N0] (axis 0 fastest)
+        const int64_t n0 = desc->orders[0], P = S / n0;
+        auto reorder = [&](const void *src, size_t es, DevBuf &dst) -> int {
+            std::vector<char> tmp(nbox * es);
+            for (int c = 0; c < p->nu; ++c)
+                for (int64_t i = 0; i < n0; ++i)
+                    for (int64_t q = 0; q < P; ++q)
+                        memcpy(tmp.data() + ((size_t)c * S + q * n0 + i) * es,
+                               (const char *)src + ((size_t)c * S + i * P + q) * es, es);
+            return upload(dst, tmp.data(), tmp.size());
+        };
+        if ((rc = reorder(desc->box_lo, rs, p->box_lo))) return rc;
+        if ((rc = reorder(desc->box_hi, rs, p->box_hi))) return rc;
+        if ((rc = reorder(desc->box_n, 4, p->box_n))) return rc;
+    } else {
+        if ((rc = upload(p->box_lo, desc->box_lo, nbox * rs))) return rc;
+        if ((rc = upload(p->box_hi, desc->box_hi, nbox * rs))) return rc;
+        if ((rc = upload(p->box_n, desc->box_n, nbox * 4))) return rc;
+    }
     if ((rc = p->V.alloc(S * rs))) return rc;
     if ((rc = p->J.alloc(S * rs))) return rc;
     if ((rc = p->pol.alloc((size_t)S * p->nu * rs))) return rc;
@@ -590,12 +662,55 @@ extern "C" int sdp_problem_destroy(sdp_problem *p)
     return SDP_OK;
 }
 
+static int ensure_scratch(sdp_problem *p, size_t bytes)
+{
+    if (p->scratch_bytes >= bytes) return SDP_OK;
+    int rc = p->scratch.alloc(bytes);
+    if (rc) { p->scratch_bytes = 0; return rc; }
+    p->scratch_bytes = bytes;
+    return SDP_OK;
+}
+
+// host (reference C order) -> device buffer in the handle's layout
+static int upload_nodes(sdp_problem *p, void *dev, const void *host, size_t elem_bytes)
+{
+    const size_t bytes = (size_t)p->S * elem_bytes;
+    if (p->layout != SDP_LAYOUT_COLUMNS) {
+        HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, p->stream));
+    } else {
+        int rc = ensure_scratch(p, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(p->scratch.p, host, bytes, hipMemcpyHostToDevice, p->stream));
+        // [N0][P] -> [P][N0]
+        if ((rc = launch_transpose(p->scratch.p, dev, p->orders[0], p->S / p->orders[0],
+                                   (int)(elem_bytes / 4), p->stream))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDP_OK;
+}
+
+// device buffer in the handle's layout -> host (reference C order)
+static int download_nodes(sdp_problem *p, void *host, const void *dev, size_t elem_bytes)
+{
+    const size_t bytes = (size_t)p->S * elem_bytes;
+    if (p->layout != SDP_LAYOUT_COLUMNS) {
+        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, p->stream));
+    } else {
+        int rc = ensure_scratch(p, bytes);
+        if (rc) return rc;
+        // [P][N0] -> [N0][P]
+        if ((rc = launch_transpose(dev, p->scratch.p, p->S / p->orders[0], p->orders[0],
+                                   (int)(elem_bytes / 4), p->stream))) return rc;
+        HIP_TRY(hipMemcpyAsync(host, p->scratch.p, bytes, hipMemcpyDeviceToHost, p->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDP_OK;
+}
+
 extern "C" int sdp_problem_set_value(sdp_problem *p, const void *host_V)
 {
     if (!p || !host_V) return fail(SDP_EINVAL, "NULL argument");
-    HIP_TRY(hipMemcpyAsync(p->V.p, host_V, p->S * real_size(p->dtype), hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    return SDP_OK;
+    return upload_nodes(p, p->V.p, host_V, real_size(p->dtype));
 }
 
 extern "C" int sdp_problem_set_policy(sdp_problem *p, const void *host_pol)
@@ -604,9 +719,7 @@ extern "C" int sdp_problem_set_policy(sdp_problem *p, const void *host_pol)
     const size_t bytes = (size_t)p->S * p->nu * real_size(p->dtype);
     int rc;
     if (!p->pol_in.p && (rc = p->pol_in.alloc(bytes))) return rc;
-    HIP_TRY(hipMemcpyAsync(p->pol_in.p, host_pol, bytes, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    return SDP_OK;
+    return upload_nodes(p, p->pol_in.p, host_pol, (size_t)p->nu * real_size(p->dtype));
 }
 
 static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t nb, int64_t ne)
@@ -870,15 +983,15 @@ extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_d
 extern "C" int sdp_problem_get_value(sdp_problem *p, void *host_J)
 {
     if (!p || !host_J) return fail(SDP_EINVAL, "NULL argument");
-    HIP_TRY(hipMemcpy(host_J, p->J.p, p->S * real_size(p->dtype), hipMemcpyDeviceToHost));
-    return SDP_OK;
+    return download_nodes(p, host_J, p->J.p, real_size(p->dtype));
 }
 
 extern "C" int sdp_problem_get_policy(sdp_problem *p, void *host_pol, int32_t *host_idx)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
-    if (host_pol) HIP_TRY(hipMemcpy(host_pol, p->pol.p, (size_t)p->S * p->nu * real_size(p->dtype), hipMemcpyDeviceToHost));
-    if (host_idx) HIP_TRY(hipMemcpy(host_idx, p->idx.p, p->S * 4, hipMemcpyDeviceToHost));
+    int rc;
+    if (host_pol && (rc = download_nodes(p, host_pol, p->pol.p, (size_t)p->nu * real_size(p->dtype)))) return rc;
+    if (host_idx && (rc = download_nodes(p, host_idx, p->idx.p, 4))) return rc;
     return SDP_OK;
 }
 

@@ -88,8 +88,9 @@ class _DeviceProblem(object):
         except Exception:
             pass
 
-    # per-node arrays cross the API in the reference's C order; the device
-    # keeps them axis-0-fastest when the column kernels are used
+    # per-node arrays cross the C API in the reference's C order; the library
+    # keeps them axis-0-fastest on the device when the column kernels are used.
+    # These two helpers express that order in numpy (host-side gather, tests).
     def _to_device_order(self, A, extra=()):
         A = np.asarray(A, dtype=self.dtype).reshape(self.shape + extra)
         if self.layout == nat.LAYOUT_COLUMNS:
@@ -104,12 +105,12 @@ class _DeviceProblem(object):
 
     def set_value(self, V):
         assert np.size(V) == self.S
-        V = self._to_device_order(V)
+        V = np.ascontiguousarray(V, dtype=self.dtype)       # reference order; the library converts
         nat.check(nat.lib().sdp_problem_set_value(self.h, nat.ptr(V)))
 
     def set_policy(self, pol):
         assert np.size(pol) == self.S * self.nu
-        pol = self._to_device_order(pol, (self.nu,))
+        pol = np.ascontiguousarray(pol, dtype=self.dtype)
         nat.check(nat.lib().sdp_problem_set_policy(self.h, nat.ptr(pol)))
 
     def sweep(self, t_k=0.0, rel_dp=False, ref_index=0):
@@ -128,15 +129,15 @@ class _DeviceProblem(object):
         nat.check(nat.lib().sdp_problem_swap(self.h))
 
     def get_value(self):
-        J = np.zeros(self.S, dtype=self.dtype)
+        J = np.empty(self.shape, dtype=self.dtype)
         nat.check(nat.lib().sdp_problem_get_value(self.h, nat.ptr(J)))
-        return self._from_device_order(J)
+        return J
 
     def get_policy(self):
-        pol = np.zeros(self.S * self.nu, dtype=self.dtype)
-        idx = np.zeros(self.S, dtype=np.int32)
+        pol = np.empty(self.shape + (self.nu,), dtype=self.dtype)
+        idx = np.empty(self.shape, dtype=np.int32)
         nat.check(nat.lib().sdp_problem_get_policy(self.h, nat.ptr(pol), nat.ptr(idx)))
-        return self._from_device_order(pol, (self.nu,)), self._from_device_order(idx)
+        return pol, idx
 
     def last_kernel_ms(self):
         ms = C.c_double(0.0)
@@ -413,10 +414,6 @@ class DPSolver(object):
         S = int(np.prod(shape))
         dt = self.dtype
         layout = nat.LAYOUT_COLUMNS if column else nat.LAYOUT_NODES
-        if column and per_node:
-            nu_, n0 = lo.shape[0], shape[0]
-            lo, hi, n = (np.ascontiguousarray(a.reshape(nu_, n0, -1).transpose(0, 2, 1))
-                         .reshape(nu_, -1) for a in (lo, hi, n))
         arrays = dict(
             axes=[np.ascontiguousarray(g, dtype=dt) for g in self.state_grid],
             box_lo=np.ascontiguousarray(lo, dtype=dt),
