@@ -75,6 +75,9 @@ def main():
     ap.add_argument('--grid', type=int, default=256, help='points per state axis')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fused', action='store_true',
+                    help='also time the opt-in fused-arithmetic variant (secondary figure)')
+    ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     from stodynprog_amd import models, dist, _native as nat
@@ -175,6 +178,28 @@ def main():
                      'note': 'gather accounting (SURVEY 8d): 2^d*T bytes per lattice cell; V '
                              'is reused from L2/Infinity Cache so frac may exceed 1'},
     }
+    if world == 1 and solver.backend_info.get('kernel') == 'column' and args.fused:
+        # secondary figure (never the headline `value`): the opt-in fused-arithmetic
+        # variant of the same kernel (weight-scaled LDS table + FMAs; J within
+        # ~1e-15 relative of the exact kernel)
+        try:
+            fs = DPSolver(sysd, dtype=dtype)
+            fs.state_grid, fs._state_grid_shape = solver.state_grid, solver._state_grid_shape
+            fs._state_ref_ind = solver._state_ref_ind
+            fs.perturb_grid, fs.perturb_proba = solver.perturb_grid, solver.perturb_proba
+            fs.control_steps = solver.control_steps
+            fs.arithmetic = 'fused'
+            for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
+                solver._cache.pop(k_).close()               # free the exact problem's buffers first
+            fprob = fs._problem()
+            fprob.set_value(V0)
+            fprob.bench_sweeps(max(args.warmup, 1))
+            fprob.swap()
+            _, fk = fprob.bench_sweeps(args.steps)
+            out['fused_arithmetic'] = {'kernel_ms': fk / args.steps, 'sweeps_per_s': 1e3 * args.steps / fk,
+                                       'note': 'opt-in DPSolver.arithmetic="fused"; not the reference rounding sequence'}
+        except Exception as e:
+            out['fused_arithmetic'] = {'error': repr(e)}
     if not args.no_cpu_baseline and world == 1:
         try:
             out['cpu_baseline'] = cpu_baseline(ref_solver, np.asarray(V0, dtype=np.float64), models)

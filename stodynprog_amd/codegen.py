@@ -154,7 +154,7 @@ def lanes_for(max_controls):
     return lanes
 
 
-def translation_unit(model, dtype, lanes, column=None):
+def translation_unit(model, dtype, lanes, column=None, fused=False):
     """column: None for the generic node-order kernels, or (N0, W) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points."""
@@ -178,6 +178,7 @@ def translation_unit(model, dtype, lanes, column=None):
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
             '#define SDP_COL_N0 {}'.format(int(column[0])),
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
+            '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
         ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_THREADS',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W')

@@ -50,6 +50,9 @@
 #ifndef SDP_COL_UNROLL_W
 #define SDP_COL_UNROLL_W 4       // unroll factor of the perturbation loop (in batches)
 #endif
+#ifndef SDP_COL_FUSED
+#define SDP_COL_FUSED 0          // 1: opt-in fused arithmetic (not the reference's rounding sequence)
+#endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
 #endif
@@ -141,8 +144,16 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
             c.lam[k] = s.w_lam[w * SDP_DT + k];
             c.oml[k] = s.w_oml[w * SDP_DT + k];
         }
+#if SDP_COL_FUSED && SDP_HAS_W
+        // fused arithmetic: the table holds p_w * inner(r), so phase B is two
+        // fused multiply-adds per cell
+        const sdp_real pw_ = ((const sdp_real *)a.proba)[w];
+        for (int r = threadIdx.x; r < N0; r += blockDim.x)
+            s.T[w * N0 + r] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r, tg, c, 0) * pw_;
+#else
         for (int r = threadIdx.x; r < N0; r += blockDim.x)
             s.T[w * N0 + r] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r, tg, c, 0);
+#endif
     }
     __syncthreads();
 }
@@ -184,6 +195,7 @@ struct SdpColWeights {
     sdp_real w[SDP_COL_W];
 #endif
 #endif
+    sdp_real psum;                         // sum of the weights (fused arithmetic only)
     const volatile sdp_cst_real *cp, *cw;  // mode 1 (volatile: stay inside the loop)
     const volatile sdp_lds_real *lp, *lw;  // mode 2
 };
@@ -209,6 +221,10 @@ SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k, sdp_r
     k.lp = (const volatile sdp_lds_real *)lds_p;
     k.lw = (const volatile sdp_lds_real *)lds_w;
     (void)gp; (void)gw;
+    k.psum = (sdp_real)0;
+#if SDP_HAS_W && SDP_COL_FUSED
+    for (int w = 0; w < SDP_COL_W; ++w) k.psum = k.psum + gp[w];
+#endif
 #if SDP_HAS_W
 #if SDP_COL_WMODE == 0
 #pragma unroll
@@ -265,7 +281,37 @@ SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
         g[j] = sdp_model_cost(x, u[j], (sdp_real)0, t);
 #endif
     }
-#if SDP_HAS_W
+#if SDP_HAS_W && SDP_COL_FUSED
+    // OPT-IN fused arithmetic (DPSolver.arithmetic = 'fused'): mathematically
+    //     sum_w p_w (g + val_w) = sum_w p_w g_w + sum_w [ (1-lam0) p_w inner_w(q0) + lam0 p_w inner_w(q0+1) ]
+    // with the table pre-scaled by p_w the cell costs two FMAs instead of the
+    // reference's six separately rounded operations.  NOT the reference's
+    // rounding sequence: J differs by a few ulp (tests bound it at 1e-12
+    // relative, the north-star tolerance is 1e-10).
+    sdp_real gacc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) gacc[j] = (sdp_real)0;
+#pragma unroll SDP_COL_UNROLL_W
+    for (int w = 0; w < Wn; ++w) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const sdp_real lo = row[j][w * N0];
+            const sdp_real hi = row[j][w * N0 + 1];
+            acc[j] = fma(lam0[j], hi, fma(oml0[j], lo, acc[j]));
+#if SDP_COST_HAS_W
+            gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t), SDP_COL_PW(k, w), gacc[j]);
+#endif
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#if SDP_COST_HAS_W
+        out[j] = gacc[j] + acc[j];
+#else
+        out[j] = fma(g[j], k.psum, acc[j]);
+#endif
+    }
+#elif SDP_HAS_W
     // The LDS reads are issued in batches of SDP_COL_BATCH perturbation points
     // (volatile keeps their order); the expectation is accumulated strictly in
     // w order.

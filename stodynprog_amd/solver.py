@@ -174,6 +174,10 @@ class DPSolver(object):
         self.comm = comm
         self.kernel = 'auto'               # 'auto' | 'generic' | 'column' (see _problem)
         self.comm_phases = 4               # multi-GPU: phases per backup (comm/compute overlap)
+        # 'exact': every floating-point operation of the reference, same order (default);
+        # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
+        #          operations, J within ~1e-15 relative of 'exact' (opt-in)
+        self.arithmetic = 'exact'
         self._cache = {}
         self.last_policy_index = None      # flat control-lattice index of the last sweep
         self.backend_info = {}
@@ -339,7 +343,7 @@ class DPSolver(object):
         s = self.sys
         parts = [id(s.dyn), id(s.cost), id(s.control_box), repr(sorted(s.params.items())),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
-                 id(self.comm), self.kernel]
+                 id(self.comm), self.kernel, self.arithmetic]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         return hash(tuple(parts))
@@ -393,8 +397,11 @@ class DPSolver(object):
         if self.kernel == 'column' and not column:
             raise ValueError('the column kernel needs a storage-separable model whose '
                              'table fits in LDS')
+        if self.arithmetic not in ('exact', 'fused'):
+            raise ValueError("arithmetic must be 'exact' or 'fused'")
         source = codegen.translation_unit(model, dt, lanes,
-                                          column=(shape[0], W) if column else None)
+                                          column=(shape[0], W) if column else None,
+                                          fused=(self.arithmetic == 'fused'))
         return dict(model=model, source=source, column=column, lanes=lanes, per_node=per_node,
                     lo=lo, hi=hi, n=n, max_u=max_u, W=W)
 
@@ -445,7 +452,8 @@ class DPSolver(object):
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
                               bounds, layout)
         self._cache[fp] = prob
-        self.backend_info = dict(mode='fused', kernel='column' if column else 'generic',
+        self.backend_info = dict(mode='traced', kernel='column' if column else 'generic',
+                                 arithmetic=self.arithmetic if column else 'exact',
                                  module=module, lanes_per_node=lanes,
                                  max_controls=max_u, box_per_node=bool(per_node),
                                  bit_exact_model=model.bit_exact,

@@ -9,7 +9,7 @@ for cfg in sys.argv[1:]:
         k, v = kv.split('=')
         env[k] = v
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '10', '--warmup', '3',
-                        '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                        '--no-cpu-baseline', '--no-fused'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     try:
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         print('{:70s} {:8.3f} ms/sweep  kernel {:8.3f} ms'.format(cfg, d['ms_per_step'], d['roofline']['kernel_ms']), flush=True)
