@@ -124,8 +124,9 @@ def separable_functions_source(model):
     (csrc/sdp_column_kernel.h) for a storage-separable model."""
     assert model.storage_separable
     out = []
-    lines = ['SDP_DEV sdp_real sdp_model_lead(const sdp_real *x, const sdp_real *u, sdp_real t)',
-             '{', '    (void)x; (void)u; (void)t;']
+    lines = ['SDP_DEV sdp_real sdp_model_lead(const sdp_real *x, const sdp_real *u, sdp_real w,',
+             '                                sdp_real t)',
+             '{', '    (void)x; (void)u; (void)w; (void)t;']
     names = _emit_body(model, model.slice_nodes([model.x_next[0]]), lines)
     lines += ['    return {};'.format(names[model.x_next[0].id]), '}']
     out.append('\n'.join(lines))
@@ -176,6 +177,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
         assert model.storage_separable
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
+            '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
             '#define SDP_COL_N0 {}'.format(int(column[0])),
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),

@@ -420,22 +420,27 @@ class TracedModel(object):
 
     @property
     def storage_separable(self):
-        """True when the next value of the LEADING state axis does not depend
-        on the perturbation, and the next values of all other axes depend
-        neither on the control nor on the leading state variable:
-            x0' = f0(x, u[, t])       x_k' = f_k(x_1.., w[, t])  for k >= 1
-        (the shape of every storage-control example of the reference: a stock
-        driven by the control next to an exogenous process driven by the
-        noise).  The partial interpolation over axes 1.. is then a function of
-        (row of axis 0, w) only and is shared by all controls and by all nodes
-        of a column along axis 0 -- see csrc/sdp_column_kernel.h."""
+        """True when the next values of all state axes but the LEADING one
+        depend neither on the control nor on the leading state variable:
+            x0' = f0(x, u, w[, t])       x_k' = f_k(x_1.., w[, t])  for k >= 1
+        i.e. a controlled stock next to an exogenous process driven by the
+        noise -- the shape of every storage-control example of the reference
+        (there f0 does not even depend on w).  The partial interpolation over
+        axes 1.. is then a function of (row of axis 0, w) only and is shared by
+        all controls and by all nodes of a column along axis 0 -- see
+        csrc/sdp_column_kernel.h."""
         if self.n_state < 2:
             return False
-        lead = self.x_next[0].deps
         trail = 0
         for n in self.x_next[1:]:
             trail |= n.deps
-        return (lead & DEP_W) == 0 and (trail & (DEP_U | DEP_X)) == 0
+        return (trail & (DEP_U | DEP_X)) == 0
+
+    @property
+    def lead_depends_on_w(self):
+        """does x0' depend on the perturbation?  (if not, its interpolation
+        cell is located once per control instead of once per lattice cell)"""
+        return bool(self.x_next[0].deps & DEP_W)
 
     @property
     def cost_depends_on_w(self):

@@ -591,3 +591,49 @@ def test_fused_arithmetic_stays_within_tolerance(gpu, name, kw):
     Ef, rf = quiet(fused.eval_policy, ue, 5, True, V * 0.1, J_ref_full=True)
     assert np.abs(Ef - Ee).max() / max(1.0, np.abs(Ee).max()) < 1e-12
     assert np.allclose(rf, re_, rtol=1e-12, atol=1e-14)
+
+
+def _reservoir_problem():
+    """controlled stock driven by the control AND the noise, next to an
+    exogenous AR(1) axis: x0' depends on w, so the column kernel locates the
+    axis-0 cell per lattice cell (SDP_LEAD_HAS_W)"""
+    s = SysDescription((2, 1, 1), name='reservoir')
+
+    def dyn(x, y, u, w):
+        return (x + u - 0.5 * w - 0.1 * y, 0.8 * y + w)
+
+    def cost(x, y, u, w):
+        return (x - 0.3) * (x - 0.3) + 0.1 * u * u + 0.05 * w * u
+
+    def box(x, y):
+        return ((-1., 1.),)
+    s.dyn, s.cost, s.control_box = dyn, cost, box
+    s.perturb_laws = [models.NormalLaw(0, 0.2)]
+    solver = DPSolver(s)
+    solver.discretize_state(-1, 1, 33, -1, 1, 17)
+    solver.discretize_perturb(-0.5, 0.5, 7)
+    solver.control_steps = (0.1,)
+    return s, solver
+
+
+def test_column_kernel_with_noise_driven_stock(gpu):
+    sysd, ref = _reservoir_problem()
+    m = ref._traced()
+    assert m.storage_separable and m.lead_depends_on_w and m.cost_depends_on_w
+    col = _clone_with_kernel(sysd, ref, 'column')
+    gen = _clone_with_kernel(sysd, ref, 'generic')
+    V = np.random.default_rng(21).standard_normal((33, 17))
+    Jc, uc = col.value_iteration(V, report_time=False)
+    Jg, ug = gen.value_iteration(V, report_time=False)
+    assert col.backend_info['kernel'] == 'column'
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(ref), V)
+    assert np.array_equal(Jc, Jo) and np.array_equal(Jg, Jo)
+    assert np.array_equal(col.last_policy_index, io) and np.array_equal(gen.last_policy_index, io)
+    assert np.array_equal(uc, uo)
+    Ec = quiet(col.eval_policy, uc, 4, False, V)
+    Eg = quiet(gen.eval_policy, uc, 4, False, V)
+    assert np.array_equal(Ec, Eg)
+    fused = _clone_with_kernel(sysd, ref, 'column')
+    fused.arithmetic = 'fused'
+    Jf, _ = fused.value_iteration(V, report_time=False)
+    assert np.abs(Jf - Jo).max() / np.abs(Jo).max() < 1e-12
