@@ -489,7 +489,10 @@ extern "C" int sdp_comm_create(int rank, int nranks, const char id[128], sdp_com
     memcpy(uid.internal, id, 128);
     int r = g_rccl.CommInitRank(&c->comm, nranks, uid, rank);
     if (r != 0) { delete c; return fail(SDP_ECOMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void **)&c->d_scalar, 8) != hipSuccess) {
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipMalloc((void **)&c->d_scalar, 8) != hipSuccess) {
         delete c; return fail(SDP_EHIP, "communicator stream/scratch allocation failed");
     }
     *out = c;
@@ -765,7 +768,12 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
     if (splits < 1) splits = 1;
     a.col_splits = splits;
     int64_t units = cols * splits;
-    int64_t blocks = (int64_t)p->cus * 8;
+    // Single GPU: a bounded grid whose workgroups stride over the units.  With
+    // a communicator: one workgroup per unit, so CUs are handed back all the
+    // time and the RCCL kernels of the previous phase's all-gather (on their
+    // own, higher-priority stream) get scheduled beside the sweep instead of
+    // behind it.
+    int64_t blocks = (p->comm && p->comm->nranks > 1) ? units : (int64_t)p->cus * 8;
     if (blocks > units) blocks = units;
     blocks = ((blocks + 7) / 8) * 8;
     if (blocks < 8) blocks = 8;
@@ -776,6 +784,8 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
 // fill every CU several times over, never more than there are node tiles
 static unsigned sweep_blocks(const sdp_problem *p, int64_t nodes)
 {
+    // (with a communicator the bounded grid is kept: the generic kernel leaves
+    // most of the LDS and half of the wave slots free for the RCCL kernels)
     const int64_t tile = (64 / p->lanes) * 4;
     int64_t tiles = (nodes + tile - 1) / tile;
     int64_t blocks = (int64_t)p->cus * 8;
