@@ -20,6 +20,11 @@ TIE_RTOL = 1e-12
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a HIP device (run on the MI355X box)')
+    # a fresh checkout has no libsdp_hip.so yet: build it once (hipcc cross-compiles
+    # gfx950 without a GPU); the tests themselves never fall back to anything else
+    from stodynprog_amd import _native as nat
+    if not os.path.exists(nat.LIB_PATH) and os.path.exists(nat.HIPCC):
+        nat.build_library()
 
 
 def golden(name):
