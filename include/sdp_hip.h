@@ -74,6 +74,21 @@ int sdp_mlinterp_f32(int d, const float *smin, const float *smax, const int64_t 
                      const float *values, int64_t n_v, const float *s, int64_t n_s,
                      float *out);
 
+/*
+ * Interpolator object with device-resident values: replaces a
+ * MlinInterpolator / MultilinearInterpolator instance that is set once and
+ * evaluated many times (stodynprog.py:269-289, multilinear.py:83-91), e.g. the
+ * policy look-ups of a simulation loop.  smin/smax are given as doubles (exact
+ * for float32 grids); host_values: [n_v][S] of `dtype`; sdp_interp_eval takes
+ * s: [d][n_s] and writes out: [n_v][n_s], both host arrays of `dtype`.
+ */
+typedef struct sdp_interp sdp_interp;
+int sdp_interp_create(int dtype, int d, const double *smin, const double *smax,
+                      const int64_t *orders, const void *host_values, int64_t n_v,
+                      sdp_interp **out);
+int sdp_interp_eval(sdp_interp *h, const void *host_s, int64_t n_s, void *host_out);
+int sdp_interp_destroy(sdp_interp *h);
+
 /* ---- value-iteration problem handle ---------------------------------------- */
 typedef struct sdp_problem sdp_problem;
 typedef struct sdp_comm sdp_comm;

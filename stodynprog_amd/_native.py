@@ -81,6 +81,9 @@ def _declare(lib):
         'sdp_synchronize': (C.c_int, []),
         'sdp_mlinterp_f64': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, i64, vp]),
         'sdp_mlinterp_f32': (C.c_int, [C.c_int, vp, vp, vp, vp, i64, vp, i64, vp]),
+        'sdp_interp_create': (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, i64, P(vp)]),
+        'sdp_interp_eval': (C.c_int, [vp, vp, i64, vp]),
+        'sdp_interp_destroy': (C.c_int, [vp]),
         'sdp_problem_create': (C.c_int, [P(sdp_problem_desc), P(vp)]),
         'sdp_problem_destroy': (C.c_int, [vp]),
         'sdp_problem_set_value': (C.c_int, [vp, vp]),

@@ -203,6 +203,70 @@ extern "C" int sdp_mlinterp_f32(int d, const float *smin, const float *smax,
 }
 
 // ---------------------------------------------------------------------------
+// interpolator handle: the value rows stay on the device between evaluations
+// (MlinInterpolator.set_values once, __call__ many times -- e.g. the policy
+// look-ups of a simulation loop, reference storage_control.py:242-251)
+// ---------------------------------------------------------------------------
+struct sdp_interp {
+    int dtype = SDP_F64, d = 0;
+    int64_t S = 0, n_v = 0;
+    int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
+    double smin[SDP_MAXD], smax[SDP_MAXD];
+    DevBuf values, pts, out;
+    size_t pts_bytes = 0, out_bytes = 0;
+};
+
+extern "C" int sdp_interp_create(int dtype, int d, const double *smin, const double *smax,
+                                 const int64_t *orders, const void *host_values, int64_t n_v,
+                                 sdp_interp **out)
+{
+    if (dtype != SDP_F64 && dtype != SDP_F32) return fail(SDP_EINVAL, "dtype must be SDP_F64 or SDP_F32");
+    if (d < 1 || d > SDP_MAXD) return fail(SDP_EDIM, "Can't interpolate in dimension strictly greater than 5");
+    if (!smin || !smax || !orders || !host_values || !out || n_v < 1) return fail(SDP_EINVAL, "bad argument");
+    std::unique_ptr<sdp_interp> h(new sdp_interp());
+    h->dtype = dtype; h->d = d; h->n_v = n_v;
+    int64_t S = 1;
+    for (int k = 0; k < d; ++k) {
+        if (orders[k] < 2) return fail(SDP_EINVAL, "orders[%d] = %lld: need at least 2 points per axis", k, (long long)orders[k]);
+        h->orders[k] = (int32_t)orders[k]; h->smin[k] = smin[k]; h->smax[k] = smax[k];
+        S *= orders[k];
+        if (S >= (int64_t)1 << 31) return fail(SDP_EINVAL, "grid too large: 32-bit vertex indices (pyx:164-165)");
+    }
+    h->S = S;
+    int rc = upload(h->values, host_values, (size_t)S * n_v * real_size(dtype));
+    if (rc) return rc;
+    *out = h.release();
+    return SDP_OK;
+}
+
+extern "C" int sdp_interp_destroy(sdp_interp *h)
+{
+    delete h;
+    return SDP_OK;
+}
+
+extern "C" int sdp_interp_eval(sdp_interp *h, const void *host_s, int64_t n_s, void *host_out)
+{
+    if (!h || n_s < 0 || (n_s && (!host_s || !host_out))) return fail(SDP_EINVAL, "bad argument");
+    if (n_s == 0) return SDP_OK;
+    const size_t rs = real_size(h->dtype);
+    const size_t pb = (size_t)h->d * n_s * rs, ob = (size_t)h->n_v * n_s * rs;
+    int rc;
+    if (h->pts_bytes < pb) { if ((rc = h->pts.alloc(pb))) return rc; h->pts_bytes = pb; }
+    if (h->out_bytes < ob) { if ((rc = h->out.alloc(ob))) return rc; h->out_bytes = ob; }
+    HIP_TRY(hipMemcpy(h->pts.p, host_s, pb, hipMemcpyHostToDevice));
+    SdpInterpArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int k = 0; k < h->d; ++k) { a.orders[k] = h->orders[k]; a.smin[k] = h->smin[k]; a.smax[k] = h->smax[k]; }
+    a.values = h->values.p; a.s = h->pts.p; a.out = h->out.p;
+    a.n_s = n_s; a.S = h->S; a.n_v = (int32_t)h->n_v; a.d = h->d;
+    rc = h->dtype == SDP_F32 ? launch_mlinterp<float>(a, 0) : launch_mlinterp<double>(a, 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(host_out, h->out.p, ob, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // built-in kernels: relative-DP shift (stodynprog.py:523-525, 760-762)
 // ---------------------------------------------------------------------------
 template <typename real>

@@ -119,13 +119,46 @@ class MultilinearInterpolator(object):
         return self.interpolate(s)
 
 
+class _DeviceValues(object):
+    """sdp_interp handle: value rows uploaded once, evaluated many times."""
+
+    def __init__(self, smin, smax, orders, values):
+        import ctypes as C
+        values = np.ascontiguousarray(values)
+        self.dtype = values.dtype
+        self.n_v = values.shape[0]
+        self.d = len(orders)
+        smin = np.ascontiguousarray(smin, dtype=np.float64)
+        smax = np.ascontiguousarray(smax, dtype=np.float64)
+        orders = np.ascontiguousarray(orders, dtype=np.int64)
+        h = C.c_void_p()
+        nat.check(nat.lib().sdp_interp_create(nat.np_real(self.dtype), self.d, nat.ptr(smin),
+                                              nat.ptr(smax), nat.ptr(orders), nat.ptr(values),
+                                              self.n_v, C.byref(h)))
+        self.h = h
+
+    def eval(self, s):
+        s = np.ascontiguousarray(s, dtype=self.dtype)
+        out = np.empty((self.n_v, s.shape[1]), dtype=self.dtype)
+        nat.check(nat.lib().sdp_interp_eval(self.h, nat.ptr(s), s.shape[1], nat.ptr(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                nat.lib().sdp_interp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class MlinInterpolator:
     """Variadic-coordinate interpolator over grid vectors (reference
     stodynprog.py:255-290).  Only the first entry, last entry and length of
     each grid vector are used: the grid is taken as uniform.
 
     Instances pickle with the reference's attribute names (ndim, _xmin, _xmax,
-    _xshape, values).
+    _xshape, values); the device copy of the values is made on first call.
     """
 
     def __init__(self, *x_grid):
@@ -139,6 +172,12 @@ class MlinInterpolator:
         assert values.ndim == self.ndim
         assert values.shape == tuple(self._xshape)
         self.values = np.ascontiguousarray(np.atleast_2d(values.ravel()))
+        self.__dict__.pop('_dev', None)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_dev', None)                 # device handles do not pickle
+        return state
 
     def __call__(self, *x_interp):
         """evaluate at coordinates `x_interp`; the output has the shape of the
@@ -147,9 +186,11 @@ class MlinInterpolator:
         x_mesh = np.broadcast_arrays(*x_interp)
         shape = x_mesh[0].shape
         dt = self.values.dtype
-        x_stack = np.vstack([np.asarray(x, dtype=dt).ravel() for x in x_mesh])
-        x_stack = np.ascontiguousarray(x_stack)
-        a = multilinear_interpolation(np.ascontiguousarray(self._xmin, dtype=dt),
-                                      np.ascontiguousarray(self._xmax, dtype=dt),
-                                      self._xshape, self.values, x_stack)
-        return a.reshape(shape)
+        x_stack = np.ascontiguousarray(np.vstack([np.asarray(x, dtype=dt).ravel() for x in x_mesh]))
+        if self.ndim > 4:
+            raise Exception("Can't interpolate in dimension strictly greater than 5")  # pyx:47
+        dev = self.__dict__.get('_dev')
+        if dev is None:
+            dev = self.__dict__['_dev'] = _DeviceValues(self._xmin, self._xmax, self._xshape,
+                                                       self.values)
+        return dev.eval(x_stack).reshape(shape)

@@ -637,3 +637,29 @@ def test_column_kernel_with_noise_driven_stock(gpu):
     fused.arithmetic = 'fused'
     Jf, _ = fused.value_iteration(V, report_time=False)
     assert np.abs(Jf - Jo).max() / np.abs(Jo).max() < 1e-12
+
+
+# ---------------------------------------------------------------- user-level scripts
+def _load_example(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', name)
+    spec = importlib.util.spec_from_file_location(name[:-3], path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_example_inventory_script(gpu):
+    J, policies = quiet(_load_example('inventory.py').main, 6, True)
+    assert np.array_equal(policies[1], [4, 3, 2, 1, 0, 0, 0, 0, 0, 0])       # example_inventory.rst:231
+    assert np.array_equal(policies[3], [5, 4, 3, 2, 1, 0, 0, 0, 0, 0])       # :239
+    assert np.allclose(J, golden('g2_inventory')['J'][5], rtol=0, atol=1e-12)
+
+
+def test_example_searev_policy_lookup_and_simulation(gpu):
+    out = quiet(_load_example('searev_storage.py').main, 100, 1, 1500, (16, 21, 21), True)
+    E, P_prod, P_grid = out['E'], out['P_prod'], out['P_grid']
+    assert np.isfinite(E).all() and E.min() > -1e-9 and E.max() < 10 + 1e-9   # storage stays in its box
+    assert P_grid.std() < P_prod.std()          # the policy smooths the power sent to the grid
+    assert out['pol'].shape == (16, 21, 21, 1) and 0 < out['J_ref'] < 1
