@@ -663,3 +663,56 @@ def test_example_searev_policy_lookup_and_simulation(gpu):
     assert np.isfinite(E).all() and E.min() > -1e-9 and E.max() < 10 + 1e-9   # storage stays in its box
     assert P_grid.std() < P_prod.std()          # the policy smooths the power sent to the grid
     assert out['pol'].shape == (16, 21, 21, 1) and 0 < out['J_ref'] < 1
+
+
+def test_column_kernel_deterministic_and_two_controls(gpu):
+    """column kernel corner cases: no perturbation (W = 0, dims of length 2),
+    two multi-point controls (Cartesian lattice, control 0 slowest), 4-D state"""
+    # deterministic, 2-D
+    s = SysDescription((2, 1), name='det')
+
+    def dyn(x, y, u):
+        return (x + 0.3 * u, 0.9 * y + 0.05)
+
+    def cost(x, y, u):
+        return (x - y) * (x - y) + 0.1 * abs(u)
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda x, y: ((-1., 1.),)
+    det = DPSolver(s)
+    det.discretize_state(-1, 1, 21, 0, 1, 9)
+    det.control_steps = (0.25,)
+    assert det._kernel_plan()['column'] and det._kernel_plan()['W'] == 0
+    V = np.random.default_rng(1).standard_normal((21, 9))
+    J, u = det.value_iteration(V, report_time=False)
+    assert det.backend_info['kernel'] == 'column'
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(det), V)
+    assert np.array_equal(J, Jo) and np.array_equal(u, uo)
+    assert np.array_equal(det.last_policy_index, io)
+
+    # two real controls + 4-D state, stochastic
+    s2 = SysDescription((4, 2, 1), name='two controls')
+
+    def dyn2(a, b, c, d, u, v, w):
+        return (a + 0.2 * u - 0.1 * v, 0.9 * b + w, 0.8 * c - 0.1 * b + 0.5 * w, 0.7 * d + 0.2 * c)
+
+    def cost2(a, b, c, d, u, v, w):
+        return (a - 0.1) * (a - 0.1) + 0.2 * u * u + 0.3 * abs(v) + 0.05 * u * v + 0.01 * b * w
+
+    def box2(a, b, c, d):
+        return ((-1., 1.), (0., 0.5 + 0.5 * (a > 0)))
+    s2.dyn, s2.cost, s2.control_box = dyn2, cost2, box2
+    s2.perturb_laws = [models.NormalLaw(0, 0.1)]
+    two = DPSolver(s2)
+    two.discretize_state(-1, 1, 9, -1, 1, 5, -1, 1, 4, -1, 1, 3)
+    two.discretize_perturb(-0.3, 0.3, 5)
+    two.control_steps = (0.25, 0.2)
+    plan = two._kernel_plan()
+    assert plan['column'] and plan['per_node'] and plan['max_u'] == 9 * 6
+    V = np.random.default_rng(3).standard_normal((9, 5, 4, 3))
+    J, u = two.value_iteration(V, report_time=False)
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(two), V)
+    assert np.array_equal(J, Jo) and np.array_equal(u, uo)
+    assert np.array_equal(two.last_policy_index, io)
+    E = quiet(two.eval_policy, u, 3, False, V)
+    Eo = vi_numpy.eval_policy(vi_numpy.Spec.from_solver(two), uo, 3, False, V)
+    assert np.array_equal(E, Eo)
