@@ -11,7 +11,6 @@ so that every operator is one IEEE operation, as in numpy on the host
 import hashlib
 import math
 import os
-import struct
 
 import numpy as np
 
@@ -223,7 +222,3 @@ def source_key(source):
     h.update(source.encode())
     h.update(' '.join(HIPCC_FLAGS[:-1]).encode())
     return h.hexdigest()[:24]
-
-
-def _f64_bits(v):
-    return struct.unpack('<Q', struct.pack('<d', v))[0]

@@ -442,6 +442,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     const int waves = blockDim.x >> 6;
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
+    // the table dimensions are compiled in: refuse a launch on any other grid
+    if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
     const sdp_real t = (sdp_real)a.t_k;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
 
@@ -542,6 +544,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     __shared__ SdpColLds sdp_lds;
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
+    if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
     const sdp_real t = (sdp_real)a.t_k;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
     SdpColShared s;
