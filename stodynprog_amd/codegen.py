@@ -182,7 +182,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
         ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_THREADS',
-                       'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W')
+                       'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
+                       'SDP_COL_A_GROUP')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             '',

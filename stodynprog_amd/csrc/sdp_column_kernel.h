@@ -55,6 +55,9 @@
 #ifndef SDP_COL_FUSED
 #define SDP_COL_FUSED 0          // 1: opt-in fused arithmetic (not the reference's rounding sequence)
 #endif
+#ifndef SDP_COL_A_GROUP
+#define SDP_COL_A_GROUP 4        // table entries per thread whose vertex loads are issued together
+#endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
 #endif
@@ -137,25 +140,44 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
         }
     }
     __syncthreads();
-    // ---- phase A: T[w][r] = lerp over the trailing axes of V[r, .] (coalesced in r)
-    for (int w = 0; w < Wn; ++w) {
-        SdpCell<sdp_real, SDP_DT, sdp_real> c;
+    // ---- phase A: T[w][r] = lerp over the trailing axes of V[r, .].  The Wn*N0
+    // entries are dealt to all threads (consecutive threads = consecutive rows r:
+    // coalesced strip reads); each thread handles SDP_COL_A_GROUP entries at a
+    // time, so that many sets of 2^(d-1) vertex loads are in flight before the
+    // first lerp needs its data.
+    constexpr int G = SDP_COL_A_GROUP;
+    constexpr int total = Wn * N0;
+    for (int item0 = threadIdx.x; item0 < total; item0 += G * blockDim.x) {
+        SdpCell<sdp_real, SDP_DT, sdp_real> c[G];
+        int r[G], w[G];
 #pragma unroll
-        for (int k = 0; k < SDP_DT; ++k) {
-            c.off[k] = s.w_off[w * SDP_DT + k];
-            c.lam[k] = s.w_lam[w * SDP_DT + k];
-            c.oml[k] = s.w_oml[w * SDP_DT + k];
+        for (int j = 0; j < G; ++j) {
+            const int item = min(item0 + j * (int)blockDim.x, total - 1);   // clamp: result unused
+            w[j] = item / N0;
+            r[j] = item - w[j] * N0;
+#pragma unroll
+            for (int k = 0; k < SDP_DT; ++k) {
+                c[j].off[k] = s.w_off[w[j] * SDP_DT + k];
+                c[j].lam[k] = s.w_lam[w[j] * SDP_DT + k];
+                c[j].oml[k] = s.w_oml[w[j] * SDP_DT + k];
+            }
         }
+        sdp_real val[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            val[j] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r[j], tg, c[j], 0);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (item0 + j * (int)blockDim.x < total) {
 #if SDP_COL_FUSED && SDP_HAS_W
-        // fused arithmetic: the table holds p_w * inner(r), so phase B is two
-        // fused multiply-adds per cell
-        const sdp_real pw_ = ((const sdp_real *)a.proba)[w];
-        for (int r = threadIdx.x; r < N0; r += blockDim.x)
-            s.T[w * N0 + r] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r, tg, c, 0) * pw_;
+                // fused arithmetic: the table holds p_w * inner(r), so phase B is
+                // two fused multiply-adds per cell
+                s.T[w[j] * N0 + r[j]] = val[j] * ((const sdp_real *)a.proba)[w[j]];
 #else
-        for (int r = threadIdx.x; r < N0; r += blockDim.x)
-            s.T[w * N0 + r] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r, tg, c, 0);
+                s.T[w[j] * N0 + r[j]] = val[j];
 #endif
+            }
+        }
     }
     __syncthreads();
 }
