@@ -148,7 +148,7 @@ def main():
     # this same command (profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) KiB
     traffic = None
     if (N, rb, world, solver.backend_info.get('kernel')) == (256, 8, 1, 'column'):
-        traffic = (2 * 1.1873e6 + 327680.0) * 1024
+        traffic = (2 * 1.02171e6 + 327680.0) * 1024
     # the column kernel's real ceiling: 6 fp64 operations per lattice cell that
     # bit-exactness does not allow to fuse, against the measured fp64 VALU
     # issue rate of the chip (profiles/ubench_fp64_rate.txt)
@@ -168,7 +168,7 @@ def main():
         'lattice_cells_per_sec': S * U * W * sweeps_per_s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_source': 'profiles/r01_col_v4_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
+                     'traffic_source': 'profiles/r01_col_v5_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
                                        'WRITE_SIZE, FETCH x2 per the gfx950 correction)' if traffic else None,
                      'fp64_valu_wave_instr_per_s': fp64_rate, 'fp64_valu_peak_measured': FP64_ISSUE_PEAK,
                      'fp64_valu_frac': fp64_rate / FP64_ISSUE_PEAK,
