@@ -241,6 +241,12 @@ class DPSolver(object):
         raise NotImplementedError('interpolation for state dimension >5'
                                   ' is not implemented.')
 
+    def _check_state_array(self, A):
+        expect_shape = self._state_grid_shape
+        if A.shape != expect_shape:
+            raise ValueError('array `A` should be of shape {:s}, not {:s}'.format(
+                str(expect_shape), str(A.shape)))
+
     def control_grids(self, state_k, t_k=None):
         """grid on the box of admissible controls at state `state_k`, using
         self.control_steps as hints (reference sdp.py:432-463).
@@ -341,7 +347,9 @@ class DPSolver(object):
 
     def _fingerprint(self, t_k):
         s = self.sys
-        parts = [id(s.dyn), id(s.cost), id(s.control_box), repr(sorted(s.params.items())),
+        # the callables themselves (hashed by identity and kept alive by the cache
+        # key, so a recycled id() can never alias a stale entry)
+        parts = [s.dyn, s.cost, s.control_box, repr(sorted(s.params.items())),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
                  id(self.comm), self.kernel, self.arithmetic]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
@@ -349,7 +357,7 @@ class DPSolver(object):
         return hash(tuple(parts))
 
     def _traced(self):
-        key = ('trace', id(self.sys.dyn), id(self.sys.cost), repr(sorted(self.sys.params.items())))
+        key = ('trace', self.sys.dyn, self.sys.cost, repr(sorted(self.sys.params.items())))
         if key not in self._cache:
             s = self.sys
             try:
@@ -485,7 +493,7 @@ class DPSolver(object):
             # the cost-to-go must be a *differential* cost, zero at the reference state
             assert J_next[ref_ind] == 0.
         J_next = np.asarray(J_next)
-        self.interp_on_state(J_next)            # shape check (ValueError) as the reference
+        self._check_state_array(J_next)         # same ValueError as interp_on_state (sdp.py:412-415)
         if report_time:
             print('value iteration...', end='')
         J_k, pol_k, J_ref = self._backup(J_next, None, rel_dp)
@@ -615,7 +623,7 @@ class DPSolver(object):
             print('\rtk = {:3d}...'.format(t_k), end='')
             k = t_k - t_ini
             J_next = J_fin if t_k == (t_fin - 1) else J[k + 1]
-            self.interp_on_state(np.asarray(J_next))
+            self._check_state_array(np.asarray(J_next))
             # the reference always passes t_k to the callbacks here (sdp.py:582)
             J[k], pol[k], _ = self._backup(np.asarray(J_next), t_k, False)
         exec_time = (datetime.now() - t_start).total_seconds()
