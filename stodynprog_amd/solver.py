@@ -703,7 +703,8 @@ class DPSolver(object):
         assert pol.shape == state_dims + (nb_control,)
         model = self._traced()
         if isinstance(model, TraceError):
-            raise NotImplementedError('eval_policy needs a traceable model: {}'.format(model))
+            return self._eval_policy_tabulated(pol, n_iter, rel_dp, J_zero, report_time,
+                                               J_ref_full, t_start)
         prob = self._problem(None if self.sys.stationnary else 0)
         prob.set_value(J_zero)
         prob.set_policy(pol)
@@ -719,6 +720,63 @@ class DPSolver(object):
             if not J_ref_full:
                 J_ref = J_ref[-1]
             return J_pol, J_ref
+        return J_pol
+
+    def _eval_policy_tabulated(self, pol, n_iter, rel_dp, J_zero, report_time, J_ref_full,
+                               t_start):
+        """eval_policy for callables that cannot be traced: dyn and cost are
+        evaluated on the host over the whole (S x W) lattice exactly as the
+        reference does (sdp.py:732-754, once: they do not change between
+        iterations), the interpolation + expectation of every iteration run on
+        the device (sdp_tab_backup with one control per node)."""
+        nat.require_gpu()
+        self._check_supported()
+        dims = self._state_grid_shape
+        d = len(dims)
+        S = int(np.prod(dims))
+        nu = len(self.sys.control)
+        w_k = self.perturb_grid[0]
+        W = len(w_k)
+        state_grid = tuple(np.reshape(self.state_grid[i], (1,) * i + (-1,) + (1,) * (d - i))
+                           for i in range(d))
+        u_k = [pol[..., i].reshape(dims + (1,)) for i in range(nu)]
+        args = state_grid + tuple(u_k) + (w_k,)
+        x_next = self.sys.dyn(*args, **self.sys.params)
+        g = self.sys.cost(*args, **self.sys.params)
+        lattice = dims + (W,)
+        xn = np.ascontiguousarray(np.vstack(
+            [np.broadcast_to(np.asarray(x, dtype=float), lattice).ravel() for x in x_next]))
+        gg = np.ascontiguousarray(np.broadcast_to(np.asarray(g, dtype=float), lattice).ravel())
+        off = np.arange(S + 1, dtype=np.int64) * W
+        proba = np.ascontiguousarray(self.perturb_proba[0], dtype=float)
+        smin = np.array([gr[0] for gr in self.state_grid], dtype=float)
+        smax = np.array([gr[-1] for gr in self.state_grid], dtype=float)
+        orders = np.array(dims, dtype=np.int64)
+        self.backend_info = dict(mode='tabulated', reason=str(self._traced()))
+        J_pol = np.ascontiguousarray(J_zero, dtype=float)
+        J_ref = np.zeros(n_iter)
+        idx = np.zeros(S, dtype=np.int64)
+        for k in range(n_iter):
+            print('\rpolicy evaluation: iter. {:d}/{:d}'.format(k, n_iter), end='')
+            h = C.c_void_p()
+            nat.check(nat.lib().sdp_tab_create(d, nat.ptr(smin), nat.ptr(smax), nat.ptr(orders),
+                                               nat.ptr(J_pol), C.byref(h)))
+            try:
+                J_new = np.zeros(S)
+                nat.check(nat.lib().sdp_tab_backup(h, S, nat.ptr(off), W, nat.ptr(proba),
+                                                   nat.ptr(xn), nat.ptr(gg), nat.ptr(J_new),
+                                                   nat.ptr(idx)))
+            finally:
+                nat.lib().sdp_tab_destroy(h)
+            J_pol = J_new.reshape(dims)
+            if rel_dp:
+                J_ref[k] = J_pol[self._state_ref_ind]               # sdp.py:760-762
+                J_pol -= J_ref[k]
+        exec_time = (datetime.now() - t_start).total_seconds()
+        if report_time:
+            print('\rpolicy evaluation run in {:.2f} s     '.format(exec_time))
+        if rel_dp:
+            return J_pol, (J_ref if J_ref_full else J_ref[-1])
         return J_pol
 
     def policy_iteration(self, pol_init, n_val, n_pol=1, rel_dp=False):

@@ -307,6 +307,13 @@ def test_tabulated_mode_for_untraceable_callables(gpu):
     assert np.array_equal(solver.last_policy_index, ref.last_policy_index)
     (Jr, r), _ = solver.value_iteration((V - V[5, 4], 0.), rel_dp=True, report_time=False)
     assert Jr[5, 4] == 0.0
+    # policy evaluation and policy iteration also work in tabulated mode
+    E, refs = quiet(solver.eval_policy, uf, 4, True, V, J_ref_full=True)
+    Ef, refs_f = quiet(ref.eval_policy, uf, 4, True, V, J_ref_full=True)
+    assert np.array_equal(E, Ef) and np.array_equal(refs, refs_f)
+    (Jp, rp), polp = quiet(solver.policy_iteration, uf, 3, 1, True)
+    (Jq, rq), polq = quiet(ref.policy_iteration, uf, 3, 1, True)
+    assert rp == rq and np.array_equal(Jp, Jq) and np.array_equal(polp, polq)
 
 
 def test_value_at_state_entry_points(gpu):
