@@ -723,3 +723,33 @@ def test_column_kernel_deterministic_and_two_controls(gpu):
     E = quiet(two.eval_policy, u, 3, False, V)
     Eo = vi_numpy.eval_policy(vi_numpy.Spec.from_solver(two), uo, 3, False, V)
     assert np.array_equal(E, Eo)
+
+
+def test_system_parameters_are_forwarded(gpu):
+    """sys.params reach the callables as keyword arguments (sdp.py:70-73,
+    439-440, 669-676) and are baked into the compiled model"""
+    s = SysDescription((2, 1, 1), params={'gain': 0.3, 'target': 0.2})
+
+    def dyn(x, y, u, w, **p):
+        return (x + p['gain'] * u, 0.9 * y + w)
+
+    def cost(x, y, u, w, **p):
+        return (x - p['target']) ** 2 + 0.1 * u * u + 0.01 * y * w
+
+    def box(x, y, **p):
+        return ((-1., 1.),)
+    s.dyn, s.cost, s.control_box = dyn, cost, box
+    s.perturb_laws = [models.NormalLaw(0, 0.1)]
+    solver = DPSolver(s)
+    solver.discretize_state(-1, 1, 17, -1, 1, 9)
+    solver.discretize_perturb(-0.3, 0.3, 5)
+    solver.control_steps = (0.2,)
+    V = np.random.default_rng(4).standard_normal((17, 9))
+    J, u = solver.value_iteration(V, report_time=False)
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+    assert np.array_equal(J, Jo) and np.array_equal(u, uo)
+    # changing a parameter changes the model (and its code object)
+    s.params['gain'] = 0.6
+    J2, _ = solver.value_iteration(V, report_time=False)
+    Jo2, _, _, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+    assert np.array_equal(J2, Jo2) and not np.array_equal(J2, J)
