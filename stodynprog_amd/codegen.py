@@ -174,14 +174,17 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
     ]
     if column is not None:
         assert model.storage_separable
+        col_cfg = column_config(column[0], column[1], model.n_state, dtype)
+        assert col_cfg is not None
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
             '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
             '#define SDP_COL_N0 {}'.format(int(column[0])),
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
+            '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
         ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
-             for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_THREADS',
+             for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
                        'SDP_COL_A_GROUP')
              if os.environ.get(k)] + [
@@ -195,13 +198,30 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
     return '\n'.join(head)
 
 
-def column_lds_bytes(n0, w, n_state, dtype):
-    """LDS bytes of the column kernel's table (struct SdpColLds)."""
+COLUMN_LDS_MAX = 160 * 1024          # LDS of one gfx950 CU
+
+
+def column_config(n0, w, n_state, dtype):
+    """Compile-time shape of the column kernel for a grid with n0 points along
+    axis 0 and w perturbation points: (threads, lds_bytes), or None if the
+    table does not fit the LDS of a CU.  512-thread workgroups while two of
+    them fit a CU, else 1024 threads (one workgroup then has to fill the CU's
+    wave slots alone).  (A table of (T[r], T[r+1]) pairs -- one LDS read per
+    cell -- was measured for 4-byte reals and did not pay: not kept.)"""
     rs = np.dtype(dtype).itemsize
     w = max(int(w), 1)
-    threads = 512                                   # SDP_COL_THREADS
-    raw = w * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs
-    return (raw + 15) // 16 * 16
+    for threads in (512, 1024):
+        raw = (w * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs)
+        lds = (raw + 15) // 16 * 16
+        if lds * (2 if threads == 512 else 1) <= COLUMN_LDS_MAX:
+            return threads, lds
+    return None
+
+
+def column_lds_bytes(n0, w, n_state, dtype):
+    """LDS bytes of the column kernel's image (struct SdpColLds), plain table."""
+    cfg = column_config(n0, w, n_state, dtype)
+    return cfg[1] if cfg else COLUMN_LDS_MAX + 1
 
 
 HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',

@@ -612,6 +612,7 @@ struct sdp_problem {
     bool comm_pending = false;
     int cus = 256;
     int refs_cap = 0;
+    int col_threads = 512;
     ~sdp_problem()
     {
         if (mod) (void)hipModuleUnload(mod);
@@ -711,6 +712,12 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
     const char *k_eval = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_evalpol_col" : "sdp_evalpol";
     e = hipModuleGetFunction(&p->f_sweep, p->mod, k_sweep);
     if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_sweep, hipGetErrorString(e));
+    if (p->layout == SDP_LAYOUT_COLUMNS) {
+        // the workgroup size the column kernels were compiled for (__launch_bounds__)
+        int mt = 0;
+        if (hipFuncGetAttribute(&mt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, p->f_sweep) == hipSuccess && mt >= 64)
+            p->col_threads = mt > 1024 ? 1024 : mt;
+    }
     e = hipModuleGetFunction(&p->f_evalpol, p->mod, k_eval);
     if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_eval, hipGetErrorString(e));
     HIP_TRY(hipStreamCreate(&p->stream));
@@ -866,8 +873,7 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
     fill_args(p, a, t_k, nb, ne);
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         // 512-thread workgroups: 8 waves share one LDS table, one lane per node
-        unsigned threads = 512;
-        if (const char *e = getenv("SDP_COL_THREADS")) threads = (unsigned)atoi(e);   // tuning only
+        const unsigned threads = (unsigned)p->col_threads;   // SDP_COL_THREADS of the code object
         const unsigned blocks = column_grid(p, a, 64);
         return launch_module(p->f_sweep, a, blocks, threads, p->stream);
     }
@@ -883,7 +889,7 @@ static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
         const unsigned blocks = column_grid(p, a, 64);       // one lane per node
         const int per_split = (p->orders[0] + a.col_splits - 1) / a.col_splits;
         unsigned threads = (unsigned)((per_split + 63) / 64) * 64;
-        if (threads > 512) threads = 512;
+        if (threads > (unsigned)p->col_threads) threads = (unsigned)p->col_threads;
         return launch_module(p->f_evalpol, a, blocks, threads, p->stream);
     }
     const int64_t nodes = ne - nb;

@@ -153,8 +153,6 @@ class _DeviceProblem(object):
 
 
 class DPSolver(object):
-    COLUMN_LDS_LIMIT = 160 * 1024          # LDS of one gfx950 CU
-
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
         (a `SysDescription`).  Implements value iteration, policy evaluation,
@@ -401,7 +399,7 @@ class DPSolver(object):
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         column = (self.kernel != 'generic' and model.storage_separable and
-                  codegen.column_lds_bytes(shape[0], W, len(shape), dt) <= self.COLUMN_LDS_LIMIT)
+                  codegen.column_config(shape[0], W, len(shape), dt) is not None)
         if self.kernel == 'column' and not column:
             raise ValueError('the column kernel needs a storage-separable model whose '
                              'table fits in LDS')
