@@ -200,6 +200,25 @@ def main():
                                        'note': 'opt-in DPSolver.arithmetic="fused"; not the reference rounding sequence'}
         except Exception as e:
             out['fused_arithmetic'] = {'error': repr(e)}
+    if world > 1 or os.environ.get('SDP_BENCH_SELFCHECK'):
+        # self-check of the sharded path (outside the timed region): rank 0 repeats
+        # the same chain of sweeps on its GPU alone and compares J bit for bit
+        try:
+            J_sharded = prob.get_value()
+            single = DPSolver(sysd, dtype=dtype)
+            single.state_grid, single._state_grid_shape = solver.state_grid, solver._state_grid_shape
+            single._state_ref_ind = solver._state_ref_ind
+            single.perturb_grid, single.perturb_proba = solver.perturb_grid, solver.perturb_proba
+            single.control_steps = solver.control_steps
+            sprob = single._problem()
+            sprob.set_value(V0)
+            if args.warmup > 0:
+                sprob.bench_sweeps(args.warmup)
+                sprob.swap()
+            sprob.bench_sweeps(args.steps)
+            out['sharded_matches_single_gpu'] = bool(np.array_equal(J_sharded, sprob.get_value()))
+        except Exception as e:
+            out['sharded_matches_single_gpu'] = repr(e)
     if not args.no_cpu_baseline and world == 1:
         try:
             out['cpu_baseline'] = cpu_baseline(ref_solver, np.asarray(V0, dtype=np.float64), models)
