@@ -132,7 +132,8 @@ int sdp_problem_set_policy(sdp_problem *p, const void *host_pol);
  * interpolation (multilinear_cython.pyx:51-300).  Reads the value buffer,
  * writes J_k, the optimal control values and their flat lattice indices.
  * With a communicator attached the J_k slabs are all-gathered (RCCL) so that
- * every rank ends with the full J_k.  rel_dp != 0: J_ref = J_k[ref_index];
+ * every rank ends with the full J_k.  rel_dp != 0: J_ref = J_k[ref_index]
+ * (ref_index: flat C-order index of the reference node, stodynprog.py:384);
  * J_k -= J_ref (stodynprog.py:523-525); *J_ref_out receives J_ref.
  * t_k: time index passed to the model of a non-stationary system.
  */

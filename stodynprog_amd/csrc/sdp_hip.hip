@@ -997,9 +997,16 @@ static int ensure_refs(sdp_problem *p, int n)
     return SDP_OK;
 }
 
-static int check_ref(const sdp_problem *p, int rel_dp, int64_t ref_index)
+// ref_index arrives as a flat index in the reference's C order (like every
+// host-side quantity of the API) and is turned into the handle's device order
+static int check_ref(const sdp_problem *p, int rel_dp, int64_t &ref_index)
 {
-    if (rel_dp && (ref_index < 0 || ref_index >= p->S)) return fail(SDP_EINVAL, "reference node %lld outside the grid", (long long)ref_index);
+    if (!rel_dp) return SDP_OK;
+    if (ref_index < 0 || ref_index >= p->S) return fail(SDP_EINVAL, "reference node %lld outside the grid", (long long)ref_index);
+    if (p->layout == SDP_LAYOUT_COLUMNS) {
+        const int64_t n0 = p->orders[0], P = p->S / n0;
+        ref_index = (ref_index % P) * n0 + ref_index / P;
+    }
     return SDP_OK;
 }
 

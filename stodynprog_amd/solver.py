@@ -467,11 +467,8 @@ class DPSolver(object):
         return prob
 
     def _ref_flat(self, prob=None):
-        """flat index of the relative-DP reference node in the device layout"""
-        ind, shape = self._state_ref_ind, self._shape()
-        if prob is not None and prob.layout == nat.LAYOUT_COLUMNS:
-            ind, shape = ind[1:] + ind[:1], shape[1:] + shape[:1]
-        return int(np.ravel_multi_index(ind, shape))
+        """flat C-order index of the relative-DP reference node (sdp.py:384)"""
+        return int(np.ravel_multi_index(self._state_ref_ind, self._shape()))
 
     # ------------------------------------------------------------ value iteration
     def value_iteration(self, J_next, rel_dp=False, report_time=True):
