@@ -110,9 +110,11 @@ SDP_DEV void sdp_col_trailing_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_
         g.M[k] = m;
         m *= a.orders[ax];
     }
+    g.shift = (sdp_real)0;
 }
 
 // phases W and A for column `c`: fills s.T.  All threads of the workgroup call it.
+template <bool SHIFT = false>
 SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
                                  const SdpColShared &s, const sdp_real *x, sdp_real t)
 {
@@ -165,7 +167,7 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
         sdp_real val[G];
 #pragma unroll
         for (int j = 0; j < G; ++j)
-            val[j] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0>::eval(V + r[j], tg, c[j], 0);
+            val[j] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0, SHIFT>::eval(V + r[j], tg, c[j], 0);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             if (item0 + j * (int)blockDim.x < total) {
@@ -573,6 +575,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     sdp_col_carve(sdp_lds, s);
     SdpGrid<sdp_real, SDP_DT> tg;
     sdp_col_trailing_grid(a, tg);
+    // fused relative-DP shift of the previous step (see SdpLerp<.., SHIFT>)
+    tg.shift = a.shift_index >= 0 ? ((const sdp_real *)a.V)[a.shift_index] : (sdp_real)0;
+    if (a.ref_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ref_out = (double)tg.shift;
     SdpLeadAxis lead;
     sdp_col_lead_axis(a, lead);
     SdpColWalk walk;
@@ -587,7 +592,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
         __syncthreads();
-        sdp_col_build_table(a, tg, s, x, t);
+        sdp_col_build_table<true>(a, tg, s, x, t);
         for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {
             const int64_t node = col * N0 + i;
             sdp_real u[1][SDP_NU], jc[1];

@@ -30,6 +30,7 @@ struct SdpGrid {
     real nm1[D];    // (real)(order - 1)
     int ordm2[D];   // order - 2
     int M[D];       // C-order strides, M[D-1] = 1 (pyx:164-165)
+    real shift;     // subtracted from every vertex value when SdpLerp<.., SHIFT = true>
 };
 
 // Per-point cell: integer offset of the lower corner along each axis and the
@@ -57,36 +58,42 @@ SDP_DEV void sdp_locate_axis(const SdpGrid<real, D> &g, int k, real s, SdpCell<r
     c.off[k] = g.M[k] * q;
 }
 
-template <typename real, int D, typename wide, int K>
+// SHIFT = true reads every vertex as V[...] - g.shift: the relative-DP shift
+// `J -= J[ref]` of the previous policy-evaluation step (stodynprog.py:760-762)
+// applied at the point of use, one rounding per vertex exactly like the
+// in-place subtraction of the reference, so the shifted array never has to be
+// written out between two steps.
+template <typename real, int D, typename wide, int K, bool SHIFT = false>
 struct SdpLerp {
     static SDP_DEV wide eval(const real *__restrict__ V, const SdpGrid<real, D> &g,
                              const SdpCell<real, D, wide> &c, int base)
     {
-        const wide lo = SdpLerp<real, D, wide, K + 1>::eval(V, g, c, base + c.off[K]);
-        const wide hi = SdpLerp<real, D, wide, K + 1>::eval(V, g, c, base + c.off[K] + g.M[K]);
+        const wide lo = SdpLerp<real, D, wide, K + 1, SHIFT>::eval(V, g, c, base + c.off[K]);
+        const wide hi = SdpLerp<real, D, wide, K + 1, SHIFT>::eval(V, g, c, base + c.off[K] + g.M[K]);
         return c.oml[K] * lo + (wide)c.lam[K] * hi;                // pyx:88,140,208,300
     }
 };
 // innermost axis: the two vertex loads; lam*v is a real x real product
-template <typename real, int D, typename wide>
-struct SdpLerp<real, D, wide, D - 1> {
+template <typename real, int D, typename wide, bool SHIFT>
+struct SdpLerp<real, D, wide, D - 1, SHIFT> {
     static SDP_DEV wide eval(const real *__restrict__ V, const SdpGrid<real, D> &g,
                              const SdpCell<real, D, wide> &c, int base)
     {
-        const real lo = V[base + c.off[D - 1]];
-        const real hi = V[base + c.off[D - 1] + g.M[D - 1]];
+        real lo = V[base + c.off[D - 1]];
+        real hi = V[base + c.off[D - 1] + g.M[D - 1]];
+        if (SHIFT) { lo = lo - g.shift; hi = hi - g.shift; }
         return c.oml[D - 1] * (wide)lo + (wide)(c.lam[D - 1] * hi);
     }
 };
 
-template <typename real, int D, typename wide = double>
+template <typename real, int D, typename wide = double, bool SHIFT = false>
 SDP_DEV real sdp_interp_point(const real *__restrict__ V, const SdpGrid<real, D> &g,
                               const real *pt)
 {
     SdpCell<real, D, wide> c;
 #pragma unroll
     for (int k = 0; k < D; ++k) sdp_locate_axis<real, D, wide>(g, k, pt[k], c);
-    return (real)SdpLerp<real, D, wide, 0>::eval(V, g, c, 0);
+    return (real)SdpLerp<real, D, wide, 0, SHIFT>::eval(V, g, c, 0);
 }
 
 template <typename real, int D>
@@ -94,6 +101,7 @@ SDP_DEV void sdp_make_grid(SdpGrid<real, D> &g, const int32_t *orders, const rea
                            const real *smax)
 {
     int m = 1;
+    g.shift = (real)0;
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         g.smin[k] = smin[k];

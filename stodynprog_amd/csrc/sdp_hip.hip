@@ -806,6 +806,7 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     a.node_begin = nb; a.node_end = ne; a.S = p->S; a.t_k = t_k;
     for (int k = 0; k < SDP_MAXD; ++k) { a.orders[k] = p->orders[k]; a.axis_off[k] = p->axis_off[k]; }
     a.W = p->W; a.box_per_node = p->box_per_node;
+    a.shift_index = -1; a.ref_out = nullptr;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
         a.col_begin = nb / p->orders[0];
@@ -880,11 +881,14 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
     return launch_module(p->f_sweep, a, sweep_blocks(p, ne - nb), 256, p->stream);
 }
 
-static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
+static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne,
+                          int64_t shift_index, double *ref_out)
 {
     if (ne <= nb) return SDP_OK;
     SdpSweepArgs a;
     fill_args(p, a, t_k, nb, ne);
+    a.shift_index = shift_index;
+    a.ref_out = ref_out;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         const unsigned blocks = column_grid(p, a, 64);       // one lane per node
         const int per_split = (p->orders[0] + a.col_splits - 1) / a.col_splits;
@@ -935,17 +939,18 @@ static int gather_phase(sdp_problem *p, int phase)
 // all-gather of phase k (communicator stream) overlaps the kernel of phase k+1
 // (problem stream); the problem stream then waits for the last gather, so
 // whatever follows (relative-DP shift, next sweep) sees the complete J.
-static int run_backup(sdp_problem *p, bool evalpol, double t_k)
+static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_index = -1,
+                      double *ref_out = nullptr)
 {
     int rc;
     if (!p->comm) {
-        return evalpol ? launch_evalpol(p, t_k, p->node_begin, p->node_end)
+        return evalpol ? launch_evalpol(p, t_k, p->node_begin, p->node_end, shift_index, ref_out)
                        : launch_sweep(p, t_k, p->node_begin, p->node_end);
     }
     const int n = p->comm->nranks, rank = p->comm->rank;
     for (int ph = 0; ph < p->n_phases; ++ph) {
         const int64_t *b = p->parts.data() + (size_t)ph * (n + 1);
-        rc = evalpol ? launch_evalpol(p, t_k, b[rank], b[rank + 1])
+        rc = evalpol ? launch_evalpol(p, t_k, b[rank], b[rank + 1], shift_index, ref_out)
                      : launch_sweep(p, t_k, b[rank], b[rank + 1]);
         if (rc) return rc;
         if (n > 1) {
@@ -1052,12 +1057,20 @@ extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_d
         return SDP_OK;
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    // Relative DP (stodynprog.py:760-762) without writing the shifted array out
+    // between steps: step k leaves the raw J_k in the J buffer; step k+1 reads
+    // every vertex as V - V[ref] (same single rounding as the reference's
+    // in-place `J_pol -= J_ref[k]`) and records J_ref[k] = V[ref]; only the last
+    // step is followed by the explicit shift kernels.  One launch per step
+    // instead of three.
+    double *refs = (double *)p->refs.p;
     for (int k = 0; k < n_iter; ++k) {
         if (k > 0) std::swap(p->V.p, p->J.p);
-        if ((rc = run_backup(p, true, 0.0))) return rc;
+        const bool fused = rel_dp && k > 0;
+        if ((rc = run_backup(p, true, 0.0, fused ? ref_index : -1, fused ? refs + (k - 1) : nullptr))) return rc;
         if ((rc = join_comm(p))) return rc;
-        if (rel_dp && (rc = rel_shift(p, ref_index, k))) return rc;
     }
+    if (rel_dp && (rc = rel_shift(p, ref_index, n_iter - 1))) return rc;
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     float ms = 0;

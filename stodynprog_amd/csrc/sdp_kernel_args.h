@@ -37,6 +37,9 @@ struct SdpSweepArgs {
     int64_t col_end;       // one past the last column
     int32_t n_lead;        // orders[0]
     int32_t col_splits;    // workgroups sharing one column (each redoes the table)
+    // ---- policy-evaluation kernels only: fused relative-DP shift ------------------
+    int64_t shift_index;   // >= 0: every V read is V[.] - V[shift_index] (device order); -1: none
+    double *ref_out;       // if set, thread 0 of workgroup 0 stores V[shift_index] there (J_ref of the previous step)
 };
 
 // Stand-alone multilinear interpolation (multilinear_cython.pyx:17-49).

@@ -102,6 +102,7 @@ SDP_DEV void sdp_grid_from_args(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_D> 
 }
 
 // expected cost of one (node, control): sum_w p_w * (g + J_next(f))
+template <bool SHIFT = false>
 SDP_DEV sdp_real sdp_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_D> &grid,
                                    const sdp_real *__restrict__ V, const sdp_real *x,
                                    const sdp_real *u, sdp_real t)
@@ -113,13 +114,13 @@ SDP_DEV sdp_real sdp_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real
     sdp_real acc = (sdp_real)0;
     for (int wi = 0; wi < a.W; ++wi) {
         sdp_model_cell(x, u, wgrid[wi], t, xn, g);
-        const sdp_real jc = g + sdp_interp_point<sdp_real, SDP_D, sdp_real>(V, grid, xn);   // stodynprog.py:677
+        const sdp_real jc = g + sdp_interp_point<sdp_real, SDP_D, sdp_real, SHIFT>(V, grid, xn);   // stodynprog.py:677
         acc = acc + jc * proba[wi];                                               // stodynprog.py:681
     }
     return acc;
 #else
     sdp_model_cell(x, u, (sdp_real)0, t, xn, g);
-    return g + sdp_interp_point<sdp_real, SDP_D, sdp_real>(V, grid, xn);                    // stodynprog.py:679-680
+    return g + sdp_interp_point<sdp_real, SDP_D, sdp_real, SHIFT>(V, grid, xn);                    // stodynprog.py:679-680
 #endif
 }
 
@@ -185,6 +186,9 @@ extern "C" __global__ void __launch_bounds__(256) sdp_evalpol(SdpSweepArgs a)
     SdpGrid<sdp_real, SDP_D> grid;
     sdp_grid_from_args(a, grid);
     const sdp_real t = (sdp_real)a.t_k;
+    // fused relative-DP shift of the previous step (see SdpLerp<.., SHIFT>)
+    grid.shift = a.shift_index >= 0 ? V[a.shift_index] : (sdp_real)0;
+    if (a.ref_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ref_out = (double)grid.shift;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t node = a.node_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
          node < a.node_end; node += stride) {
@@ -192,6 +196,6 @@ extern "C" __global__ void __launch_bounds__(256) sdp_evalpol(SdpSweepArgs a)
         sdp_node_coords(a, node, x);
 #pragma unroll
         for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-        ((sdp_real *)a.J)[node] = sdp_expected_cost(a, grid, V, x, u, t);
+        ((sdp_real *)a.J)[node] = sdp_expected_cost<true>(a, grid, V, x, u, t);
     }
 }
