@@ -753,3 +753,66 @@ def test_system_parameters_are_forwarded(gpu):
     J2, _ = solver.value_iteration(V, report_time=False)
     Jo2, _, _, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
     assert np.array_equal(J2, Jo2) and not np.array_equal(J2, J)
+
+
+# ---------------------------------------------------------------- randomised models
+def _random_expr(rng, leaves, depth):
+    """random numpy expression over the given leaf names, built from operators
+    whose device results are correctly rounded (bit-exact against numpy)"""
+    if depth == 0 or rng.random() < 0.2:
+        if rng.random() < 0.3:
+            return repr(float(np.round(rng.uniform(-2, 2), 3)))
+        return leaves[rng.integers(len(leaves))]
+    a = _random_expr(rng, leaves, depth - 1)
+    b = _random_expr(rng, leaves, depth - 1)
+    kind = rng.integers(9)
+    if kind == 0:
+        return '({} + {})'.format(a, b)
+    if kind == 1:
+        return '({} - {})'.format(a, b)
+    if kind == 2:
+        return '({} * {})'.format(a, b)
+    if kind == 3:
+        return '({} / (1.5 + np.abs({})))'.format(a, b)
+    if kind == 4:
+        return 'np.where({} > {}, {}, {})'.format(a, b, a, _random_expr(rng, leaves, depth - 1))
+    if kind == 5:
+        return 'np.minimum({}, {})'.format(a, b)
+    if kind == 6:
+        return 'np.maximum({}, {})'.format(a, b)
+    if kind == 7:
+        return 'np.sqrt(np.abs({}))'.format(a)
+    return '(-{}) ** 2'.format(a)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_models_match_numpy_bit_for_bit(gpu, seed):
+    """tracer + code generator fuzz: random dyn / cost expressions (2 states,
+    1 control, 1 perturbation), one sweep on the GPU against the numpy oracle
+    calling the very same Python callables"""
+    rng = np.random.default_rng(1000 + seed)
+    separable = seed % 2 == 0                  # exercise both kernel families
+    lead = _random_expr(rng, ['x', 'y', 'u'] if separable else ['x', 'y', 'u', 'w'], 3)
+    trail = _random_expr(rng, ['y', 'w'] if separable else ['x', 'y', 'u', 'w'], 3)
+    cst = _random_expr(rng, ['x', 'y', 'u', 'w'], 4)
+    ns = {'np': np}
+    exec('def dyn(x, y, u, w):\n    return (0.5 * x + 0.2 * ({}), 0.5 * y + 0.2 * ({}))\n'
+         'def cost(x, y, u, w):\n    return {} + 0.0 * u\n'.format(lead, trail, cst), ns)
+    s = SysDescription((2, 1, 1), name='fuzz %d' % seed)
+    s.dyn, s.cost = ns['dyn'], ns['cost']
+    s.control_box = lambda x, y: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.3)]
+    solver = DPSolver(s)
+    solver.discretize_state(-1, 1, 13, -1, 1, 11)
+    solver.discretize_perturb(-0.6, 0.6, 5)
+    solver.control_steps = (0.25,)
+    model = solver._traced()
+    assert not isinstance(model, TraceError) and model.bit_exact
+    V = rng.standard_normal((13, 11))
+    with np.errstate(all='ignore'):
+        J, u = solver.value_iteration(V, report_time=False)
+        Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+    assert solver.backend_info['kernel'] == ('column' if model.storage_separable else 'generic')
+    assert np.array_equal(J, Jo, equal_nan=True), (lead, trail, cst)
+    assert np.array_equal(solver.last_policy_index, io)
+    assert np.array_equal(u, uo)
