@@ -241,3 +241,36 @@ def test_package_surface():
                  'control_grids', 'value_iteration', 'bellman_recursion', '_value_at_state_loop',
                  '_value_at_state_vect', 'eval_policy', 'policy_iteration', 'print_summary'):
         assert hasattr(DPSolver, name), name
+
+
+def test_reference_pickle_format_round_trip(tmp_path):
+    """interpolator pickles carry the reference's class path and attribute
+    names (searev/P_sto_law.dat format) in both directions"""
+    import pickletools
+    from stodynprog_amd import compat, MlinInterpolator
+    _, solver = models.nas_demo(n_E=5, n_P=4)
+    it = solver.interp_on_state(np.arange(20.).reshape(5, 4))
+    path = tmp_path / 'law.dat'
+    compat.dump_interpolator(it, str(path))
+    raw = path.read_bytes()
+    names = [arg for op, arg, _ in pickletools.genops(raw) if op.name == 'GLOBAL']
+    assert 'stodynprog.stodynprog MlinInterpolator' in names
+    assert not any(n.startswith('stodynprog_amd') for n in names)
+    back = compat.load_interpolator(str(path))
+    assert isinstance(back, MlinInterpolator)
+    assert set(vars(back)) == {'ndim', '_xmin', '_xmax', '_xshape', 'values'}
+    assert back.ndim == 2 and np.array_equal(back.values, it.values)
+    assert np.array_equal(back._xshape, [5, 4]) and back._xshape.dtype == np.int64
+    import sys
+    assert 'stodynprog.stodynprog' not in sys.modules      # the writer cleans up its shim
+
+
+@pytest.mark.skipif(not __import__('os').path.exists(
+    '/root/reference/examples/20 Searev storage control/P_sto_law.dat'),
+    reason='reference checkout not present (GPU box)')
+def test_load_the_reference_searev_policy_pickle():
+    from stodynprog_amd import compat
+    it = compat.load_interpolator('/root/reference/examples/20 Searev storage control/P_sto_law.dat')
+    assert it.ndim == 3 and list(it._xshape) == [31, 61, 61]
+    assert it.values.shape == (1, 31 * 61 * 61)
+    assert np.allclose(it._xmax, [10., 1.016, 0.908])

@@ -119,3 +119,21 @@ def test_mlin_interpolator_broadcast_wrapper(gpu):
     ref = c_oracle.mlinterp(it._xmin, it._xmax, it._xshape, it.values,
                             np.array([[0.33], [0.2], [2.9]]))
     assert it(0.33, 0.2, 2.9) == ref[0, 0]
+
+
+def test_pickled_interpolator_evaluates_after_reload(gpu, tmp_path):
+    from stodynprog_amd import compat
+    xg, yg = np.linspace(0, 1, 6), np.linspace(-1, 1, 5)
+    X, Y = np.meshgrid(xg, yg, indexing='ij')
+    it = MlinInterpolator(xg, yg)
+    it.set_values(X * 2 - Y)
+    before = it(0.37, 0.12)
+    compat.dump_interpolator(it, str(tmp_path / 'it.dat'))
+    again = compat.load_interpolator(str(tmp_path / 'it.dat'))
+    assert again(0.37, 0.12) == before
+    assert pickle_roundtrip(it)(0.37, 0.12) == before
+
+
+def pickle_roundtrip(obj):
+    import pickle
+    return pickle.loads(pickle.dumps(obj))
