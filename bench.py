@@ -36,7 +36,7 @@ def algorithmic_bytes(S, U, W, d, real_bytes, nu):
     return S * U * W * (2 ** d) * real_bytes + S * (2 * real_bytes + 4 * nu)
 
 
-def cpu_baseline(solver, V0, models, budget_s=12.0):
+def cpu_baseline(solver, V0, models, budget_s=18.0):
     """Time the C oracle on a bounded slab of nodes with all host cores."""
     from oracle import c_oracle
     S = V0.size
