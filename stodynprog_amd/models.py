@@ -297,3 +297,32 @@ def synthetic3d_V0(state_grid, dtype=np.float64):
     V = V - (0.2 * x1) * x2
     V = V + 0.1 / (1.0 + x2 * x2)
     return np.ascontiguousarray(V, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------
+# 6. Small finite-horizon, time-dependent problem (bellman_recursion)
+# ----------------------------------------------------------------------------
+def finite_horizon(api=None, n_x=17, n_w=5):
+    """1 state, 1 control, 1 perturbation; dynamics, cost and admissible box
+    all depend on the time index (first argument, reference sdp.py:89-91)."""
+    SysDescription, DPSolver = _classes(api)
+    fh = SysDescription((1, 1, 1), stationnary=False, name='finite horizon')
+
+    def fh_dyn(k, x, u, w):
+        return (0.9 * x + u + w + 0.05 * k,)
+    fh.dyn = fh_dyn
+
+    def fh_cost(k, x, u, w):
+        return (x - 0.1 * k) ** 2 + 0.1 * u * u
+
+    fh.cost = fh_cost
+
+    def fh_box(k, x):
+        return ((-1., 1. + 0.5 * k),)
+    fh.control_box = fh_box
+    fh.perturb_laws = [NormalLaw(0, 0.1)]
+    solver = DPSolver(fh)
+    solver.discretize_state(-2, 2, n_x)
+    solver.discretize_perturb(-0.3, 0.3, n_w)
+    solver.control_steps = (0.125,)
+    return fh, solver

@@ -322,7 +322,16 @@ def g7():
          J2=J2, pol2=pol2, idx2=idx2, margin2=mar2)
 
 
-ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7)
+def g8():
+    """finite-horizon Bellman recursion of a time-dependent system (sdp.py:536-591)."""
+    print('g8 bellman recursion')
+    _, dpsolv = models.finite_horizon(ref)
+    J_fin = dpsolv.state_grid[0] ** 2
+    J, pol = quiet(dpsolv.bellman_recursion, 5, J_fin)
+    save('g8_bellman', J=J, pol=pol, J_fin=J_fin)
+
+
+ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or sorted(ALL)

@@ -330,6 +330,17 @@ def test_value_at_state_entry_points(gpu):
         assert J_loop == J_opt and tuple(u_loop) == tuple(u_opt)
 
 
+def test_bellman_recursion_against_reference(gpu):
+    """finite-horizon recursion of a time-dependent system against the
+    reference's own bellman_recursion (sdp.py:536-591)"""
+    g = golden('g8_bellman')
+    _, solver = models.finite_horizon()
+    J, pol = quiet(solver.bellman_recursion, 5, g['J_fin'])
+    assert J.shape == g['J'].shape and pol.shape == g['pol'].shape
+    assert np.abs(J - g['J']).max() <= 1e-13 * np.abs(g['J']).max()
+    assert np.array_equal(pol, g['pol'])
+
+
 def test_bellman_recursion_time_dependent(gpu):
     s = SysDescription((1, 1, 1), stationnary=False)
 

@@ -188,3 +188,15 @@ def test_eval_policy_oracle_vs_reference():
     assert '{:g}'.format(J_ref[-1]) == '0.105724'
     J7 = vi_numpy.eval_policy(spec, pol, 7)
     assert np.abs(J7 - g['ar1_J7']).max() < 1e-12
+
+
+def test_bellman_recursion_oracle_vs_reference():
+    g = golden('g8_bellman')
+    _, solver = models.finite_horizon()
+    spec = vi_numpy.Spec.from_solver(solver)
+    nxt = g['J_fin']
+    for t in (4, 3, 2, 1, 0):
+        J, pol, _, _ = vi_numpy.value_iteration(spec, nxt, t_k=t)
+        assert np.abs(J - g['J'][t]).max() <= 1e-13 * max(1.0, np.abs(g['J'][t]).max())
+        assert np.array_equal(pol, g['pol'][t])
+        nxt = J
