@@ -400,6 +400,14 @@ class DPSolver(object):
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         column = (self.kernel != 'generic' and model.storage_separable and
                   codegen.column_config(shape[0], W, len(shape), dt) is not None)
+        if not column and self.kernel != 'generic':
+            k = model.separable_axis_hint()
+            if k is not None and not self._cache.get('hinted'):
+                self._cache['hinted'] = True
+                import warnings
+                warnings.warn('state variable "{}" is the only one driven by the control: listing it '
+                              'FIRST in dyn/cost/control_box (and in discretize_state) lets the fast '
+                              'column kernel run this model'.format(self.sys.state[k]))
         if self.kernel == 'column' and not column:
             raise ValueError('the column kernel needs a storage-separable model whose '
                              'table fits in LDS')

@@ -436,6 +436,39 @@ class TracedModel(object):
             trail |= n.deps
         return (trail & (DEP_U | DEP_X)) == 0
 
+    def separable_axis_hint(self):
+        """index k > 0 of a state variable that would make the model
+        storage-separable if it came first (all other next-state values
+        independent of the control and of x_k), or None.  Needs per-variable
+        dependency sets, so the graph is walked once per candidate."""
+        if self.n_state < 2 or self.storage_separable:
+            return None
+        reach = {}
+
+        def leaves(node):
+            if node.id not in reach:
+                if node.op == 'var':
+                    reach[node.id] = frozenset([node.value])
+                else:
+                    acc = frozenset()
+                    for a in node.args:
+                        acc = acc | leaves(a)
+                    reach[node.id] = acc
+            return reach[node.id]
+
+        for k in range(1, self.n_state):
+            ok = True
+            for j, n in enumerate(self.x_next):
+                if j == k:
+                    continue
+                deps = leaves(n)
+                if 'x%d' % k in deps or any(v.startswith('u') for v in deps):
+                    ok = False
+                    break
+            if ok:
+                return k
+        return None
+
     @property
     def lead_depends_on_w(self):
         """does x0' depend on the perturbation?  (if not, its interpolation

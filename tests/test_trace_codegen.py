@@ -128,3 +128,32 @@ def test_solver_reports_untraceable_model_without_gpu():
     solver = DPSolver(s)
     solver.discretize_state(0, 1, 3)
     assert isinstance(solver._traced(), TraceError)
+
+
+def test_hint_when_the_controlled_stock_is_not_listed_first():
+    import warnings
+    s = SysDescription((2, 1, 1))
+
+    def dyn(p, e, u, w):                    # exogenous price first, stock second
+        return (0.8 * p + w, e + 0.5 * u)
+
+    def cost(p, e, u, w):
+        return p * u + 0.01 * u * u
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda p, e: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.2)]
+    solver = DPSolver(s)
+    solver.discretize_state(-1, 1, 9, 0, 1, 11)
+    solver.discretize_perturb(-0.5, 0.5, 5)
+    solver.control_steps = (0.25,)
+    model = solver._traced()
+    assert not model.storage_separable and model.separable_axis_hint() == 1
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        plan = solver._kernel_plan()
+        solver._kernel_plan()                          # only once
+    assert not plan['column']
+    assert len(rec) == 1 and '"e"' in str(rec[0].message) and 'FIRST' in str(rec[0].message)
+    # a genuinely coupled model gets no hint
+    _, inv = models.inventory()
+    assert inv._traced().separable_axis_hint() is None
