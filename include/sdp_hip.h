@@ -154,7 +154,8 @@ int sdp_problem_swap(sdp_problem *p);
 int sdp_problem_get_value(sdp_problem *p, void *host_J);            /* S reals            */
 int sdp_problem_get_policy(sdp_problem *p, void *host_pol /* [S][nu] reals or NULL */,
                            int32_t *host_idx /* [S] or NULL */);
-/* Policy rows of the handle's own slab only (no all-gather of policies). */
+/* With a communicator attached this is a collective call: the policy rows of the
+ * other ranks' parts are all-gathered first (every rank must call it). */
 
 /* HIP-event duration of the last sweep / eval kernel launch(es), milliseconds. */
 int sdp_problem_last_kernel_ms(sdp_problem *p, double *ms);

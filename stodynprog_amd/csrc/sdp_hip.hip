@@ -902,35 +902,39 @@ static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne,
     return launch_module(p->f_evalpol, a, (unsigned)blocks, 256, p->stream);
 }
 
-// Exchange of one phase of J (in place in the J buffer) on the communicator's
-// stream: rank r owns [b[r], b[r+1]) of the phase; equal parts go through one
-// ncclAllGather, uneven ones through grouped broadcasts.
-static int gather_phase(sdp_problem *p, int phase)
+// Exchange of one phase of a per-node array (in place) on the communicator's
+// stream: rank r owns nodes [b[r], b[r+1]) of the phase, elem_bytes bytes per
+// node; equal parts go through one ncclAllGather, uneven ones through grouped
+// broadcasts.  Moved as raw bytes, so it serves J, the policy and the index.
+static int gather_phase_of(sdp_problem *p, int phase, void *buffer, size_t elem_bytes)
 {
-    const size_t rs = real_size(p->dtype);
-    const int dt = p->dtype == SDP_F32 ? NCCL_FLOAT32 : NCCL_FLOAT64;
     const int n = p->comm->nranks;
     const int64_t *b = p->parts.data() + (size_t)phase * (n + 1);
     bool even = true;
     const int64_t len0 = b[1] - b[0];
     for (int r = 0; r < n; ++r) even = even && (b[r + 1] - b[r] == len0);
     if (b[n] == b[0]) return SDP_OK;
-    char *base = (char *)p->J.p;
+    char *base = (char *)buffer;
     hipStream_t cs = p->comm->stream;
     if (even) {
-        NCCL_TRY(g_rccl.AllGather(base + b[p->comm->rank] * rs, base + b[0] * rs, (size_t)len0, dt,
-                                  p->comm->comm, cs));
+        NCCL_TRY(g_rccl.AllGather(base + b[p->comm->rank] * elem_bytes, base + b[0] * elem_bytes,
+                                  (size_t)len0 * elem_bytes, NCCL_INT8, p->comm->comm, cs));
     } else {
         NCCL_TRY(g_rccl.GroupStart());
         for (int r = 0; r < n; ++r) {
             const int64_t cnt = b[r + 1] - b[r];
             if (cnt == 0) continue;
-            void *ptr = base + b[r] * rs;
-            NCCL_TRY(g_rccl.Broadcast(ptr, ptr, (size_t)cnt, dt, r, p->comm->comm, cs));
+            void *ptr = base + b[r] * elem_bytes;
+            NCCL_TRY(g_rccl.Broadcast(ptr, ptr, (size_t)cnt * elem_bytes, NCCL_INT8, r, p->comm->comm, cs));
         }
         NCCL_TRY(g_rccl.GroupEnd());
     }
     return SDP_OK;
+}
+
+static int gather_phase(sdp_problem *p, int phase)
+{
+    return gather_phase_of(p, phase, p->J.p, real_size(p->dtype));
 }
 
 // One backup (Bellman sweep or fixed-policy evaluation) over the nodes this
@@ -1086,10 +1090,26 @@ extern "C" int sdp_problem_get_value(sdp_problem *p, void *host_J)
     return download_nodes(p, host_J, p->J.p, real_size(p->dtype));
 }
 
+// after a sharded sweep every rank holds the policy rows of its own parts only:
+// collect the others (on request -- the sweep itself never pays for this)
+static int gather_policy(sdp_problem *p)
+{
+    if (!p->comm || p->comm->nranks == 1) return SDP_OK;
+    int rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int ph = 0; ph < p->n_phases; ++ph) {
+        if ((rc = gather_phase_of(p, ph, p->pol.p, (size_t)p->nu * real_size(p->dtype)))) return rc;
+        if ((rc = gather_phase_of(p, ph, p->idx.p, 4))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(p->comm->stream));
+    return SDP_OK;
+}
+
 extern "C" int sdp_problem_get_policy(sdp_problem *p, void *host_pol, int32_t *host_idx)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
     int rc;
+    if ((rc = gather_policy(p))) return rc;
     if (host_pol && (rc = download_nodes(p, host_pol, p->pol.p, (size_t)p->nu * real_size(p->dtype)))) return rc;
     if (host_idx && (rc = download_nodes(p, host_idx, p->idx.p, 4))) return rc;
     return SDP_OK;

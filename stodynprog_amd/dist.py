@@ -13,7 +13,8 @@ the J_k slabs are exchanged with ONE all-gather:
   * GlooCommunicator  -- host arrays over torch.distributed/gloo; used for the
     rendezvous of the RCCL unique id and by the CPU tests of the slab logic.
 
-Policies are not gathered: each rank keeps the policy rows of its own slab.
+Policies are gathered only on request (sdp_problem_get_policy is then a collective call);
+the timed sweep never pays for it.
 """
 import os
 
