@@ -177,8 +177,9 @@ def compile_model(source, verbose=False):
     if os.path.exists(out):
         return out
     src = os.path.join(KCACHE, key + '.hip')
-    with open(src, 'w') as f:
+    with open(src + '.tmp.{}'.format(os.getpid()), 'w') as f:     # ranks may compile concurrently
         f.write(source)
+    os.replace(f.name, src)
     tmp = out + '.tmp.{}'.format(os.getpid())
     cmd = [HIPCC] + codegen.HIPCC_FLAGS + ['-o', tmp, src]
     if verbose:

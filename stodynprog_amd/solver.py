@@ -91,8 +91,8 @@ class _DeviceProblem(object):
     # per-node arrays cross the C API in the reference's C order; the library
     # keeps them axis-0-fastest on the device when the column kernels are used.
     # These two helpers express that order in numpy (host-side gather, tests).
-    def _to_device_order(self, A, extra=()):
-        A = np.asarray(A, dtype=self.dtype).reshape(self.shape + extra)
+    def _to_device_order(self, A, extra=(), dtype=None):
+        A = np.asarray(A, dtype=dtype or self.dtype).reshape(self.shape + extra)
         if self.layout == nat.LAYOUT_COLUMNS:
             A = np.moveaxis(A, 0, len(self.shape) - 1)
         return np.ascontiguousarray(A)
@@ -528,6 +528,16 @@ class DPSolver(object):
                 J_ref = J_k[self._state_ref_ind]              # sdp.py:523-525
                 J_k -= J_ref
         pol_k, idx = prob.get_policy()
+        if host_comm:
+            # every rank returns the complete policy, like the single-process call
+            nu = len(self.sys.control)
+            bounds = self.comm.slab_bounds(prob.dev_shape)
+            pd = prob._to_device_order(pol_k, (nu,)).reshape(-1)
+            self.comm.all_gather_slabs(pd, bounds * nu)
+            pol_k = prob._from_device_order(pd, (nu,))
+            idd = prob._to_device_order(idx, (), np.asarray(idx).dtype).reshape(-1)
+            self.comm.all_gather_slabs(idd, bounds)
+            idx = prob._from_device_order(idd)
         self.last_policy_index = idx
         return J_k, pol_k, J_ref
 
@@ -714,8 +724,24 @@ class DPSolver(object):
         for k in range(n_iter):
             # progress line of the reference; the iterations themselves run in one device call
             print('\rpolicy evaluation: iter. {:d}/{:d}'.format(k, n_iter), end='')
-        J_ref = prob.eval_policy(n_iter, rel_dp, self._ref_flat(prob) if rel_dp else 0)
-        J_pol = prob.get_value()
+        if self.comm is not None and not self.comm.is_device:
+            # host-side (gloo) communicator: one device call per iteration, the
+            # slabs meet in host memory in between (test path; RCCL stays on device)
+            bounds = self.comm.slab_bounds(prob.dev_shape)
+            J_pol, J_ref = np.asarray(J_zero, dtype=self.dtype), np.zeros(n_iter)
+            for k in range(n_iter):
+                if k:
+                    prob.set_value(J_pol)
+                prob.eval_policy(1, False, 0)
+                Jd = prob._to_device_order(prob.get_value()).reshape(-1)
+                self.comm.all_gather_slabs(Jd, bounds)
+                J_pol = prob._from_device_order(Jd)
+                if rel_dp:
+                    J_ref[k] = J_pol[self._state_ref_ind]          # sdp.py:757-760
+                    J_pol -= J_pol[self._state_ref_ind]
+        else:
+            J_ref = prob.eval_policy(n_iter, rel_dp, self._ref_flat(prob) if rel_dp else 0)
+            J_pol = prob.get_value()
         exec_time = (datetime.now() - t_start).total_seconds()
         if report_time:
             print('\rpolicy evaluation run in {:.2f} s     '.format(exec_time))

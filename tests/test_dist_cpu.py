@@ -61,10 +61,10 @@ class FakeProblem(object):
     """stands for _DeviceProblem: computes this rank's slab with the oracle"""
     layout = 0
     dev_shape = spec.shape
-    def _to_device_order(self, A):
+    def _to_device_order(self, A, extra=(), dtype=None):
         return np.ascontiguousarray(A)
-    def _from_device_order(self, A):
-        return A.reshape(spec.shape)
+    def _from_device_order(self, A, extra=()):
+        return A.reshape(spec.shape + extra)
     def set_value(self, V):
         self.V = np.array(V, dtype=float)
     def sweep(self, t_k, rel_dp, ref_index):
@@ -90,6 +90,7 @@ s._problem = lambda t_k=None: FakeProblem()
 
 V0 = np.zeros(spec.shape)
 J1, pol1 = s.value_iteration(V0, report_time=False)
+idx1 = s.last_policy_index
 Jd = J1 - J1[s._state_ref_ind]
 (J2, J2ref), pol2 = s.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
 
@@ -97,6 +98,9 @@ Jd = J1 - J1[s._state_ref_ind]
 E1, _, _, _ = vi_numpy.value_iteration(spec, V0)
 (E2, E2ref), _, _, _ = vi_numpy.value_iteration(spec, (E1 - E1[spec.ref_ind], 0.), rel_dp=True)
 assert np.array_equal(J1, E1), 'gathered J differs from the single-process sweep'
+_, Epol, Eidx, _ = vi_numpy.value_iteration(spec, V0)
+assert np.array_equal(pol1, Epol.reshape(pol1.shape)), 'gathered policy differs'
+assert np.array_equal(idx1, Eidx.reshape(spec.shape))
 assert np.array_equal(J2, E2) and J2ref == E2ref
 assert J2[s._state_ref_ind] == 0.0
 assert comm.allreduce_max(float(rank)) == world - 1

@@ -1,0 +1,100 @@
+"""Sharded sweeps with the real HIP kernels: two processes share the one GPU of
+the test box, each computes its slab of every backup through the C ABI and
+the slabs meet over gloo (host memory).  The gathered results must equal the
+single-process sweep bit for bit -- value, policy values, policy indices,
+relative-DP reference cost, fixed-policy evaluation -- for the column layout
+(slabs of columns) and for the node layout (slabs of rows).
+
+RCCL itself needs one GPU per rank, which the test box does not have: the
+device-side exchange is covered on one rank (test_gpu_sweep.py) and by
+bench.py's `sharded_matches_single_gpu` self-check on the multi-GPU node."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch.distributed as tdist
+tdist.init_process_group('gloo', init_method='env://')
+from stodynprog_amd import models
+from stodynprog_amd.dist import GlooCommunicator
+
+comm = GlooCommunicator()
+rank = comm.rank
+rng = np.random.default_rng(11)                     # same stream on both ranks
+
+CASES = [('synthetic3d', dict(N=20), 'column'),
+         ('storage_ar1', dict(), 'column'),          # 61 column planes: uneven slabs
+         ('nas_demo', dict(), None),
+         ('inventory', dict(), None)]
+for name, kw, kernel in CASES:
+    _, one = getattr(models, name)(**kw)
+    _, two = getattr(models, name)(**kw)
+    two.comm = comm
+    shape = one._state_grid_shape
+    V0 = rng.standard_normal(shape)
+    J1, p1 = one.value_iteration(V0, report_time=False)
+    i1 = one.last_policy_index
+    J2, p2 = two.value_iteration(V0, report_time=False)
+    i2 = two.last_policy_index
+    if kernel is not None:
+        assert one.backend_info['kernel'] == kernel == two.backend_info['kernel'], one.backend_info
+    assert two._cache and any(k[0] == 'problem' for k in two._cache)
+    prob = [v for k, v in two._cache.items() if k[0] == 'problem'][0]
+    lo, hi = prob.node_range
+    assert hi - lo < V0.size, 'the sharded solver must sweep a strict slab'
+    assert np.array_equal(J1, J2), name
+    assert np.array_equal(p1, p2), name
+    assert np.array_equal(i1, i2), name
+    # relative DP: shift after the gather
+    ref = one._state_ref_ind
+    Jd = J1 - J1[ref]
+    (Ja, ra), _ = one.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
+    (Jb, rb), _ = two.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
+    assert np.array_equal(Ja, Jb) and ra == rb and Jb[ref] == 0.0, name
+    # fixed-policy evaluation, plain and relative
+    Ea = one.eval_policy(p1, 3, report_time=False)
+    Eb = two.eval_policy(p1, 3, report_time=False)
+    assert np.array_equal(Ea, Eb), name
+    Ea, fa = one.eval_policy(p1, 4, rel_dp=True, report_time=False, J_ref_full=True)
+    Eb, fb = two.eval_policy(p1, 4, rel_dp=True, report_time=False, J_ref_full=True)
+    assert np.array_equal(fa, fb), (name, fa, fb)
+    assert np.array_equal(Ea, Eb), name
+    print('rank', rank, name, 'ok', flush=True)
+comm.barrier()
+print('rank', rank, 'all ok', flush=True)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_one_gpu_sharded_sweeps_match_single_process(gpu, tmp_path):
+    pytest.importorskip('torch')
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=560)[0].decode() for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, out)
+        assert 'rank {} all ok'.format(rank) in out
