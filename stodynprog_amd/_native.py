@@ -124,6 +124,7 @@ def lib():
                     'HIP extension {} is missing: build it with '
                     '`python -c "import __graft_entry__ as g; g.build()"` '
                     '(needs hipcc); there is no CPU fallback'.format(LIB_PATH))
+            _torch_runtime_first()
             try:
                 loaded = C.CDLL(LIB_PATH)
             except OSError as e:
@@ -131,6 +132,39 @@ def lib():
             EXPORTS = _declare(loaded)
             _lib = loaded
     return _lib
+
+
+def _torch_runtime_first():
+    """The PyTorch-ROCm wheel ships its own copies of libamdhip64 / libhsa-runtime64
+    / librccl.  A process that maps libsdp_hip.so (linked against /opt/rocm) first
+    and torch afterwards holds TWO ROCm runtimes, and RCCL then binds to the one
+    that never initialised a device (measured: ncclCommInitRank fails with
+    hsa_system_get_info 4107 / 'no ROCm-capable device').  Multi-process runs use
+    torch.distributed for the rendezvous, so under a launcher (WORLD_SIZE > 1)
+    torch is imported BEFORE the library: the dynamic linker then resolves the
+    library's libamdhip64.so.7 to the copy already mapped and one runtime serves
+    everything.  Single-process use never imports torch."""
+    import sys
+    if 'torch' in sys.modules or int(os.environ.get('WORLD_SIZE', '1') or 1) <= 1:
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
+def rocm_runtimes():
+    """Paths of the distinct libamdhip64 objects mapped into this process."""
+    seen = []
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                path = line.split()[-1]
+                if 'libamdhip64' in path and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
 
 
 def check(rc):

@@ -114,8 +114,16 @@ class RcclCommunicator(_Base):
         import ctypes as C
         from . import _native as nat
         self.rank, self.nranks = int(rank), int(nranks)
+        runtimes = nat.rocm_runtimes()
+        if len(runtimes) > 1:
+            raise nat.NativeError(
+                'two HIP runtimes are mapped in this process ({}): libsdp_hip.so was loaded '
+                'before torch.  RCCL cannot initialise in that state; import torch before '
+                'stodynprog_amd (a launcher that sets WORLD_SIZE does it for you)'
+                .format(', '.join(runtimes)))
         h = C.c_void_p()
-        nat.check(nat.lib().sdp_comm_create(self.rank, self.nranks, unique_id, C.byref(h)))
+        with _stdout_to_stderr():          # RCCL prints a version banner on stdout at init
+            nat.check(nat.lib().sdp_comm_create(self.rank, self.nranks, unique_id, C.byref(h)))
         self.handle = h
         self._nat = nat
 
@@ -155,13 +163,13 @@ def from_env():
     local = int(os.environ.get('LOCAL_RANK', rank))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist        # before the library: one ROCm runtime (see _native)
     from . import _native as nat
     nat.check(nat.lib().sdp_set_device(local))
-    import torch.distributed as dist
     if not dist.is_initialized():
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
     host = GlooCommunicator()
-    with _stdout_to_stderr():          # RCCL prints a version banner on stdout at init
+    with _stdout_to_stderr():          # nothing native may write into the caller's stdout
         uid = RcclCommunicator.new_unique_id() if rank == 0 else None
         uid = host.broadcast_bytes(uid, src=0)
         dev = RcclCommunicator(rank, world, uid)

@@ -2,6 +2,7 @@
 exactly as the RCCL path does on GPUs.  The per-rank sweep is played by the
 CPU oracle (no GPU here); what is under test is the partition, the all-gather
 assembly (uneven slabs included) and the relative-DP shift after the gather."""
+import importlib.util
 import os
 import socket
 import subprocess
@@ -121,7 +122,8 @@ def _free_port():
 
 @pytest.mark.timeout(300)
 def test_two_rank_gloo_sweep_matches_single_process(tmp_path):
-    pytest.importorskip('torch')
+    if importlib.util.find_spec('torch') is None:      # not imported here: see _native.py
+        pytest.skip('torch not installed')
     script = tmp_path / 'worker.py'
     script.write_text(WORKER.format(root=ROOT))
     port = _free_port()
@@ -135,3 +137,19 @@ def test_two_rank_gloo_sweep_matches_single_process(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, out)
         assert 'rank {} ok'.format(rank) in out
+
+
+def test_library_load_puts_torch_first_under_a_launcher():
+    """_native._torch_runtime_first: with WORLD_SIZE > 1 torch is imported before
+    libsdp_hip.so is mapped, so that one ROCm runtime serves torch, the library
+    and RCCL; without a launcher the library never pulls torch in."""
+    if importlib.util.find_spec('torch') is None:      # not imported here: see _native.py
+        pytest.skip('torch not installed')
+    code = ("import sys; sys.path.insert(0, {!r}); from stodynprog_amd import _native as nat; "
+            "nat.lib(); print('torch' in sys.modules, len(nat.rocm_runtimes()))").format(ROOT)
+    for world, expect in (('2', 'True 1'), ('1', 'False 1')):
+        env = dict(os.environ, WORLD_SIZE=world)
+        out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=200)
+        assert out.returncode == 0, out.stdout.decode()
+        assert out.stdout.decode().strip().splitlines()[-1] == expect, out.stdout.decode()

@@ -8,6 +8,7 @@ relative-DP reference cost, fixed-policy evaluation -- for the column layout
 RCCL itself needs one GPU per rank, which the test box does not have: the
 device-side exchange is covered on one rank (test_gpu_sweep.py) and by
 bench.py's `sharded_matches_single_gpu` self-check on the multi-GPU node."""
+import importlib.util
 import os
 import socket
 import subprocess
@@ -84,7 +85,8 @@ def _free_port():
 
 @pytest.mark.timeout(600)
 def test_two_processes_one_gpu_sharded_sweeps_match_single_process(gpu, tmp_path):
-    pytest.importorskip('torch')
+    if importlib.util.find_spec('torch') is None:      # not imported here: see _native.py
+        pytest.skip('torch not installed')
     script = tmp_path / 'worker.py'
     script.write_text(WORKER.format(root=ROOT))
     port = _free_port()
@@ -98,3 +100,33 @@ def test_two_processes_one_gpu_sharded_sweeps_match_single_process(gpu, tmp_path
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank {} failed:\n{}'.format(rank, out)
         assert 'rank {} all ok'.format(rank) in out
+
+
+LOAD_ORDER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+from stodynprog_amd import _native as nat
+nat.lib()                                   # WORLD_SIZE=2 in the environment: torch goes first
+assert 'torch' in sys.modules
+import torch.distributed
+assert len(nat.rocm_runtimes()) == 1, nat.rocm_runtimes()
+from stodynprog_amd.dist import RcclCommunicator
+nat.check(nat.lib().sdp_set_device(0))
+c = RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
+c.barrier()
+assert c.allreduce_max(3.5) == 3.5
+c.close()
+print('load order ok', flush=True)
+'''
+
+
+@pytest.mark.timeout(300)
+def test_one_rocm_runtime_when_torch_and_rccl_share_the_process(gpu, tmp_path):
+    """Regression: libsdp_hip.so mapped before torch left two HIP runtimes in
+    the process and ncclCommInitRank failed ('no ROCm-capable device')."""
+    script = tmp_path / 'order.py'
+    script.write_text(LOAD_ORDER.format(root=ROOT))
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=280)
+    assert out.returncode == 0 and b'load order ok' in out.stdout, out.stdout.decode()
