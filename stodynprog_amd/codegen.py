@@ -174,7 +174,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
     ]
     if column is not None:
         assert model.storage_separable
-        col_cfg = column_config(column[0], column[1], model.n_state, dtype)
+        wpair = use_wpair(model, dtype)
+        col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair)
         assert col_cfg is not None
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
@@ -183,6 +184,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
             '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
+            '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
         ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
@@ -201,17 +203,31 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
 COLUMN_LDS_MAX = 160 * 1024          # LDS of one gfx950 CU
 
 
-def column_config(n0, w, n_state, dtype):
+def use_wpair(model, dtype):
+    """float32 tables interleave perturbation points 2k and 2k+1 (SDP_COL_WPAIR of
+    csrc/sdp_column_kernel.h): one 8-byte LDS read serves two lattice cells.
+    Needs a perturbation and an x0' that does not depend on it (one axis-0 cell
+    per control).  Same bits as the plain layout; measured on 256^3 x 64 x 32:
+    exact 6.05 -> 5.77 ms, fused 4.43 -> 3.66 ms.  (A table of (T[r], T[r+1])
+    pairs was also measured for 4-byte reals and did not pay: not kept.)"""
+    if os.environ.get('SDP_COL_WPAIR'):                 # A/B runs
+        return bool(int(os.environ['SDP_COL_WPAIR']))
+    return (np.dtype(dtype).itemsize == 4 and model.n_perturb > 0
+            and not model.lead_depends_on_w)
+
+
+def column_config(n0, w, n_state, dtype, wpair=False):
     """Compile-time shape of the column kernel for a grid with n0 points along
     axis 0 and w perturbation points: (threads, lds_bytes), or None if the
     table does not fit the LDS of a CU.  512-thread workgroups while two of
     them fit a CU, else 1024 threads (one workgroup then has to fill the CU's
-    wave slots alone).  (A table of (T[r], T[r+1]) pairs -- one LDS read per
-    cell -- was measured for 4-byte reals and did not pay: not kept.)"""
+    wave slots alone).  `wpair`: the table holds whole pairs of perturbation
+    points (an odd count is rounded up)."""
     rs = np.dtype(dtype).itemsize
     w = max(int(w), 1)
+    tw = w + (w & 1) if wpair else w
     for threads in (512, 1024):
-        raw = (w * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs)
+        raw = (tw * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs)
         lds = (raw + 15) // 16 * 16
         if lds * (2 if threads == 512 else 1) <= COLUMN_LDS_MAX:
             return threads, lds

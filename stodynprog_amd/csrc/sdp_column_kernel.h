@@ -61,7 +61,16 @@
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
 #endif
+#ifndef SDP_COL_WPAIR
+#define SDP_COL_WPAIR 0          // 1 (4-byte reals): the table interleaves perturbation points 2k and
+#endif                           //    2k+1, T2[k][r] = (inner_2k(r), inner_2k+1(r)); one 8-byte LDS read
+                                 //    serves two cells and the cell arithmetic runs as packed fp32
+#if SDP_COL_WPAIR && (!SDP_HAS_W || SDP_LEAD_HAS_W)
+#error "SDP_COL_WPAIR needs a perturbation and an x0' that does not depend on it"
+#endif
 constexpr int SDP_DT = SDP_D - 1;
+// rows of the LDS table: perturbation points, rounded up to whole pairs for the pair layout
+constexpr int SDP_COL_TW = SDP_COL_WPAIR ? (SDP_COL_W + 1) / 2 * 2 : SDP_COL_W;
 
 struct SdpColShared {
     sdp_real *T;        // [Wn][N0]
@@ -74,7 +83,7 @@ struct SdpColShared {
 
 // statically sized LDS image (a single workgroup may use up to 160 KiB)
 struct __attribute__((aligned(16))) SdpColLds {
-    sdp_real T[SDP_COL_W * SDP_COL_N0];
+    sdp_real T[SDP_COL_TW * SDP_COL_N0];
     sdp_real w_lam[SDP_COL_W * SDP_DT];
     sdp_real w_oml[SDP_COL_W * SDP_DT];
     sdp_real pw[SDP_COL_W];                // weight / point copies (SDP_COL_WMODE 2)
@@ -174,9 +183,14 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
 #if SDP_COL_FUSED && SDP_HAS_W
                 // fused arithmetic: the table holds p_w * inner(r), so phase B is
                 // two fused multiply-adds per cell
-                s.T[w[j] * N0 + r[j]] = val[j] * ((const sdp_real *)a.proba)[w[j]];
+                const sdp_real entry = val[j] * ((const sdp_real *)a.proba)[w[j]];
 #else
-                s.T[w[j] * N0 + r[j]] = val[j];
+                const sdp_real entry = val[j];
+#endif
+#if SDP_COL_WPAIR
+                s.T[((w[j] >> 1) * N0 + r[j]) * 2 + (w[j] & 1)] = entry;
+#else
+                s.T[w[j] * N0 + r[j]] = entry;
 #endif
             }
         }
@@ -276,6 +290,132 @@ SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k, sdp_r
 #endif
 }
 
+#if SDP_COL_WPAIR
+// Pair layout (4-byte reals): perturbation points 2k, 2k+1 of one control are
+// processed together.  Each lane of the packed operations below is the
+// reference's operation on the same operands (v_pk_mul_f32 / v_pk_add_f32 round
+// each half like the scalar instruction), and the expectation is accumulated
+// in w order (first .x, then .y), so the result is bit-identical to the plain
+// layout; the fused variant keeps two partial sums (even / odd points).
+typedef sdp_real sdp_v2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) sdp_v2 sdp_lds_v2;
+
+template <int K>
+SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
+                                   const sdp_real *T, const sdp_real *x,
+                                   const sdp_real (*u)[SDP_NU], sdp_real t, sdp_real *out)
+{
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    constexpr int WP = Wn / 2;                      // whole pairs; an odd last point is the tail
+    sdp_real lam0[K], oml0[K], acc[K], g[K];
+    const volatile sdp_lds_v2 *row[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const sdp_real xn0 = sdp_model_lead(x, u[j], (sdp_real)0, t);
+        const sdp_real sn = (xn0 - l.smin) / l.span;                    /* pyx:75 */
+        const sdp_real p = sn * l.nm1;
+        const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);          /* pyx:78 */
+        lam0[j] = p - (sdp_real)q0;                                     /* pyx:81 */
+        oml0[j] = (sdp_real)1 - lam0[j];
+        row[j] = (const volatile sdp_lds_v2 *)T + q0;
+        acc[j] = (sdp_real)0;
+#if !SDP_COST_HAS_W
+        g[j] = sdp_model_cost(x, u[j], (sdp_real)0, t);
+#endif
+    }
+    constexpr int B = SDP_COL_BATCH;
+#if SDP_COL_FUSED
+    sdp_v2 acc2[K];
+    sdp_real gacc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { acc2[j] = (sdp_v2)(0); gacc[j] = (sdp_real)0; }
+#endif
+#pragma unroll SDP_COL_UNROLL_W
+    for (int p0 = 0; p0 < WP; p0 += B) {
+        sdp_v2 lo[B][K], hi[B][K];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (p0 + b < WP) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    lo[b][j] = row[j][(p0 + b) * N0];
+                    hi[b][j] = row[j][(p0 + b) * N0 + 1];
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (p0 + b < WP) {
+                const int w = 2 * (p0 + b);
+#if SDP_COL_FUSED
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    acc2[j] = __builtin_elementwise_fma((sdp_v2)(lam0[j]), hi[b][j],
+                              __builtin_elementwise_fma((sdp_v2)(oml0[j]), lo[b][j], acc2[j]));
+#if SDP_COST_HAS_W
+                    gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t), SDP_COL_PW(k, w), gacc[j]);
+                    gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w + 1), t), SDP_COL_PW(k, w + 1), gacc[j]);
+#endif
+                }
+#else
+                sdp_v2 pw2;
+                pw2.x = SDP_COL_PW(k, w);
+                pw2.y = SDP_COL_PW(k, w + 1);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const sdp_v2 val = (sdp_v2)(oml0[j]) * lo[b][j] + (sdp_v2)(lam0[j]) * hi[b][j];  // pyx:88-300
+                    sdp_v2 g2;
+#if SDP_COST_HAS_W
+                    g2.x = sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t);
+                    g2.y = sdp_model_cost(x, u[j], SDP_COL_GW(k, w + 1), t);
+#else
+                    g2 = (sdp_v2)(g[j]);
+#endif
+                    const sdp_v2 jc = g2 + val;                       // stodynprog.py:677
+                    const sdp_v2 tt = jc * pw2;
+                    acc[j] = acc[j] + tt.x;                           // stodynprog.py:681, w order
+                    acc[j] = acc[j] + tt.y;
+                }
+#endif
+            }
+    }
+#if SDP_COL_FUSED
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = acc2[j].x + acc2[j].y;
+#endif
+    if (Wn & 1) {                                   // odd W: the last point sits alone in its pair
+        constexpr int w = Wn - 1;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const sdp_real lo = row[j][WP * N0].x;
+            const sdp_real hi = row[j][WP * N0 + 1].x;
+#if SDP_COL_FUSED
+            acc[j] = fma(lam0[j], hi, fma(oml0[j], lo, acc[j]));
+#if SDP_COST_HAS_W
+            gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t), SDP_COL_PW(k, w), gacc[j]);
+#endif
+#else
+            const sdp_real val = oml0[j] * lo + lam0[j] * hi;
+#if SDP_COST_HAS_W
+            g[j] = sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t);
+#endif
+            const sdp_real jc = g[j] + val;
+            acc[j] = acc[j] + jc * SDP_COL_PW(k, w);
+#endif
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#if SDP_COL_FUSED && SDP_COST_HAS_W
+        out[j] = gacc[j] + acc[j];
+#elif SDP_COL_FUSED
+        out[j] = fma(g[j], k.psum, acc[j]);
+#else
+        out[j] = acc[j];
+#endif
+    }
+}
+#else   // plain layout
 // Expected cost of K controls of one node out of the table.  The K cost
 // chains are independent, so interleaving them gives the in-order wave K times
 // the instruction-level parallelism per LDS round trip (and one scalar load of
@@ -417,6 +557,7 @@ SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
 #endif
 #undef SDP_COL_LOCATE
 }
+#endif  // SDP_COL_WPAIR
 
 SDP_DEV void sdp_col_store(const SdpSweepArgs &a, int64_t node, const SdpBox &box,
                            sdp_real best, int ibest)

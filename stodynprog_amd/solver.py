@@ -399,7 +399,8 @@ class DPSolver(object):
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         column = (self.kernel != 'generic' and model.storage_separable and
-                  codegen.column_config(shape[0], W, len(shape), dt) is not None)
+                  codegen.column_config(shape[0], W, len(shape), dt,
+                                        codegen.use_wpair(model, dt)) is not None)
         if not column and self.kernel != 'generic':
             k = model.separable_axis_hint()
             if k is not None and not self._cache.get('hinted'):

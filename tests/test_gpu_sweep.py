@@ -451,6 +451,66 @@ def test_column_and_generic_kernels_agree_bitwise(gpu, name, kw):
     assert np.array_equal(Ec, Eg) and np.array_equal(refs_c, refs_g)
 
 
+def _priced_storage_problem(n_w):
+    """stock + exogenous price; the cost depends on the perturbation, x0' does not"""
+    s = SysDescription((2, 1, 1), name='priced storage')
+
+    def dyn(e, p, u, w):
+        return (e + 0.25 * u, 0.7 * p + w)
+
+    def cost(e, p, u, w):
+        return (p + 0.5 * w) * u + 0.05 * u * u + 0.01 * (e - 1.0) * (e - 1.0)
+
+    def box(e, p):
+        return ((-1., 1.),)
+    s.dyn, s.cost, s.control_box = dyn, cost, box
+    s.perturb_laws = [models.NormalLaw(0, 0.3)]
+    solver = DPSolver(s)
+    solver.discretize_state(0, 2, 37, -1, 1, 11)
+    solver.discretize_perturb(-0.9, 0.9, n_w)
+    solver.control_steps = (0.125,)
+    return s, solver
+
+
+@pytest.mark.parametrize('case', ['storage_ar1', 'searev', 'synthetic3d', 'priced-8', 'priced-7', 'priced-1'])
+def test_float32_pair_table_matches_generic_kernel_bitwise(gpu, case):
+    """float32 column kernels keep perturbation points 2k, 2k+1 side by side in
+    the LDS table (SDP_COL_WPAIR: 8-byte reads, packed arithmetic).  Same bits
+    as the per-cell generic kernel in float32 -- even and odd W (tail point),
+    cost with and without w, eval_policy -- and the fused variant within the
+    float32 tolerance of the north star (1e-5)."""
+    if case.startswith('priced'):
+        sysd, ref = _priced_storage_problem(int(case.split('-')[1]))
+    else:
+        kw = {'storage_ar1': dict(n_E=33, n_P=20, steps=(0.05, 0.1)),
+              'searev': dict(n_E=17, n_S=12, n_A=9, step=0.01),
+              'synthetic3d': dict(N=24)}[case]
+        sysd, ref = getattr(models, case)(**kw)
+    from stodynprog_amd import codegen
+    assert codegen.use_wpair(ref._traced(), np.float32) and not codegen.use_wpair(ref._traced(), np.float64)
+    col = _clone_with_kernel(sysd, ref, 'column', np.float32)
+    gen = _clone_with_kernel(sysd, ref, 'generic', np.float32)
+    V = np.random.default_rng(5).standard_normal(ref._state_grid_shape).astype(np.float32)
+    Jc, uc = col.value_iteration(V, report_time=False)
+    Jg, ug = gen.value_iteration(V, report_time=False)
+    assert col.backend_info['kernel'] == 'column' and gen.backend_info['kernel'] == 'generic'
+    assert '#define SDP_COL_WPAIR 1' in col._kernel_plan()['source']
+    assert Jc.dtype == np.float32
+    assert np.array_equal(Jc, Jg) and np.array_equal(uc, ug)
+    assert np.array_equal(col.last_policy_index, gen.last_policy_index)
+    Ec = quiet(col.eval_policy, ug, 5, False, V * np.float32(0.1))
+    Eg = quiet(gen.eval_policy, ug, 5, False, V * np.float32(0.1))
+    assert np.array_equal(Ec, Eg)
+    fused = _clone_with_kernel(sysd, ref, 'column', np.float32)
+    fused.arithmetic = 'fused'
+    Jf, _ = fused.value_iteration(V, report_time=False)
+    assert np.abs(Jf.astype(float) - Jc).max() / np.abs(Jc).max() < 1e-5
+    # and float32 stays within 1e-5 of the float64 sweep of the same problem
+    f64 = _clone_with_kernel(sysd, ref, 'column')
+    Jd, _ = f64.value_iteration(V.astype(float), report_time=False)
+    assert np.abs(Jc - Jd).max() / np.abs(Jd).max() < 1e-5
+
+
 def test_column_kernel_is_the_default_for_storage_problems(gpu):
     for name in ('nas_demo', 'storage_ar1', 'searev', 'synthetic3d'):
         _, s = getattr(models, name)()

@@ -4,7 +4,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d "$OUT" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fused > "$OUT/bench.json" 2> "$OUT/log.txt"
+rocprofv3 --pmc "$@" --output-format csv -d "$OUT" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fused $PMC_BENCH_ARGS > "$OUT/bench.json" 2> "$OUT/log.txt"
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of column-kernel build knobs on the GPU box (tuning aid).
-usage: python tools/tune.py "K1=v K2=v" "K1=v ..." ...   (one bench run per argument)"""
+usage: python tools/tune.py "K1=v K2=v" "K1=v ..." ...   (one bench run per argument);
+extra bench.py arguments from $TUNE_BENCH_ARGS (e.g. "--dtype float32 --grid 512")"""
 import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for cfg in sys.argv[1:]:
@@ -9,7 +10,8 @@ for cfg in sys.argv[1:]:
         k, v = kv.split('=')
         env[k] = v
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '10', '--warmup', '3',
-                        '--no-cpu-baseline', '--no-fused'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                        '--no-cpu-baseline', '--no-fused'] + os.environ.get('TUNE_BENCH_ARGS', '').split(),
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     try:
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         print('{:70s} {:8.3f} ms/sweep  kernel {:8.3f} ms'.format(cfg, d['ms_per_step'], d['roofline']['kernel_ms']), flush=True)
