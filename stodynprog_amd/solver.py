@@ -508,6 +508,48 @@ class DPSolver(object):
             J_k = J_k, J_ref
         return J_k, pol_k
 
+    def value_iterations(self, J_next, n_iter, rel_dp=False, report_time=True, J_ref_full=False):
+        """`n_iter` successive calls of `value_iteration`, each fed with the
+        result of the previous one -- the loop every user of the reference
+        writes by hand (doc/example_inventory.py:98-109, AR1 notebook) -- but
+        with the cost-to-go kept on the device between sweeps: one upload, one
+        download.  NOT in the reference API.  Same results, bit for bit, as
+
+            for k in range(n_iter): J, pol = self.value_iteration(J, rel_dp)
+
+        Returns (J_k, pol_k) of the last sweep; J_k is (J_diff, J_ref) with
+        `rel_dp` (J_ref: last reference cost, or all of them if J_ref_full)."""
+        t_start = datetime.now()
+        assert n_iter >= 1
+        if rel_dp:
+            J_next, J_ref = J_next
+            assert J_next[self._state_ref_ind] == 0.
+        J_next = np.asarray(J_next)
+        self._check_state_array(J_next)
+        host_comm = self.comm is not None and not self.comm.is_device
+        refs = np.zeros(n_iter)
+        if isinstance(self._traced(), TraceError) or host_comm:
+            J_k = J_next                    # host callbacks / host exchange: sweep by sweep
+            for k in range(n_iter):
+                J_k, pol_k, r = self._backup(J_k, None, rel_dp)
+                refs[k] = 0.0 if r is None else r
+        else:
+            prob = self._problem(None)
+            prob.set_value(J_next)
+            ref_flat = self._ref_flat(prob) if rel_dp else 0
+            for k in range(n_iter):
+                if k:
+                    prob.swap()             # J of the previous sweep becomes J_next
+                refs[k] = prob.sweep(0.0, rel_dp, ref_flat)
+            J_k = prob.get_value()
+            pol_k, self.last_policy_index = prob.get_policy()
+        if report_time:
+            exec_time = (datetime.now() - t_start).total_seconds()
+            print('{:d} value iterations run in {:.2f} s'.format(n_iter, exec_time))
+        if rel_dp:
+            return (J_k, refs if J_ref_full else refs[-1]), pol_k
+        return J_k, pol_k
+
     def _backup(self, J_next, t_k, rel_dp):
         """One sweep: fused kernel when the model is traceable, else tabulated."""
         model = self._traced()

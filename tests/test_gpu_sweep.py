@@ -56,6 +56,49 @@ def test_value_iteration_prints_like_the_reference(gpu, capsys):
 
 
 # ---------------------------------------------------------------- NaS demo
+def test_value_iterations_device_resident_loop(gpu):
+    """DPSolver.value_iterations (extension): n sweeps with the cost-to-go kept
+    on the device = the user's loop over value_iteration, bit for bit"""
+    g = golden('g2_inventory')
+    _, inv = models.inventory()
+    J, pol = quiet(inv.value_iterations, np.zeros(10), 6)
+    assert_sweep_parity(J, inv.last_policy_index, g['J'][5], g['idx'][5], g['margin'][5], 'inventory x6')
+    assert np.array_equal(pol, g['pol'][5])
+    for name, kw in (('synthetic3d', dict(N=20)), ('storage_ar1', dict(n_E=21, n_P=15, steps=(0.1, 0.1)))):
+        _, a = getattr(models, name)(**kw)
+        _, b = getattr(models, name)(**kw)
+        V = np.random.default_rng(8).standard_normal(a._state_grid_shape)
+        V -= V[a._state_ref_ind]
+        Ja, refs_a = V, []
+        for k in range(4):
+            (Ja, r), pa = a.value_iteration((Ja, 0.), rel_dp=True, report_time=False)
+            refs_a.append(r)
+        (Jb, refs_b), pb = quiet(b.value_iterations, (V, 0.), 4, True, J_ref_full=True)
+        assert np.array_equal(Ja, Jb) and np.array_equal(pa, pb) and np.array_equal(refs_a, refs_b)
+        assert np.array_equal(a.last_policy_index, b.last_policy_index)
+        Jc, pc = quiet(b.value_iterations, V, 1)
+        Jd, pd = a.value_iteration(V, report_time=False)
+        assert np.array_equal(Jc, Jd) and np.array_equal(pc, pd)
+    # untraceable callables take the sweep-by-sweep path
+    s = SysDescription((1, 1, 1))
+
+    def dyn(x, u, w):
+        return (x + np.asarray(u).reshape(np.shape(u)) - w,)        # needs a concrete array
+    s.dyn = dyn
+    s.cost = lambda x, u, w: np.where(x > 0, 0.5 * x, -3. * x) + u
+    s.control_box = lambda x: ((0., 4.),)
+    s.perturb_laws = [models.DiscreteLaw([0, 1, 2], [0.3, 0.4, 0.3])]
+    t = DPSolver(s)
+    t.discretize_state(-2, 5, 8)
+    t.discretize_perturb(0, 2, 3)
+    t.control_steps = (1.,)
+    assert isinstance(t._traced(), TraceError)
+    J2, p2 = quiet(t.value_iterations, np.zeros(8), 2)
+    J1, _ = t.value_iteration(np.zeros(8), report_time=False)
+    J1, p1 = t.value_iteration(J1, report_time=False)
+    assert np.array_equal(J1, J2) and np.array_equal(p1, p2)
+
+
 def test_nas_demo_two_sweeps(gpu):
     g = golden('g7_nas')
     _, solver = models.nas_demo()
