@@ -325,6 +325,45 @@ def test_nan_and_inf_costs_follow_numpy_argmin(gpu):
     assert io[0] == 0
 
 
+def test_column_kernel_nan_inf_costs_and_chunk_merge(gpu):
+    """NaN / inf costs through the column kernel: few nodes per column, so the
+    control lattice is cut into chunks over the waves and the partial minima
+    are merged through LDS -- first NaN wins, all-inf keeps index 0, ties keep
+    the first index (numpy argmin, stodynprog.py:686)."""
+    s = SysDescription((2, 1, 1))
+
+    def dyn(x, y, u, w):
+        return (x + 0.5 * u, 0.5 * y + w)
+
+    def cost(x, y, u, w):
+        plateau = np.where(np.abs(u) < 0.3, 0. * u, u * u)              # exact ties around u = 0
+        bad = np.where(u > 0.9, np.nan, np.where(u < -0.9, np.inf, plateau))
+        return np.where(x > 0.4, bad, np.where(x < -0.4, np.inf + 0. * u, plateau)) + 0. * y
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda x, y: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.1)]
+    ref = DPSolver(s)
+    ref.discretize_state(-1, 1, 9, -1, 1, 5)
+    ref.discretize_perturb(-0.2, 0.2, 3)
+    ref.control_steps = (2. / 200,)                    # 201 controls, 9 nodes per column
+    assert ref._traced().storage_separable
+    V = np.add.outer(np.linspace(0, 1, 9), np.linspace(0, 0.5, 5) ** 2)
+    with np.errstate(all='ignore'):
+        Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(ref), V)
+    assert np.isnan(Jo[-1]).all() and np.isinf(Jo[0]).all() and (io[0] == 0).all()
+    for kernel, dtype in (('column', np.float64), ('generic', np.float64), ('column', np.float32)):
+        sol = _clone_with_kernel(s, ref, kernel, dtype)
+        J, u = sol.value_iteration(V, report_time=False)
+        assert sol.backend_info['kernel'] == kernel
+        if dtype == np.float64:
+            assert np.array_equal(J, Jo, equal_nan=True), kernel
+            assert np.array_equal(sol.last_policy_index, io), kernel
+            assert np.array_equal(u, uo), kernel
+        else:
+            assert np.array_equal(np.isnan(J), np.isnan(Jo)) and np.array_equal(np.isinf(J), np.isinf(Jo))
+            assert (sol.last_policy_index[0] == 0).all()      # (the first NaN moves with float32 rounding of u)
+
+
 def test_tabulated_mode_for_untraceable_callables(gpu):
     _, ref = models.nas_demo(n_E=11, n_P=9, n_w=5)
     sysd = SysDescription((2, 1, 1), name='untraceable')
