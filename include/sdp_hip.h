@@ -126,6 +126,16 @@ int sdp_problem_set_value(sdp_problem *p, const void *host_V);
 /* pol of eval_policy (stodynprog.py:693,723): [S][nu] reals (control values). */
 int sdp_problem_set_policy(sdp_problem *p, const void *host_pol);
 
+/* Lifted model constants.  A finite-horizon problem whose callables look data
+ * up by time index (reference examples/01 Deterministic storage control/
+ * det_storage_control.py:89, `P_req = p['P_req_data'][k]`, called from
+ * DPSolver.bellman_recursion, stodynprog.py:582) is traced one time step at a
+ * time; the constants of the step become the array `sdp_model_prm[n]` of the
+ * code object (same `real` type as the problem), so all steps share one kernel.
+ * Sets those n values for the launches that follow.  n must equal the count
+ * the code object declares (0 when it declares none). */
+int sdp_problem_set_params(sdp_problem *p, const void *values, int32_t n);
+
 /*
  * One Bellman backup over the handle's node slab -- DPSolver.value_iteration
  * (stodynprog.py:466-534) fused with _value_at_state_vect (639-691) and the

@@ -88,6 +88,7 @@ def _declare(lib):
         'sdp_problem_destroy': (C.c_int, [vp]),
         'sdp_problem_set_value': (C.c_int, [vp, vp]),
         'sdp_problem_set_policy': (C.c_int, [vp, vp]),
+        'sdp_problem_set_params': (C.c_int, [vp, vp, i32]),
         'sdp_problem_vi_sweep': (C.c_int, [vp, dbl, C.c_int, i64, P(dbl)]),
         'sdp_problem_eval_policy': (C.c_int, [vp, i32, C.c_int, i64, vp]),
         'sdp_problem_swap': (C.c_int, [vp]),

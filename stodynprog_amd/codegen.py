@@ -40,10 +40,12 @@ def real_literal(value):
     return '(sdp_real)({})'.format(float(value).hex())
 
 
-def _emit_node(n, name):
+def _emit_node(n, name, param_index=None):
     a = [name(x) for x in n.args]
     op = n.op
     if op == 'const':
+        if param_index is not None and n.id in param_index:
+            return 'sdp_model_prm[{}]'.format(param_index[n.id])     # lifted constant
         return real_literal(n.value)
     if op == 'bconst':
         return 'true' if n.value else 'false'
@@ -89,7 +91,7 @@ def _emit_body(model, nodes, lines):
         return names[n.id]
 
     for n in nodes:
-        expr = _emit_node(n, name)
+        expr = _emit_node(n, name, getattr(model, 'param_index', None))
         if n.op in ('const', 'bconst', 'var'):
             names[n.id] = expr              # inline leaves
             continue
@@ -168,7 +170,12 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
         '#define SDP_LANES {}'.format(int(lanes)),
         '#include "sdp_device.h"',
         'typedef SDP_REAL sdp_real;',
-        '',
+        ''] + ([
+        # lifted constants (TracedModel.lift_constants): set per launch through
+        # sdp_problem_set_params; uniform loads from constant memory
+        '#define SDP_NPARAMS {}'.format(len(model.param_index)),
+        'extern "C" { __constant__ sdp_real sdp_model_prm[SDP_NPARAMS]; }     // a definition',
+        ''] if getattr(model, 'param_index', None) else []) + [
         model_function_source(model),
         '',
     ]

@@ -601,6 +601,8 @@ struct sdp_problem {
     size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
     hipFunction_t f_sweep = nullptr, f_evalpol = nullptr;
+    hipDeviceptr_t prm_dev = nullptr;     // `sdp_model_prm` of the code object (lifted model constants)
+    size_t prm_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     double last_kernel_ms = 0;
@@ -720,6 +722,12 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
     }
     e = hipModuleGetFunction(&p->f_evalpol, p->mod, k_eval);
     if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_eval, hipGetErrorString(e));
+    // lifted model constants (codegen: `__constant__ sdp_real sdp_model_prm[]`), if any
+    if (hipModuleGetGlobal(&p->prm_dev, &p->prm_bytes, p->mod, "sdp_model_prm") != hipSuccess) {
+        (void)hipGetLastError();
+        p->prm_dev = nullptr;
+        p->prm_bytes = 0;
+    }
     HIP_TRY(hipStreamCreate(&p->stream));
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
@@ -727,6 +735,20 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
     HIP_TRY(hipEventCreate(&p->ev3));
     guard.release();
     *out = p;
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_params(sdp_problem *p, const void *values, int32_t n)
+{
+    if (!p || n < 0 || (n > 0 && !values)) return fail(SDP_EINVAL, "sdp_problem_set_params: bad arguments");
+    const size_t bytes = (size_t)n * real_size(p->dtype);
+    if (bytes != p->prm_bytes)
+        return fail(SDP_EINVAL, "sdp_problem_set_params: the code object declares %zu parameter(s), %d given",
+                    p->prm_bytes / real_size(p->dtype), (int)n);
+    if (!bytes) return SDP_OK;
+    // on the problem's stream: ordered after the launches that still read the old values
+    HIP_TRY(hipMemcpyAsync(p->prm_dev, values, bytes, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));        // `values` may be reused by the caller
     return SDP_OK;
 }
 

@@ -326,3 +326,56 @@ def finite_horizon(api=None, n_x=17, n_w=5):
     solver.discretize_perturb(-0.3, 0.3, n_w)
     solver.control_steps = (0.125,)
     return fh, solver
+
+
+# ----------------------------------------------------------------------------
+# 7. Deterministic storage with time-indexed input data (bellman_recursion)
+# ----------------------------------------------------------------------------
+def pv_profile(T, dt=0.5):
+    """Closed-form stand-in for the measured PV production of the reference's
+    example (pv_prod.csv is not shipped): clipped day arcs with a slow
+    modulation, only + - * / abs (reproducible bit for bit)."""
+    k = np.arange(T, dtype=float)
+    h = (k * dt) % 24.0                                  # hour of day
+    arc = 1.0 - ((h - 12.5) / 6.5) * ((h - 12.5) / 6.5)  # parabola, zero at 6:00 and 19:00
+    day = np.floor(k * dt / 24.0)
+    scale = 0.55 + 0.15 * ((day * 3.0) % 4.0) / 3.0
+    return np.where(arc > 0, arc * scale, 0.0)
+
+
+def pv_storage(api=None, T=48, N_E=50, u_step=0.001, dt=0.5, loss=0.05):
+    """Storage smoothing the output of a PV plant with perfect knowledge of the
+    production -- the shape of the reference's finite-horizon examples
+    (examples/01 Deterministic storage control/pv_storage_control.py:48-98 and
+    det_storage_control.py:58-98): one state (stored energy), one control, no
+    perturbation, `stationnary=False`, and a cost that LOOKS UP the production
+    of the time step in a data array (`P_prod_data[k]`).  The admissible box
+    uses np.max / np.min on scalar tuples like the reference's."""
+    SysDescription, DPSolver = _classes(api)
+    E_rated, P_rated = 2.0, 1.0
+    P_prod_data = pv_profile(T, dt)
+    sto = SysDescription((1, 1, 0), name='Deterministic Storage for PV', stationnary=False)
+
+    def dyn_sto(k, E_sto, P_sto):
+        E_sto_n = E_sto + (P_sto - loss * abs(P_sto)) * dt
+        return (E_sto_n,)
+
+    def admissible_controls(k, E_sto):
+        P_neg = np.max((-E_sto / (1 + loss) / dt, -P_rated))
+        P_pos = np.min(((E_rated - E_sto) / (1 - loss) / dt, P_rated))
+        return ((P_neg, P_pos),)
+
+    def cost_model(k, E_sto, P_sto):
+        P_prod = P_prod_data[k]
+        P_grid = P_prod - P_sto
+        over = np.where(P_grid > 0.4, P_grid - 0.4, 0)
+        neg = np.where(P_grid < 0, P_grid, 0)
+        return over ** 2 + neg ** 2 + 0 * P_sto ** 2
+    sto.dyn = dyn_sto
+    sto.control_box = admissible_controls
+    sto.cost = cost_model
+    solver = DPSolver(sto)
+    solver.discretize_state(0, E_rated, N_E)
+    solver.control_steps = (u_step,)
+    solver.P_prod_data = P_prod_data
+    return sto, solver

@@ -113,6 +113,11 @@ class _DeviceProblem(object):
         pol = np.ascontiguousarray(pol, dtype=self.dtype)
         nat.check(nat.lib().sdp_problem_set_policy(self.h, nat.ptr(pol)))
 
+    def set_params(self, values):
+        """lifted model constants of the launches that follow (sdp_problem_set_params)"""
+        values = np.ascontiguousarray(values, dtype=self.dtype)
+        nat.check(nat.lib().sdp_problem_set_params(self.h, nat.ptr(values), int(values.size)))
+
     def sweep(self, t_k=0.0, rel_dp=False, ref_index=0):
         ref = C.c_double(0.0)
         nat.check(nat.lib().sdp_problem_vi_sweep(self.h, float(t_k), int(bool(rel_dp)),
@@ -366,6 +371,32 @@ class DPSolver(object):
             self._cache[key] = model
         return self._cache[key]
 
+    def _trace_now(self, t_k=None):
+        """Trace the callables for ONE call (value_iteration, a step of
+        bellman_recursion, eval_policy).  Traced afresh every time, like the
+        reference evaluates the callables at call time (stodynprog.py:674-676):
+        module-level data they read may have changed since the last call.
+
+        A time-dependent system whose callables need a concrete time index
+        (`data[k]`) cannot be traced with a symbolic k; it is traced for the
+        step `t_k` alone and the constants of the step are lifted into kernel
+        parameters (trace.TracedModel.lift_constants), so the steps of a
+        horizon share one code object.  Returns a TracedModel or a TraceError."""
+        s = self.sys
+        try:
+            return trace_model(s.dyn, s.cost, len(s.state), len(s.control), len(s.perturb),
+                               s.params, s.stationnary)
+        except TraceError as e:
+            if s.stationnary or t_k is None:
+                return e
+            try:
+                model = trace_model(s.dyn, s.cost, len(s.state), len(s.control),
+                                    len(s.perturb), s.params, s.stationnary, t_value=int(t_k))
+            except TraceError:
+                return e
+            model.lift_constants()
+            return model
+
     def _check_supported(self):
         if len(self.perturb_grid) > 1:
             raise NotImplementedError('only one perturbation variable is supported '
@@ -377,24 +408,43 @@ class DPSolver(object):
         if d > 4:
             raise Exception("Can't interpolate in dimension strictly greater than 5")
 
-    def _kernel_plan(self, box_t=None):
+    def _box_plan(self, box_t=None):
+        """Control-box table of the current discretisation (cached: the scalar
+        fallback of _box_table is a Python loop over the nodes)."""
+        key = ('box', self._fingerprint(box_t))
+        bp = self._cache.get(key)
+        if bp is None:
+            lo, hi, n = self._box_table(box_t)
+            per_node = not (np.all(lo == lo[:, :1]) and np.all(hi == hi[:, :1])
+                            and np.all(n == n[:, :1]))
+            max_u = int(np.prod(n.astype(np.int64), axis=0).max())
+            if max_u >= 2 ** 31:
+                raise ValueError('control lattice too large')
+            if not per_node:
+                lo, hi, n = lo[:, :1], hi[:, :1], n[:, :1]
+            lo, hi, n = (np.ascontiguousarray(a) for a in (lo, hi, n))
+            digest = hash((lo.tobytes(), hi.tobytes(), n.tobytes()))
+            bp = dict(lo=lo, hi=hi, n=n, per_node=per_node, max_u=max_u,
+                      lanes=codegen.lanes_for(max_u), digest=digest)
+            if box_t is not None:           # one table per time step: keep only the latest
+                for k in [k for k in self._cache if k[0] == 'box']:
+                    del self._cache[k]
+            self._cache[key] = bp
+        return bp
+
+    def _kernel_plan(self, box_t=None, model=None):
         """Everything that determines the model code object of the current
         discretisation (no GPU needed): control-box table, lanes per node,
-        kernel family, generated source."""
-        model = self._traced()
+        kernel family, generated source.  `model`: the trace to plan for
+        (default: the cached symbolic trace of `_traced`)."""
+        if model is None:
+            model = self._traced()
         if isinstance(model, TraceError):
             raise model
         shape = self._shape()
         dt = self.dtype
-        lo, hi, n = self._box_table(box_t)
-        per_node = not (np.all(lo == lo[:, :1]) and np.all(hi == hi[:, :1])
-                        and np.all(n == n[:, :1]))
-        max_u = int(np.prod(n.astype(np.int64), axis=0).max())
-        if max_u >= 2 ** 31:
-            raise ValueError('control lattice too large')
-        lanes = codegen.lanes_for(max_u)
-        if not per_node:
-            lo, hi, n = lo[:, :1], hi[:, :1], n[:, :1]
+        bp = self._box_plan(box_t)
+        lanes = bp['lanes']
         W = len(self.perturb_grid[0]) if self.perturb_grid else 0
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
@@ -417,19 +467,34 @@ class DPSolver(object):
         source = codegen.translation_unit(model, dt, lanes,
                                           column=(shape[0], W) if column else None,
                                           fused=(self.arithmetic == 'fused'))
-        return dict(model=model, source=source, column=column, lanes=lanes, per_node=per_node,
-                    lo=lo, hi=hi, n=n, max_u=max_u, W=W)
+        return dict(model=model, source=source, column=column, lanes=lanes,
+                    per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
+                    max_u=bp['max_u'], W=W, box_digest=bp['digest'])
 
-    def _problem(self, t_k=None):
-        """Device problem for the current discretisation (cached)."""
+    def _problem(self, t_k=None, model=None):
+        """Device problem for the current discretisation and callables.  The
+        handle is reused from call to call (and from time step to time step)
+        as long as the generated source and the control-box table are the
+        same; lifted constants are re-sent on every call."""
         self._check_supported()
         box_t = None if self.sys.stationnary else t_k
-        fp = ('problem', self._fingerprint(box_t))
+        if model is None:
+            model = self._trace_now(t_k)
+        if isinstance(model, TraceError):
+            raise model
+        plan = self._kernel_plan(box_t, model)
+        fp = ('problem', self._fingerprint(None), plan['box_digest'], hash(plan['source']))
         prob = self._cache.get(fp)
-        if prob is not None:
-            return prob
+        if prob is None:
+            prob = self._create_problem(fp, plan)
+        if model.param_index is not None:
+            prob.set_params(model.param_values())
+        self.backend_info = dict(prob.info, time_specialized=model.t_value is not None,
+                                 lifted_constants=len(model.param_index or ()))
+        return prob
+
+    def _create_problem(self, fp, plan):
         nat.require_gpu()
-        plan = self._kernel_plan(box_t)
         model, source, column, lanes = plan['model'], plan['source'], plan['column'], plan['lanes']
         per_node, lo, hi, n, max_u, W = (plan[k] for k in ('per_node', 'lo', 'hi', 'n', 'max_u', 'W'))
         shape = self._shape()
@@ -467,12 +532,12 @@ class DPSolver(object):
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
                               bounds, layout)
         self._cache[fp] = prob
-        self.backend_info = dict(mode='traced', kernel='column' if column else 'generic',
-                                 arithmetic=self.arithmetic if column else 'exact',
-                                 module=module, lanes_per_node=lanes,
-                                 max_controls=max_u, box_per_node=bool(per_node),
-                                 bit_exact_model=model.bit_exact,
-                                 inexact_ops=model.inexact_ops())
+        prob.info = dict(mode='traced', kernel='column' if column else 'generic',
+                         arithmetic=self.arithmetic if column else 'exact',
+                         module=module, lanes_per_node=lanes,
+                         max_controls=max_u, box_per_node=bool(per_node),
+                         bit_exact_model=model.bit_exact,
+                         inexact_ops=model.inexact_ops())
         return prob
 
     def _ref_flat(self, prob=None):
@@ -528,13 +593,14 @@ class DPSolver(object):
         self._check_state_array(J_next)
         host_comm = self.comm is not None and not self.comm.is_device
         refs = np.zeros(n_iter)
-        if isinstance(self._traced(), TraceError) or host_comm:
+        model = self._trace_now(None)
+        if isinstance(model, TraceError) or host_comm:
             J_k = J_next                    # host callbacks / host exchange: sweep by sweep
             for k in range(n_iter):
                 J_k, pol_k, r = self._backup(J_k, None, rel_dp)
                 refs[k] = 0.0 if r is None else r
         else:
-            prob = self._problem(None)
+            prob = self._problem(None, model)
             prob.set_value(J_next)
             ref_flat = self._ref_flat(prob) if rel_dp else 0
             for k in range(n_iter):
@@ -552,10 +618,10 @@ class DPSolver(object):
 
     def _backup(self, J_next, t_k, rel_dp):
         """One sweep: fused kernel when the model is traceable, else tabulated."""
-        model = self._traced()
+        model = self._trace_now(t_k)
         if isinstance(model, TraceError):
             return self._backup_tabulated(J_next, t_k, rel_dp)
-        prob = self._problem(t_k)
+        prob = self._problem(t_k, model)
         prob.set_value(J_next)
         # with a host-side (gloo) communicator the slabs are exchanged through
         # host memory after the sweep; with RCCL the library does it on device
@@ -602,7 +668,7 @@ class DPSolver(object):
         h = C.c_void_p()
         nat.check(nat.lib().sdp_tab_create(d, nat.ptr(smin), nat.ptr(smax), nat.ptr(orders),
                                            nat.ptr(V), C.byref(h)))
-        self.backend_info = dict(mode='tabulated', reason=str(self._traced()))
+        self.backend_info = dict(mode='tabulated', reason=str(self._trace_now(None)))
         J_k = np.zeros(S)
         idx_k = np.zeros(S, dtype=np.int64)
         pol_k = np.zeros((S, nu))
@@ -757,11 +823,12 @@ class DPSolver(object):
         assert J_zero.shape == state_dims
         nb_control = len(self.sys.control)
         assert pol.shape == state_dims + (nb_control,)
-        model = self._traced()
+        t_pol = None if self.sys.stationnary else 0
+        model = self._trace_now(t_pol)
         if isinstance(model, TraceError):
             return self._eval_policy_tabulated(pol, n_iter, rel_dp, J_zero, report_time,
                                                J_ref_full, t_start)
-        prob = self._problem(None if self.sys.stationnary else 0)
+        prob = self._problem(t_pol, model)
         prob.set_value(J_zero)
         prob.set_policy(pol)
         for k in range(n_iter):
@@ -824,7 +891,7 @@ class DPSolver(object):
         smin = np.array([gr[0] for gr in self.state_grid], dtype=float)
         smax = np.array([gr[-1] for gr in self.state_grid], dtype=float)
         orders = np.array(dims, dtype=np.int64)
-        self.backend_info = dict(mode='tabulated', reason=str(self._traced()))
+        self.backend_info = dict(mode='tabulated', reason=str(self._trace_now(None)))
         J_pol = np.ascontiguousarray(J_zero, dtype=float)
         J_ref = np.zeros(n_iter)
         idx = np.zeros(S, dtype=np.int64)

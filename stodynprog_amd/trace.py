@@ -67,9 +67,13 @@ class Node(object):
 class Graph(object):
     """Hash-consed expression DAG (common sub-expressions are shared)."""
 
-    def __init__(self):
+    def __init__(self, unique_consts=False):
         self.nodes = []
         self._memo = {}
+        # step-by-step traces (trace_model(t_value=...)): every occurrence of a real
+        # constant is its own node, so that the DAG's shape cannot depend on which
+        # VALUES happen to coincide (data of a night hour equal to a literal 0)
+        self.unique_consts = unique_consts
 
     def _intern(self, key, op, args, value, kind, deps):
         n = self._memo.get(key)
@@ -86,6 +90,8 @@ class Graph(object):
         value = float(value)
         # key on the bit pattern: -0.0 and 0.0, and NaN payloads, stay distinct
         key = ('const', np.float64(value).tobytes())
+        if self.unique_consts:
+            key = ('const', len(self.nodes))
         return self._intern(key, 'const', (), value, 'r', 0)
 
     def bconst(self, value):
@@ -384,6 +390,38 @@ class TracedModel(object):
         self.cost = cost              # Node (real)
         self.n_state, self.n_control, self.n_perturb = n_state, n_control, n_perturb
         self.time_dep = time_dep
+        self.t_value = None           # concrete time index of a step-by-step trace
+        self.param_index = None       # node id -> slot, after lift_constants()
+
+    def lift_constants(self):
+        """Turn every real constant of the live DAG into a kernel parameter
+        (slot order = recording order): codegen then emits `sdp_model_prm[slot]`
+        instead of a literal, so models that differ only by constants -- the time
+        steps of a finite-horizon problem with time-indexed data -- share one
+        code object.  Returns the parameter values of THIS model."""
+        consts = [n for n in self.live_nodes() if n.op == 'const']
+        self.param_index = {n.id: i for i, n in enumerate(consts)}
+        return [n.value for n in consts]
+
+    def param_values(self):
+        return [n.value for n in self.live_nodes() if n.op == 'const']
+
+    def structure_key(self):
+        """Text identifying the live DAG up to the values of its real
+        constants (two models with equal keys generate the same source once
+        their constants are lifted)."""
+        live = self.live_nodes()
+        pos = {n.id: i for i, n in enumerate(live)}
+        parts = []
+        for n in live:
+            if n.op == 'const':
+                parts.append('c')
+            elif n.op in ('var', 'bconst'):
+                parts.append('{}:{}'.format(n.op, n.value))
+            else:
+                parts.append('{}({})'.format(n.op, ','.join(str(pos[a.id]) for a in n.args)))
+        outs = [pos[n.id] for n in self.x_next] + [pos[self.cost.id]]
+        return ';'.join(parts) + '|' + ','.join(map(str, outs))
 
     def live_nodes(self):
         """Nodes reachable from the outputs, in topological (creation) order."""
@@ -480,17 +518,25 @@ class TracedModel(object):
         return bool(self.cost.deps & DEP_W)
 
 
-def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True):
+def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True,
+                t_value=None):
     """Trace `dyn` and `cost` with symbolic x, u, w (and t_k first when the
-    system is time dependent), in the argument order of sdp.py:668-672."""
+    system is time dependent), in the argument order of sdp.py:668-672.
+
+    t_value: for a time-dependent system, trace ONE time step with the concrete
+    time index `t_value` instead of a symbol.  Callables that look data up by
+    time (`p['P_req_data'][k]`, reference examples/01 .../det_storage_control.py:89)
+    cannot take a symbolic k; traced step by step their data become constants
+    of the DAG, which `TracedModel.lift_constants` turns into kernel parameters
+    so that all time steps of one structure share one code object."""
     params = params or {}
-    g = Graph()
+    g = Graph(unique_consts=t_value is not None)
     xs = [Sym(g, g.var('x%d' % i, DEP_X if i == 0 else DEP_XR)) for i in range(n_state)]
     us = [Sym(g, g.var('u%d' % i, DEP_U)) for i in range(n_control)]
     ws = [Sym(g, g.var('w%d' % i, DEP_W)) for i in range(n_perturb)]
     args = xs + us + ws
     if not stationnary:
-        args = [Sym(g, g.var('t', DEP_T))] + args
+        args = [Sym(g, g.var('t', DEP_T)) if t_value is None else t_value] + args
     some = xs[0] if xs else Sym(g, g.const(0.0))
 
     def as_real_node(v, what):
@@ -525,7 +571,10 @@ def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationna
     except Exception as e:
         raise TraceError('cost function not traceable: {}: {}'.format(type(e).__name__, e))
     cnode = as_real_node(c, 'cost function')
-    return TracedModel(g, x_next, cnode, n_state, n_control, n_perturb, not stationnary)
+    model = TracedModel(g, x_next, cnode, n_state, n_control, n_perturb,
+                        (not stationnary) and t_value is None)
+    model.t_value = t_value
+    return model
 
 
 def evaluate(model, x, u, w, t=None):

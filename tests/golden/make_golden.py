@@ -331,7 +331,19 @@ def g8():
     save('g8_bellman', J=J, pol=pol, J_fin=J_fin)
 
 
-ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8)
+def g9():
+    """finite horizon with time-indexed data (the shape of the reference's
+    examples/01 .../pv_storage_control.py): 48 steps, 50 nodes, <= 2001 controls."""
+    print('g9 pv storage, time-indexed data')
+    _, dpsolv = models.pv_storage(ref)
+    J_fin = np.zeros(50)
+    t0 = time.time()
+    J, pol = quiet(dpsolv.bellman_recursion, 48, J_fin)
+    save('g9_pv_storage', J=J, pol=pol, P_prod=dpsolv.P_prod_data,
+         seconds=np.array(time.time() - t0))
+
+
+ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or sorted(ALL)

@@ -87,7 +87,7 @@ s = solver_mod.DPSolver(sysd, comm=comm)
 s.state_grid, s.perturb_grid, s.perturb_proba = ref.state_grid, ref.perturb_grid, ref.perturb_proba
 s._state_grid_shape, s._state_ref_ind = ref._state_grid_shape, ref._state_ref_ind
 s.control_steps = ref.control_steps
-s._problem = lambda t_k=None: FakeProblem()
+s._problem = lambda t_k=None, model=None: FakeProblem()
 
 V0 = np.zeros(spec.shape)
 J1, pol1 = s.value_iteration(V0, report_time=False)

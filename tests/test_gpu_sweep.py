@@ -423,6 +423,40 @@ def test_bellman_recursion_against_reference(gpu):
     assert np.array_equal(pol, g['pol'])
 
 
+def test_bellman_recursion_with_time_indexed_data(gpu, monkeypatch):
+    """The reference's finite-horizon examples look their input up by time
+    index inside the cost (`P_prod_data[k]`, examples/01 .../pv_storage_control.py:82):
+    a symbolic k cannot index an array, so each step is traced with its concrete
+    k and the constants of the step are lifted into kernel parameters -- every
+    step runs the SAME fused code object, none falls back to host callbacks.
+    All 48 steps equal the reference bit for bit (J and policy values)."""
+    from stodynprog_amd import _native as nat
+    g = golden('g9_pv_storage')
+    _, solver = models.pv_storage()
+    assert isinstance(solver._traced(), TraceError)           # no symbolic-time trace
+    step0, step1 = solver._trace_now(0), solver._trace_now(30)
+    assert step0.t_value == 0 and step0.param_index and not step0.time_dep
+    assert step0.structure_key() == step1.structure_key()
+    assert step0.param_values() != step1.param_values()
+    compiled = []
+    real_compile = nat.compile_model
+    monkeypatch.setattr(nat, 'compile_model', lambda src, **k: compiled.append(src) or real_compile(src, **k))
+    J, pol = quiet(solver.bellman_recursion, 48, np.zeros(50))
+    assert solver.backend_info['mode'] == 'traced' and solver.backend_info['time_specialized']
+    assert solver.backend_info['lifted_constants'] == len(step0.param_index)
+    assert len(set(compiled)) == 1, 'all time steps must share one code object'
+    assert '__constant__ sdp_real sdp_model_prm' in compiled[0]
+    assert np.array_equal(J, g['J'])
+    assert np.array_equal(pol, g['pol'])
+    # the data array changes (another scenario): no stale constants, no new kernel
+    solver.P_prod_data *= 0.5
+    J2, _ = quiet(solver.bellman_recursion, 48, np.zeros(50))
+    assert len(set(compiled)) == 1 and not np.array_equal(J2, J)
+    spec = vi_numpy.Spec.from_solver(solver)
+    Jo, _, _, _ = vi_numpy.value_iteration(spec, J2[1], t_k=0)
+    assert np.array_equal(J2[0], Jo)
+
+
 def test_bellman_recursion_time_dependent(gpu):
     s = SysDescription((1, 1, 1), stationnary=False)
 

@@ -200,3 +200,19 @@ def test_bellman_recursion_oracle_vs_reference():
         assert np.abs(J - g['J'][t]).max() <= 1e-13 * max(1.0, np.abs(g['J'][t]).max())
         assert np.array_equal(pol, g['pol'][t])
         nxt = J
+
+
+def test_pv_storage_time_indexed_data_oracle_vs_reference():
+    """finite horizon whose cost looks data up by time index (the shape of the
+    reference's examples/01 .../pv_storage_control.py): numpy oracle against
+    the reference's bellman_recursion, all 48 steps, bit for bit"""
+    g = golden('g9_pv_storage')
+    _, solver = models.pv_storage()
+    assert np.array_equal(solver.P_prod_data, g['P_prod'])
+    spec = vi_numpy.Spec.from_solver(solver)
+    nxt = np.zeros(50)
+    for t in range(47, -1, -1):
+        J, pol, _, _ = vi_numpy.value_iteration(spec, nxt, t_k=t)
+        assert np.array_equal(J, g['J'][t]), t
+        assert np.array_equal(pol, g['pol'][t]), t
+        nxt = J
