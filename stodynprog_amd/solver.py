@@ -384,8 +384,20 @@ class DPSolver(object):
         horizon share one code object.  Returns a TracedModel or a TraceError."""
         s = self.sys
         try:
-            return trace_model(s.dyn, s.cost, len(s.state), len(s.control), len(s.perturb),
-                               s.params, s.stationnary)
+            model = trace_model(s.dyn, s.cost, len(s.state), len(s.control), len(s.perturb),
+                                s.params, s.stationnary)
+            # Constants stay literals in the generated source (the compiler folds
+            # them) until the SAME expression structure shows up with other values
+            # -- a parameter study looping over a cost coefficient, say; from then on
+            # they are lifted too, so the study compiles at most two code objects.
+            key = ('struct', model.structure_key())
+            bits = np.asarray(model.param_values(), dtype=float).tobytes()
+            seen = self._cache.setdefault(key, dict(bits=bits, lifted=False))
+            if not seen['lifted'] and seen['bits'] != bits:
+                seen['lifted'] = True
+            if seen['lifted']:
+                model.lift_constants()
+            return model
         except TraceError as e:
             if s.stationnary or t_k is None:
                 return e

@@ -457,6 +457,49 @@ def test_bellman_recursion_with_time_indexed_data(gpu, monkeypatch):
     assert np.array_equal(J2[0], Jo)
 
 
+def test_parameter_study_compiles_at_most_two_code_objects(gpu, monkeypatch):
+    """The callables are traced at every call (module-level data may change,
+    as in the reference where they are plain Python calls).  A loop over a
+    cost coefficient keeps one expression structure: the first value is
+    compiled with literal constants, the second switches to lifted constants,
+    every later value reuses that code object -- and every result equals the
+    numpy oracle evaluated with the same coefficient, bit for bit.  (A value
+    that coincides with another constant of the model merges two DAG leaves
+    and counts as a new structure: one more compile, same results.)"""
+    from stodynprog_amd import _native as nat
+    coef = {'penalty': 0.1, 'loss': 0.02}
+    s = SysDescription((2, 1, 1), name='study')
+
+    def dyn(e, p, u, w):
+        return (e + u - coef['loss'] * abs(u), 0.8 * p + w)
+
+    def cost(e, p, u, w):
+        return (p - u) * (p - u) + coef['penalty'] * u * u
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda e, p: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.3)]
+    solver = DPSolver(s)
+    solver.discretize_state(0, 4, 21, -2, 2, 13)
+    solver.discretize_perturb(-0.9, 0.9, 5)
+    solver.control_steps = (0.05,)
+    compiled = []
+    real_compile = nat.compile_model
+    monkeypatch.setattr(nat, 'compile_model', lambda src, **k: compiled.append(src) or real_compile(src, **k))
+    V = np.random.default_rng(4).standard_normal((21, 13))
+    results = []
+    for penalty, loss in ((0.1, 0.02), (0.2, 0.02), (0.4, 0.05), (0.75, 0.01), (0.1, 0.02)):
+        coef['penalty'], coef['loss'] = penalty, loss
+        J, pol = solver.value_iteration(V, report_time=False)
+        Jo, polo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+        assert np.array_equal(J, Jo) and np.array_equal(pol, polo), (penalty, loss)
+        assert np.array_equal(solver.last_policy_index, io)
+        results.append(J)
+    assert len(set(compiled)) == 2, len(set(compiled))
+    assert 'sdp_model_prm' not in compiled[0] and 'sdp_model_prm' in compiled[-1]
+    assert solver.backend_info['lifted_constants'] > 0 and solver.backend_info['kernel'] == 'column'
+    assert np.array_equal(results[0], results[-1]) and not np.array_equal(results[0], results[1])
+
+
 def test_bellman_recursion_time_dependent(gpu):
     s = SysDescription((1, 1, 1), stationnary=False)
 
