@@ -425,6 +425,8 @@ class DPSolver(object):
         fallback of _box_table is a Python loop over the nodes)."""
         key = ('box', self._fingerprint(box_t))
         bp = self._cache.get(key)
+        if bp is not None and not self._box_still_valid(bp, box_t):
+            bp = None                       # the callback reads data that changed: rebuild
         if bp is None:
             lo, hi, n = self._box_table(box_t)
             per_node = not (np.all(lo == lo[:, :1]) and np.all(hi == hi[:, :1])
@@ -443,6 +445,42 @@ class DPSolver(object):
                     del self._cache[k]
             self._cache[key] = bp
         return bp
+
+    def _box_still_valid(self, bp, box_t, n_probe=64):
+        """The reference calls control_box at every node of every sweep
+        (stodynprog.py:440); here the table is cached, so module-level data the
+        callback reads (a rated power, a capacity) could change unnoticed.  Each
+        call re-evaluates the callback at `n_probe` nodes (the corners, the
+        centre and a different random sample every time) and compares with the
+        cached table; any difference rebuilds it."""
+        shape = self._shape()
+        S = int(np.prod(shape))
+        self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
+        rng = np.random.default_rng(self._box_probe_round)
+        probe = set(rng.integers(0, S, size=min(S, n_probe)).tolist())
+        probe.update([0, S - 1, S // 2])
+        lead = () if box_t is None else (box_t,)
+        lo, hi, n = bp['lo'], bp['hi'], bp['n']
+        try:
+            for flat in probe:
+                ind = np.unravel_index(flat, shape)
+                x = tuple(g[i] for g, i in zip(self.state_grid, ind))
+                box = self.sys.control_box(*(lead + x), **self.sys.params)
+                col = flat if bp['per_node'] else 0
+                for c, (a, b) in enumerate(box):
+                    a, b = float(a), float(b)
+                    with np.errstate(all='ignore'):
+                        n_interv = (b - a) / self.control_steps[c]
+                    if n_interv < 0.1:
+                        a = b = (a + b) / 2
+                        npts = 1
+                    else:
+                        npts = int(np.ceil(n_interv) + 1)
+                    if not (_same(lo[c, col], a) and _same(hi[c, col], b) and n[c, col] == npts):
+                        return False
+        except Exception:
+            return False
+        return True
 
     def _kernel_plan(self, box_t=None, model=None):
         """Everything that determines the model code object of the current

@@ -500,6 +500,35 @@ def test_parameter_study_compiles_at_most_two_code_objects(gpu, monkeypatch):
     assert np.array_equal(results[0], results[-1]) and not np.array_equal(results[0], results[1])
 
 
+def test_control_box_reading_changed_data_is_not_served_stale(gpu):
+    """the control-box table is cached; a rating read from module-level data
+    that changes between two calls must be noticed (probe of the callback at
+    every call) -- the reference evaluates control_box at every sweep"""
+    rating = {'P': 1.0, 'E': 4.0}
+    s = SysDescription((2, 1, 1), name='ratings')
+    s.dyn = lambda e, p, u, w: (e + u, 0.8 * p + w)
+    s.cost = lambda e, p, u, w: (p - u) * (p - u)
+
+    def box(e, p):
+        return ((np.max((-e, -rating['P'])), np.min((rating['E'] - e, rating['P']))),)
+    s.control_box = box
+    s.perturb_laws = [models.NormalLaw(0, 0.3)]
+    solver = DPSolver(s)
+    solver.discretize_state(0, 4, 21, -2, 2, 13)
+    solver.discretize_perturb(-0.9, 0.9, 5)
+    solver.control_steps = (0.05,)
+    V = np.random.default_rng(4).standard_normal((21, 13))
+    seen = []
+    for P in (1.0, 0.5, 0.5, 2.0):
+        rating['P'] = P
+        J, pol = solver.value_iteration(V, report_time=False)
+        Jo, polo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+        assert np.array_equal(J, Jo) and np.array_equal(pol, polo), P
+        assert np.abs(pol).max() <= P
+        seen.append(J)
+    assert not np.array_equal(seen[0], seen[1]) and np.array_equal(seen[1], seen[2])
+
+
 def test_bellman_recursion_time_dependent(gpu):
     s = SysDescription((1, 1, 1), stationnary=False)
 
