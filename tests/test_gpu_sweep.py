@@ -931,6 +931,13 @@ def test_example_searev_policy_lookup_and_simulation(gpu):
     assert out['pol'].shape == (16, 21, 21, 1) and 0 < out['J_ref'] < 1
 
 
+def test_example_pv_storage_finite_horizon(gpu):
+    J, pol, E, P_sto = quiet(_load_example('pv_storage.py').main, 48, 50)
+    g = golden('g9_pv_storage')
+    assert np.array_equal(J, g['J']) and np.array_equal(pol, g['pol'])
+    assert E.min() > -1e-9 and E.max() < 2 + 1e-9 and np.abs(P_sto).max() <= 1.0
+
+
 def test_column_kernel_deterministic_and_two_controls(gpu):
     """column kernel corner cases: no perturbation (W = 0, dims of length 2),
     two multi-point controls (Cartesian lattice, control 0 slowest), 4-D state"""
