@@ -291,8 +291,7 @@ class DPSolver(object):
             x = tuple(g[i] for g, i in zip(self.state_grid, ind))
             return self.sys.control_box(*(lead + x), **params)
 
-        lo = hi = None
-        try:
+        def vectorised():
             # open (sparse) grids: axis k has shape (1,..,N_k,..,1), so a box that
             # ignores the state, or depends on one axis only, stays small
             d = len(shape)
@@ -313,20 +312,37 @@ class DPSolver(object):
                 else:
                     lo_v[c] = np.broadcast_to(a, shape).ravel()
                     hi_v[c] = np.broadcast_to(b, shape).ravel()
+            # accepted only if it reproduces the scalar calls the reference makes
             rng = np.random.default_rng(12345)
             probe = set(rng.integers(0, S, size=min(S, 48)).tolist())
             probe.update([0, S - 1, S // 2])
-            ok = True
             for flat in probe:
                 sb = scalar_box(flat)
                 col = 0 if constant else flat
                 for c, (a, b) in enumerate(sb):
                     if not (_same(lo_v[c, col], a) and _same(hi_v[c, col], b)):
-                        ok = False
-            if ok:
-                lo, hi = lo_v, hi_v
-        except Exception:
-            lo = hi = None
+                        return None
+            return lo_v, hi_v
+
+        lo = hi = None
+        # 1) the callback as it is, on whole-grid arrays; 2) the same with
+        # np.max / np.min of a TUPLE of operands read as an elementwise
+        # maximum / minimum -- the idiom of every control_box of the reference's
+        # examples (`np.max((-E/dt, -P_rated))`, AR1 notebook cell 15,
+        # searev/storage_control.py:76-78), which is scalar-only as written;
+        # 3) node by node, like the reference.
+        for patch in (False, True):
+            try:
+                if patch:
+                    with _TupleMinMax():
+                        got = vectorised()
+                else:
+                    got = vectorised()
+            except Exception:
+                got = None
+            if got is not None:
+                lo, hi = got
+                break
         if lo is None:
             lo = np.empty((nu, S))
             hi = np.empty((nu, S))
@@ -1033,6 +1049,42 @@ class DPSolver(object):
             print('  control combinations:'
                   ' [{:,d} to {:,d}] possible values ({:,.1f} on average)'.format(
                       tot.min(), tot.max(), tot.mean()))
+
+
+class _TupleMinMax(object):
+    """While active, np.max / np.min / np.amax / np.amin called on a tuple or
+    list of SEVERAL operands, at least one of them an array, return their
+    elementwise maximum / minimum (NaN-propagating, like the reduction they
+    stand for when the operands are scalars).  Used only inside the
+    whole-grid evaluation of control_box, whose result is then checked against
+    unpatched scalar calls."""
+    NAMES = (('max', np.maximum), ('amax', np.maximum), ('min', np.minimum), ('amin', np.minimum))
+
+    def __enter__(self):
+        self.saved = {}
+        for name, ufunc in self.NAMES:
+            if not hasattr(np, name):
+                continue
+            orig = getattr(np, name)
+            self.saved[name] = orig
+            setattr(np, name, self._wrap(orig, ufunc))
+        return self
+
+    @staticmethod
+    def _wrap(orig, ufunc):
+        def reduce_operands(a, *args, **kw):
+            if (isinstance(a, (tuple, list)) and len(a) >= 2 and not args and not kw
+                    and any(np.ndim(v) > 0 for v in a)):
+                out = a[0]
+                for v in a[1:]:
+                    out = ufunc(out, v)
+                return out
+            return orig(a, *args, **kw)
+        return reduce_operands
+
+    def __exit__(self, *exc):
+        for name, orig in self.saved.items():
+            setattr(np, name, orig)
 
 
 def _same(a, b):

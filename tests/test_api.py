@@ -274,3 +274,38 @@ def test_load_the_reference_searev_policy_pickle():
     assert it.ndim == 3 and list(it._xshape) == [31, 61, 61]
     assert it.values.shape == (1, 31 * 61 * 61)
     assert np.allclose(it._xmax, [10., 1.016, 0.908])
+
+
+def test_control_box_table_vectorises_the_tuple_min_max_idiom():
+    """the reference's control_box callbacks use np.max((a, b)) on scalars
+    (AR1 notebook cell 15, searev/storage_control.py:76-78): scalar-only as
+    written.  The table builder evaluates them on whole-grid arrays with
+    np.max / np.min of a tuple read elementwise, accepts the result only if it
+    reproduces scalar calls, and must give the node-by-node table bit for bit;
+    numpy itself is left untouched afterwards."""
+    import itertools
+    from stodynprog_amd import models, solver as solver_mod
+    for name, kw, t in (('searev', dict(n_E=12, n_S=7, n_A=5), None), ('storage_ar1', {}, None),
+                        ('pv_storage', {}, 5), ('nas_demo', {}, None)):
+        _, s = getattr(models, name)(**kw)
+        box = s.sys.control_box
+        lo, hi, n = s._box_table(t)
+        S = lo.shape[1]
+        lead = () if t is None else (t,)
+        for flat, x in enumerate(itertools.product(*s.state_grid)):
+            for c, (a, b) in enumerate(box(*(lead + x))):
+                n_interv = (b - a) / s.control_steps[c]
+                col = flat if S > 1 else 0
+                if n_interv < 0.1:
+                    assert n[c, col] == 1 and lo[c, col] == (a + b) / 2
+                else:
+                    assert n[c, col] == int(np.ceil(n_interv) + 1)
+                    assert lo[c, col] == a and hi[c, col] == b
+    assert np.max((1.0, 3.0)) == 3.0 and np.max.__name__ in ('max', 'amax')
+    assert np.max(np.array([[1., 5.], [2., 0.]]), axis=0).tolist() == [2., 5.]
+    # a box that is NOT what the elementwise reading gives must not be accepted
+    _, s = models.storage_ar1()
+    s.sys.control_box = lambda E, P: ((float(np.max((np.min((E, 2.)), 0.5))) - 3.0, 1.0), (0., 0.))
+    lo, hi, n = s._box_table()
+    E = s.state_grid[0]
+    assert np.array_equal(lo[0].reshape(41, 61)[:, 0], np.maximum(np.minimum(E, 2.), 0.5) - 3.0)
