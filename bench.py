@@ -148,7 +148,7 @@ def main():
     # this same command (profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) KiB
     traffic = None
     if (N, rb, world, solver.backend_info.get('kernel')) == (256, 8, 1, 'column'):
-        traffic = (2 * 1.02171e6 + 327680.0) * 1024
+        traffic = (2 * 1.0205e6 + 327680.0) * 1024
     # the column kernel's real ceiling: 6 fp64 operations per lattice cell that
     # bit-exactness does not allow to fuse, against the measured fp64 VALU
     # issue rate of the chip (profiles/ubench_fp64_rate.txt)
@@ -163,12 +163,14 @@ def main():
                                '(BASELINE.json configs[3])'.format(N, U, W),
                    'state_nodes': S, 'controls': U, 'perturbations': W,
                    'kernel_family': solver.backend_info.get('kernel'),
-                   'sharding': 'outer axis of the device layout over {} rank(s), RCCL all-gather of J'.format(world)},
+                   'sharding': ('single GPU' if world == 1 else
+                                'columns dealt in phases x {} ranks; RCCL all-gather of each phase of J '
+                                'under the kernel of the next phase'.format(world))},
         'state_cells_per_sec': S * sweeps_per_s,
         'lattice_cells_per_sec': S * U * W * sweeps_per_s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_source': 'profiles/r01_col_v5_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
+                     'traffic_source': 'profiles/r01_final_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
                                        'WRITE_SIZE, FETCH x2 per the gfx950 correction)' if traffic else None,
                      'fp64_valu_wave_instr_per_s': fp64_rate, 'fp64_valu_peak_measured': FP64_ISSUE_PEAK,
                      'fp64_valu_frac': fp64_rate / FP64_ISSUE_PEAK,
