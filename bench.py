@@ -67,7 +67,8 @@ def cpu_baseline(solver, V0, models, budget_s=18.0):
     }
 
 
-def main():
+def run():
+    """everything but the final print; returns the result dict on rank 0, else None"""
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -91,6 +92,9 @@ def main():
         dev_comm = host_comm = None
         nat.require_gpu()
         nat.check(nat.lib().sdp_set_device(0))
+        if os.environ.get('SDP_BENCH_SINGLE_RANK_COMM'):
+            # test hook: drive the multi-GPU code path (phases, streams, tuning) on one GPU
+            dev_comm = dist.RcclCommunicator(0, 1, dist.RcclCommunicator.new_unique_id())
     if args.gpus != world and rank == 0:
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
 
@@ -106,15 +110,40 @@ def main():
     V0 = models.synthetic3d_V0(solver.state_grid, dtype=dtype)
     S, U, W, d, nu = V0.size, models.SYNTH['n_u'], len(solver.perturb_grid[0]), 3, 1
 
-    prob = solver._problem()
-    assert solver.backend_info['max_controls'] == U
-    prob.set_value(V0)
-
     def sync_all():
         nat.check(nat.lib().sdp_synchronize())
         if dev_comm is not None:
             dev_comm.barrier()
             nat.check(nat.lib().sdp_synchronize())
+
+    phase_times = None
+    if dev_comm is not None:
+        # Untimed tuning of the comm/compute overlap: how many phases a backup is cut
+        # into (each phase's all-gather runs under the next phase's kernel).  Few
+        # phases leave a long last gather exposed, many add launches and small
+        # collectives; the best count depends on the rank count and the fabric.
+        # Every rank times the same candidates; the max over ranks decides, so all
+        # ranks pick the same count.
+        if os.environ.get('SDP_COMM_PHASES'):
+            solver.comm_phases = int(os.environ['SDP_COMM_PHASES'])
+        else:
+            phase_times = {}
+            for ph in (2, 4, 8, 16):
+                solver.comm_phases = ph
+                trial = solver._problem()
+                trial.set_value(V0)
+                trial.bench_sweeps(2)
+                trial.swap()
+                sync_all()
+                t0 = time.perf_counter()
+                trial.bench_sweeps(3)
+                sync_all()
+                phase_times[ph] = dev_comm.allreduce_max(time.perf_counter() - t0) / 3 * 1e3
+            solver.comm_phases = min(phase_times, key=lambda k: (phase_times[k], k))
+
+    prob = solver._problem()
+    assert solver.backend_info['max_controls'] == U
+    prob.set_value(V0)
 
     # warm-up sweeps (untimed), ping-pong like the timed ones
     if args.warmup > 0:
@@ -130,7 +159,7 @@ def main():
         kernel_ms = dev_comm.allreduce_max(kernel_ms)
 
     if rank != 0:
-        return
+        return None
     ms_per_step = elapsed * 1e3 / args.steps
     sweeps_per_s = args.steps / elapsed
     rb = dtype.itemsize
@@ -163,9 +192,11 @@ def main():
                                '(BASELINE.json configs[3])'.format(N, U, W),
                    'state_nodes': S, 'controls': U, 'perturbations': W,
                    'kernel_family': solver.backend_info.get('kernel'),
-                   'sharding': ('single GPU' if world == 1 else
-                                'columns dealt in phases x {} ranks; RCCL all-gather of each phase of J '
-                                'under the kernel of the next phase'.format(world))},
+                   'sharding': ('single GPU' if dev_comm is None else
+                                'columns dealt in {} phases x {} ranks; RCCL all-gather of each phase '
+                                'of J under the kernel of the next phase'.format(
+                                    int(prob.parts.shape[0]), world)),
+                   'comm_phase_tuning_ms_per_sweep': phase_times},
         'state_cells_per_sec': S * sweeps_per_s,
         'lattice_cells_per_sec': S * U * W * sweeps_per_s,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -226,7 +257,17 @@ def main():
             out['cpu_baseline'] = cpu_baseline(ref_solver, np.asarray(V0, dtype=np.float64), models)
         except Exception as e:                       # the baseline must never hide the GPU number
             out['cpu_baseline'] = {'value': None, 'error': repr(e)}
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    # native libraries (RCCL's version banner, stdio-buffered until exit) must not
+    # write into stdout: it carries exactly ONE line, the JSON result of rank 0
+    from stodynprog_amd.dist import _stdout_to_stderr
+    with _stdout_to_stderr():
+        out = run()
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -189,7 +189,15 @@ class _stdout_to_stderr(object):
         os.dup2(2, 1)
 
     def __exit__(self, *exc):
+        import ctypes
         import sys
         sys.stdout.flush()
+        try:
+            # the native text sits in the C library's stdio buffer (stdout is a pipe:
+            # fully buffered) and would otherwise be flushed into the REAL stdout at
+            # exit, after the program's own output
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)

@@ -370,7 +370,7 @@ class DPSolver(object):
         # key, so a recycled id() can never alias a stale entry)
         parts = [s.dyn, s.cost, s.control_box, repr(sorted(s.params.items())),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
-                 id(self.comm), self.kernel, self.arithmetic]
+                 id(self.comm), self.comm_phases, self.kernel, self.arithmetic]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         return hash(tuple(parts))
