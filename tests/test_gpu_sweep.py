@@ -938,6 +938,44 @@ def test_example_pv_storage_finite_horizon(gpu):
     assert E.min() > -1e-9 and E.max() < 2 + 1e-9 and np.abs(P_sto).max() <= 1.0
 
 
+def test_column_kernel_four_state_axes(gpu):
+    """d = 4 (the largest dimension the reference's interpolation dispatches,
+    multilinear_cython.pyx:211-300): a stock next to a 3-axis exogenous process;
+    the column kernel tabulates a trilinear partial interpolation per (w, row)"""
+    s = SysDescription((4, 1, 1), name='four axes')
+
+    def dyn(e, a, b, c, u, w):
+        return (e + 0.5 * u - 0.02 * abs(u),
+                0.7 * a + 0.2 * b + w,
+                0.6 * b - 0.3 * c + 0.5 * w,
+                0.5 * c + 0.1 * a - 0.25 * w)
+
+    def cost(e, a, b, c, u, w):
+        return (a + 0.5 * b - u) * (a + 0.5 * b - u) + 0.1 * c * u + 0.05 * (e - 1.0) * (e - 1.0)
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda e, a, b, c: ((np.max((-e / 0.5, -1.)), np.min(((2. - e) / 0.5, 1.))),)
+    s.perturb_laws = [models.NormalLaw(0, 0.2)]
+    ref = DPSolver(s)
+    ref.discretize_state(0, 2, 11, -1, 1, 7, -1, 1, 6, -1, 1, 5)
+    ref.discretize_perturb(-0.6, 0.6, 6)
+    ref.control_steps = (0.1,)
+    assert ref._traced().storage_separable
+    V = np.random.default_rng(17).standard_normal((11, 7, 6, 5))
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(ref), V)
+    for kernel in ('column', 'generic'):
+        sol = _clone_with_kernel(s, ref, kernel)
+        J, u = sol.value_iteration(V, report_time=False)
+        assert sol.backend_info['kernel'] == kernel
+        assert np.array_equal(J, Jo) and np.array_equal(u, uo), kernel
+        assert np.array_equal(sol.last_policy_index, io)
+    E1 = quiet(_clone_with_kernel(s, ref, 'column').eval_policy, uo, 3, True, V, J_ref_full=True)
+    E2 = quiet(_clone_with_kernel(s, ref, 'generic').eval_policy, uo, 3, True, V, J_ref_full=True)
+    assert np.array_equal(E1[0], E2[0]) and np.array_equal(E1[1], E2[1])
+    f32 = _clone_with_kernel(s, ref, 'column', np.float32)
+    Jf, _ = f32.value_iteration(V, report_time=False)
+    assert np.abs(Jf - Jo).max() / np.abs(Jo).max() < 1e-5
+
+
 def test_column_kernel_deterministic_and_two_controls(gpu):
     """column kernel corner cases: no perturbation (W = 0, dims of length 2),
     two multi-point controls (Cartesian lattice, control 0 slowest), 4-D state"""
