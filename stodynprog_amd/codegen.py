@@ -251,13 +251,22 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
                '-fno-fast-math', '-std=c++17', '-I', CSRC]
 
 
+_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h')
+_digest_cache = {}
+
+
 def _headers_digest():
-    h = hashlib.sha256()
-    for fn in ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h',
-               'sdp_column_kernel.h'):
-        with open(os.path.join(CSRC, fn), 'rb') as f:
-            h.update(f.read())
-    return h
+    """sha256 state over the kernel headers (re-read only when a file changes)"""
+    stamp = tuple(os.stat(os.path.join(CSRC, fn)).st_mtime_ns for fn in _HEADERS)
+    h = _digest_cache.get(stamp)
+    if h is None:
+        h = hashlib.sha256()
+        for fn in _HEADERS:
+            with open(os.path.join(CSRC, fn), 'rb') as f:
+                h.update(f.read())
+        _digest_cache.clear()
+        _digest_cache[stamp] = h
+    return h.copy()
 
 
 def source_key(source):

@@ -549,7 +549,8 @@ class DPSolver(object):
         if isinstance(model, TraceError):
             raise model
         plan = self._kernel_plan(box_t, model)
-        fp = ('problem', self._fingerprint(None), plan['box_digest'], hash(plan['source']))
+        fp = ('problem', self._fingerprint(None), plan['box_digest'],
+              codegen.source_key(plan['source']))
         prob = self._cache.get(fp)
         if prob is None:
             prob = self._create_problem(fp, plan)
