@@ -1151,7 +1151,12 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
     int rc;
     if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
     if ((rc = ensure_refs(p, 1))) return rc;
-    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    struct Events {                         // destroyed on every return path
+        std::vector<hipEvent_t> v;
+        ~Events() { for (auto e : v) if (e) (void)hipEventDestroy(e); }
+    } events;
+    events.v.assign(2 * (size_t)reps, nullptr);
+    std::vector<hipEvent_t> &ev = events.v;
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(p->ev2, p->stream));
     for (int r = 0; r < reps; ++r) {
@@ -1174,7 +1179,6 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
     }
     if (kernel_ms) *kernel_ms = ksum;
     p->last_kernel_ms = ksum / reps;
-    for (auto &e : ev) (void)hipEventDestroy(e);
     return SDP_OK;
 }
 
