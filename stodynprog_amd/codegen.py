@@ -80,7 +80,57 @@ def _emit_node(n, name, param_index=None):
         return '({} ? {} : {})'.format(a[0], a[1], a[2])
     if op == 'b2r':
         return '({} ? (sdp_real)1 : (sdp_real)0)'.format(a[0])
+    if op == 'interp1':
+        return 'sdp_interp1_{}({})'.format(n.value, a[0])
     raise NotImplementedError(op)
+
+
+# np.interp on the device: numpy's arr_interp (compiled_base.c) restated --
+# range checks first (binary_search_with_guess), the largest j with
+# xp[j] <= x, then the same three floating-point operations and the same
+# fall-backs for non-finite results.
+INTERP_SOURCE = '''SDP_DEV sdp_real sdp_np_interp(sdp_real x, const sdp_real *xp, const sdp_real *fp, int n,
+                                sdp_real left, sdp_real right)
+{
+    if (n == 1) return x < xp[0] ? left : (x > xp[0] ? right : fp[0]);
+    if (x != x) return x;
+    if (x > xp[n - 1]) return right;
+    if (x < xp[0]) return left;
+    int imin = 0, imax = n;
+    while (imin < imax) {
+        const int imid = imin + ((imax - imin) >> 1);
+        if (x >= xp[imid]) imin = imid + 1; else imax = imid;
+    }
+    const int j = imin - 1;
+    if (j == n - 1) return fp[j];
+    if (xp[j] == x) return fp[j];
+    const sdp_real slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    sdp_real r = slope * (x - xp[j]) + fp[j];
+    if (r != r) {
+        r = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+    }
+    return r;
+}
+'''
+
+
+def interp_tables_source(model):
+    """Tables and per-table wrappers of the np.interp nodes of `model`."""
+    used = sorted({n.value for n in model.live_nodes() if n.op == 'interp1'})
+    if not used:
+        return ''
+    out = [INTERP_SOURCE]
+    for tid in used:
+        xp, fp, left, right = model.graph.tables[tid][:4]
+        out.append('__constant__ sdp_real sdp_tabx_{}[{}] = {{{}}};'.format(
+            tid, xp.size, ', '.join(real_literal(v) for v in xp)))
+        out.append('__constant__ sdp_real sdp_tabf_{}[{}] = {{{}}};'.format(
+            tid, fp.size, ', '.join(real_literal(v) for v in fp)))
+        out.append('SDP_DEV sdp_real sdp_interp1_{0}(sdp_real x)\n{{\n    return sdp_np_interp('
+                   'x, sdp_tabx_{0}, sdp_tabf_{0}, {1}, {2}, {3});\n}}'.format(
+                       tid, xp.size, real_literal(left), real_literal(right)))
+    return '\n'.join(out) + '\n'
 
 
 def _emit_body(model, nodes, lines):
@@ -175,7 +225,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
         # sdp_problem_set_params; uniform loads from constant memory
         '#define SDP_NPARAMS {}'.format(len(model.param_index)),
         'extern "C" { __constant__ sdp_real sdp_model_prm[SDP_NPARAMS]; }     // a definition',
-        ''] if getattr(model, 'param_index', None) else []) + [
+        ''] if getattr(model, 'param_index', None) else []) + (
+        [interp_tables_source(model)] if interp_tables_source(model) else []) + [
         model_function_source(model),
         '',
     ]

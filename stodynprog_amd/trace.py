@@ -9,8 +9,9 @@ function with one IEEE operation per recorded operator, in the recorded order
 (contraction off), so results match numpy bit for bit for + - * / sqrt abs,
 comparisons and selects.
 
+Lookup tables are traceable through `np.interp(x, xp, fp)` (concrete tables).
 Anything that needs a concrete value (`if x > 0:`, `float(x)`, `max(a, b)`,
-indexing a table with x) raises TraceError; the solver then reports the model
+indexing an array with x) raises TraceError; the solver then reports the model
 as not traceable (tabulated mode evaluates such callables on the host).
 """
 import math
@@ -47,13 +48,15 @@ _OPS = {
     'and': (2, 'b'), 'or': (2, 'b'), 'xor': (2, 'b'), 'not': (1, 'b'),
     'isnan': (1, 'b'), 'isfinite': (1, 'b'), 'isinf': (1, 'b'),
     'select': (3, 'r'), 'bselect': (3, 'b'), 'b2r': (1, 'r'),
+    'interp1': (1, 'r'),         # np.interp(x, xp, fp): node.value = index into Graph.tables
 }
 
 # ops whose device result is the correctly rounded IEEE result (bit-exact vs numpy)
 EXACT_OPS = {'add', 'sub', 'mul', 'div', 'neg', 'abs', 'sqrt', 'square', 'recip',
              'min', 'max', 'fmin', 'fmax', 'floor', 'ceil', 'trunc', 'rint', 'sign',
              'lt', 'le', 'gt', 'ge', 'eq', 'ne', 'and', 'or', 'xor', 'not', 'isnan',
-             'isfinite', 'isinf', 'select', 'bselect', 'b2r', 'var', 'const', 'bconst'}
+             'isfinite', 'isinf', 'select', 'bselect', 'b2r', 'var', 'const', 'bconst',
+             'interp1'}
 
 
 class Node(object):
@@ -74,6 +77,7 @@ class Graph(object):
         # constant is its own node, so that the DAG's shape cannot depend on which
         # VALUES happen to coincide (data of a night hour equal to a literal 0)
         self.unique_consts = unique_consts
+        self.tables = []          # lookup tables of np.interp nodes: (xp, fp, left, right)
 
     def _intern(self, key, op, args, value, kind, deps):
         n = self._memo.get(key)
@@ -96,6 +100,17 @@ class Graph(object):
 
     def bconst(self, value):
         return self._intern(('bconst', bool(value)), 'bconst', (), bool(value), 'b', 0)
+
+    def interp(self, x, xp, fp, left, right):
+        """np.interp(x, xp, fp, left, right) with concrete 1-D tables"""
+        key = (xp.tobytes(), fp.tobytes(), np.float64(left).tobytes(), np.float64(right).tobytes())
+        for tid, t in enumerate(self.tables):
+            if t[4] == key:
+                break
+        else:
+            tid = len(self.tables)
+            self.tables.append((xp, fp, float(left), float(right), key))
+        return self._intern(('interp1', x.id, tid), 'interp1', (x,), tid, 'r', x.deps)
 
     def op(self, op, *args):
         arity, kind = _OPS[op]
@@ -301,6 +316,8 @@ class Sym(object):
             return Sym(args[0].g, args[0]._lift(fill))
         if name in ('isnan', 'isfinite', 'isinf'):
             return args[0]._un(name, args[0])
+        if name == 'interp':
+            return _interp(*args, **kwargs)
         raise TraceError('numpy function `{}` is not traceable'.format(name))
 
 
@@ -370,6 +387,30 @@ def _where(cond, a, b):
     return Sym(g, g.op('select', c, sym._real(an), sym._real(bn)))
 
 
+def _interp(x, xp, fp, left=None, right=None, period=None):
+    """np.interp with a symbolic abscissa and concrete tables (an efficiency
+    curve, a tariff): recorded as one `interp1` node; the device function
+    generated for it (codegen.INTERP_SOURCE) repeats numpy's arithmetic
+    (numpy/_core/src/multiarray/compiled_base.c, arr_interp) operation for
+    operation, so the node is bit-exact like + - * /."""
+    if not isinstance(x, Sym) or isinstance(xp, Sym) or isinstance(fp, Sym):
+        raise TraceError('np.interp is traceable for a symbolic x and concrete tables only')
+    if period is not None:
+        raise TraceError('np.interp(period=...) is not traceable')
+    try:
+        xp = np.ascontiguousarray(xp, dtype=np.float64)
+        fp = np.ascontiguousarray(fp, dtype=np.float64)
+    except (TypeError, ValueError):
+        raise TraceError('np.interp tables must be real arrays')
+    if xp.ndim != 1 or fp.ndim != 1 or xp.size != fp.size or xp.size == 0:
+        raise TraceError('np.interp tables must be 1-D, of equal non-zero length')
+    if isinstance(left, Sym) or isinstance(right, Sym):
+        raise TraceError('np.interp left/right must be numbers')
+    left = fp[0] if left is None else float(left)
+    right = fp[-1] if right is None else float(right)
+    return Sym(x.g, x.g.interp(x._real(x.n), xp, fp, left, right))
+
+
 def _clip(a, lo, hi):
     # np.clip(a, lo, hi) == minimum(maximum(a, lo), hi)
     sym = _any_sym(a, lo, hi)
@@ -418,6 +459,10 @@ class TracedModel(object):
                 parts.append('c')
             elif n.op in ('var', 'bconst'):
                 parts.append('{}:{}'.format(n.op, n.value))
+            elif n.op == 'interp1':
+                import hashlib
+                digest = hashlib.sha256(b''.join(self.graph.tables[n.value][4])).hexdigest()[:16]
+                parts.append('interp1[{}]({})'.format(digest, pos[n.args[0].id]))
             else:
                 parts.append('{}({})'.format(n.op, ','.join(str(pos[a.id]) for a in n.args)))
         outs = [pos[n.id] for n in self.x_next] + [pos[self.cost.id]]
@@ -598,6 +643,9 @@ def evaluate(model, x, u, w, t=None):
                 env[n.id] = np.float64(n.value)
             elif n.op == 'bconst':
                 env[n.id] = np.bool_(n.value)
+            elif n.op == 'interp1':
+                xp, fp, left, right = model.graph.tables[n.value][:4]
+                env[n.id] = np.interp(env[n.args[0].id], xp, fp, left, right)
             else:
                 env[n.id] = f[n.op](*[env[a.id] for a in n.args])
     return [env[n.id] for n in model.x_next], env[model.cost.id]

@@ -938,6 +938,43 @@ def test_example_pv_storage_finite_horizon(gpu):
     assert E.min() > -1e-9 and E.max() < 2 + 1e-9 and np.abs(P_sto).max() <= 1.0
 
 
+def test_models_with_lookup_tables_np_interp(gpu):
+    """np.interp inside dyn / cost (an efficiency curve, a tariff) runs on the
+    fused kernels: results equal the numpy oracle, which calls np.interp itself,
+    bit for bit -- column and generic kernels, points on, between and outside the
+    table abscissae"""
+    eff_x = np.array([-1., -0.5, 0., 0.25, 1.])
+    eff_y = np.array([0.80, 0.92, 1.0, 0.95, 0.85])
+    s = SysDescription((2, 1, 1), name='lookup tables')
+
+    def dyn(e, p, u, w):
+        return (e + 0.5 * u * np.interp(u, eff_x, eff_y), 0.7 * p + w)
+
+    def cost(e, p, u, w):
+        tariff = np.interp(p, [-0.5, 0., 0.5], [0.2, 1.0, 3.0], left=0.1, right=5.0)
+        return tariff * (p - u) * (p - u) + np.interp(e, [0.5, 3.5], [1., 0.], left=2., right=2.) + 0. * w
+    s.dyn, s.cost = dyn, cost
+    s.control_box = lambda e, p: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.3)]
+    ref = DPSolver(s)
+    ref.discretize_state(0, 4, 21, -1, 1, 13)
+    ref.discretize_perturb(-0.9, 0.9, 5)
+    ref.control_steps = (0.125,)          # hits the abscissae -1, -0.5, 0, 0.25, 1 exactly
+    model = ref._traced()
+    assert not isinstance(model, TraceError) and model.bit_exact and model.storage_separable
+    V = np.random.default_rng(23).standard_normal((21, 13))
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(ref), V)
+    for kernel in ('column', 'generic'):
+        sol = _clone_with_kernel(s, ref, kernel)
+        J, u = sol.value_iteration(V, report_time=False)
+        assert sol.backend_info['mode'] == 'traced' and sol.backend_info['kernel'] == kernel
+        assert np.array_equal(J, Jo) and np.array_equal(u, uo), kernel
+        assert np.array_equal(sol.last_policy_index, io)
+    f32 = _clone_with_kernel(s, ref, 'column', np.float32)
+    Jf, _ = f32.value_iteration(V, report_time=False)
+    assert np.abs(Jf - Jo).max() / np.abs(Jo).max() < 1e-5
+
+
 def test_column_kernel_four_state_axes(gpu):
     """d = 4 (the largest dimension the reference's interpolation dispatches,
     multilinear_cython.pyx:211-300): a stock next to a 3-axis exogenous process;

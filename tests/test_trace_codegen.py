@@ -157,3 +157,41 @@ def test_hint_when_the_controlled_stock_is_not_listed_first():
     # a genuinely coupled model gets no hint
     _, inv = models.inventory()
     assert inv._traced().separable_axis_hint() is None
+
+
+def test_np_interp_is_traced_with_numpy_semantics():
+    """np.interp(symbolic x, concrete tables): one `interp1` node, interpreted
+    with np.interp on the host; the generated device function restates numpy's
+    arr_interp (range checks, bisection, slope * (x - xp[j]) + fp[j])"""
+    xp = np.array([-1., 0., 0.5, 2.])
+    fp = np.array([0.9, 0.95, 0.8, 0.6])
+
+    def dyn(e, p, u, w):
+        return (e + u * np.interp(u, xp, fp), 0.5 * p + w)
+
+    def cost(e, p, u, w):
+        return np.interp(p + w, [0., 1.], [1., 3.], left=-1., right=7.) * u + np.interp(u, [0.25], [4.])
+    m = trace_model(dyn, cost, 2, 1, 1)
+    assert m.bit_exact and m.storage_separable
+    assert len(m.graph.tables) == 3
+    rng = np.random.default_rng(0)
+    u = np.concatenate([rng.uniform(-2, 3, 200), xp, [np.nan, -np.inf, np.inf, 0.25]])
+    w = rng.uniform(-1, 1, u.size)
+    with np.errstate(all='ignore'):
+        xn, g = evaluate(m, [0.3, 0.4], [u], [w])
+        assert np.array_equal(xn[0], dyn(0.3, 0.4, u, w)[0], equal_nan=True)
+        assert np.array_equal(g, cost(0.3, 0.4, u, w), equal_nan=True)
+    src = codegen.translation_unit(m, np.float64, 64, column=(21, 5))
+    assert 'sdp_np_interp' in src and 'sdp_tabx_2[1]' in src and 'sdp_interp1_0(' in src
+    # same table twice -> one table; a different table -> a different structure
+    m2 = trace_model(lambda e, p, u, w: (e + np.interp(u, xp, fp) + np.interp(w, xp, fp), p),
+                     lambda e, p, u, w: u * 0., 2, 1, 1)
+    assert len(m2.graph.tables) == 1
+    m3 = trace_model(dyn, lambda e, p, u, w: np.interp(p + w, [0., 1.], [1., 3.5], left=-1., right=7.) * u
+                     + np.interp(u, [0.25], [4.]), 2, 1, 1)
+    assert m3.structure_key() != m.structure_key()
+    for bad in (lambda e, p, u, w: np.interp(u, xp, fp, period=1.),
+                lambda e, p, u, w: np.interp(0.3, xp, fp * u),
+                lambda e, p, u, w: np.interp(u, xp, fp[:-1])):
+        with pytest.raises(TraceError):
+            trace_model(lambda e, p, u, w: (e + u, p), bad, 2, 1, 1)
