@@ -280,6 +280,12 @@ class Sym(object):
             return sym._un(_UFUNC_UN[name], inputs[0])
         if name in ('power', 'float_power'):
             return _power(inputs[0], inputs[1])
+        if name == 'heaviside':
+            x, h0 = inputs
+            # 0 for x < 0, h0 for x == 0, 1 for x > 0, NaN for NaN (numpy's definition)
+            return _where(sym._bin('lt', x, 0.0), 0.0,
+                          _where(sym._bin('gt', x, 0.0), 1.0,
+                                 _where(sym._bin('eq', x, 0.0), h0, x)))
         if name == 'positive':
             return sym
         if name == 'reciprocal':
@@ -318,6 +324,8 @@ class Sym(object):
             return args[0]._un(name, args[0])
         if name == 'interp':
             return _interp(*args, **kwargs)
+        if name == 'select':
+            return _select(*args, **kwargs)
         raise TraceError('numpy function `{}` is not traceable'.format(name))
 
 
@@ -385,6 +393,16 @@ def _where(cond, a, b):
     if an.kind == 'b' and bn.kind == 'b':
         return Sym(g, g.op('bselect', c, an, bn))
     return Sym(g, g.op('select', c, sym._real(an), sym._real(bn)))
+
+
+def _select(condlist, choicelist, default=0):
+    """np.select: the first true condition wins -- nested selects, last to first"""
+    if len(condlist) != len(choicelist) or not condlist:
+        raise TraceError('np.select needs condition and choice lists of equal non-zero length')
+    out = default
+    for cond, choice in zip(reversed(list(condlist)), reversed(list(choicelist))):
+        out = _where(cond, choice, out)
+    return out
 
 
 def _interp(x, xp, fp, left=None, right=None, period=None):

@@ -195,3 +195,21 @@ def test_np_interp_is_traced_with_numpy_semantics():
                 lambda e, p, u, w: np.interp(u, xp, fp[:-1])):
         with pytest.raises(TraceError):
             trace_model(lambda e, p, u, w: (e + u, p), bad, 2, 1, 1)
+
+
+def test_select_and_heaviside_are_traced():
+    def dyn(x, u, w):
+        step = np.heaviside(u - 0.25, 0.5)
+        return (x + np.select([u < -1, u < 0, u < 1], [-1. + 0 * u, 0.5 * u, u * u], default=2.) * step + w,)
+
+    def cost(x, u, w):
+        return np.select([w > 0.5], [u]) + np.heaviside(w, u)
+    m = trace_model(dyn, cost, 1, 1, 1)
+    assert m.bit_exact
+    rng = np.random.default_rng(3)
+    u = np.concatenate([rng.uniform(-2, 2, 300), [0.25, -1., 0., 1., np.nan]])
+    w = np.concatenate([rng.uniform(-1, 1, 300), [0., 0.5, -0., np.nan, 0.]])
+    with np.errstate(all='ignore'):
+        xn, g = evaluate(m, [0.3], [u], [w])
+        assert np.array_equal(xn[0], dyn(0.3, u, w)[0], equal_nan=True)
+        assert np.array_equal(g, cost(0.3, u, w), equal_nan=True)
