@@ -3,7 +3,7 @@
 256^3 x 64 x 32 fp64 sweep of the benchmark problem on the GPU against the C
 oracle (oracle/sdp_oracle.c, OpenMP over the host cores) on ALL 16.7 M nodes --
 J bit for bit, policy index exact.  Takes ~40 s of CPU on the 256-thread box.
-usage: python tools/full_parity.py [N]"""
+usage: python tests/full_parity.py [N]   (also run by tests/test_gpu_full_size.py)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
