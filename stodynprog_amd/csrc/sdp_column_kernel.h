@@ -122,6 +122,48 @@ SDP_DEV void sdp_col_trailing_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_
     g.shift = (sdp_real)0;
 }
 
+// The nested lerp of SdpLerp<real, SDP_DT, real> (sdp_device.h; reference
+// multilinear_cython.pyx:88-300, last axis innermost) split in two: the vertex
+// loads, in the nest's order, and the arithmetic on the loaded values -- the
+// same operations on the same operands, so the result is bit-identical.
+template <int K>
+struct SdpColGather {
+    static SDP_DEV void run(const sdp_real *__restrict__ V, const SdpGrid<sdp_real, SDP_DT> &g,
+                            const int *off, int base, sdp_real *vals)
+    {
+        SdpColGather<K + 1>::run(V, g, off, base + off[K], vals);
+        SdpColGather<K + 1>::run(V, g, off, base + off[K] + g.M[K], vals + (1 << (SDP_DT - K - 1)));
+    }
+};
+template <>
+struct SdpColGather<SDP_DT> {
+    static SDP_DEV void run(const sdp_real *__restrict__ V, const SdpGrid<sdp_real, SDP_DT> &,
+                            const int *, int base, sdp_real *vals)
+    {
+        vals[0] = V[base];
+    }
+};
+template <int K, bool SHIFT>
+struct SdpColNest {
+    static SDP_DEV sdp_real run(const sdp_real *vals, const sdp_real *lam, const sdp_real *oml,
+                                sdp_real shift)
+    {
+        const sdp_real lo = SdpColNest<K + 1, SHIFT>::run(vals, lam, oml, shift);
+        const sdp_real hi = SdpColNest<K + 1, SHIFT>::run(vals + (1 << (SDP_DT - K - 1)), lam, oml, shift);
+        return oml[K] * lo + lam[K] * hi;
+    }
+};
+template <bool SHIFT>
+struct SdpColNest<SDP_DT - 1, SHIFT> {
+    static SDP_DEV sdp_real run(const sdp_real *vals, const sdp_real *lam, const sdp_real *oml,
+                                sdp_real shift)
+    {
+        sdp_real lo = vals[0], hi = vals[1];
+        if (SHIFT) { lo = lo - shift; hi = hi - shift; }
+        return oml[SDP_DT - 1] * lo + lam[SDP_DT - 1] * hi;
+    }
+};
+
 // phases W and A for column `c`: fills s.T.  All threads of the workgroup call it.
 template <bool SHIFT = false>
 SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
@@ -154,43 +196,49 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
     // ---- phase A: T[w][r] = lerp over the trailing axes of V[r, .].  The Wn*N0
     // entries are dealt to all threads (consecutive threads = consecutive rows r:
     // coalesced strip reads); each thread handles SDP_COL_A_GROUP entries at a
-    // time, so that many sets of 2^(d-1) vertex loads are in flight before the
-    // first lerp needs its data.
+    // time.  The 2^(d-1) vertex loads of the whole group are issued first -- only
+    // the loaded values live in registers meanwhile; the interpolation weights
+    // are re-read from LDS afterwards -- so one memory round trip serves
+    // SDP_COL_A_GROUP entries.
     constexpr int G = SDP_COL_A_GROUP;
+    constexpr int NV = 1 << SDP_DT;
     constexpr int total = Wn * N0;
     for (int item0 = threadIdx.x; item0 < total; item0 += G * blockDim.x) {
-        SdpCell<sdp_real, SDP_DT, sdp_real> c[G];
-        int r[G], w[G];
+        sdp_real vals[G][NV];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int item = min(item0 + j * (int)blockDim.x, total - 1);   // clamp: result unused
-            w[j] = item / N0;
-            r[j] = item - w[j] * N0;
+            const int w = item / N0;
+            const int r = item - w * N0;
+            int off[SDP_DT];
 #pragma unroll
-            for (int k = 0; k < SDP_DT; ++k) {
-                c[j].off[k] = s.w_off[w[j] * SDP_DT + k];
-                c[j].lam[k] = s.w_lam[w[j] * SDP_DT + k];
-                c[j].oml[k] = s.w_oml[w[j] * SDP_DT + k];
-            }
+            for (int k = 0; k < SDP_DT; ++k) off[k] = s.w_off[w * SDP_DT + k];
+            SdpColGather<0>::run(V + r, tg, off, 0, vals[j]);
         }
-        sdp_real val[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-            val[j] = SdpLerp<sdp_real, SDP_DT, sdp_real, 0, SHIFT>::eval(V + r[j], tg, c[j], 0);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-            if (item0 + j * (int)blockDim.x < total) {
+            const int item = item0 + j * (int)blockDim.x;
+            if (item < total) {
+                const int w = item / N0;
+                const int r = item - w * N0;
+                sdp_real lam[SDP_DT], oml[SDP_DT];
+#pragma unroll
+                for (int k = 0; k < SDP_DT; ++k) {
+                    lam[k] = s.w_lam[w * SDP_DT + k];
+                    oml[k] = s.w_oml[w * SDP_DT + k];
+                }
+                const sdp_real val = SdpColNest<0, SHIFT>::run(vals[j], lam, oml, tg.shift);
 #if SDP_COL_FUSED && SDP_HAS_W
                 // fused arithmetic: the table holds p_w * inner(r), so phase B is
                 // two fused multiply-adds per cell
-                const sdp_real entry = val[j] * ((const sdp_real *)a.proba)[w[j]];
+                const sdp_real entry = val * ((const sdp_real *)a.proba)[w];
 #else
-                const sdp_real entry = val[j];
+                const sdp_real entry = val;
 #endif
 #if SDP_COL_WPAIR
-                s.T[((w[j] >> 1) * N0 + r[j]) * 2 + (w[j] & 1)] = entry;
+                s.T[((w >> 1) * N0 + r) * 2 + (w & 1)] = entry;
 #else
-                s.T[w[j] * N0 + r[j]] = entry;
+                s.T[w * N0 + r] = entry;
 #endif
             }
         }
