@@ -498,9 +498,16 @@ static RcclApi g_rccl;
 static int rccl_load()
 {
     if (g_rccl.h) return SDP_OK;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // SDP_RCCL_LIBRARY: another library with the same nccl* entry points (the tests
+    // load a host-staged stand-in to run several ranks on the one GPU of the test box)
+    const char *override_path = getenv("SDP_RCCL_LIBRARY");
+    const char *names[] = {override_path && *override_path ? override_path : "librccl.so",
+                           "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
-    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h || (override_path && *override_path)) break;     // an explicit path must load
+    }
     if (!h) return fail(SDP_ECOMM, "cannot load librccl.so: %s", dlerror());
 #define SYM(field, name)                                                         \
     *(void **)(&g_rccl.field) = dlsym(h, name);                                  \

@@ -130,3 +130,118 @@ def test_one_rocm_runtime_when_torch_and_rccl_share_the_process(gpu, tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, timeout=280)
     assert out.returncode == 0 and b'load order ok' in out.stdout, out.stdout.decode()
+
+
+# ---------------------------------------------------------------------------
+# several ranks through the LIBRARY's exchange path (sdp_comm_*, phased backups,
+# in-place gathers, policy gather) on one GPU: RCCL refuses two ranks on one
+# device, so the nccl* entry points come from tests/mock_rccl.cpp (host-staged,
+# blocking) through SDP_RCCL_LIBRARY.  Everything above the collective calls is
+# the product code that runs on the multi-GPU node.
+# ---------------------------------------------------------------------------
+def _build_mock(tmp_path):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available to build the collective stand-in')
+    out = str(tmp_path / 'libmock_rccl.so')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17',
+                           '-o', out, os.path.join(ROOT, 'tests', 'mock_rccl.cpp'), '-lrt'])
+    return out
+
+
+def _run_ranks(script, world, extra_env, timeout=560, argv=()):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1',
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
+        procs.append(subprocess.Popen([sys.executable, str(script)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank {} failed:\n{}\n{}'.format(rank, so.decode(), se.decode()[-3000:])
+    return [so.decode() for so, _ in outs]
+
+
+LIB_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from stodynprog_amd import models, dist
+dev, host = dist.from_env()
+assert dev.is_device and dev.nranks == int(os.environ['WORLD_SIZE'])
+rank = dev.rank
+rng = np.random.default_rng(5)
+
+def quiet(fn, *a, **k):
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3),
+         ('storage_ar1', dict(), 4),                  # 61 columns: uneven parts -> broadcasts
+         ('nas_demo', dict(), 4), ('inventory', dict(), 4)]
+for name, kw, phases in CASES:
+    _, one = getattr(models, name)(**kw)
+    _, two = getattr(models, name)(**kw)
+    two.comm = dev
+    two.comm_phases = phases
+    V0 = rng.standard_normal(one._state_grid_shape)
+    J1, p1 = one.value_iteration(V0, report_time=False); i1 = one.last_policy_index
+    J2, p2 = two.value_iteration(V0, report_time=False); i2 = two.last_policy_index
+    prob = [v for k, v in two._cache.items() if k[0] == 'problem'][0]
+    assert prob.parts is not None and prob.parts.shape[1] == dev.nranks + 1
+    assert np.array_equal(J1, J2), name
+    assert np.array_equal(p1, p2) and np.array_equal(i1, i2), name      # get_policy gathers
+    ref = one._state_ref_ind
+    Jd = J1 - J1[ref]
+    (Ja, ra), _ = one.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
+    (Jb, rb), _ = two.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
+    assert np.array_equal(Ja, Jb) and ra == rb, name
+    Ea, fa = quiet(one.eval_policy, p1, 5, True, V0, J_ref_full=True)
+    Eb, fb = quiet(two.eval_policy, p1, 5, True, V0, J_ref_full=True)     # fused shift, all ranks
+    assert np.array_equal(fa, fb), (name, fa, fb)
+    assert np.array_equal(Ea, Eb), name
+    Ka, _ = quiet(one.value_iterations, V0, 3)
+    Kb, _ = quiet(two.value_iterations, V0, 3)
+    assert np.array_equal(Ka, Kb), name
+    print('rank', rank, name, phases, 'ok', flush=True)
+dev.barrier()
+print('rank', rank, 'all ok', flush=True)
+'''
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world', [2, 3])
+def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world):
+    if importlib.util.find_spec('torch') is None:
+        pytest.skip('torch not installed')
+    mock = _build_mock(tmp_path)
+    script = tmp_path / 'lib_worker.py'
+    script.write_text(LIB_WORKER.format(root=ROOT))
+    outs = _run_ranks(script, world, dict(SDP_RCCL_LIBRARY=mock))
+    for rank, out in enumerate(outs):
+        assert 'rank {} all ok'.format(rank) in out, out
+
+
+@pytest.mark.timeout(900)
+def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (env of
+    torch.distributed.run), two ranks on the one GPU through the stand-in:
+    phase tuning, timed region, max over ranks, one JSON line on rank 0, and the
+    sharded result checked against a single-GPU chain of sweeps"""
+    import json
+    if importlib.util.find_spec('torch') is None:
+        pytest.skip('torch not installed')
+    mock = _build_mock(tmp_path)
+    outs = _run_ranks(os.path.join(ROOT, 'bench.py'), 2, dict(SDP_RCCL_LIBRARY=mock),
+                      argv=['--gpus', '2', '--grid', '48', '--steps', '3', '--warmup', '1',
+                            '--no-cpu-baseline'])
+    assert outs[1].strip() == ''
+    lines = outs[0].strip().splitlines()
+    assert len(lines) == 1, outs[0]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True, d
+    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == {'2', '4', '8', '16'}
+    assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
