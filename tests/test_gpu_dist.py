@@ -213,7 +213,7 @@ print('rank', rank, 'all ok', flush=True)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world):
     if importlib.util.find_spec('torch') is None:
         pytest.skip('torch not installed')
