@@ -208,6 +208,9 @@ for name, kw, phases in CASES:
     assert np.array_equal(Ka, Kb), name
     print('rank', rank, name, phases, 'ok', flush=True)
 dev.barrier()
+for k in [k for k in list(two._cache) if k[0] == 'problem']:
+    two._cache.pop(k).close()
+dev.close()
 print('rank', rank, 'all ok', flush=True)
 '''
 
@@ -245,3 +248,6 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
     assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True, d
     assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == {'2', '4', '8', '16'}
     assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
+    import glob
+    for leftover in glob.glob('/dev/shm/sdp_mock_*'):      # bench.py leaves its communicator to the OS
+        os.unlink(leftover)
