@@ -78,6 +78,7 @@ class Graph(object):
         # VALUES happen to coincide (data of a night hour equal to a literal 0)
         self.unique_consts = unique_consts
         self.tables = []          # lookup tables of np.interp nodes: (xp, fp, left, right)
+        self.scalar_pow = set()   # ids of nodes standing for a numpy SCALAR power (see _power)
 
     def _intern(self, key, op, args, value, kind, deps):
         n = self._memo.get(key)
@@ -279,7 +280,7 @@ class Sym(object):
         if name in _UFUNC_UN:
             return sym._un(_UFUNC_UN[name], inputs[0])
         if name in ('power', 'float_power'):
-            return _power(inputs[0], inputs[1])
+            return _power(inputs[0], inputs[1], ufunc=True)
         if name == 'heaviside':
             x, h0 = inputs
             # 0 for x < 0, h0 for x == 0, 1 for x > 0, NaN for NaN (numpy's definition)
@@ -362,23 +363,38 @@ def _as_bool(sym, v):
     return sym.g.op('ne', n, sym.g.const(0.0))      # numpy truthiness of a real
 
 
-def _power(base, expo):
+def _power(base, expo, ufunc=False):
+    """`base ** expo` (operator) or `np.power(base, expo)` (ufunc=True), as numpy
+    evaluates them:
+      * ndarray ** python scalar takes numpy's fast paths (number.c,
+        fast_scalar_power): 2 -> square, 1 -> copy, 0.5 -> sqrt, -1 -> reciprocal,
+        0 -> ones; every other exponent runs the pow loop;
+      * np.power only special-cases the exponent 2 (x * x in the loop);
+      * a sub-expression that depends on the state (and time) only is a numpy
+        SCALAR when the reference evaluates the callable node by node
+        (stodynprog.py:674-676): scalar ** goes through libm pow, which differs
+        from the correctly rounded x*x / sqrt / 1/x in ~0.09 % of the values by
+        one ulp [measured].  The device keeps the correctly rounded operation (the
+        closest it can get) and the node is flagged: the model then reports
+        `scalar_pow` among its inexact operations instead of claiming bit parity."""
     sym = _any_sym(base, expo)
     if _is_plain_number(expo):
         e = float(expo)
         b = sym._real(sym._lift(base))
-        # numpy's fast paths for scalar exponents (array_power / fast_scalar_power):
-        # 2 -> square, 1 -> positive, 0.5 -> sqrt, -1 -> reciprocal, 0 -> ones
+        op = None
         if e == 2.0:
-            return Sym(sym.g, sym.g.op('square', b))
-        if e == 1.0:
-            return Sym(sym.g, b)
-        if e == 0.5:
-            return Sym(sym.g, sym.g.op('sqrt', b))
-        if e == -1.0:
-            return Sym(sym.g, sym.g.op('recip', b))
-        if e == 0.0:
-            return Sym(sym.g, sym.g.const(1.0))
+            op = 'square'
+        elif not ufunc:
+            if e == 1.0:
+                return Sym(sym.g, b)
+            if e == 0.0:
+                return Sym(sym.g, sym.g.const(1.0))
+            op = {0.5: 'sqrt', -1.0: 'recip'}.get(e)
+        if op is not None:
+            node = sym.g.op(op, b)
+            if not ufunc and (b.deps & (DEP_U | DEP_W)) == 0:
+                sym.g.scalar_pow.add(node.id)
+            return Sym(sym.g, node)
     return sym._bin('pow', base, expo)
 
 
@@ -502,10 +518,14 @@ class TracedModel(object):
     def bit_exact(self):
         """True when every op is correctly rounded on the device (so the model
         evaluates bit-identically to numpy on the host)."""
-        return all(n.op in EXACT_OPS for n in self.live_nodes())
+        return not self.inexact_ops()
 
     def inexact_ops(self):
-        return sorted({n.op for n in self.live_nodes() if n.op not in EXACT_OPS})
+        live = self.live_nodes()
+        ops = {n.op for n in live if n.op not in EXACT_OPS}
+        if any(n.id in self.graph.scalar_pow for n in live):
+            ops.add('scalar_pow')
+        return sorted(ops)
 
     def slice_nodes(self, outputs):
         """Nodes reachable from `outputs` only, in topological order."""

@@ -1148,12 +1148,20 @@ def test_random_models_match_numpy_bit_for_bit(gpu, seed):
     solver.discretize_perturb(-0.6, 0.6, 5)
     solver.control_steps = (0.25,)
     model = solver._traced()
-    assert not isinstance(model, TraceError) and model.bit_exact
+    assert not isinstance(model, TraceError)
+    # a power of a state-only sub-expression is a numpy SCALAR power (libm pow) in the
+    # reference: flagged by the tracer, one ulp off in ~0.1 % of the values
+    assert model.inexact_ops() in ([], ['scalar_pow'])
     V = rng.standard_normal((13, 11))
     with np.errstate(all='ignore'):
         J, u = solver.value_iteration(V, report_time=False)
-        Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+        Jo, uo, io, mo = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
     assert solver.backend_info['kernel'] == ('column' if model.storage_separable else 'generic')
-    assert np.array_equal(J, Jo, equal_nan=True), (lead, trail, cst)
-    assert np.array_equal(solver.last_policy_index, io)
-    assert np.array_equal(u, uo)
+    if model.bit_exact:
+        assert np.array_equal(J, Jo, equal_nan=True), (lead, trail, cst)
+        assert np.array_equal(solver.last_policy_index, io)
+        assert np.array_equal(u, uo)
+    else:
+        assert np.allclose(J, Jo, rtol=1e-13, atol=1e-15, equal_nan=True), (lead, trail, cst)
+        clear = mo > 1e-12 * max(1.0, np.nanmax(np.abs(Jo)))
+        assert np.array_equal(solver.last_policy_index[clear], io[clear])

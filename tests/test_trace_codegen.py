@@ -213,3 +213,82 @@ def test_select_and_heaviside_are_traced():
         xn, g = evaluate(m, [0.3], [u], [w])
         assert np.array_equal(xn[0], dyn(0.3, u, w)[0], equal_nan=True)
         assert np.array_equal(g, cost(0.3, u, w), equal_nan=True)
+
+
+def _fuzz_expr(rng, leaves, depth):
+    """random numpy expression: arithmetic, comparisons, selects, min/max, clip,
+    rounding functions, np.interp and np.select"""
+    if depth == 0 or rng.random() < 0.2:
+        if rng.random() < 0.3:
+            return repr(float(np.round(rng.uniform(-2, 2), 3)))
+        return leaves[rng.integers(len(leaves))]
+    a = _fuzz_expr(rng, leaves, depth - 1)
+    b = _fuzz_expr(rng, leaves, depth - 1)
+    c = _fuzz_expr(rng, leaves, depth - 1)
+    forms = ['({a} + {b})', '({a} - {b})', '({a} * {b})', '({a} / (1.5 + np.abs({b})))',
+             'np.where({a} > {b}, {a}, {c})', 'np.where(np.logical_and({a} <= {b}, np.logical_not({c} < 0.1)), {b}, {c})',
+             'np.minimum({a}, {b})', 'np.maximum({a}, {b})', 'np.sqrt(np.abs({a}))',
+             '(-{a}) ** 2', 'abs({a}) ** 0.5', 'np.clip({a}, -0.5, {b})', 'np.floor({a})',
+             'np.ceil({a} * 3.0) / 3.0', 'np.sign({a}) * {b}', '(({a} > {b}) * 2.0 - ({a} == {b}))',
+             'np.interp({a}, [-1.0, -0.2, 0.3, 1.5], [2.0, -1.0, 0.5, 0.25])',
+             'np.select([{a} < -0.5, {a} < {b}], [{b}, {c}], default=1.25)',
+             'np.heaviside({a}, 0.5) * {b}', 'np.fmax({a}, np.fmin({b}, {c}))',
+             'np.square({a})', 'np.trunc({a} * 2.5)', 'np.rint({a} * 2.0)',
+             '(1.0 / (2.0 + {a} * {a}))']
+    return forms[rng.integers(len(forms))].format(a=a, b=b, c=c)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_tracer_fuzz_interpreted_dag_equals_the_callable(seed):
+    """random callables over (x, y, u, w): the recorded DAG, interpreted with
+    numpy, must reproduce the callable bit for bit on random lattices, every
+    recorded operator must be one the device evaluates exactly, and the
+    generated source must contain one statement per live operator"""
+    rng = np.random.default_rng(7000 + seed)
+    exprs = [_fuzz_expr(rng, ['x', 'y', 'u', 'w'], 4) for _ in range(3)]
+    ns = {'np': np}
+    exec('def dyn(x, y, u, w):\n    return ({}, {})\n'
+         'def cost(x, y, u, w):\n    return {} + 0.0 * u\n'.format(*exprs), ns)
+    m = trace_model(ns['dyn'], ns['cost'], 2, 1, 1)
+    # `scalar ** c` on state-only sub-expressions is libm pow in numpy (flagged, 1 ulp)
+    assert m.inexact_ops() in ([], ['scalar_pow']), m.inexact_ops()
+    exact = m.bit_exact
+
+    def same(a, b):
+        a, b = np.broadcast_to(a, (17, 9)), np.broadcast_to(b, (17, 9))
+        if exact:
+            return np.array_equal(a, b, equal_nan=True)
+        with np.errstate(all='ignore'):
+            return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))
+                               | (np.abs(a - b) <= 4 * np.spacing(np.maximum(np.abs(a), np.abs(b))))))
+    for _ in range(3):
+        x, y = rng.uniform(-1.5, 1.5, 2)
+        u = np.round(rng.uniform(-2, 2, (17, 1)), 2)
+        w = np.round(rng.uniform(-1, 1, (1, 9)), 2)
+        with np.errstate(all='ignore'):
+            xn_t, g_t = evaluate(m, [x, y], [u], [w])
+            xn = ns['dyn'](x, y, u, w)
+            g = ns['cost'](x, y, u, w)
+        for a, b in zip(xn_t, xn):
+            assert same(a, b), exprs
+        assert same(g_t, g), exprs
+    src = codegen.model_function_source(m)
+    live_ops = [n for n in m.live_nodes() if n.op not in ('var', 'const', 'bconst')]
+    assert src.count('    const ') == len(live_ops)
+
+
+def test_power_follows_numpy_array_ufunc_and_scalar_rules():
+    """u ** 0.5 is sqrt and u ** 2 is u*u for arrays (numpy's fast paths),
+    np.power(u, 0.5) is the pow loop, np.power(u, 2) is u*u; a power of a
+    state-only expression is a numpy SCALAR power in the reference (libm pow):
+    kept as the correctly rounded operation but flagged"""
+    m = trace_model(lambda x, u, w: (x + u ** 0.5 + u ** 2 + u ** -1.0 + np.power(u, 2),), lambda x, u, w: u * 0., 1, 1, 1)
+    assert m.bit_exact and 'pow' not in {n.op for n in m.live_nodes()}
+    m = trace_model(lambda x, u, w: (x + np.power(u, 0.5),), lambda x, u, w: u * 0., 1, 1, 1)
+    assert m.inexact_ops() == ['pow']
+    m = trace_model(lambda x, u, w: (x + u,), lambda x, u, w: (x - 0.3) ** 2 + u * u, 1, 1, 1)
+    assert m.inexact_ops() == ['scalar_pow'] and not m.bit_exact
+    m = trace_model(lambda x, u, w: (x + u,), lambda x, u, w: (x - 0.3) * (x - 0.3) + (u - x) ** 2, 1, 1, 1)
+    assert m.bit_exact
+    m = trace_model(lambda x, u, w: (x + u,), lambda x, u, w: np.square(x - 0.3) + np.power(x, 2) + u, 1, 1, 1)
+    assert m.bit_exact                                   # ufunc loops: x*x for scalars too
