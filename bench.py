@@ -177,7 +177,7 @@ def run():
     # this same command (profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) KiB
     traffic = None
     if (N, rb, world, solver.backend_info.get('kernel')) == (256, 8, 1, 'column'):
-        traffic = (2 * 1.0205e6 + 327680.0) * 1024
+        traffic = (2 * 989401.0 + 327680.0) * 1024
     # the column kernel's real ceiling: 6 fp64 operations per lattice cell that
     # bit-exactness does not allow to fuse, against the measured fp64 VALU
     # issue rate of the chip (profiles/ubench_fp64_rate.txt)
