@@ -128,8 +128,8 @@ def run():
             solver.comm_phases = int(os.environ['SDP_COMM_PHASES'])
         else:
             phase_times = {}
-            for ph in (2, 4, 8, 16):
-                solver.comm_phases = ph
+            for ph, taper in ((2, False), (4, False), (8, False), (16, False), (4, True), (8, True)):
+                solver.comm_phases, solver.comm_taper = ph, taper
                 trial = solver._problem()
                 trial.set_value(V0)
                 trial.bench_sweeps(2)
@@ -138,8 +138,10 @@ def run():
                 t0 = time.perf_counter()
                 trial.bench_sweeps(3)
                 sync_all()
-                phase_times[ph] = dev_comm.allreduce_max(time.perf_counter() - t0) / 3 * 1e3
-            solver.comm_phases = min(phase_times, key=lambda k: (phase_times[k], k))
+                phase_times['{}{}'.format(ph, 't' if taper else '')] = \
+                    dev_comm.allreduce_max(time.perf_counter() - t0) / 3 * 1e3
+            best = min(phase_times, key=lambda k: (phase_times[k], k))
+            solver.comm_phases, solver.comm_taper = int(best.rstrip('t')), best.endswith('t')
 
     prob = solver._problem()
     assert solver.backend_info['max_controls'] == U
@@ -193,9 +195,10 @@ def run():
                    'state_nodes': S, 'controls': U, 'perturbations': W,
                    'kernel_family': solver.backend_info.get('kernel'),
                    'sharding': ('single GPU' if dev_comm is None else
-                                'columns dealt in {} phases x {} ranks; RCCL all-gather of each phase '
+                                'columns dealt in {} {}phases x {} ranks; RCCL all-gather of each phase '
                                 'of J under the kernel of the next phase'.format(
-                                    int(prob.parts.shape[0]), world)),
+                                    int(prob.parts.shape[0]), 'tapered ' if solver.comm_taper else '',
+                                    world)),
                    'comm_phase_tuning_ms_per_sweep': phase_times},
         'state_cells_per_sec': S * sweeps_per_s,
         'lattice_cells_per_sec': S * U * W * sweeps_per_s,

@@ -37,17 +37,24 @@ def slab_bounds(shape, nranks):
     return bounds
 
 
-def phase_partition(n_units, unit, nranks, n_phases):
+def phase_partition(n_units, unit, nranks, n_phases, taper=False):
     """Node bounds [n_phases][nranks+1] for the overlapped multi-GPU backup:
     `n_units` work units of `unit` nodes each (columns of the column layout, or
     single nodes) are cut into `n_phases` contiguous phases and every phase
-    into one contiguous part per rank, all as even as possible.  Phases let
-    the all-gather of one phase run under the kernel of the next."""
+    into one contiguous part per rank, as even as possible.  Phases let the
+    all-gather of one phase run under the kernel of the next; only the LAST
+    phase's gather is exposed, so with `taper` the phases shrink linearly
+    (weights n, n-1, .., 1: 40/30/20/10 % for four) and the exposed gather
+    moves the smallest share."""
     n_phases = max(1, min(int(n_phases), max(1, n_units // max(nranks, 1))))
+    weights = [n_phases - k if taper else 1 for k in range(n_phases)]
+    total = sum(weights)
+    cuts = [0]
+    for k in range(n_phases):
+        cuts.append(n_units * sum(weights[:k + 1]) // total)
     bounds = np.zeros((n_phases, nranks + 1), dtype=np.int64)
     for ph in range(n_phases):
-        lo = n_units * ph // n_phases
-        hi = n_units * (ph + 1) // n_phases
+        lo, hi = cuts[ph], cuts[ph + 1]
         for r in range(nranks + 1):
             bounds[ph, r] = (lo + (hi - lo) * r // nranks) * unit
     return bounds

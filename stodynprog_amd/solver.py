@@ -177,6 +177,7 @@ class DPSolver(object):
         self.comm = comm
         self.kernel = 'auto'               # 'auto' | 'generic' | 'column' (see _problem)
         self.comm_phases = 4               # multi-GPU: phases per backup (comm/compute overlap)
+        self.comm_taper = False            # multi-GPU: shrinking phases (smallest gather exposed)
         # 'exact': every floating-point operation of the reference, same order (default);
         # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
         #          operations, J within ~1e-15 relative of 'exact' (opt-in)
@@ -370,7 +371,7 @@ class DPSolver(object):
         # key, so a recycled id() can never alias a stale entry)
         parts = [s.dyn, s.cost, s.control_box, repr(sorted(s.params.items())),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
-                 id(self.comm), self.comm_phases, self.kernel, self.arithmetic]
+                 id(self.comm), self.comm_phases, self.comm_taper, self.kernel, self.arithmetic]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         return hash(tuple(parts))
@@ -584,7 +585,8 @@ class DPSolver(object):
             # each phase's all-gather with the next phase's kernel
             from .dist import phase_partition
             unit = shape[0] if column else 1
-            bounds = phase_partition(S // unit, unit, self.comm.nranks, self.comm_phases)
+            bounds = phase_partition(S // unit, unit, self.comm.nranks, self.comm_phases,
+                                     self.comm_taper)
             node_range = (0, S)
         elif self.comm is not None:
             bounds = self.comm.slab_bounds(dev_shape)

@@ -153,3 +153,17 @@ def test_library_load_puts_torch_first_under_a_launcher():
                              stderr=subprocess.STDOUT, timeout=200)
         assert out.returncode == 0, out.stdout.decode()
         assert out.stdout.decode().strip().splitlines()[-1] == expect, out.stdout.decode()
+
+
+def test_tapered_phase_partition_covers_every_unit_once():
+    for n_units, unit, nranks, n_phases in ((65536, 256, 8, 4), (400, 20, 3, 8), (61, 41, 2, 4), (10, 1, 8, 4)):
+        for taper in (False, True):
+            b = dist.phase_partition(n_units, unit, nranks, n_phases, taper)
+            assert b[0, 0] == 0 and b[-1, -1] == n_units * unit
+            assert (np.diff(b, axis=1) >= 0).all() and (b % unit == 0).all()
+            assert np.array_equal(b[1:, 0], b[:-1, -1])              # phases are contiguous
+            sizes = (b[:, -1] - b[:, 0]) // unit
+            if taper and len(sizes) > 1 and n_units >= 8 * len(sizes):
+                assert (np.diff(sizes) <= 0).all() and sizes[-1] < sizes[0]
+    b = dist.phase_partition(65536, 256, 8, 4, True)
+    assert [int(x) for x in (b[:, -1] - b[:, 0]) // 256] == [26214, 19661, 13107, 6554]

@@ -179,14 +179,14 @@ def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
 
-CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3),
+CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3), ('synthetic3d', dict(N=20), -4),
          ('storage_ar1', dict(), 4),                  # 61 columns: uneven parts -> broadcasts
          ('nas_demo', dict(), 4), ('inventory', dict(), 4)]
 for name, kw, phases in CASES:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
     two.comm = dev
-    two.comm_phases = phases
+    two.comm_phases, two.comm_taper = abs(phases), phases < 0          # negative: tapered phases
     V0 = rng.standard_normal(one._state_grid_shape)
     J1, p1 = one.value_iteration(V0, report_time=False); i1 = one.last_policy_index
     J2, p2 = two.value_iteration(V0, report_time=False); i2 = two.last_policy_index
@@ -246,7 +246,7 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
     assert len(lines) == 1, outs[0]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True, d
-    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == {'2', '4', '8', '16'}
+    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == {'2', '4', '8', '16', '4t', '8t'}
     assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
     import glob
     for leftover in glob.glob('/dev/shm/sdp_mock_*'):      # bench.py leaves its communicator to the OS
