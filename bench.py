@@ -1,22 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the value-iteration sweep on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
 
 A step is ONE Bellman sweep (DPSolver.value_iteration's device work, reference
-stodynprog/stodynprog.py:466-534) over the synthetic benchmark problem of
-BASELINE.json config 4: 256^3 state nodes x 64 controls x 32 perturbation
-points, fp64, value array resident in HBM and ping-ponged between sweeps.
-With N > 1 (one process per GPU, launched by torch.distributed.run) the outer
-state axis is sharded over the ranks and the J slabs are all-gathered with RCCL
-after every sweep, inside the timed region.
+stodynprog/stodynprog.py:466-534) with the value array resident in HBM and
+ping-ponged between sweeps.  Default workload: BASELINE.json configs[3], the
+configuration the metric is quoted on (synthetic 256^3 state nodes x 64
+controls x 32 perturbation points, fp64).  `--config` selects the other
+BASELINE configs (ar1 = configs[1], searev = configs[2], synth512f32 =
+configs[4]) for their own bench lines.
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is the
-gather-accounted HBM-read roofline of SURVEY.md section 8(d); `cpu_baseline`
-is the C oracle (oracle/sdp_oracle.c, a port of the reference algorithm) timed
-on this box's host cores on a bounded slab of the same workload.
+With N > 1 (one process per GPU, launched by `python -m torch.distributed.run`;
+the processes themselves never import torch) the outer state axis is sharded
+over the ranks and the J slabs are all-gathered with RCCL after every sweep,
+inside the timed region.
+
+Prints ONE JSON line on rank 0.
+  roofline      the column kernel removes the 2^d-vertex gather per lattice cell
+                (LDS table), so its binding resource is fp64 VALU issue:
+                achieved = fp64 wave-instructions per launch (rocprofv3 PMC counts
+                of this very command, profiles/pmc_<workload>.json) / kernel
+                duration (HIP events on the kernel's stream, measured here);
+                peak = 256 CU x 4 SIMD x 2.4 GHz / 4 clk = 6.144e11 /s (the 78.6
+                TFLOP/s fp64-vector spec expressed in wave64 instructions).  The
+                gather-accounted contract figure of SURVEY.md 8(d) and the HBM
+                utilisation from the measured traffic are reported beside it.
+  cpu_baseline  the C oracle (oracle/sdp_oracle.c, a port of the reference
+                algorithm) timed on this box's host cores on a bounded sample of
+                the same workload: single thread (faithful to the reference
+                build, reference setup.py:18-22 has no -fopenmp) and all cores.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -27,69 +43,182 @@ sys.path.insert(0, ROOT)
 
 import numpy as np
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-FP64_ISSUE_PEAK = 4.85e11      # fp64 VALU wave-instructions/s, measured (profiles/ubench_fp64_rate.txt)
+# ---- peaks (MI355X: /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+N_SIMD = 256 * 4
+CLOCK_SPEC_HZ = 2.4e9
+# one wave64 fp64 VALU instruction occupies its SIMD for 4 clocks (16 lanes/clk:
+# 78.6 TFLOP/s = 1024 SIMD x 16 lanes x 2 flop x 2.4 GHz); plain fp32 for 2
+FP64_ISSUE_PEAK = N_SIMD * CLOCK_SPEC_HZ / 4        # 6.144e11 wave-instructions/s
+FP32_ISSUE_PEAK = N_SIMD * CLOCK_SPEC_HZ / 2
+
+WORKLOADS = {
+    # name: (models.<builder>, kwargs, dtype, BASELINE.json configs[] index, label)
+    'synth256': ('synthetic3d', dict(N=256), 'float64', 3,
+                 'synthetic3d {n}^3 state x 64 controls x 32 perturbations'),
+    'synth512f32': ('synthetic3d', dict(N=512), 'float32', 4,
+                    'synthetic3d {n}^3 state x 64 controls x 32 perturbations, fp32 with policy indices'),
+    'ar1': ('storage_ar1', dict(n_E=200, n_P=200, steps=(8. / 49, 0.1)), 'float64', 1,
+            'storage-AR1 200x200 state (SoC, mismatch) x <=50 controls x 9 perturbations'),
+    'searev': ('searev', dict(n_E=128, n_S=128, n_A=128, step=2.2 / 31), 'float64', 2,
+               'Searev + storage 128^3 state x <=32 controls x 9 perturbations'),
+}
 
 
-def algorithmic_bytes(S, U, W, d, real_bytes, nu):
-    """S*U*W*2^d*T gathered + S*(T read + T write + 4*nu index)."""
-    return S * U * W * (2 ** d) * real_bytes + S * (2 * real_bytes + 4 * nu)
+def algorithmic_bytes(S, cells, d, real_bytes, nu):
+    """cells*2^d*T gathered + S*(T read + T write + 4*nu index)."""
+    return cells * (2 ** d) * real_bytes + S * (2 * real_bytes + 4 * nu)
 
 
-def cpu_baseline(solver, V0, models, budget_s=18.0):
-    """Time the C oracle on a bounded slab of nodes with all host cores."""
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline_synth(solver, V0, models, U, budget_single=8.0, budget_all=12.0):
+    """C oracle on bounded samples of random nodes: one thread, then all cores."""
     from oracle import c_oracle
     S = V0.size
-    U, W = 64, len(solver.perturb_grid[0])
-    threads = c_oracle.max_threads()
+    W = len(solver.perturb_grid[0])
     rng = np.random.default_rng(1)
 
-    def run(n):
+    def run(n, threads):
         nodes = np.sort(rng.integers(0, S, n))
         t0 = time.perf_counter()
         c_oracle.vi_synth3d(solver.state_grid, V0, models.SYNTH_PAR, -1., 1., U,
                             solver.perturb_grid[0], solver.perturb_proba[0],
                             node_ids=nodes, n_threads=threads)
         return time.perf_counter() - t0
-    run(64 * threads)                                   # warm-up (page in V0, spawn threads)
-    n0 = 512 * threads
-    t_probe = run(n0)
-    n = int(max(n0, min(S, n0 * budget_s / max(t_probe, 1e-6))))
-    t = run(n)
-    cells_per_s = n * U * W / t
-    return {
-        'value': cells_per_s / (S * U * W), 'unit': 'sweeps/s', 'cores': threads,
-        'kind': 'port',
-        'lattice_cells_per_s': cells_per_s,
-        'sample': '{} random state nodes x {} controls x {} perturbations of the same '
-                  '256^3 problem ({:.1f} s of OpenMP C oracle, scaled linearly to a full '
-                  'sweep)'.format(n, U, W, t),
-    }
+
+    def leg(threads, budget):
+        run(64 * threads, threads)                      # warm-up (page in V0, spawn threads)
+        n0 = 512 * threads
+        t_probe = run(n0, threads)
+        n = int(max(n0, min(S, n0 * budget / max(t_probe, 1e-6))))
+        t = run(n, threads)
+        cells_per_s = n * U * W / t
+        return {'value': cells_per_s / (S * U * W), 'unit': 'sweeps/s', 'cores': threads,
+                'lattice_cells_per_s': cells_per_s,
+                'sample': '{} random state nodes x {} controls x {} perturbations of the same '
+                          'problem ({:.1f} s of the C oracle on {} thread{}, scaled linearly to a '
+                          'full sweep)'.format(n, U, W, t, threads, '' if threads == 1 else 's')}
+    single = leg(1, budget_single)
+    out = dict(single, kind='port', cpu_model=cpu_model(),
+               note='single thread = the reference build (no OpenMP, reference setup.py:18-22); '
+                    'the port has no Python/numpy staging and is ~3.7x faster per core than the '
+                    'real reference (BASELINE.md section 5)')
+    threads = c_oracle.max_threads()
+    if threads > 1:
+        out['all_cores'] = leg(threads, budget_all)
+    return out
 
 
-def run():
+def cpu_baseline_numpy(solver, V0, cells_per_sweep, budget=15.0):
+    """numpy restatement of the reference's per-node loop (oracle/vi_numpy.py,
+    the reference's own structure: one Python iteration per node), one thread,
+    on a bounded sample of random nodes."""
+    from oracle import vi_numpy
+    spec = vi_numpy.Spec.from_solver(solver)
+    S = V0.size
+    W = max(len(solver.perturb_grid[0]) if solver.perturb_grid else 1, 1)
+    rng = np.random.default_rng(1)
+    lo, hi, n = solver._box_table()
+    per_node = np.prod(n.astype(np.int64), axis=0)
+
+    def run(k):
+        nodes = np.sort(rng.integers(0, S, k))
+        t0 = time.perf_counter()
+        vi_numpy.value_iteration(spec, V0, nodes=nodes)
+        cells = float(per_node[nodes].sum() if per_node.size > 1 else per_node[0] * k) * W
+        return time.perf_counter() - t0, cells
+    run(8)
+    t_probe, _ = run(64)
+    k = int(max(64, min(S, 64 * budget / max(t_probe, 1e-6))))
+    t, cells = run(k)
+    return {'value': cells / t / cells_per_sweep, 'unit': 'sweeps/s', 'cores': 1, 'kind': 'port',
+            'lattice_cells_per_s': cells / t, 'cpu_model': cpu_model(),
+            'sample': '{} random state nodes of the same problem ({:.1f} s of oracle/vi_numpy.py, the '
+                      'reference-shaped per-node numpy loop, one thread; scaled linearly by lattice '
+                      'cells to a full sweep)'.format(k, t)}
+
+
+def load_pmc(key):
+    """Latest committed PMC summary of this workload's bench command
+    (profiles/pmc_<key>.json, written by tools/summarize_prof.py)."""
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_{}.json'.format(key))))
+    if not paths:
+        return None, None
+    try:
+        with open(paths[-1]) as f:
+            return json.load(f), os.path.relpath(paths[-1], ROOT)
+    except (OSError, ValueError):
+        return None, None
+
+
+def load_clock():
+    """in-kernel clock of the sweep kernel (s_memtime / s_memrealtime stamps of the
+    diagnostic build, tools/clock_probe.py -> profiles/clock.json)"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'clock.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def build_solver(args, models, DPSolver, comm):
+    name, kw, dtype, cfg, label = WORKLOADS[args.config]
+    kw = dict(kw)
+    if args.grid and name == 'synthetic3d':
+        kw['N'] = args.grid
+    if args.dtype:
+        dtype = args.dtype
+    dtype = np.dtype(dtype)
+    sysd, ref_solver = getattr(models, name)(**kw)
+    solver = DPSolver(sysd, dtype=dtype, comm=comm)
+    for attr in ('state_grid', '_state_grid_shape', '_state_ref_ind', '_state_ref',
+                 'perturb_grid', 'perturb_proba', 'control_steps'):
+        setattr(solver, attr, getattr(ref_solver, attr))
+    if name == 'synthetic3d':
+        V0 = models.synthetic3d_V0(solver.state_grid, dtype=dtype)
+    else:
+        # smooth closed-form start (no RNG): squared distance to the grid centre
+        parts = []
+        for g in solver.state_grid_full:
+            g = np.asarray(g, dtype=np.float64)
+            parts.append(((g - g.mean()) / (g.max() - g.min())) ** 2)
+        V0 = np.ascontiguousarray(np.broadcast_to(sum(parts), solver._state_grid_shape), dtype=dtype)
+    n = kw.get('N', solver._state_grid_shape[0])
+    return sysd, ref_solver, solver, V0, dtype, cfg, label.format(n=n), name
+
+
+def clone_solver(DPSolver, sysd, solver, dtype, **attrs):
+    s = DPSolver(sysd, dtype=dtype)
+    for attr in ('state_grid', '_state_grid_shape', '_state_ref_ind', '_state_ref',
+                 'perturb_grid', 'perturb_proba', 'control_steps'):
+        setattr(s, attr, getattr(solver, attr))
+    for k, v in attrs.items():
+        setattr(s, k, v)
+    return s
+
+
+def run(args):
     """everything but the final print; returns the result dict on rank 0, else None"""
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--grid', type=int, default=256, help='points per state axis')
-    ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--fused', action='store_true',
-                    help='also time the opt-in fused-arithmetic variant (secondary figure)')
-    ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
-    args = ap.parse_args()
-
     from stodynprog_amd import models, dist, _native as nat
     from stodynprog_amd.solver import DPSolver
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
-        dev_comm, host_comm = dist.from_env()
+        dev_comm, _ = dist.from_env()
     else:
-        dev_comm = host_comm = None
+        dev_comm = None
         nat.require_gpu()
         nat.check(nat.lib().sdp_set_device(0))
         if os.environ.get('SDP_BENCH_SINGLE_RANK_COMM'):
@@ -98,17 +227,18 @@ def run():
     if args.gpus != world and rank == 0:
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
 
-    dtype = np.dtype(args.dtype)
-    N = args.grid
-    sysd, ref_solver = models.synthetic3d(N=N)
-    solver = DPSolver(sysd, dtype=dtype, comm=dev_comm)
-    solver.state_grid = ref_solver.state_grid
-    solver._state_grid_shape = ref_solver._state_grid_shape
-    solver._state_ref_ind = ref_solver._state_ref_ind
-    solver.perturb_grid, solver.perturb_proba = ref_solver.perturb_grid, ref_solver.perturb_proba
-    solver.control_steps = ref_solver.control_steps
-    V0 = models.synthetic3d_V0(solver.state_grid, dtype=dtype)
-    S, U, W, d, nu = V0.size, models.SYNTH['n_u'], len(solver.perturb_grid[0]), 3, 1
+    sysd, ref_solver, solver, V0, dtype, cfg, label, model_name = build_solver(args, models, DPSolver, dev_comm)
+    if args.kernel:
+        solver.kernel = args.kernel
+    S = V0.size
+    d = V0.ndim
+    nu = len(sysd.control)
+    W = len(solver.perturb_grid[0]) if solver.perturb_grid else 0
+    bp = solver._box_plan()
+    per_node = np.prod(bp['n'].astype(np.int64), axis=0)
+    lattice = float(per_node.sum() if bp['per_node'] else per_node[0] * S)   # (node, control) pairs
+    cells = lattice * max(W, 1)                                               # lattice cells per sweep
+    U_max = int(bp['max_u'])
 
     def sync_all():
         nat.check(nat.lib().sdp_synchronize())
@@ -144,8 +274,9 @@ def run():
             solver.comm_phases, solver.comm_taper = int(best.rstrip('t')), best.endswith('t')
 
     prob = solver._problem()
-    assert solver.backend_info['max_controls'] == U
+    assert solver.backend_info['max_controls'] == U_max
     prob.set_value(V0)
+    kernel_family = solver.backend_info.get('kernel')
 
     # warm-up sweeps (untimed), ping-pong like the timed ones
     if args.warmup > 0:
@@ -165,66 +296,105 @@ def run():
     ms_per_step = elapsed * 1e3 / args.steps
     sweeps_per_s = args.steps / elapsed
     rb = dtype.itemsize
-    # roofline of the dominant kernel (sdp_sweep): algorithmic bytes of the
-    # nodes ONE launch processes / its average duration (HIP events on the
-    # kernel's stream, measured above inside the timed region)
+    # ---- roofline of the dominant kernel: the share of the sweep ONE launch chain of
+    # this rank processes / its average duration (HIP events on the kernel's stream,
+    # measured above inside the timed region)
     if prob.parts is not None:       # sharded: this rank's nodes, summed over its phase launches
-        nodes_per_launch = int((prob.parts[:, rank + 1] - prob.parts[:, rank]).sum())
+        share = float((prob.parts[:, rank + 1] - prob.parts[:, rank]).sum()) / S
     else:
-        nodes_per_launch = prob.node_range[1] - prob.node_range[0]
-    bytes_launch = algorithmic_bytes(nodes_per_launch, U, W, d, rb, nu)
+        share = float(prob.node_range[1] - prob.node_range[0]) / S
     k_ms = kernel_ms / args.steps
-    achieved = bytes_launch / (k_ms * 1e-3) / 1e9
-    # HBM-side traffic of one launch from the committed rocprofv3 PMC passes of
-    # this same command (profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) KiB
+    k_s = k_ms * 1e-3
+    kname = {'column': 'sdp_sweep_col', 'generic': 'sdp_sweep', 'staged': 'sdp_sweep_lds'}.get(
+        kernel_family, 'sdp_sweep')
+    pmc_key = '{}_{}_{}'.format(args.config if not args.grid else '{}{}'.format(model_name, args.grid),
+                                'f64' if rb == 8 else 'f32', kernel_family)
+    pmc, pmc_path = load_pmc(pmc_key)
+    issue_peak = FP64_ISSUE_PEAK if rb == 8 else FP32_ISSUE_PEAK
+    analytic = cells * 6 / 64.0                        # 6 operations per lattice cell, never fusable
+    if pmc and pmc.get('valu_wave_instr'):
+        counted = float(pmc['valu_wave_instr'])
+        count_source = ('{}: {} per {} dispatch (rocprofv3 --pmc of this command)'
+                        .format(pmc_path, pmc.get('valu_wave_instr_counters', 'SQ_INSTS_VALU_*'), kname))
+    else:
+        counted = analytic
+        count_source = ('analytic lower bound: 6 {} operations per lattice cell (2 mul + add of the outer '
+                        'lerp, cost add, weight mul, accumulate); no PMC summary committed for this '
+                        'workload'.format('fp64' if rb == 8 else 'fp32'))
+    instr_launch = counted * share
+    achieved = instr_launch / k_s
     traffic = None
-    if (N, rb, world, solver.backend_info.get('kernel')) == (256, 8, 1, 'column'):
-        traffic = (2 * 989401.0 + 327680.0) * 1024
-    # the column kernel's real ceiling: 6 fp64 operations per lattice cell that
-    # bit-exactness does not allow to fuse, against the measured fp64 VALU
-    # issue rate of the chip (profiles/ubench_fp64_rate.txt)
-    fp64_wave_instr = nodes_per_launch * U * W * 6 / 64.0
-    fp64_rate = fp64_wave_instr / (k_ms * 1e-3)
+    traffic_source = None
+    if pmc and pmc.get('hbm_bytes') and world == 1:
+        traffic = float(pmc['hbm_bytes'])
+        traffic_source = '{}: {}'.format(pmc_path, pmc.get('hbm_bytes_formula', '2 x FETCH_SIZE + WRITE_SIZE'))
+    clock = load_clock()
+    roof = {
+        'bound': 'fp64_valu' if rb == 8 else 'fp32_valu',
+        'achieved': achieved, 'peak': issue_peak, 'unit': 'wave-instr/s', 'frac': achieved / issue_peak,
+        'traffic': traffic, 'traffic_source': traffic_source,
+        'kernel': kname, 'kernel_ms': k_ms,
+        'valu_wave_instr_per_launch': instr_launch, 'count_source': count_source,
+        'analytic_min_wave_instr_per_launch': analytic * share,
+        'peak_source': 'spec: 256 CU x 4 SIMD x 2.4 GHz / {} clk per wave64 {} VALU instruction '
+                       '(MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s, fp64 half of it)'.format(
+                           4 if rb == 8 else 2, 'fp64' if rb == 8 else 'fp32'),
+        'why_not_hbm': 'the column kernel tabulates the inner lerps of a column in LDS, so the 2^d-vertex '
+                       'gather per lattice cell never reaches L2/HBM; HBM is a few % utilised (hbm block) '
+                       'and the 6 separately rounded operations per cell that bit-exactness forbids to '
+                       'fuse bind the kernel' if kernel_family == 'column' else
+                       'per-cell gathers: bound by vector-memory/LDS gather issue, see DESIGN.md section 4',
+    }
+    if clock and clock.get('sweep_kernel_ghz'):
+        ghz = float(clock['sweep_kernel_ghz'])
+        peak_clk = N_SIMD * ghz * 1e9 / (4 if rb == 8 else 2)
+        roof['measured_clock_ghz'] = ghz
+        roof['peak_at_measured_clock'] = peak_clk
+        roof['frac_at_measured_clock'] = achieved / peak_clk
+        roof['clock_source'] = 'profiles/clock.json (s_memtime / s_memrealtime stamps, diagnostic build)'
+        cpi = clock.get('fp64_clk_per_wave_instr_measured')
+        if cpi and rb == 8:
+            # the ubench does not reach 4 clk per fp64 wave-instruction either (8 waves/SIMD,
+            # independent chains): what the pipe sustains at the clock the sweep kernel holds
+            roof['fp64_clk_per_wave_instr_measured'] = cpi
+            roof['frac_of_measured_issue_rate'] = achieved / (N_SIMD * ghz * 1e9 / cpi)
+    if traffic:
+        roof['hbm'] = {'achieved_GBps': traffic / k_s / 1e9, 'peak_GBps': HBM_PEAK_GBS,
+                       'frac': traffic / k_s / 1e9 / HBM_PEAK_GBS,
+                       'compulsory_bytes': S * (2 * rb + rb * nu + 4)}
+    bytes_launch = algorithmic_bytes(S, cells, d, rb, nu) * share
+    roof['gather_contract'] = {
+        'algorithmic_bytes_per_launch': bytes_launch, 'GBps': bytes_launch / k_s / 1e9,
+        'frac_of_hbm_peak': bytes_launch / k_s / 1e9 / HBM_PEAK_GBS,
+        'note': 'SURVEY 8(d) contract figure: 2^d*T bytes per lattice cell as if every vertex came from '
+                'HBM.  NOT a utilisation: the table removes those reads, so this exceeds 1 by design '
+                '(north_star bar: >= 0.5)'}
     out = {
         'metric': 'vi_sweeps_per_sec', 'value': sweeps_per_s, 'unit': 'sweeps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64' if rb == 8 else 'f32', 'data': 'synthetic',
-        'config': {'workload': 'synthetic3d {0}^3 state x {1} controls x {2} perturbations '
-                               '(BASELINE.json configs[3])'.format(N, U, W),
-                   'state_nodes': S, 'controls': U, 'perturbations': W,
-                   'kernel_family': solver.backend_info.get('kernel'),
+        'config': {'workload': '{} (BASELINE.json configs[{}])'.format(label, cfg),
+                   'state_nodes': S, 'controls_max': U_max, 'perturbations': W,
+                   'lattice_cells_per_sweep': cells,
+                   'kernel_family': kernel_family,
                    'sharding': ('single GPU' if dev_comm is None else
                                 'columns dealt in {} {}phases x {} ranks; RCCL all-gather of each phase '
                                 'of J under the kernel of the next phase'.format(
                                     int(prob.parts.shape[0]), 'tapered ' if solver.comm_taper else '',
                                     world)),
-                   'comm_phase_tuning_ms_per_sweep': phase_times},
+                   'comm_phase_tuning_ms_per_sweep': phase_times,
+                   'torch_imported': 'torch' in sys.modules},
         'state_cells_per_sec': S * sweeps_per_s,
-        'lattice_cells_per_sec': S * U * W * sweeps_per_s,
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'traffic_source': 'profiles/r01_final_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
-                                       'WRITE_SIZE, FETCH x2 per the gfx950 correction)' if traffic else None,
-                     'fp64_valu_wave_instr_per_s': fp64_rate, 'fp64_valu_peak_measured': FP64_ISSUE_PEAK,
-                     'fp64_valu_frac': fp64_rate / FP64_ISSUE_PEAK,
-                     'kernel': 'sdp_sweep_col' if solver.backend_info.get('kernel') == 'column' else 'sdp_sweep',
-                     'kernel_ms': k_ms,
-                     'algorithmic_bytes_per_launch': bytes_launch,
-                     'note': 'gather accounting (SURVEY 8d): 2^d*T bytes per lattice cell; V '
-                             'is reused from L2/Infinity Cache so frac may exceed 1'},
+        'lattice_cells_per_sec': cells * sweeps_per_s,
+        'roofline': roof,
     }
-    if world == 1 and solver.backend_info.get('kernel') == 'column' and args.fused:
+    if world == 1 and kernel_family == 'column' and args.fused:
         # secondary figure (never the headline `value`): the opt-in fused-arithmetic
         # variant of the same kernel (weight-scaled LDS table + FMAs; J within
         # ~1e-15 relative of the exact kernel)
         try:
-            fs = DPSolver(sysd, dtype=dtype)
-            fs.state_grid, fs._state_grid_shape = solver.state_grid, solver._state_grid_shape
-            fs._state_ref_ind = solver._state_ref_ind
-            fs.perturb_grid, fs.perturb_proba = solver.perturb_grid, solver.perturb_proba
-            fs.control_steps = solver.control_steps
-            fs.arithmetic = 'fused'
+            fs = clone_solver(DPSolver, sysd, solver, dtype, arithmetic='fused')
             for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
                 solver._cache.pop(k_).close()               # free the exact problem's buffers first
             fprob = fs._problem()
@@ -241,11 +411,7 @@ def run():
         # the same chain of sweeps on its GPU alone and compares J bit for bit
         try:
             J_sharded = prob.get_value()
-            single = DPSolver(sysd, dtype=dtype)
-            single.state_grid, single._state_grid_shape = solver.state_grid, solver._state_grid_shape
-            single._state_ref_ind = solver._state_ref_ind
-            single.perturb_grid, single.perturb_proba = solver.perturb_grid, solver.perturb_proba
-            single.control_steps = solver.control_steps
+            single = clone_solver(DPSolver, sysd, solver, dtype, kernel=solver.kernel)
             sprob = single._problem()
             sprob.set_value(V0)
             if args.warmup > 0:
@@ -257,18 +423,49 @@ def run():
             out['sharded_matches_single_gpu'] = repr(e)
     if not args.no_cpu_baseline and world == 1:
         try:
-            out['cpu_baseline'] = cpu_baseline(ref_solver, np.asarray(V0, dtype=np.float64), models)
+            if model_name == 'synthetic3d':
+                out['cpu_baseline'] = cpu_baseline_synth(ref_solver, np.asarray(V0, dtype=np.float64),
+                                                         models, U_max)
+            else:
+                out['cpu_baseline'] = cpu_baseline_numpy(ref_solver, np.asarray(V0, dtype=np.float64), cells)
         except Exception as e:                       # the baseline must never hide the GPU number
             out['cpu_baseline'] = {'value': None, 'error': repr(e)}
     return out
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='synth256', choices=sorted(WORKLOADS))
+    ap.add_argument('--grid', type=int, default=0,
+                    help='synthetic workloads: points per state axis (default: the config\'s)')
+    ap.add_argument('--dtype', default=None, choices=['float64', 'float32'])
+    ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged'],
+                    help='kernel family (default: auto)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fused', action='store_true',
+                    help='also time the opt-in fused-arithmetic variant (secondary figure)')
+    ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    rank = int(os.environ.get('RANK', '0'))
     # native libraries (RCCL's version banner, stdio-buffered until exit) must not
     # write into stdout: it carries exactly ONE line, the JSON result of rank 0
     from stodynprog_amd.dist import _stdout_to_stderr
-    with _stdout_to_stderr():
-        out = run()
+    try:
+        with _stdout_to_stderr():
+            out = run(args)
+    except BaseException as e:                        # a failed run still prints ONE JSON line
+        import traceback
+        traceback.print_exc()
+        err = {'metric': 'vi_sweeps_per_sec', 'value': None, 'unit': 'sweeps/s',
+               'n_gpus': int(os.environ.get('WORLD_SIZE', '1')), 'steps': args.steps,
+               'warmup': args.warmup, 'error': '{}: {}'.format(type(e).__name__, e),
+               'rank': rank}
+        if rank == 0:
+            print(json.dumps(err), flush=True)
+        sys.exit(1)
     if out is not None:
         print(json.dumps(out), flush=True)
 

@@ -175,6 +175,14 @@ int sdp_problem_last_kernel_ms(sdp_problem *p, double *ms);
 int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp, int64_t ref_index,
                              double *loop_ms, double *kernel_ms);
 
+/* Diagnostic (tools/clock_probe.py): code objects built with -DSDP_STAMP=1 record
+ * s_memtime / s_memrealtime of thread 0 of every workgroup at kernel entry and
+ * exit.  enable != 0 allocates the stamp buffer (the launches that follow fill
+ * it); host != NULL copies n_words 64-bit words out ([workgroup][4]); enable == 0
+ * frees it.  Production code objects never touch the buffer. */
+int sdp_problem_debug_stamps(sdp_problem *p, int enable, unsigned long long *host,
+                             int64_t n_words);
+
 /* ---- tabulated backup (models that cannot be traced into device code) ------- */
 /*
  * Replaces the numeric part of DPSolver._value_at_state_vect
@@ -195,10 +203,17 @@ int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_off, int64_t
                    const double *g /* [n_cells] */, double *J_out /* [n_nodes] */,
                    int64_t *idx_out /* [n_nodes] */);
 
-/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------- */
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------
+ * librccl.so is dlopen()ed on first use.  TEST HOOK: when the environment variable
+ * SDP_RCCL_LIBRARY names a shared object, the nccl* entry points are taken from it
+ * instead (tests/mock_rccl.cpp: a host-staged stand-in that lets several ranks
+ * share the ONE GPU of the test box, which RCCL itself refuses).  Never set it in
+ * production; sdp_comm_create reports the library it bound through
+ * sdp_comm_library(). */
 int sdp_comm_unique_id(char id[128]);                       /* rank 0 */
 int sdp_comm_create(int rank, int nranks, const char id[128], sdp_comm **out);
 int sdp_comm_destroy(sdp_comm *c);
+const char *sdp_comm_library(void);      /* path/name the nccl* symbols came from, "" if not loaded */
 /*
  * Shard the handle's backups over the ranks of `c`.  The node range (device
  * order) is cut into n_phases contiguous phases and every phase into one part

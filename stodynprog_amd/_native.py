@@ -96,6 +96,8 @@ def _declare(lib):
         'sdp_problem_get_policy': (C.c_int, [vp, vp, vp]),
         'sdp_problem_last_kernel_ms': (C.c_int, [vp, P(dbl)]),
         'sdp_problem_bench_sweeps': (C.c_int, [vp, i32, C.c_int, i64, P(dbl), P(dbl)]),
+        'sdp_problem_debug_stamps': (C.c_int, [vp, C.c_int, vp, i64]),
+        'sdp_comm_library': (C.c_char_p, []),
         'sdp_comm_unique_id': (C.c_int, [C.c_char_p]),
         'sdp_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_char_p, P(vp)]),
         'sdp_comm_destroy': (C.c_int, [vp]),
@@ -125,7 +127,6 @@ def lib():
                     'HIP extension {} is missing: build it with '
                     '`python -c "import __graft_entry__ as g; g.build()"` '
                     '(needs hipcc); there is no CPU fallback'.format(LIB_PATH))
-            _torch_runtime_first()
             try:
                 loaded = C.CDLL(LIB_PATH)
             except OSError as e:
@@ -135,27 +136,17 @@ def lib():
     return _lib
 
 
-def _torch_runtime_first():
-    """The PyTorch-ROCm wheel ships its own copies of libamdhip64 / libhsa-runtime64
-    / librccl.  A process that maps libsdp_hip.so (linked against /opt/rocm) first
-    and torch afterwards holds TWO ROCm runtimes, and RCCL then binds to the one
-    that never initialised a device (measured: ncclCommInitRank fails with
-    hsa_system_get_info 4107 / 'no ROCm-capable device').  Multi-process runs use
-    torch.distributed for the rendezvous, so under a launcher (WORLD_SIZE > 1)
-    torch is imported BEFORE the library: the dynamic linker then resolves the
-    library's libamdhip64.so.7 to the copy already mapped and one runtime serves
-    everything.  Single-process use never imports torch."""
-    import sys
-    if 'torch' in sys.modules or int(os.environ.get('WORLD_SIZE', '1') or 1) <= 1:
-        return
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
-
-
 def rocm_runtimes():
-    """Paths of the distinct libamdhip64 objects mapped into this process."""
+    """Paths of the distinct libamdhip64 objects mapped into this process.
+
+    The PyTorch-ROCm wheel ships its own copies of libamdhip64 / libhsa-runtime64
+    / librccl.  A process that maps libsdp_hip.so (linked against /opt/rocm) and
+    imports torch AFTERWARDS holds two ROCm runtimes, and RCCL then binds to the
+    one that never initialised a device (measured: ncclCommInitRank fails with
+    hsa_system_get_info 4107 / 'no ROCm-capable device').  This package never
+    imports torch (the multi-process rendezvous is dist.FileRendezvous), so its
+    own processes hold one runtime; `RcclCommunicator` checks this list and
+    refuses to start in a process where the user mixed the two."""
     seen = []
     try:
         with open('/proc/self/maps') as f:

@@ -218,6 +218,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
         '#define SDP_NU {}'.format(model.n_control),
         '#define SDP_HAS_W {}'.format(1 if model.n_perturb else 0),
         '#define SDP_LANES {}'.format(int(lanes)),
+        ] + (['#define SDP_STAMP 1     // diagnostic build: in-kernel clock stamps (tools/clock_probe.py)']
+             if os.environ.get('SDP_STAMP') == '1' else []) + [
         '#include "sdp_device.h"',
         'typedef SDP_REAL sdp_real;',
         ''] + ([

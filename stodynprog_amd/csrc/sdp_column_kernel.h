@@ -650,6 +650,7 @@ SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
+    SDP_STAMP_BEGIN(a);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -750,6 +751,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             }
         }
     }
+    SDP_STAMP_END(a);
 }
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)

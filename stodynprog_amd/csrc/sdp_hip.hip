@@ -494,6 +494,9 @@ struct RcclApi {
     const char *(*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
+static std::string g_rccl_name;
+
+extern "C" const char *sdp_comm_library(void) { return g_rccl_name.c_str(); }
 
 static int rccl_load()
 {
@@ -506,6 +509,7 @@ static int rccl_load()
     void *h = nullptr;
     for (const char *n : names) {
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) g_rccl_name = n;
         if (h || (override_path && *override_path)) break;     // an explicit path must load
     }
     if (!h) return fail(SDP_ECOMM, "cannot load librccl.so: %s", dlerror());
@@ -604,7 +608,8 @@ struct sdp_problem {
     int64_t S = 0, node_begin = 0, node_end = 0;
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
-    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch;
+    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps;
+    int64_t stamp_words = 0;
     size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
     hipFunction_t f_sweep = nullptr, f_evalpol = nullptr;
@@ -836,6 +841,7 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     for (int k = 0; k < SDP_MAXD; ++k) { a.orders[k] = p->orders[k]; a.axis_off[k] = p->axis_off[k]; }
     a.W = p->W; a.box_per_node = p->box_per_node;
     a.shift_index = -1; a.ref_out = nullptr;
+    a.stamps = (unsigned long long *)p->stamps.p;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
         a.col_begin = nb / p->orders[0];
@@ -1148,6 +1154,28 @@ extern "C" int sdp_problem_last_kernel_ms(sdp_problem *p, double *ms)
 {
     if (!p || !ms) return fail(SDP_EINVAL, "NULL argument");
     *ms = p->last_kernel_ms;
+    return SDP_OK;
+}
+
+// diagnostic: clock stamps of SDP_STAMP code objects (see sdp_kernel_args.h)
+extern "C" int sdp_problem_debug_stamps(sdp_problem *p, int enable, unsigned long long *host,
+                                        int64_t n_words)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (enable && !p->stamps.p) {
+        const int64_t words = (int64_t)65536 * 4;           // room for any grid the library launches
+        int rc = p->stamps.alloc((size_t)words * 8);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(p->stamps.p, 0, (size_t)words * 8));
+        p->stamp_words = words;
+    }
+    if (host && n_words > 0) {
+        if (!p->stamps.p) return fail(SDP_EINVAL, "stamps were never enabled");
+        if (n_words > p->stamp_words) n_words = p->stamp_words;
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpy(host, p->stamps.p, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    }
+    if (!enable && p->stamps.p) { (void)hipFree(p->stamps.p); p->stamps.p = nullptr; p->stamp_words = 0; }
     return SDP_OK;
 }
 

@@ -40,6 +40,10 @@ struct SdpSweepArgs {
     // ---- policy-evaluation kernels only: fused relative-DP shift ------------------
     int64_t shift_index;   // >= 0: every V read is V[.] - V[shift_index] (device order); -1: none
     double *ref_out;       // if set, thread 0 of workgroup 0 stores V[shift_index] there (J_ref of the previous step)
+    // ---- diagnostic builds only (SDP_STAMP code objects; null in production) ----
+    // [gridDim.x][4] words: s_memtime / s_memrealtime of thread 0 at kernel entry and exit
+    // (in-kernel clock = d memtime / d memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS item 6)
+    unsigned long long *stamps;
 };
 
 // Stand-alone multilinear interpolation (multilinear_cython.pyx:17-49).

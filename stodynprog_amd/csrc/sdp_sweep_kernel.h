@@ -27,6 +27,28 @@
 
 typedef SDP_REAL sdp_real;
 
+// Diagnostic builds (-DSDP_STAMP=1, never the production code object): thread 0
+// of every workgroup records the shader clock and the 100 MHz reference clock at
+// kernel entry and exit into a buffer nothing else reads.
+#ifndef SDP_STAMP
+#define SDP_STAMP 0
+#endif
+#if SDP_STAMP
+#define SDP_STAMP_BEGIN(a)                                                             \
+    if ((a).stamps && threadIdx.x == 0) {                                              \
+        (a).stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();                 \
+        (a).stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();             \
+    }
+#define SDP_STAMP_END(a)                                                               \
+    if ((a).stamps && threadIdx.x == 0) {                                              \
+        (a).stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();                 \
+        (a).stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();             \
+    }
+#else
+#define SDP_STAMP_BEGIN(a)
+#define SDP_STAMP_END(a)
+#endif
+
 // Control lattice of one node: per control (lo, hi, n) and numpy.linspace
 // point generation (stodynprog.py:458): u_i = i*step + lo, last point == hi.
 struct SdpBox {

@@ -10,8 +10,9 @@ the J_k slabs are exchanged with ONE all-gather:
 
   * RcclCommunicator  -- device buffers, RCCL over xGMI, called inside
     sdp_problem_vi_sweep on the sweep's stream (include/sdp_hip.h);
-  * GlooCommunicator  -- host arrays over torch.distributed/gloo; used for the
-    rendezvous of the RCCL unique id and by the CPU tests of the slab logic.
+  * GlooCommunicator  -- host arrays over torch.distributed/gloo; used ONLY by
+    the tests of the slab logic (CPU, world_size 2).  The product never imports
+    torch: the RCCL unique id travels through a file (`FileRendezvous`).
 
 Policies are gathered only on request (sdp_problem_get_policy is then a collective call);
 the timed sweep never pays for it.
@@ -20,7 +21,8 @@ import os
 
 import numpy as np
 
-__all__ = ['slab_bounds', 'phase_partition', 'RcclCommunicator', 'GlooCommunicator', 'from_env']
+__all__ = ['slab_bounds', 'phase_partition', 'RcclCommunicator', 'GlooCommunicator',
+           'FileRendezvous', 'from_env']
 
 
 def slab_bounds(shape, nranks):
@@ -125,8 +127,9 @@ class RcclCommunicator(_Base):
         if len(runtimes) > 1:
             raise nat.NativeError(
                 'two HIP runtimes are mapped in this process ({}): libsdp_hip.so was loaded '
-                'before torch.  RCCL cannot initialise in that state; import torch before '
-                'stodynprog_amd (a launcher that sets WORLD_SIZE does it for you)'
+                'and PyTorch-ROCm (which bundles its own runtime) imported afterwards.  RCCL '
+                'cannot initialise in that state; either do not import torch in this process '
+                '(stodynprog_amd never needs it) or import it BEFORE stodynprog_amd'
                 .format(', '.join(runtimes)))
         h = C.c_void_p()
         with _stdout_to_stderr():          # RCCL prints a version banner on stdout at init
@@ -157,31 +160,109 @@ class RcclCommunicator(_Base):
             self.handle = None
 
 
+class FileRendezvous(object):
+    """Hand-off of the 128-byte RCCL unique id between the ranks of ONE node
+    through a file (default directory /dev/shm), with nothing but the Python
+    standard library: a process that shards sweeps never imports torch.
+
+    Rank 0 writes the id atomically (temp file + rename); the others poll for
+    it.  The file name is built from what the launcher gives every rank of one
+    job and no rank of another: MASTER_PORT, the launcher's pid (the workers
+    of `python -m torch.distributed.run` are children of one agent process),
+    torchelastic's run id and restart count.  A file older than this process
+    minus `stale_s` seconds is ignored (left behind by a crashed job), rank 0
+    replaces any such file and removes its own once every rank has joined the
+    communicator.  SDP_RENDEZVOUS_FILE overrides the path (ranks started by
+    hand from different shells)."""
+
+    def __init__(self, rank, world, timeout_s=None, stale_s=180.0):
+        self.rank, self.world = int(rank), int(world)
+        self.timeout_s = float(os.environ.get('SDP_RENDEZVOUS_TIMEOUT', 600)
+                               if timeout_s is None else timeout_s)
+        self.stale_s = float(stale_s)
+        self.path = os.environ.get('SDP_RENDEZVOUS_FILE') or self.default_path()
+
+    @staticmethod
+    def default_path():
+        import tempfile
+        base = os.environ.get('SDP_RENDEZVOUS_DIR') or (
+            '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK)
+            else tempfile.gettempdir())
+        key = '_'.join(str(v) for v in (
+            os.environ.get('MASTER_PORT', '0'), os.getppid(),
+            os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
+            os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'),
+            os.environ.get('WORLD_SIZE', '1')))
+        key = ''.join(c if (c.isalnum() or c in '_-') else '-' for c in key)
+        return os.path.join(base, 'sdp_rccl_uid_' + key)
+
+    def publish(self, payload):
+        """rank 0: make `payload` (bytes) visible to the other ranks"""
+        tmp = '{}.tmp.{}'.format(self.path, os.getpid())
+        with open(tmp, 'wb') as f:
+            f.write(len(payload).to_bytes(4, 'little') + payload)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, self.path)          # atomic: readers see nothing or everything
+
+    def fetch(self):
+        """other ranks: wait for rank 0's payload"""
+        import time
+        t0 = time.time()
+        delay = 0.002
+        while True:
+            try:
+                st = os.stat(self.path)
+                if st.st_mtime >= t0 - self.stale_s:
+                    with open(self.path, 'rb') as f:
+                        raw = f.read()
+                    if len(raw) >= 4 and len(raw) == 4 + int.from_bytes(raw[:4], 'little'):
+                        return raw[4:]
+            except OSError:
+                pass
+            if time.time() - t0 > self.timeout_s:
+                raise TimeoutError('rank {}: no RCCL unique id from rank 0 at {} after {:.0f} s'
+                                   .format(self.rank, self.path, self.timeout_s))
+            time.sleep(delay)
+            delay = min(delay * 1.5, 0.1)
+
+    def exchange(self, payload=None):
+        if self.rank == 0:
+            self.publish(payload)
+            return payload
+        return self.fetch()
+
+    def cleanup(self):
+        if self.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
 def from_env():
     """Communicator of a process started by `python -m torch.distributed.run`
-    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the
-    environment): selects GPU LOCAL_RANK, exchanges the RCCL unique id through
-    a gloo group and returns (RcclCommunicator, GlooCommunicator).  With
-    WORLD_SIZE absent or 1 returns (None, None)."""
+    -- or by anything else that sets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_PORT: selects GPU LOCAL_RANK, hands rank 0's RCCL unique id to the
+    other ranks through `FileRendezvous` (no torch, no gloo: the sharded
+    process holds ONE ROCm runtime, the system one) and returns
+    (RcclCommunicator, FileRendezvous).  With WORLD_SIZE absent or 1 returns
+    (None, None)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1:
         return None, None
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    import torch.distributed as dist        # before the library: one ROCm runtime (see _native)
     from . import _native as nat
     nat.check(nat.lib().sdp_set_device(local))
-    if not dist.is_initialized():
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-    host = GlooCommunicator()
+    rdv = FileRendezvous(rank, world)
     with _stdout_to_stderr():          # nothing native may write into the caller's stdout
-        uid = RcclCommunicator.new_unique_id() if rank == 0 else None
-        uid = host.broadcast_bytes(uid, src=0)
+        uid = rdv.exchange(RcclCommunicator.new_unique_id() if rank == 0 else None)
         dev = RcclCommunicator(rank, world, uid)
-        dev.barrier()
-    return dev, host
+        dev.barrier()                  # every rank has read the id and joined
+    rdv.cleanup()
+    return dev, rdv
 
 
 class _stdout_to_stderr(object):

@@ -139,20 +139,58 @@ def test_two_rank_gloo_sweep_matches_single_process(tmp_path):
         assert 'rank {} ok'.format(rank) in out
 
 
-def test_library_load_puts_torch_first_under_a_launcher():
-    """_native._torch_runtime_first: with WORLD_SIZE > 1 torch is imported before
-    libsdp_hip.so is mapped, so that one ROCm runtime serves torch, the library
-    and RCCL; without a launcher the library never pulls torch in."""
-    if importlib.util.find_spec('torch') is None:      # not imported here: see _native.py
-        pytest.skip('torch not installed')
-    code = ("import sys; sys.path.insert(0, {!r}); from stodynprog_amd import _native as nat; "
+def test_library_load_never_imports_torch():
+    """north_star: "no PyTorch".  Loading the library -- also under a launcher
+    (WORLD_SIZE > 1) -- must not pull torch in: the sharded process holds ONE ROCm
+    runtime, the system one, and the RCCL unique id travels through a file."""
+    code = ("import sys; sys.path.insert(0, {!r}); from stodynprog_amd import _native as nat, dist; "
             "nat.lib(); print('torch' in sys.modules, len(nat.rocm_runtimes()))").format(ROOT)
-    for world, expect in (('2', 'True 1'), ('1', 'False 1')):
-        env = dict(os.environ, WORLD_SIZE=world)
+    for world in ('2', '1'):
+        env = dict(os.environ, WORLD_SIZE=world, RANK='0')
         out = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE,
                              stderr=subprocess.STDOUT, timeout=200)
         assert out.returncode == 0, out.stdout.decode()
-        assert out.stdout.decode().strip().splitlines()[-1] == expect, out.stdout.decode()
+        assert out.stdout.decode().strip().splitlines()[-1] == 'False 1', out.stdout.decode()
+
+
+def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
+    """dist.FileRendezvous: atomic publish by rank 0, polling readers, stale
+    files of a crashed job ignored, rank 0 removes its file."""
+    import threading
+    import time
+    monkeypatch.setenv('SDP_RENDEZVOUS_DIR', str(tmp_path))
+    monkeypatch.setenv('MASTER_PORT', '29123')
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    payload = bytes(range(128))
+    path = dist.FileRendezvous.default_path()
+    assert path.startswith(str(tmp_path)) and '29123' in path and str(os.getppid()) in path
+    # a stale file (previous crashed job, same key) must not be taken for the new id
+    with open(path, 'wb') as f:
+        f.write((128).to_bytes(4, 'little') + b'x' * 128)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    got = {}
+
+    def reader(r):
+        got[r] = dist.FileRendezvous(r, 4, timeout_s=20).exchange()
+
+    threads = [threading.Thread(target=reader, args=(r,)) for r in (1, 2, 3)]
+    for t in threads:
+        t.start()
+    time.sleep(0.3)
+    assert not got                                     # still waiting: the stale file is ignored
+    r0 = dist.FileRendezvous(0, 4)
+    assert r0.exchange(payload) == payload
+    for t in threads:
+        t.join(20)
+    assert got == {1: payload, 2: payload, 3: payload}
+    r0.cleanup()
+    assert not os.path.exists(path)
+    # a truncated file (writer died mid-way; cannot happen with rename, but be strict)
+    with open(path, 'wb') as f:
+        f.write((128).to_bytes(4, 'little') + b'short')
+    with pytest.raises(TimeoutError):
+        dist.FileRendezvous(1, 4, timeout_s=0.3).exchange()
 
 
 def test_tapered_phase_partition_covers_every_unit_once():

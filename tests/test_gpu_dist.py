@@ -106,24 +106,37 @@ LOAD_ORDER = r'''
 import os, sys
 sys.path.insert(0, {root!r})
 from stodynprog_amd import _native as nat
-nat.lib()                                   # WORLD_SIZE=2 in the environment: torch goes first
-assert 'torch' in sys.modules
-import torch.distributed
+nat.lib()                                   # WORLD_SIZE=2 in the environment
+assert 'torch' not in sys.modules           # north_star: no PyTorch in the product
 assert len(nat.rocm_runtimes()) == 1, nat.rocm_runtimes()
 from stodynprog_amd.dist import RcclCommunicator
 nat.check(nat.lib().sdp_set_device(0))
-c = RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
+c = RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())     # real RCCL, the system runtime
 c.barrier()
 assert c.allreduce_max(3.5) == 3.5
 c.close()
+assert 'torch' not in sys.modules
+# a user process that mixes in PyTorch AFTER the library holds two runtimes: refused, with the reason
+import torch
+if len(nat.rocm_runtimes()) > 1:
+    try:
+        RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
+        raise SystemExit('two runtimes were not refused')
+    except nat.NativeError as e:
+        assert 'two HIP runtimes' in str(e)
 print('load order ok', flush=True)
+# two runtimes in one process also collide in their exit handlers (measured: 'double free
+# or corruption' at interpreter shutdown) -- one more reason the product never imports torch
+os._exit(0)
 '''
 
 
 @pytest.mark.timeout(300)
-def test_one_rocm_runtime_when_torch_and_rccl_share_the_process(gpu, tmp_path):
-    """Regression: libsdp_hip.so mapped before torch left two HIP runtimes in
-    the process and ncclCommInitRank failed ('no ROCm-capable device')."""
+def test_real_rccl_without_torch_and_two_runtime_guard(gpu, tmp_path):
+    """The sharded process never imports torch: real RCCL (system librccl + system
+    HIP runtime) initialises with the library alone.  Regression of round 1:
+    libsdp_hip.so mapped before torch left two HIP runtimes in the process and
+    ncclCommInitRank failed ('no ROCm-capable device') -- now refused up front."""
     script = tmp_path / 'order.py'
     script.write_text(LOAD_ORDER.format(root=ROOT))
     env = dict(os.environ, WORLD_SIZE='2', RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -169,7 +182,8 @@ import os, sys
 sys.path.insert(0, {root!r})
 import numpy as np
 from stodynprog_amd import models, dist
-dev, host = dist.from_env()
+dev, rdv = dist.from_env()
+assert 'torch' not in sys.modules                   # the rendezvous is a file, not gloo
 assert dev.is_device and dev.nranks == int(os.environ['WORLD_SIZE'])
 rank = dev.rank
 rng = np.random.default_rng(5)
@@ -218,8 +232,6 @@ print('rank', rank, 'all ok', flush=True)
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('world', [2, 3, 8])
 def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world):
-    if importlib.util.find_spec('torch') is None:
-        pytest.skip('torch not installed')
     mock = _build_mock(tmp_path)
     script = tmp_path / 'lib_worker.py'
     script.write_text(LIB_WORKER.format(root=ROOT))
@@ -235,8 +247,6 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
     phase tuning, timed region, max over ranks, one JSON line on rank 0, and the
     sharded result checked against a single-GPU chain of sweeps"""
     import json
-    if importlib.util.find_spec('torch') is None:
-        pytest.skip('torch not installed')
     mock = _build_mock(tmp_path)
     outs = _run_ranks(os.path.join(ROOT, 'bench.py'), 2, dict(SDP_RCCL_LIBRARY=mock),
                       argv=['--gpus', '2', '--grid', '48', '--steps', '3', '--warmup', '1',
