@@ -62,6 +62,10 @@ WORKLOADS = {
             'storage-AR1 200x200 state (SoC, mismatch) x <=50 controls x 9 perturbations'),
     'searev': ('searev', dict(n_E=128, n_S=128, n_A=128, step=2.2 / 31), 'float64', 2,
                'Searev + storage 128^3 state x <=32 controls x 9 perturbations'),
+    # not a BASELINE config: the benchmark problem with the control also driving x1
+    # (x1' += 0.1 u) -- not storage-separable, runs the LDS-staged tile kernel
+    'coupled256': ('synthetic3d_coupled', dict(N=256), 'float64', None,
+                   'synthetic3d {n}^3 x 64 controls x 32 perturbations, control-coupled x1 (non-separable)'),
 }
 
 
@@ -175,7 +179,7 @@ def load_clock():
 def build_solver(args, models, DPSolver, comm):
     name, kw, dtype, cfg, label = WORKLOADS[args.config]
     kw = dict(kw)
-    if args.grid and name == 'synthetic3d':
+    if args.grid and name.startswith('synthetic3d'):
         kw['N'] = args.grid
     if args.dtype:
         dtype = args.dtype
@@ -185,7 +189,7 @@ def build_solver(args, models, DPSolver, comm):
     for attr in ('state_grid', '_state_grid_shape', '_state_ref_ind', '_state_ref',
                  'perturb_grid', 'perturb_proba', 'control_steps'):
         setattr(solver, attr, getattr(ref_solver, attr))
-    if name == 'synthetic3d':
+    if name.startswith('synthetic3d'):
         V0 = models.synthetic3d_V0(solver.state_grid, dtype=dtype)
     else:
         # smooth closed-form start (no RNG): squared distance to the grid centre
@@ -374,7 +378,8 @@ def run(args):
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64' if rb == 8 else 'f32', 'data': 'synthetic',
-        'config': {'workload': '{} (BASELINE.json configs[{}])'.format(label, cfg),
+        'config': {'workload': ('{} (BASELINE.json configs[{}])'.format(label, cfg) if cfg is not None
+                                else '{} (not a BASELINE config)'.format(label)),
                    'state_nodes': S, 'controls_max': U_max, 'perturbations': W,
                    'lattice_cells_per_sweep': cells,
                    'kernel_family': kernel_family,

@@ -46,6 +46,13 @@ extern "C" {
  */
 #define SDP_LAYOUT_NODES   0
 #define SDP_LAYOUT_COLUMNS 1
+/* Sweep kernel of a SDP_LAYOUT_NODES handle:
+ *   SDP_VARIANT_DIRECT  `sdp_sweep`: one global load per interpolation vertex;
+ *   SDP_VARIANT_STAGED  `sdp_sweep_lds`: a workgroup owns a tile of nodes and
+ *                       stages the value sub-block its next states reach in LDS
+ *                       (csrc/sdp_staged_kernel.h).  Same results, bit for bit. */
+#define SDP_VARIANT_DIRECT 0
+#define SDP_VARIANT_STAGED 1
 
 const char *sdp_last_error(void);
 
@@ -109,13 +116,17 @@ typedef struct sdp_problem_desc {
     int32_t box_per_node;       /* 0: one box for all nodes, 1: arrays over nodes */
     int32_t lanes_per_node;     /* SDP_LANES the code object was built with */
     int32_t layout;             /* SDP_LAYOUT_NODES | SDP_LAYOUT_COLUMNS (see below) */
-    int32_t reserved;           /* must be 0 */
+    int32_t variant;            /* SDP_VARIANT_DIRECT | SDP_VARIANT_STAGED (node layout only, see below) */
     const void *box_lo;         /* control_grids() lower ends: [nu] or [nu][S] reals */
     const void *box_hi;         /* upper ends */
     const int32_t *box_n;       /* points per control: [nu] or [nu][S] */
     int64_t node_begin;         /* slab of C-order node ids owned by this handle */
     int64_t node_end;           /*   ([0,S) on a single GPU) */
     const char *module_path;    /* gfx950 code object of the traced model (sdp_sweep, sdp_evalpol) */
+    int32_t tile[4];            /* SDP_VARIANT_STAGED: node-tile shape the code object was built with */
+    int32_t col_seg_nodes;      /* SDP_LAYOUT_COLUMNS with a row window (code object built with SDP_COL_ROWS
+                                 * < orders[0]): nodes of a column one workgroup takes at most; 0 = no window */
+    int32_t reserved;           /* must be 0 */
 } sdp_problem_desc;
 
 int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **out);

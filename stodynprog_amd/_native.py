@@ -21,6 +21,7 @@ KCACHE = os.path.join(_HERE, '_kcache')
 
 SDP_F64, SDP_F32 = 0, 1
 LAYOUT_NODES, LAYOUT_COLUMNS = 0, 1
+VARIANT_DIRECT, VARIANT_STAGED = 0, 1
 _ERR = {-1: ValueError, -2: Exception, -3: RuntimeError, -4: MemoryError,
         -5: RuntimeError, -6: RuntimeError}
 
@@ -40,10 +41,12 @@ class sdp_problem_desc(C.Structure):
         ('axes', C.c_void_p * 4),
         ('wgrid', C.c_void_p), ('proba', C.c_void_p),
         ('box_per_node', C.c_int32), ('lanes_per_node', C.c_int32),
-        ('layout', C.c_int32), ('reserved', C.c_int32),
+        ('layout', C.c_int32), ('variant', C.c_int32),
         ('box_lo', C.c_void_p), ('box_hi', C.c_void_p), ('box_n', C.c_void_p),
         ('node_begin', C.c_int64), ('node_end', C.c_int64),
         ('module_path', C.c_char_p),
+        ('tile', C.c_int32 * 4),
+        ('col_seg_nodes', C.c_int32), ('reserved', C.c_int32),
     ]
 
 

@@ -206,10 +206,14 @@ def lanes_for(max_controls):
     return lanes
 
 
-def translation_unit(model, dtype, lanes, column=None, fused=False):
+def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None):
     """column: None for the generic node-order kernels, or (N0, W) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
-    model on a grid with N0 points along axis 0 and W perturbation points."""
+    model on a grid with N0 points along axis 0 and W perturbation points.
+    staged: None, or the dict of `staged_config` to also build the LDS-staged
+    generic kernel of csrc/sdp_staged_kernel.h (node order, any traceable model).
+    window: None, or the tuple of `column_window_config` (column kernel whose
+    table holds a window of rows of axis 0)."""
     real = {'float64': 'double', 'float32': 'float'}[np.dtype(dtype).name]
     head = [
         '// generated by stodynprog_amd.codegen -- do not edit',
@@ -234,8 +238,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
     ]
     if column is not None:
         assert model.storage_separable
-        wpair = use_wpair(model, dtype)
-        col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair)
+        wpair = use_wpair(model, dtype) and window is None
+        col_cfg = window if window is not None else column_config(column[0], column[1], model.n_state,
+                                                                  dtype, wpair)
         assert col_cfg is not None
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
@@ -245,7 +250,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
             '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
             '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
-        ] + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
+        ] + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
                        'SDP_COL_A_GROUP')
@@ -255,9 +260,124 @@ def translation_unit(model, dtype, lanes, column=None, fused=False):
             '#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h',
             '',
         ]
+    elif staged is not None:
+        tile = tuple(staged['tile']) + (1,) * (4 - len(staged['tile']))
+        head += ['#define SDP_STG_THREADS {}'.format(int(staged['threads']))] + [
+            '#define SDP_STG_T{} {}'.format(k, int(tile[k])) for k in range(4)] + [
+            '#define SDP_STG_CU {}'.format(int(staged['cu'])),
+            '#define SDP_STG_CW {}'.format(int(staged['cw'])),
+            '#define SDP_STG_CAP {}'.format(int(staged['cap'])),
+            '#include "sdp_staged_kernel.h"    // also brings in sdp_sweep_kernel.h',
+            '']
     else:
         head += ['#include "sdp_sweep_kernel.h"', '']
     return '\n'.join(head)
+
+
+# ---------------------------------------------------------------------------
+# LDS-staged generic kernel (csrc/sdp_staged_kernel.h): tile / chunk planning
+# ---------------------------------------------------------------------------
+STAGED_TILES = {1: (512,), 2: (16, 32), 3: (8, 8, 8), 4: (4, 4, 4, 8)}
+STAGED_LDS_BYTES = 76 * 1024         # per workgroup: two 512-thread workgroups per CU
+
+
+def staged_row_stride(length, tile_last, d, rs):
+    """sdp_stg_row_stride of csrc/sdp_staged_kernel.h"""
+    if d == 1 or tile_last >= 32 or rs != 8:
+        return length | 1
+    return (length + tile_last - 1) // (2 * tile_last) * (2 * tile_last) + tile_last
+
+
+def staged_config(model, state_grid, perturb_grid, box, dtype, t_value=0.0, n_samples=24):
+    """Tile shape, chunk sizes and LDS budget of the staged kernel for `model`
+    on this discretisation.  The chunk (controls x perturbation points whose
+    next states share one staged box) is the largest whose box -- measured by
+    evaluating the traced dynamics with numpy at the corners of sample tiles
+    and chunks, exactly what the kernel does per chunk -- fits the budget for
+    most samples.  A bad choice costs time only: cells outside the staged box
+    read global memory (csrc/sdp_staged_kernel.h).
+    box: dict with lo, hi, n ([nu][S] or [nu][1]) and per_node."""
+    from .trace import evaluate
+    d = model.n_state
+    rs = np.dtype(dtype).itemsize
+    shape = tuple(len(g) for g in state_grid)
+    tile = STAGED_TILES[d]
+    cap = STAGED_LDS_BYTES // rs
+    W = len(perturb_grid[0]) if perturb_grid and model.n_perturb else 0
+    wg = np.asarray(perturb_grid[0], dtype=float) if W else np.zeros(1)
+    Wn = max(W, 1)
+    nu = model.n_control
+    lo, hi, n = box['lo'], box['hi'], box['n']
+    S = int(np.prod(shape))
+    rng = np.random.default_rng(2024)
+    smin = np.array([g[0] for g in state_grid], dtype=float)
+    span = np.array([g[-1] - g[0] for g in state_grid], dtype=float)
+    nm1 = np.array([len(g) - 1 for g in state_grid], dtype=float)
+    tiles_per = [-(-shape[k] // tile[k]) for k in range(d)]
+
+    def control_values(flat_nodes, ci):
+        """numpy.linspace point `ci` (flat C-order lattice index, clipped) of each node"""
+        col = flat_nodes if box['per_node'] else np.zeros_like(flat_nodes)
+        nn = n[:, col].astype(np.int64)
+        tot = np.prod(nn, axis=0)
+        flat = np.minimum(ci, tot - 1)
+        out = []
+        for c in range(nu - 1, -1, -1):
+            k = flat % nn[c]
+            flat = flat // nn[c]
+            l, h = lo[c, col], hi[c, col]
+            step = np.where(nn[c] > 1, (h - l) / np.maximum(nn[c] - 1, 1), 0.0)
+            out.append(np.where(k == nn[c] - 1, h, k * step + l))
+        return out[::-1], tot
+
+    def volume(cu, cw):
+        vols = []
+        for _ in range(n_samples):
+            torg = [int(rng.integers(0, tiles_per[k])) * tile[k] for k in range(d)]
+            # corner nodes of the tile (clipped to the grid)
+            idx = np.array(np.meshgrid(*[[torg[k], min(torg[k] + tile[k], shape[k]) - 1]
+                                         for k in range(d)], indexing='ij')).reshape(d, -1)
+            flat = np.ravel_multi_index(tuple(idx), shape)
+            x = [np.asarray(state_grid[k], dtype=float)[idx[k]] for k in range(d)]
+            _, tot = control_values(flat, 0)
+            c0 = int(rng.integers(0, max(int(tot.max()) - cu, 0) + 1))
+            w0 = int(rng.integers(0, max(Wn - cw, 0) + 1))
+            qlo = np.full(d, np.inf)
+            qhi = np.full(d, -np.inf)
+            for ci in (c0, c0 + cu - 1):
+                u, _ = control_values(flat, ci)
+                for wi in (w0, min(w0 + cw, Wn) - 1):
+                    with np.errstate(all='ignore'):
+                        xn, _ = evaluate(model, x, u, [wg[wi]] if model.n_perturb else [], t_value)
+                    for k in range(d):
+                        p = (np.asarray(xn[k], dtype=float) - smin[k]) / span[k] * nm1[k]
+                        q = np.clip(np.floor(np.nan_to_num(p, nan=0.0, posinf=1e9, neginf=-1e9)),
+                                    0, shape[k] - 2)
+                        qlo[k] = min(qlo[k], q.min())
+                        qhi[k] = max(qhi[k], q.max())
+            ext = [min(qhi[k] + 1, shape[k] - 2) + 2 - max(qlo[k] - 1, 0) for k in range(d)]
+            ext[-1] = staged_row_stride(int(ext[-1]), tile[-1], d, rs)
+            vols.append(float(np.prod(ext)))
+        return float(np.percentile(vols, 80))
+
+    cws = sorted({max(1, Wn >> s) for s in range(0, 8)}, reverse=True)
+    best = None
+    # controls interleaved per chunk (what depends on w alone is shared by them).  Measured on
+    # the control-coupled 256^3 x 64 x 32 problem: 4 -> 93.7 ms, 2 -> 120.3 ms (4 spills five
+    # registers at the 128-VGPR bound two workgroups per CU impose; still faster)
+    cus = (4, 2, 1)
+    if os.environ.get('SDP_STG_CU'):                    # A/B runs
+        cus = (int(os.environ['SDP_STG_CU']),)
+    for cu in cus:
+        for cw in cws:
+            if best is not None and cu * cw <= best[0] * best[1]:
+                continue
+            if volume(cu, cw) <= cap:
+                best = (cu, cw)
+                break                          # smaller cw only shrinks the chunk
+    if best is None:
+        best = (1, 1)
+    return dict(threads=int(np.prod(tile)), tile=tile, cu=best[0], cw=best[1], cap=int(cap))
 
 
 COLUMN_LDS_MAX = 160 * 1024          # LDS of one gfx950 CU
@@ -287,10 +407,36 @@ def column_config(n0, w, n_state, dtype, wpair=False):
     w = max(int(w), 1)
     tw = w + (w & 1) if wpair else w
     for threads in (512, 1024):
-        raw = (tw * n0 * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs)
-        lds = (raw + 15) // 16 * 16
+        lds = _column_lds(tw, w, n0, n_state, rs, threads)
         if lds * (2 if threads == 512 else 1) <= COLUMN_LDS_MAX:
             return threads, lds
+    return None
+
+
+def _column_lds(tw, w, rows, n_state, rs, threads):
+    raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16)
+    return (raw + 15) // 16 * 16
+
+
+def column_window_config(n0, w, n_state, dtype, reach_rows):
+    """Row-window shape of the column kernel for a grid whose full W x n0 table
+    does not fit the LDS of a CU (SDP_COL_ROWS of csrc/sdp_column_kernel.h):
+    (threads, lds_bytes, rows, seg_nodes) or None.  A unit is a segment of
+    `seg_nodes` nodes of a column; its table holds `rows` rows of axis 0, enough
+    for the segment plus `reach_rows` (the rows the controls of ONE node span,
+    measured by the caller) plus the interpolation partner and a margin.  Two
+    512-thread workgroups per CU while that leaves segments of >= 64 nodes,
+    else one 1024-thread workgroup."""
+    rs = np.dtype(dtype).itemsize
+    w = max(int(w), 1)
+    for threads, wgs in ((512, 2), (1024, 1)):
+        budget = COLUMN_LDS_MAX // wgs
+        fixed = _column_lds(w, w, 0, n_state, rs, threads)
+        rows = (budget - fixed) // (w * rs)
+        rows = min(rows // 32 * 32, n0)
+        seg = (rows - int(reach_rows) - 4) // 64 * 64
+        if rows >= 128 and seg >= 64:
+            return threads, _column_lds(w, w, rows, n_state, rs, threads), int(rows), int(min(seg, n0))
     return None
 
 
@@ -304,7 +450,8 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
                '-fno-fast-math', '-std=c++17', '-I', CSRC]
 
 
-_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h')
+_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h',
+            'sdp_staged_kernel.h')
 _digest_cache = {}
 
 

@@ -35,6 +35,16 @@
 //   SDP_COL_N0, SDP_COL_W            points of axis 0 / perturbation points (1 if
 //                                    deterministic): compile-time, they size the
 //                                    statically allocated LDS table
+//   SDP_COL_ROWS                     rows of axis 0 the table holds (default: all
+//                                    SDP_COL_N0).  Fewer = ROW WINDOW, for grids
+//                                    whose W x N0 table exceeds the LDS of a CU:
+//                                    a unit (column, segment of nodes) tabulates
+//                                    only the rows its next states reach -- a
+//                                    prediction from the first / last control of
+//                                    every node; a control whose rows fall outside
+//                                    the window interpolates from global memory,
+//                                    same operations, so the result never depends
+//                                    on the prediction
 #pragma once
 #include "sdp_sweep_kernel.h"
 
@@ -68,6 +78,13 @@
 #if SDP_COL_WPAIR && (!SDP_HAS_W || SDP_LEAD_HAS_W)
 #error "SDP_COL_WPAIR needs a perturbation and an x0' that does not depend on it"
 #endif
+#ifndef SDP_COL_ROWS
+#define SDP_COL_ROWS SDP_COL_N0
+#endif
+#if SDP_COL_ROWS < SDP_COL_N0 && (SDP_COL_WPAIR || SDP_COL_FUSED)
+#error "the row window is built for the plain table layout with exact arithmetic"
+#endif
+constexpr bool SDP_COL_WINDOW = SDP_COL_ROWS < SDP_COL_N0;
 constexpr int SDP_DT = SDP_D - 1;
 // rows of the LDS table: perturbation points, rounded up to whole pairs for the pair layout
 constexpr int SDP_COL_TW = SDP_COL_WPAIR ? (SDP_COL_W + 1) / 2 * 2 : SDP_COL_W;
@@ -79,11 +96,12 @@ struct SdpColShared {
     sdp_real *w_oml;    // [Wn][SDP_DT]
     sdp_real *part_J;   // [chunks][nodes of the unit], chunks*nodes <= SDP_COL_THREADS
     int *part_i;
+    int r0;             // first row of axis 0 held by the table (0 without a row window)
 };
 
 // statically sized LDS image (a single workgroup may use up to 160 KiB)
 struct __attribute__((aligned(16))) SdpColLds {
-    sdp_real T[SDP_COL_TW * SDP_COL_N0];
+    sdp_real T[SDP_COL_TW * SDP_COL_ROWS];
     sdp_real w_lam[SDP_COL_W * SDP_DT];
     sdp_real w_oml[SDP_COL_W * SDP_DT];
     sdp_real pw[SDP_COL_W];                // weight / point copies (SDP_COL_WMODE 2)
@@ -91,6 +109,7 @@ struct __attribute__((aligned(16))) SdpColLds {
     sdp_real part_J[SDP_COL_THREADS];      // partial minima of the control chunks
     int part_i[SDP_COL_THREADS];
     int w_off[SDP_COL_W * SDP_DT];
+    int win[2][2];                         // row window: per parity (min row, minus max row) of the unit
 };
 static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
 
@@ -102,6 +121,7 @@ SDP_DEV void sdp_col_carve(SdpColLds &m, SdpColShared &s)
     s.w_off = m.w_off;
     s.part_J = m.part_J;
     s.part_i = m.part_i;
+    s.r0 = 0;
 }
 
 // grid of the trailing axes over the axis-0-fastest array: strides in elements
@@ -164,18 +184,14 @@ struct SdpColNest<SDP_DT - 1, SHIFT> {
     }
 };
 
-// phases W and A for column `c`: fills s.T.  All threads of the workgroup call it.
-template <bool SHIFT = false>
-SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
-                                 const SdpColShared &s, const sdp_real *x, sdp_real t)
+// phase W for column `c`: trailing cell of every perturbation point -> s.w_*
+SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                             const SdpColShared &s, const sdp_real *x, sdp_real t)
 {
-    constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
-    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
 #if SDP_HAS_W
     const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
 #endif
-    // ---- phase W: trailing cell of every perturbation point
     for (int w = threadIdx.x; w < Wn; w += blockDim.x) {
         sdp_real xn[SDP_D];
 #if SDP_HAS_W
@@ -192,14 +208,22 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
             s.w_oml[w * SDP_DT + k] = c.oml[k];
         }
     }
-    __syncthreads();
-    // ---- phase A: T[w][r] = lerp over the trailing axes of V[r, .].  The Wn*N0
-    // entries are dealt to all threads (consecutive threads = consecutive rows r:
-    // coalesced strip reads); each thread handles SDP_COL_A_GROUP entries at a
-    // time.  The 2^(d-1) vertex loads of the whole group are issued first -- only
-    // the loaded values live in registers meanwhile; the interpolation weights
-    // are re-read from LDS afterwards -- so one memory round trip serves
-    // SDP_COL_A_GROUP entries.
+}
+
+// phase A: T[w][r - s.r0] = lerp over the trailing axes of V[r, .] for the
+// SDP_COL_ROWS rows from s.r0 on.  The Wn*rows entries are dealt to all threads
+// (consecutive threads = consecutive rows r: coalesced strip reads); each thread
+// handles SDP_COL_A_GROUP entries at a time.  The 2^(d-1) vertex loads of the
+// whole group are issued first -- only the loaded values live in registers
+// meanwhile; the interpolation weights are re-read from LDS afterwards -- so one
+// memory round trip serves SDP_COL_A_GROUP entries.
+template <bool SHIFT = false>
+SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                             const SdpColShared &s)
+{
+    constexpr int N0 = SDP_COL_ROWS;        // rows held by the table (the whole axis without a window)
+    constexpr int Wn = SDP_COL_W;
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V + s.r0;
     constexpr int G = SDP_COL_A_GROUP;
     constexpr int NV = 1 << SDP_DT;
     constexpr int total = Wn * N0;
@@ -243,7 +267,25 @@ SDP_DEV void sdp_col_build_table(const SdpSweepArgs &a, const SdpGrid<sdp_real, 
             }
         }
     }
-    __syncthreads();
+}
+
+// inner(r) = lerp over the trailing axes of V[r, .] at the cell of perturbation
+// point w, straight from global memory: what phase A tabulates, for a row the
+// table does not hold (row window only).  Same loads, same operations.
+template <bool SHIFT>
+SDP_DEV sdp_real sdp_col_inner_global(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                                      const SdpColShared &s, int w, int r)
+{
+    sdp_real vals[1 << SDP_DT], lam[SDP_DT], oml[SDP_DT];
+    int off[SDP_DT];
+#pragma unroll
+    for (int k = 0; k < SDP_DT; ++k) {
+        off[k] = s.w_off[w * SDP_DT + k];
+        lam[k] = s.w_lam[w * SDP_DT + k];
+        oml[k] = s.w_oml[w * SDP_DT + k];
+    }
+    SdpColGather<0>::run((const sdp_real *)a.V + r, tg, off, 0, vals);
+    return SdpColNest<0, SHIFT>::run(vals, lam, oml, tg.shift);
 }
 
 struct SdpLeadAxis {
@@ -273,8 +315,6 @@ SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
 #define SDP_COL_WMODE 1
 #endif
 
-typedef const __attribute__((address_space(4))) sdp_real sdp_cst_real;
-typedef __attribute__((address_space(3))) sdp_real sdp_lds_real;
 
 struct SdpColWeights {
 #if SDP_COL_WMODE == 0 && SDP_HAS_W
@@ -348,11 +388,13 @@ SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k, sdp_r
 typedef sdp_real sdp_v2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) sdp_v2 sdp_lds_v2;
 
-template <int K>
-SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
-                                   const sdp_real *T, const sdp_real *x,
+template <int K, bool SHIFT = false>
+SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &, const SdpGrid<sdp_real, SDP_DT> &,
+                                   const SdpColShared &s, const SdpColWeights &k, const SdpLeadAxis &l,
+                                   const sdp_real *x,
                                    const sdp_real (*u)[SDP_NU], sdp_real t, sdp_real *out)
 {
+    const sdp_real *T = s.T;
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
     constexpr int WP = Wn / 2;                      // whole pairs; an odd last point is the tail
@@ -464,18 +506,74 @@ SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
     }
 }
 #else   // plain layout
+// Row window only: expected cost of ONE control whose rows of axis 0 are not in
+// the table -- the operations of sdp_col_expected_cost on values interpolated
+// straight from global memory (sdp_col_inner_global), so the same bits.
+template <bool SHIFT>
+SDP_DEV sdp_real sdp_col_cost_global(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                                     const SdpColShared &s, const SdpColWeights &k,
+                                     const SdpLeadAxis &l, const sdp_real *x, const sdp_real *u,
+                                     sdp_real t)
+{
+    sdp_real lam0, oml0, g;
+    int q0;
+#define SDP_COL_LOCATE1(wval)                                                           \
+    {                                                                                  \
+        const sdp_real xn0_ = sdp_model_lead(x, u, (wval), t);                         \
+        const sdp_real sn_ = (xn0_ - l.smin) / l.span;                  /* pyx:75 */   \
+        const sdp_real p_ = sn_ * l.nm1;                                               \
+        q0 = max(min(sdp_trunc_i32(p_), l.ordm2), 0);                   /* pyx:78 */   \
+        lam0 = p_ - (sdp_real)q0;                                       /* pyx:81 */   \
+        oml0 = (sdp_real)1 - lam0;                                                     \
+    }
+#if !SDP_LEAD_HAS_W || !SDP_HAS_W
+    SDP_COL_LOCATE1((sdp_real)0)
+#endif
+#if !SDP_COST_HAS_W || !SDP_HAS_W
+    g = sdp_model_cost(x, u, (sdp_real)0, t);
+#endif
+#if SDP_HAS_W
+    sdp_real acc = (sdp_real)0;
+    for (int w = 0; w < SDP_COL_W; ++w) {
+#if SDP_LEAD_HAS_W
+        SDP_COL_LOCATE1(SDP_COL_GW(k, w))
+#endif
+        const sdp_real lo = sdp_col_inner_global<SHIFT>(a, tg, s, w, q0);
+        const sdp_real hi = sdp_col_inner_global<SHIFT>(a, tg, s, w, q0 + 1);
+        const sdp_real val = oml0 * lo + lam0 * hi;                   // pyx:88-300
+#if SDP_COST_HAS_W
+        g = sdp_model_cost(x, u, SDP_COL_GW(k, w), t);
+#endif
+        const sdp_real jc = g + val;                                  // stodynprog.py:677
+        acc = acc + jc * SDP_COL_PW(k, w);                            // stodynprog.py:681
+    }
+    return acc;
+#else
+    const sdp_real lo = sdp_col_inner_global<SHIFT>(a, tg, s, 0, q0);
+    const sdp_real hi = sdp_col_inner_global<SHIFT>(a, tg, s, 0, q0 + 1);
+    return g + (oml0 * lo + lam0 * hi);
+#endif
+#undef SDP_COL_LOCATE1
+}
+
 // Expected cost of K controls of one node out of the table.  The K cost
 // chains are independent, so interleaving them gives the in-order wave K times
 // the instruction-level parallelism per LDS round trip (and one scalar load of
 // p_w serves K cells); each chain is evaluated exactly as for K = 1.
-template <int K>
-SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
-                                   const sdp_real *T, const sdp_real *x,
+// With a row window (SDP_COL_ROWS < SDP_COL_N0) a control whose rows q0, q0+1
+// are not both in the table reads row 0 instead (in bounds, value unused) and
+// is recomputed from global memory at the end.
+template <int K, bool SHIFT = false>
+SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                                   const SdpColShared &s, const SdpColWeights &k, const SdpLeadAxis &l,
+                                   const sdp_real *x,
                                    const sdp_real (*u)[SDP_NU], sdp_real t, sdp_real *out)
 {
-    constexpr int N0 = SDP_COL_N0;
+    const sdp_real *T = s.T;
+    constexpr int N0 = SDP_COL_ROWS;        // row stride of the table
     constexpr int Wn = SDP_COL_W;
     sdp_real lam0[K], oml0[K], acc[K], g[K];
+    bool outside[K];
     // two separate 8-byte LDS reads per cell (rows q0 and q0+1 of T[w]): as
     // ds_read_b64 they cost 2 LDS cycles each, conflict-free (bank = row);
     // `volatile` keeps the compiler from fusing them into ds_read2_b64, which
@@ -489,10 +587,18 @@ SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
         const int q0_ = max(min(sdp_trunc_i32(p_), l.ordm2), 0);        /* pyx:78 */   \
         lam0[j] = p_ - (sdp_real)q0_;                                   /* pyx:81 */   \
         oml0[j] = (sdp_real)1 - lam0[j];                                               \
-        row[j] = (const volatile sdp_lds_real *)(T + q0_);                             \
+        int rel_ = q0_;                                                                \
+        if (SDP_COL_WINDOW) {                                                          \
+            rel_ = q0_ - s.r0;                                                         \
+            const bool in_ = (unsigned)rel_ < (unsigned)(SDP_COL_ROWS - 1);            \
+            outside[j] = outside[j] || !in_;                                           \
+            rel_ = in_ ? rel_ : 0;                                                     \
+        }                                                                              \
+        row[j] = (const volatile sdp_lds_real *)(T + rel_);                            \
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
+        outside[j] = false;
 #if !SDP_LEAD_HAS_W || !SDP_HAS_W
         SDP_COL_LOCATE(j, (sdp_real)0)
 #endif
@@ -604,6 +710,11 @@ SDP_DEV void sdp_col_expected_cost(const SdpColWeights &k, const SdpLeadAxis &l,
     }
 #endif
 #undef SDP_COL_LOCATE
+    if (SDP_COL_WINDOW) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+            if (outside[j]) out[j] = sdp_col_cost_global<SHIFT>(a, tg, s, k, l, x, u[j], t);
+    }
 }
 #endif  // SDP_COL_WPAIR
 
@@ -647,6 +758,82 @@ SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
     x[0] = (sdp_real)0;
 }
 
+// Row window of a unit (nodes i_lo .. i_hi-1 of column `col`): predicted from
+// the rows the first and the last control of every node lead to (and the first
+// / last perturbation point when x0' depends on it) -- exact when x0' is monotone
+// in u and w, which is what a stock is; anything else costs time, not
+// correctness (sdp_col_expected_cost).  `pol`: fixed-policy evaluation, the
+// one control of a node is its policy value.  Every thread of the workgroup
+// calls it; the result is published by sdp_col_window_read after a barrier.
+SDP_DEV int sdp_col_guess_row(const SdpLeadAxis &l, sdp_real rspan, sdp_real xn0)
+{
+    const sdp_real p = (xn0 - l.smin) * rspan;         // (prediction only: reciprocal, not pyx:75)
+    return max(min(sdp_trunc_i32(p), l.ordm2), 0);
+}
+
+template <bool POL>
+SDP_DEV void sdp_col_window_predict(const SdpSweepArgs &a, const SdpLeadAxis &l, int (*win)[2],
+                                    int parity, int64_t col, int i_lo, int i_hi, sdp_real *x,
+                                    sdp_real t)
+{
+    if (!SDP_COL_WINDOW) return;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+    const sdp_real rspan = l.nm1 / l.span;
+    int qmin = INT_MAX, nqmax = INT_MAX;
+    for (int i = i_lo + (int)threadIdx.x; i < i_hi; i += blockDim.x) {
+        const int64_t node = col * SDP_COL_N0 + i;
+        x[0] = axis0[i];
+        SdpBox box;
+        if (!POL) sdp_load_box(a, node, box);
+#pragma unroll
+        for (int cc = 0; cc < (POL ? 1 : 2); ++cc) {
+            sdp_real u[SDP_NU];
+            if (POL) {
+#pragma unroll
+                for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+            } else {
+                sdp_controls_at(box, cc ? box.total - 1 : 0, u);
+            }
+#if SDP_LEAD_HAS_W && SDP_HAS_W
+#pragma unroll
+            for (int ww = 0; ww < 2; ++ww) {
+                const int q = sdp_col_guess_row(l, rspan, sdp_model_lead(x, u, ((const sdp_real *)a.wgrid)[ww ? SDP_COL_W - 1 : 0], t));
+                qmin = min(qmin, q);
+                nqmax = min(nqmax, -q);
+            }
+#else
+            const int q = sdp_col_guess_row(l, rspan, sdp_model_lead(x, u, (sdp_real)0, t));
+            qmin = min(qmin, q);
+            nqmax = min(nqmax, -q);
+#endif
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        qmin = min(qmin, __shfl_xor(qmin, m, 64));
+        nqmax = min(nqmax, __shfl_xor(nqmax, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && qmin != INT_MAX) {
+        atomicMin(&win[parity][0], qmin);
+        atomicMin(&win[parity][1], nqmax);
+    }
+}
+
+// after the barrier that follows sdp_col_window_predict: first row of the table.
+// The window is centred on the predicted rows when they fit (one row of margin
+// below), and starts at the lowest predicted row otherwise.
+SDP_DEV int sdp_col_window_read(int (*win)[2], int parity)
+{
+    if (!SDP_COL_WINDOW) return 0;
+    const int qmin = __builtin_amdgcn_readfirstlane(win[parity][0]);
+    const int qmax = -__builtin_amdgcn_readfirstlane(win[parity][1]);
+    if (threadIdx.x < 2) win[parity ^ 1][threadIdx.x] = INT_MAX;     // for the next unit
+    if (qmin == INT_MAX) return 0;
+    const int need = qmax + 2 - qmin;                                 // rows qmin .. qmax+1
+    int r0 = need < SDP_COL_ROWS ? qmin - (SDP_COL_ROWS - need) / 2 : qmin;
+    return max(min(r0, SDP_COL_N0 - SDP_COL_ROWS), 0);
+}
+
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
@@ -671,6 +858,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     sdp_col_walk(a, walk);
     SdpColWeights wts;
     sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+    if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
+    int parity = 0;
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
@@ -680,7 +869,13 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
         __syncthreads();                       // readers of the previous table are done
-        sdp_col_build_table(a, tg, s, x, t);
+        sdp_col_window_predict<false>(a, lead, sdp_lds.win, parity, col, i_lo, i_hi, x, t);
+        sdp_col_phase_w(a, tg, s, x, t);
+        __syncthreads();
+        s.r0 = sdp_col_window_read(sdp_lds.win, parity);
+        parity ^= 1;
+        sdp_col_phase_a<false>(a, tg, s);
+        __syncthreads();
 
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
         // per wavefront: their rows q0 are consecutive, so the LDS reads are
@@ -711,7 +906,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                     sdp_real u[K][SDP_NU], jc[K];
 #pragma unroll
                     for (int j = 0; j < K; ++j) sdp_controls_at(box, ci + j, u[j]);
-                    sdp_col_expected_cost<K>(wts, lead, s.T, x, u, t, jc);
+                    sdp_col_expected_cost<K>(a, tg, s, wts, lead, x, u, t, jc);
 #pragma unroll
                     for (int j = 0; j < K; ++j)
                         if (ibest == INT_MAX || sdp_better_seq(jc[j], best)) { best = jc[j]; ibest = ci + j; }
@@ -719,7 +914,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 for (; ci < c_hi; ++ci) {                     // remainder
                     sdp_real u[1][SDP_NU], jc[1];
                     sdp_controls_at(box, ci, u[0]);
-                    sdp_col_expected_cost<1>(wts, lead, s.T, x, u, t, jc);
+                    sdp_col_expected_cost<1>(a, tg, s, wts, lead, x, u, t, jc);
                     if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
                 }
                 if (chunks == 1) {
@@ -775,6 +970,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     sdp_col_walk(a, walk);
     SdpColWeights wts;
     sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+    if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
+    int parity = 0;
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
         const int part = (int)(unit % a.col_splits);
@@ -783,14 +980,20 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
         __syncthreads();
-        sdp_col_build_table<true>(a, tg, s, x, t);
+        sdp_col_window_predict<true>(a, lead, sdp_lds.win, parity, col, i_lo, i_hi, x, t);
+        sdp_col_phase_w(a, tg, s, x, t);
+        __syncthreads();
+        s.r0 = sdp_col_window_read(sdp_lds.win, parity);
+        parity ^= 1;
+        sdp_col_phase_a<true>(a, tg, s);
+        __syncthreads();
         for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {
             const int64_t node = col * N0 + i;
             sdp_real u[1][SDP_NU], jc[1];
             x[0] = axis0[i];
 #pragma unroll
             for (int c = 0; c < SDP_NU; ++c) u[0][c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-            sdp_col_expected_cost<1>(wts, lead, s.T, x, u, t, jc);
+            sdp_col_expected_cost<1, true>(a, tg, s, wts, lead, x, u, t, jc);
             ((sdp_real *)a.J)[node] = jc[0];
         }
     }

@@ -604,7 +604,9 @@ extern "C" int sdp_comm_barrier(sdp_comm *c)
 // problem handle
 // ---------------------------------------------------------------------------
 struct sdp_problem {
-    int dtype = SDP_F64, d = 0, nu = 0, W = 0, lanes = 64, box_per_node = 0, layout = 0;
+    int dtype = SDP_F64, d = 0, nu = 0, W = 0, lanes = 64, box_per_node = 0, layout = 0, variant = 0;
+    int stg_threads = 0, col_seg = 0;
+    int64_t stg_tiles = 0;
     int64_t S = 0, node_begin = 0, node_end = 0;
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
@@ -722,7 +724,19 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         if (p->node_begin % p->orders[0] || p->node_end % p->orders[0])
             return fail(SDP_EINVAL, "column layout: the node slab must consist of whole columns");
     }
-    const char *k_sweep = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_sweep_col" : "sdp_sweep";
+    p->variant = desc->variant;
+    p->col_seg = desc->col_seg_nodes > 0 ? desc->col_seg_nodes : 0;
+    if (p->variant != SDP_VARIANT_DIRECT && p->variant != SDP_VARIANT_STAGED) return fail(SDP_EINVAL, "unknown kernel variant %d", p->variant);
+    if (p->variant == SDP_VARIANT_STAGED) {
+        if (p->layout != SDP_LAYOUT_NODES) return fail(SDP_EINVAL, "the staged kernel works on the node layout");
+        p->stg_tiles = 1;
+        for (int k = 0; k < p->d; ++k) {
+            if (desc->tile[k] < 1) return fail(SDP_EINVAL, "staged kernel: tile[%d] = %d", k, (int)desc->tile[k]);
+            p->stg_tiles *= (p->orders[k] + desc->tile[k] - 1) / desc->tile[k];
+        }
+    }
+    const char *k_sweep = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_sweep_col"
+                          : (p->variant == SDP_VARIANT_STAGED ? "sdp_sweep_lds" : "sdp_sweep");
     const char *k_eval = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_evalpol_col" : "sdp_evalpol";
     e = hipModuleGetFunction(&p->f_sweep, p->mod, k_sweep);
     if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_sweep, hipGetErrorString(e));
@@ -731,6 +745,15 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         int mt = 0;
         if (hipFuncGetAttribute(&mt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, p->f_sweep) == hipSuccess && mt >= 64)
             p->col_threads = mt > 1024 ? 1024 : mt;
+    }
+    if (p->variant == SDP_VARIANT_STAGED) {
+        int mt = 0;
+        if (hipFuncGetAttribute(&mt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, p->f_sweep) != hipSuccess || mt < 64)
+            return fail(SDP_EMODULE, "cannot read the workgroup size of sdp_sweep_lds");
+        p->stg_threads = mt;
+        int64_t tile_nodes = 1;
+        for (int k = 0; k < p->d; ++k) tile_nodes *= desc->tile[k];
+        if (tile_nodes != mt) return fail(SDP_EINVAL, "staged kernel: tile of %lld nodes but workgroups of %d threads", (long long)tile_nodes, mt);
     }
     e = hipModuleGetFunction(&p->f_evalpol, p->mod, k_eval);
     if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_eval, hipGetErrorString(e));
@@ -873,6 +896,8 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
     if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    // row window: a workgroup's table covers the rows reachable from col_seg nodes
+    if (p->col_seg > 0 && splits < (n0 + p->col_seg - 1) / p->col_seg) splits = (n0 + p->col_seg - 1) / p->col_seg;
     a.col_splits = splits;
     int64_t units = cols * splits;
     // Single GPU: a bounded grid whose workgroups stride over the units.  With
@@ -912,6 +937,14 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
         const unsigned threads = (unsigned)p->col_threads;   // SDP_COL_THREADS of the code object
         const unsigned blocks = column_grid(p, a, 64);
         return launch_module(p->f_sweep, a, blocks, threads, p->stream);
+    }
+    if (p->variant == SDP_VARIANT_STAGED) {
+        // bounded grid of tile-walking workgroups (LDS admits two per CU; a few per slot
+        // even out tiles of different cost), a multiple of 8 for the XCD-contiguous walk
+        int64_t blocks = (int64_t)p->cus * 4;
+        if (blocks > p->stg_tiles) blocks = p->stg_tiles;
+        blocks = ((blocks + 7) / 8) * 8;
+        return launch_module(p->f_sweep, a, (unsigned)blocks, (unsigned)p->stg_threads, p->stream);
     }
     return launch_module(p->f_sweep, a, sweep_blocks(p, ne - nb), 256, p->stream);
 }

@@ -49,6 +49,11 @@ typedef SDP_REAL sdp_real;
 #define SDP_STAMP_END(a)
 #endif
 
+// constant address space: wave-uniform reads through it become scalar loads
+// (s_load_*) whose results feed VALU instructions as SGPR operands
+typedef const __attribute__((address_space(4))) sdp_real sdp_cst_real;
+typedef __attribute__((address_space(3))) sdp_real sdp_lds_real;
+
 // Control lattice of one node: per control (lo, hi, n) and numpy.linspace
 // point generation (stodynprog.py:458): u_i = i*step + lo, last point == hi.
 struct SdpBox {

@@ -283,6 +283,43 @@ def synthetic3d(api=None, N=256, n_w=32):
     return syn, solver
 
 
+def synthetic3d_coupled(api=None, N=256, n_w=32, gain=0.1, cross=0.0):
+    """The synthetic benchmark with the control ALSO driving the second state
+    variable (x1' += gain * u) -- no longer storage-separable: the partial
+    interpolation over axes 1.. differs from control to control, so the column
+    kernel's table does not apply and the LDS-staged tile kernel runs
+    (csrc/sdp_staged_kernel.h).  `cross` != 0 additionally couples x1' to x0
+    (a fully coupled model: no axis is exogenous)."""
+    SysDescription, DPSolver = _classes(api)
+    p = SYNTH
+    b, a11, a12, a21, a22, c = p['b'], p['a11'], p['a12'], p['a21'], p['a22'], p['c']
+    m1, m2, k1, k0, eps, kx = p['m1'], p['m2'], p['k1'], p['k0'], p['eps'], p['kx']
+    syn = SysDescription((3, 1, 1), name='Synthetic 3-D benchmark, control-coupled')
+
+    def coupled_dyn(x0, x1, x2, u, w):
+        x0n = x0 + b * u
+        x1n = m1 + a11 * x1 + a12 * x2 + w + gain * u + cross * x0
+        x2n = m2 + a21 * x1 + a22 * x2 + c * w
+        return (x0n, x1n, x2n)
+    syn.dyn = coupled_dyn
+
+    def synth_box(x0, x1, x2):
+        return ((-1., 1.),)
+    syn.control_box = synth_box
+
+    def synth_cost(x0, x1, x2, u, w):
+        e = (k1 * x1 - k0) - u
+        return e * e + eps * (u * u) + kx * x0
+    syn.cost = synth_cost
+    syn.perturb_laws = [NormalLaw(0, p['sigma'])]
+
+    solver = DPSolver(syn)
+    solver.discretize_state(0, 1, N, 0, 1, N, 0, 1, N)
+    solver.discretize_perturb(-3 * p['sigma'], 3 * p['sigma'], n_w)
+    solver.control_steps = (p['u_step'],)
+    return syn, solver
+
+
 def synthetic3d_V0(state_grid, dtype=np.float64):
     """Closed-form initial cost-to-go on the grid (only + - * /: reproducible)."""
     x0 = np.asarray(state_grid[0], dtype=np.float64).reshape(-1, 1, 1)

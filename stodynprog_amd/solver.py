@@ -38,7 +38,7 @@ class _DeviceProblem(object):
     """Owner of one sdp_problem handle (include/sdp_hip.h)."""
 
     def __init__(self, desc_arrays, module_path, dtype, shape, nu, W, lanes, box_per_node,
-                 node_range, comm=None, slab_bounds=None, layout=0):
+                 node_range, comm=None, slab_bounds=None, layout=0, staged=None, col_seg_nodes=0):
         self._keep = desc_arrays            # host arrays referenced by the descriptor
         self.layout = int(layout)
         self.dtype = np.dtype(dtype)
@@ -60,6 +60,11 @@ class _DeviceProblem(object):
         d.box_per_node = int(box_per_node)
         d.lanes_per_node = int(lanes)
         d.layout = int(layout)
+        d.col_seg_nodes = int(col_seg_nodes)
+        d.variant = nat.VARIANT_STAGED if staged else nat.VARIANT_DIRECT
+        if staged:
+            for k, n in enumerate(staged['tile']):
+                d.tile[k] = int(n)
         d.box_lo = desc_arrays['box_lo'].ctypes.data
         d.box_hi = desc_arrays['box_hi'].ctypes.data
         d.box_n = desc_arrays['box_n'].ctypes.data
@@ -175,7 +180,10 @@ class DPSolver(object):
         self.control_steps = (1.,) * len(self.sys.control)
         self.dtype = np.dtype(dtype)
         self.comm = comm
-        self.kernel = 'auto'               # 'auto' | 'generic' | 'column' (see _problem)
+        # 'auto': column kernel for storage-separable models whose table fits LDS, else the
+        # LDS-staged tile kernel; 'column' / 'staged' / 'generic' (one global load per
+        # vertex, the first kernel) force a family.  All give the same bits.
+        self.kernel = 'auto'
         self.comm_phases = 4               # multi-GPU: phases per backup (comm/compute overlap)
         self.comm_taper = False            # multi-GPU: shrinking phases (smallest gather exposed)
         # 'exact': every floating-point operation of the reference, same order (default);
@@ -515,10 +523,20 @@ class DPSolver(object):
         W = len(self.perturb_grid[0]) if self.perturb_grid else 0
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
-        column = (self.kernel != 'generic' and model.storage_separable and
+        if self.kernel not in ('auto', 'generic', 'column', 'staged'):
+            raise ValueError("kernel must be 'auto', 'column', 'staged' or 'generic'")
+        column = (self.kernel in ('auto', 'column') and model.storage_separable and
                   codegen.column_config(shape[0], W, len(shape), dt,
                                         codegen.use_wpair(model, dt)) is not None)
-        if not column and self.kernel != 'generic':
+        window = None
+        if (not column and self.kernel in ('auto', 'column') and model.storage_separable
+                and self.arithmetic == 'exact'):
+            # the W x N0 table exceeds the LDS of a CU: tabulate a window of rows per
+            # segment of the column (csrc/sdp_column_kernel.h, SDP_COL_ROWS)
+            window = codegen.column_window_config(shape[0], W, len(shape), dt,
+                                                  self._lead_reach_rows(model, bp, box_t))
+            column = window is not None
+        if not column and self.kernel in ('auto', 'column'):
             k = model.separable_axis_hint()
             if k is not None and not self._cache.get('hinted'):
                 self._cache['hinted'] = True
@@ -531,12 +549,53 @@ class DPSolver(object):
                              'table fits in LDS')
         if self.arithmetic not in ('exact', 'fused'):
             raise ValueError("arithmetic must be 'exact' or 'fused'")
+        staged = None
+        if not column and self.kernel in ('auto', 'staged'):
+            key = ('staged', model.structure_key(), bp['digest'], str(dt), shape, W)
+            staged = self._cache.get(key)
+            if staged is None:
+                staged = codegen.staged_config(model, self.state_grid, self.perturb_grid, bp, dt,
+                                               0.0 if box_t is None else float(box_t))
+                self._cache[key] = staged
         source = codegen.translation_unit(model, dt, lanes,
                                           column=(shape[0], W) if column else None,
-                                          fused=(self.arithmetic == 'fused'))
-        return dict(model=model, source=source, column=column, lanes=lanes,
+                                          fused=(self.arithmetic == 'fused'), staged=staged,
+                                          window=window)
+        return dict(model=model, source=source, column=column, lanes=lanes, staged=staged,
+                    window=window,
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
                     max_u=bp['max_u'], W=W, box_digest=bp['digest'])
+
+    def _lead_reach_rows(self, model, bp, box_t=None, n_samples=4096):
+        """Rows of axis 0 the controls (and perturbation points) of ONE node span:
+        max over sampled nodes of the distance, in grid rows, between the next
+        values of the leading state variable at the ends of the node's control
+        lattice -- the same prediction the windowed column kernel makes per unit."""
+        from .trace import evaluate
+        shape = self._shape()
+        S = int(np.prod(shape))
+        rng = np.random.default_rng(7)
+        flat = np.unique(np.concatenate([rng.integers(0, S, size=min(S, n_samples)), [0, S - 1]]))
+        idx = np.unravel_index(flat, shape)
+        x = [np.asarray(g, dtype=float)[i] for g, i in zip(self.state_grid, idx)]
+        col = flat if bp['per_node'] else np.zeros_like(flat)
+        nu = len(self.sys.control)
+        ends = []
+        for first in (True, False):
+            ends.append([bp['lo'][c, col] if first else bp['hi'][c, col] for c in range(nu)])
+        wg = np.asarray(self.perturb_grid[0], dtype=float) if (self.perturb_grid and model.n_perturb) else None
+        ws = [None] if wg is None else ([wg[0], wg[-1]] if model.lead_depends_on_w else [wg[0]])
+        g0 = np.asarray(self.state_grid[0], dtype=float)
+        rows = []
+        for u in ends:
+            for w in ws:
+                with np.errstate(all='ignore'):
+                    xn, _ = evaluate(model, x, u, [] if w is None else [w],
+                                     0.0 if box_t is None else float(box_t))
+                p = (np.asarray(xn[0], dtype=float) - g0[0]) / (g0[-1] - g0[0]) * (len(g0) - 1)
+                rows.append(np.clip(np.nan_to_num(p, nan=0.0, posinf=1e9, neginf=-1e9), 0, len(g0) - 2))
+        rows = np.array([np.broadcast_to(r, flat.shape) for r in rows])
+        return int(np.ceil((rows.max(axis=0) - rows.min(axis=0)).max())) + 1
 
     def _problem(self, t_k=None, model=None):
         """Device problem for the current discretisation and callables.  The
@@ -599,9 +658,14 @@ class DPSolver(object):
         prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
                               per_node, node_range,
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
-                              bounds, layout)
+                              bounds, layout, plan['staged'],
+                              plan['window'][3] if plan['window'] else 0)
         self._cache[fp] = prob
-        prob.info = dict(mode='traced', kernel='column' if column else 'generic',
+        prob.info = dict(mode='traced',
+                         kernel='column' if column else ('staged' if plan['staged'] else 'generic'),
+                         staged=plan['staged'],
+                         row_window=(dict(rows=plan['window'][2], segment_nodes=plan['window'][3])
+                                     if plan['window'] else None),
                          arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),

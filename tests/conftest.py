@@ -31,22 +31,72 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
 
 
+def _report(line):
+    """append to the parity report (committed as profiles/rNN_parity_report.txt) when
+    SDP_PARITY_REPORT names a file"""
+    path = os.environ.get('SDP_PARITY_REPORT')
+    if path:
+        with open(path, 'a') as f:
+            f.write(line.rstrip('\n') + '\n')
+
+
+def prove_ties(solver, J_next, flat_nodes, idx_ours, idx_ref, what, tie_rtol=TIE_RTOL, t_k=None):
+    """Per-node proof that an argmin index differing from the reference's is a TIE:
+    the complete per-control expected-cost vector of the node is recomputed with
+    the CPU oracle (oracle/vi_numpy.backup_node, pinned against the reference's
+    golden vectors by tests/test_oracle.py) from the same cost-to-go, and the costs
+    of the two indices must agree within tie_rtol * max(1, |J|).  Returns the
+    largest cost gap found (0.0 when nothing differs)."""
+    from oracle import vi_numpy
+    spec = vi_numpy.Spec.from_solver(solver)
+    interp = vi_numpy.Interp(*spec.state_grid)
+    interp.set_values(np.asarray(J_next, dtype=float))
+    worst = 0.0
+    for flat, io, ir in zip(flat_nodes, idx_ours, idx_ref):
+        ind = np.unravel_index(int(flat), spec.shape)
+        x_k = tuple(g[i] for g, i in zip(spec.state_grid, ind))
+        J_opt, u_opt, flat_opt, margin, Jfull = vi_numpy.backup_node(spec, x_k, interp, t_k, full=True)
+        costs = np.asarray(Jfull, dtype=float).ravel()
+        gap = abs(costs[int(io)] - costs[int(ir)])
+        tol = tie_rtol * max(1.0, abs(float(J_opt)))
+        assert gap <= tol, ('{}: node {} picks control {} (cost {!r}) where the reference picks {} '
+                            '(cost {!r}): gap {:.3e} > {:.3e}, not a tie'.format(
+                                what, int(flat), int(io), costs[int(io)], int(ir), costs[int(ir)], gap, tol))
+        # and neither may be worse than the true minimum by more than the tie level
+        assert costs[int(io)] - costs.min() <= tol and costs[int(ir)] - costs.min() <= tol, what
+        worst = max(worst, gap)
+    return worst
+
+
 def assert_sweep_parity(J, idx, J_ref, idx_ref, margin_ref, what='', rtol=RTOL_J,
-                        tie_rtol=TIE_RTOL):
-    """J within rtol of the reference everywhere; argmin index identical
-    wherever the reference's best/second-best margin is above the tie level."""
+                        tie_rtol=TIE_RTOL, prove=None, nodes=None):
+    """J within rtol of the reference everywhere; argmin index identical, or PROVED
+    a tie node by node: `prove` = (solver, J_next[, t_k]) lets every differing node be
+    re-evaluated with the CPU oracle (prove_ties); `nodes` = flat C-order ids of the
+    compared entries when they are a sample of the grid.  Without `prove` any
+    difference fails.  Returns (max relative error of J, number of differing indices)."""
     J, J_ref = np.asarray(J, dtype=float), np.asarray(J_ref, dtype=float)
     scale = max(1.0, float(np.abs(J_ref).max()))
     err = np.abs(J - J_ref).max() / scale
     assert err < rtol, '{}: max |dJ|/|J| = {:.3e}'.format(what, err)
     idx, idx_ref = np.asarray(idx).astype(np.int64), np.asarray(idx_ref).astype(np.int64)
     diff = idx != idx_ref
-    if diff.any():
-        tie = np.asarray(margin_ref) <= tie_rtol * np.maximum(1.0, np.abs(J_ref))
-        bad = diff & ~tie
-        assert not bad.any(), '{}: {} argmin mismatches outside near-ties (of {} nodes)'.format(
-            what, int(bad.sum()), diff.size)
-    return err, int(diff.sum())
+    ndiff = int(diff.sum())
+    gap = 0.0
+    if ndiff:
+        assert prove is not None, ('{}: {} argmin indices differ from the reference and no tie proof '
+                                   'was requested'.format(what, ndiff))
+        where = np.flatnonzero(diff.ravel())
+        flat = where if nodes is None else np.asarray(nodes).ravel()[where]
+        gap = prove_ties(prove[0], prove[1], flat, idx.ravel()[where], idx_ref.ravel()[where], what,
+                         tie_rtol, prove[2] if len(prove) > 2 else None)
+        # the reference's own best / second-best margin must say "tie" as well
+        tie = np.asarray(margin_ref).ravel()[where] <= tie_rtol * np.maximum(1.0, np.abs(J_ref.ravel()[where]))
+        assert tie.all(), '{}: {} differing nodes have a reference margin above the tie level'.format(
+            what, int((~tie).sum()))
+    _report('{:32s} nodes {:9d}  max|dJ|/|J| {:.2e}  index differences {:5d}  (all proved ties, '
+            'largest cost gap {:.2e})'.format(what, diff.size, err, ndiff, gap))
+    return err, ndiff
 
 
 def have_gpu():

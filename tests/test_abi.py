@@ -52,9 +52,26 @@ def test_error_convention_without_gpu():
     assert lib.sdp_comm_create(3, 2, b'x' * 128, C.byref(h)) == -1
 
 
-def test_descriptor_layout_matches_the_header():
-    # 4*int32 + 4*int64 + 4 ptr + 2 ptr + 4*int32 + 3 ptr + 2*int64 + ptr
-    assert C.sizeof(nat.sdp_problem_desc) == 16 + 32 + 32 + 16 + 16 + 24 + 16 + 8
+def test_descriptor_layout_matches_the_header(tmp_path):
+    """sizeof / offsetof of every field of sdp_problem_desc as gcc lays the struct of
+    include/sdp_hip.h out, against the ctypes mirror in _native.py"""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    fields = [name for name, _ in nat.sdp_problem_desc._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sdp_hip.h"\nint main(void) {\n'
+                   + '  printf("%zu\\n", sizeof(sdp_problem_desc));\n'
+                   + ''.join('  printf("%zu\\n", offsetof(sdp_problem_desc, {}));\n'.format(f) for f in fields)
+                   + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', str(exe), str(src)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert nums[0] == C.sizeof(nat.sdp_problem_desc)
+    assert nums[1:] == [getattr(nat.sdp_problem_desc, f).offset for f in fields]
+    # 4*int32 + 4*int64 + 4 ptr + 2 ptr + 4*int32 + 3 ptr + 2*int64 + ptr + 4*int32 + 2*int32
+    assert nums[0] == 16 + 32 + 32 + 16 + 16 + 24 + 16 + 8 + 16 + 8
 
 
 def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
