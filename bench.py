@@ -113,12 +113,12 @@ def cpu_baseline_synth(solver, V0, models, U, budget_single=8.0, budget_all=12.0
                 'sample': '{} random state nodes x {} controls x {} perturbations of the same '
                           'problem ({:.1f} s of the C oracle on {} thread{}, scaled linearly to a '
                           'full sweep)'.format(n, U, W, t, threads, '' if threads == 1 else 's')}
+    threads = c_oracle.max_threads()                   # before the 1-thread leg pins OpenMP to 1
     single = leg(1, budget_single)
     out = dict(single, kind='port', cpu_model=cpu_model(),
                note='single thread = the reference build (no OpenMP, reference setup.py:18-22); '
                     'the port has no Python/numpy staging and is ~3.7x faster per core than the '
                     'real reference (BASELINE.md section 5)')
-    threads = c_oracle.max_threads()
     if threads > 1:
         out['all_cores'] = leg(threads, budget_all)
     return out

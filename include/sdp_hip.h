@@ -169,6 +169,38 @@ int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int64_t ref_ind
 int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_dp, int64_t ref_index,
                             double *J_ref_out);
 
+/*
+ * The whole of one DPSolver.value_iteration call with host arrays in and out
+ * (stodynprog.py:466-534; the reference takes J_next and returns fresh J_k, pol_k
+ * every call): upload of host_V (NULL: keep the device's value buffer), backup,
+ * relative-DP shift, download of J_k, of the policy values (host_pol, may be NULL)
+ * and of the lattice indices (host_idx, may be NULL), queued back to back with one
+ * synchronisation at the end.  Buffers from sdp_host_alloc (page-locked) move at
+ * PCIe rate; any other host memory works too, slower.
+ */
+int sdp_problem_backup_host(sdp_problem *p, const void *host_V, double t_k, int rel_dp,
+                            int64_t ref_index, void *host_J, void *host_pol, int32_t *host_idx,
+                            double *J_ref_out);
+int sdp_host_alloc(size_t bytes, void **out);      /* page-locked host memory */
+int sdp_host_free(void *ptr);
+
+/*
+ * Batched closed-loop simulation without leaving the device -- the loop of the
+ * reference's examples (examples/20 Searev storage control/storage_control.py:242-251:
+ * `P_sto[k] = P_sto_law(E[k], Speed[k], Accel[k]); x[k+1] = sys.dyn(x[k], P_sto[k], w[k])`,
+ * one interpolator call per step).  For B trajectories and T steps:
+ *     u[k] = policy(x[k])            every control component interpolated from host_pol
+ *                                    ([nu][S] control values on the state grid, C order;
+ *                                    same arithmetic as sdp_mlinterp_*)
+ *     x[k+1] = dyn(x[k], u[k], w[k]), g[k] = cost(x[k], u[k], w[k])    (the traced model)
+ * host_x0 [d][B]; host_w [T][B] (NULL for a deterministic system); outputs host_x
+ * [T+1][d][B] (x[0] = x0), host_u [T][nu][B], host_g [T][B] (may be NULL).  t0: time
+ * index of step 0 for a non-stationary system.
+ */
+int sdp_problem_simulate(sdp_problem *p, const void *host_pol, int64_t B, int64_t T,
+                         const void *host_x0, const void *host_w, double t0,
+                         void *host_x, void *host_u, void *host_g);
+
 /* Make the last J_k the next J_next without leaving the device. */
 int sdp_problem_swap(sdp_problem *p);
 

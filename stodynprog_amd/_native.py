@@ -100,6 +100,10 @@ def _declare(lib):
         'sdp_problem_last_kernel_ms': (C.c_int, [vp, P(dbl)]),
         'sdp_problem_bench_sweeps': (C.c_int, [vp, i32, C.c_int, i64, P(dbl), P(dbl)]),
         'sdp_problem_debug_stamps': (C.c_int, [vp, C.c_int, vp, i64]),
+        'sdp_problem_backup_host': (C.c_int, [vp, vp, dbl, C.c_int, i64, vp, vp, vp, P(dbl)]),
+        'sdp_problem_simulate': (C.c_int, [vp, vp, i64, i64, vp, vp, dbl, vp, vp, vp]),
+        'sdp_host_alloc': (C.c_int, [C.c_size_t, P(vp)]),
+        'sdp_host_free': (C.c_int, [vp]),
         'sdp_comm_library': (C.c_char_p, []),
         'sdp_comm_unique_id': (C.c_int, [C.c_char_p]),
         'sdp_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_char_p, P(vp)]),
@@ -222,6 +226,69 @@ def compile_model(source, verbose=False):
             src, e.stdout.decode(errors='replace')))
     os.replace(tmp, out)
     return out
+
+
+# ---------------------------------------------------------------------------
+# page-locked host arrays (sdp_host_alloc) for what crosses the API every call
+# ---------------------------------------------------------------------------
+class _PinnedBlock(object):
+    """One page-locked allocation; goes back to the pool when the numpy arrays
+    viewing it are gone."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+    def __del__(self):
+        try:
+            _pinned_release(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+_pinned_free = {}            # nbytes -> [ptr, ...]
+_pinned_live = {}            # ptr -> nbytes of blocks currently viewed by arrays
+PINNED_KEEP = 6              # free blocks kept per size
+
+
+def _pinned_release(ptr, nbytes):
+    _pinned_live.pop(ptr, None)
+    free = _pinned_free.setdefault(nbytes, [])
+    if len(free) < PINNED_KEEP:
+        free.append(ptr)
+    elif _lib is not None:
+        _lib.sdp_host_free(C.c_void_p(ptr))
+
+
+def pinned_empty(shape, dtype):
+    """numpy array of `shape` / `dtype` in page-locked memory (uninitialised).
+    An ordinary, writable ndarray for the caller; the memory returns to a small
+    pool when the array and its views are garbage-collected."""
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    nbytes_alloc = max(nbytes, 8)
+    free = _pinned_free.get(nbytes_alloc)
+    if free:
+        ptr = free.pop()
+    else:
+        p = C.c_void_p()
+        check(lib().sdp_host_alloc(nbytes_alloc, C.byref(p)))
+        ptr = p.value
+    _pinned_live[ptr] = nbytes_alloc
+    buf = (C.c_char * nbytes_alloc).from_address(ptr)
+    buf._sdp_block = _PinnedBlock(ptr, nbytes_alloc)          # lifetime: array -> buf -> block
+    return np.frombuffer(buf, dtype=dt, count=nbytes // dt.itemsize).reshape(shape)
+
+
+def is_pinned(a):
+    """does the array's memory lie inside a live page-locked block of ours?"""
+    if not isinstance(a, np.ndarray) or not a.flags.c_contiguous:
+        return False
+    lo = a.ctypes.data
+    hi = lo + a.nbytes
+    for ptr, n in _pinned_live.items():
+        if ptr <= lo and hi <= ptr + n:
+            return True
+    return False
 
 
 def np_real(dtype):

@@ -173,7 +173,7 @@ def model_function_source(model):
 def separable_functions_source(model):
     """C++ text of the three slices used by the column kernel
     (csrc/sdp_column_kernel.h) for a storage-separable model."""
-    assert model.storage_separable
+    assert model.column_shareable
     out = []
     lines = ['SDP_DEV sdp_real sdp_model_lead(const sdp_real *x, const sdp_real *u, sdp_real w,',
              '                                sdp_real t)',
@@ -181,8 +181,9 @@ def separable_functions_source(model):
     names = _emit_body(model, model.slice_nodes([model.x_next[0]]), lines)
     lines += ['    return {};'.format(names[model.x_next[0].id]), '}']
     out.append('\n'.join(lines))
-    lines = ['SDP_DEV void sdp_model_trail(const sdp_real *x, sdp_real w, sdp_real t, sdp_real *xn)',
-             '{', '    (void)x; (void)w; (void)t;']
+    lines = ['SDP_DEV void sdp_model_trail(const sdp_real *x, const sdp_real *u, sdp_real w, sdp_real t,',
+             '                                sdp_real *xn)',
+             '{', '    (void)x; (void)u; (void)w; (void)t;']
     names = _emit_body(model, model.slice_nodes(model.x_next[1:]), lines)
     for k, n in enumerate(model.x_next[1:]):
         lines.append('    xn[{}] = {};'.format(k + 1, names[n.id]))
@@ -237,7 +238,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         '',
     ]
     if column is not None:
-        assert model.storage_separable
+        assert model.column_shareable
         wpair = use_wpair(model, dtype) and window is None
         col_cfg = window if window is not None else column_config(column[0], column[1], model.n_state,
                                                                   dtype, wpair)
@@ -245,6 +246,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
             '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
+            '#define SDP_TRAIL_HAS_U {}'.format(1 if model.trail_depends_on_u else 0),
             '#define SDP_COL_N0 {}'.format(int(column[0])),
             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
@@ -253,7 +255,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         ] + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             '',
@@ -393,7 +395,7 @@ def use_wpair(model, dtype):
     if os.environ.get('SDP_COL_WPAIR'):                 # A/B runs
         return bool(int(os.environ['SDP_COL_WPAIR']))
     return (np.dtype(dtype).itemsize == 4 and model.n_perturb > 0
-            and not model.lead_depends_on_w)
+            and not model.lead_depends_on_w and not model.trail_depends_on_u)
 
 
 def column_config(n0, w, n_state, dtype, wpair=False):

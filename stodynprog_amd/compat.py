@@ -21,11 +21,28 @@ _REFERENCE_PATHS = {('stodynprog.stodynprog', 'MlinInterpolator'),
                     ('stodynprog', 'MlinInterpolator')}
 
 
+# what an interpolator pickle of the reference actually needs (Python 2 old-style
+# instance or Python 3 object + numpy arrays); anything else is refused: a .dat
+# file is data, not a program
+_ALLOWED_GLOBALS = {
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+    ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+    ('numpy', 'ndarray'), ('numpy', 'dtype'),
+    ('copy_reg', '_reconstructor'), ('copyreg', '_reconstructor'),
+    ('__builtin__', 'object'), ('builtins', 'object'),
+    ('_codecs', 'encode'),                       # numpy's py3 protocol-2 payload: encode(str, 'latin1')
+}
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if (module, name) in _REFERENCE_PATHS:
             return MlinInterpolator
-        return super(_Unpickler, self).find_class(module, name)
+        if (module, name) in _ALLOWED_GLOBALS:
+            return super(_Unpickler, self).find_class(module, name)
+        raise pickle.UnpicklingError(
+            'interpolator pickle refers to {}.{}: only MlinInterpolator instances made of '
+            'numpy arrays are accepted'.format(module, name))
 
 
 def load_interpolator(file):

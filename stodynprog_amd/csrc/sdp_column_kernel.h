@@ -29,7 +29,13 @@
 //   sdp_model_lead(x, u, w, t)       -> x0'
 //   SDP_LEAD_HAS_W                   0: x0' does not depend on w, its cell is
 //                                    located once per control (the storage case)
-//   sdp_model_trail(x, w, t, xn)     fills xn[1..SDP_D-1]  (x[0] is not read)
+//   sdp_model_trail(x, u, w, t, xn)  fills xn[1..SDP_D-1]  (x[0] is not read)
+//   SDP_TRAIL_HAS_U                  0: the trailing next states do not depend on the
+//                                    control (storage-separable).  1: they do -- the
+//                                    table then differs from control to control and
+//                                    is rebuilt for each one (kernels at the end of
+//                                    this file); needs the nodes of a column to share
+//                                    their control values (box independent of x0)
 //   sdp_model_cost(x, u, w, t)       -> g
 //   SDP_COST_HAS_W                   0: g is hoisted out of the w loop
 //   SDP_COL_N0, SDP_COL_W            points of axis 0 / perturbation points (1 if
@@ -68,6 +74,9 @@
 #ifndef SDP_COL_A_GROUP
 #define SDP_COL_A_GROUP 4        // table entries per thread whose vertex loads are issued together
 #endif
+#ifndef SDP_COL_A_ORDER
+#define SDP_COL_A_ORDER 0        // table build: 0 entries dealt round-robin, 1 consecutive w per thread
+#endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
 #endif
@@ -78,8 +87,14 @@
 #if SDP_COL_WPAIR && (!SDP_HAS_W || SDP_LEAD_HAS_W)
 #error "SDP_COL_WPAIR needs a perturbation and an x0' that does not depend on it"
 #endif
+#ifndef SDP_TRAIL_HAS_U
+#define SDP_TRAIL_HAS_U 0
+#endif
 #ifndef SDP_COL_ROWS
 #define SDP_COL_ROWS SDP_COL_N0
+#endif
+#if SDP_TRAIL_HAS_U && (SDP_COL_WPAIR || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
+#error "control-dependent trailing dynamics: plain full table, exact arithmetic only"
 #endif
 #if SDP_COL_ROWS < SDP_COL_N0 && (SDP_COL_WPAIR || SDP_COL_FUSED)
 #error "the row window is built for the plain table layout with exact arithmetic"
@@ -186,7 +201,7 @@ struct SdpColNest<SDP_DT - 1, SHIFT> {
 
 // phase W for column `c`: trailing cell of every perturbation point -> s.w_*
 SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
-                             const SdpColShared &s, const sdp_real *x, sdp_real t)
+                             const SdpColShared &s, const sdp_real *x, const sdp_real *u, sdp_real t)
 {
     constexpr int Wn = SDP_COL_W;
 #if SDP_HAS_W
@@ -195,9 +210,9 @@ SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
     for (int w = threadIdx.x; w < Wn; w += blockDim.x) {
         sdp_real xn[SDP_D];
 #if SDP_HAS_W
-        sdp_model_trail(x, wgrid[w], t, xn);
+        sdp_model_trail(x, u, wgrid[w], t, xn);
 #else
-        sdp_model_trail(x, (sdp_real)0, t, xn);
+        sdp_model_trail(x, u, (sdp_real)0, t, xn);
 #endif
         SdpCell<sdp_real, SDP_DT, sdp_real> c;
 #pragma unroll
@@ -226,6 +241,53 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
     const sdp_real *__restrict__ V = (const sdp_real *)a.V + s.r0;
     constexpr int G = SDP_COL_A_GROUP;
     constexpr int NV = 1 << SDP_DT;
+#if SDP_COL_A_ORDER == 1
+    // a thread keeps its row r and takes G CONSECUTIVE perturbation points per round:
+    // neighbouring points share part of their 2^(d-1) vertex strips (the cell of an
+    // exogenous process moves by about one grid step per point), so the second read of
+    // a strip comes from the CU's L1 instead of L2
+    constexpr int LANES_R = SDP_COL_THREADS < N0 ? SDP_COL_THREADS : N0;   // threads along the rows
+    constexpr int GROUPS = SDP_COL_THREADS / LANES_R;                        // thread groups along w
+    constexpr int W_PER = (Wn + GROUPS - 1) / GROUPS;
+    const int grp = threadIdx.x / LANES_R;
+    const int w_lo = grp * W_PER, w_hi = min(Wn, w_lo + W_PER);
+    for (int r = threadIdx.x - grp * LANES_R; r < N0 && grp < GROUPS; r += LANES_R) {
+        for (int w0 = w_lo; w0 < w_hi; w0 += G) {
+            sdp_real vals[G][NV];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int w = min(w0 + j, w_hi - 1);                 // clamp: result unused
+                int off[SDP_DT];
+#pragma unroll
+                for (int k = 0; k < SDP_DT; ++k) off[k] = s.w_off[w * SDP_DT + k];
+                SdpColGather<0>::run(V + r, tg, off, 0, vals[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int w = w0 + j;
+                if (w < w_hi) {
+                    sdp_real lam[SDP_DT], oml[SDP_DT];
+#pragma unroll
+                    for (int k = 0; k < SDP_DT; ++k) {
+                        lam[k] = s.w_lam[w * SDP_DT + k];
+                        oml[k] = s.w_oml[w * SDP_DT + k];
+                    }
+                    const sdp_real val = SdpColNest<0, SHIFT>::run(vals[j], lam, oml, tg.shift);
+#if SDP_COL_FUSED && SDP_HAS_W
+                    const sdp_real entry = val * ((const sdp_real *)a.proba)[w];
+#else
+                    const sdp_real entry = val;
+#endif
+#if SDP_COL_WPAIR
+                    s.T[((w >> 1) * N0 + r) * 2 + (w & 1)] = entry;
+#else
+                    s.T[w * N0 + r] = entry;
+#endif
+                }
+            }
+        }
+    }
+#else
     constexpr int total = Wn * N0;
     for (int item0 = threadIdx.x; item0 < total; item0 += G * blockDim.x) {
         sdp_real vals[G][NV];
@@ -267,6 +329,7 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
             }
         }
     }
+#endif
 }
 
 // inner(r) = lerp over the trailing axes of V[r, .] at the cell of perturbation
@@ -834,6 +897,7 @@ SDP_DEV int sdp_col_window_read(int (*win)[2], int parity)
     return max(min(r0, SDP_COL_N0 - SDP_COL_ROWS), 0);
 }
 
+#if !SDP_TRAIL_HAS_U
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
@@ -870,7 +934,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, col, x);
         __syncthreads();                       // readers of the previous table are done
         sdp_col_window_predict<false>(a, lead, sdp_lds.win, parity, col, i_lo, i_hi, x, t);
-        sdp_col_phase_w(a, tg, s, x, t);
+        sdp_col_phase_w(a, tg, s, x, nullptr, t);
         __syncthreads();
         s.r0 = sdp_col_window_read(sdp_lds.win, parity);
         parity ^= 1;
@@ -981,7 +1045,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
         sdp_col_coords(a, col, x);
         __syncthreads();
         sdp_col_window_predict<true>(a, lead, sdp_lds.win, parity, col, i_lo, i_hi, x, t);
-        sdp_col_phase_w(a, tg, s, x, t);
+        sdp_col_phase_w(a, tg, s, x, nullptr, t);
         __syncthreads();
         s.r0 = sdp_col_window_read(sdp_lds.win, parity);
         parity ^= 1;
@@ -998,5 +1062,106 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
         }
     }
 }
+
+#else   // SDP_TRAIL_HAS_U
+// ---------------------------------------------------------------------------
+// Trailing next states that depend on the control (but not on x0), e.g. a stock
+// whose use also moves the exogenous-looking process:
+//     x0' = f0(x, u[, w])      xk' = fk(x1.., u, w),  k >= 1
+// inner(r) of the header comment then depends on (r, u, w).  The nodes of a column
+// still share it control by control PROVIDED they share the control values (the
+// admissible box does not depend on x0; checked on the host), so the workgroup
+// loops over the controls and, for each one, rebuilds the W x N0 table (phases W
+// and A: 2^(d-1) coalesced strip reads + the trailing lerps per entry) and runs
+// phase B for its nodes: per lattice cell the table costs as much as it saves in
+// a gather kernel's 2^d scattered reads and full lerp nest (about 15 operations
+// and 2^(d-1) coalesced loads instead of about 100 operations), and nothing else
+// changes: same operations on the same operands in the same order, argmin in
+// control order in-lane.  A unit holds at most blockDim.x nodes (col_splits).
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
+{
+    __shared__ SdpColLds sdp_lds;
+    SDP_STAMP_BEGIN(a);
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
+    const sdp_real t = (sdp_real)a.t_k;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+    SdpColShared s;
+    sdp_col_carve(sdp_lds, s);
+    SdpGrid<sdp_real, SDP_DT> tg;
+    sdp_col_trailing_grid(a, tg);
+    SdpLeadAxis lead;
+    sdp_col_lead_axis(a, lead);
+    SdpColWalk walk;
+    sdp_col_walk(a, walk);
+    SdpColWeights wts;
+    sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+
+    for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
+        const int64_t col = a.col_begin + unit / a.col_splits;
+        const int part = (int)(unit % a.col_splits);
+        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
+        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        sdp_real x[SDP_D];
+        sdp_col_coords(a, col, x);
+        // the controls of the column (every node of it has this box)
+        SdpBox box;
+        sdp_load_box(a, col * N0 + i_lo, box);
+        const int i = i_lo + (int)threadIdx.x;
+        const bool mine = i < i_hi;
+        if (mine) x[0] = axis0[i];
+        sdp_real best = INFINITY;
+        int ibest = INT_MAX;
+        for (int ci = 0; ci < box.total; ++ci) {
+            sdp_real u[1][SDP_NU], jc[1];
+            sdp_controls_at(box, ci, u[0]);
+            sdp_col_phase_w(a, tg, s, x, u[0], t);      // (its inputs x[1..], u, w are workgroup-uniform)
+            __syncthreads();                            // also: phase B of the previous control is done
+            sdp_col_phase_a<false>(a, tg, s);
+            __syncthreads();
+            if (mine) {
+                sdp_col_expected_cost<1>(a, tg, s, wts, lead, x, u, t, jc);
+                if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
+            }
+        }
+        __syncthreads();
+        if (mine) sdp_col_store(a, col * N0 + i, box, best, ibest);
+    }
+    SDP_STAMP_END(a);
+}
+
+// fixed-policy backup: every node has its own control, so nothing is shared -- one
+// lane per node gathers its 2^d vertices from the column-ordered value array
+// (sdp_expected_cost of sdp_sweep_kernel.h with this layout's strides)
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)
+{
+    constexpr int N0 = SDP_COL_N0;
+    if (a.n_lead != N0) return;
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+    SdpGrid<sdp_real, SDP_D> grid;
+    sdp_grid_from_args(a, grid);
+    {   // strides of the axis-0-fastest order
+        int m = N0;
+        grid.M[0] = 1;
+#pragma unroll
+        for (int k = SDP_D - 1; k >= 1; --k) { grid.M[k] = m; m *= a.orders[k]; }
+    }
+    const sdp_real t = (sdp_real)a.t_k;
+    grid.shift = a.shift_index >= 0 ? V[a.shift_index] : (sdp_real)0;
+    if (a.ref_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ref_out = (double)grid.shift;
+    const int64_t first = a.col_begin * N0, last = a.col_end * N0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t node = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; node < last; node += stride) {
+        sdp_real x[SDP_D], u[SDP_NU];
+        sdp_col_coords(a, node / N0, x);
+        x[0] = axis0[node % N0];
+#pragma unroll
+        for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+        ((sdp_real *)a.J)[node] = sdp_expected_cost<true>(a, grid, V, x, u, t);
+    }
+}
+#endif  // SDP_TRAIL_HAS_U
 
 #endif  // SDP_D >= 2

@@ -346,6 +346,23 @@ struct sdp_tab {
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     double smin[SDP_MAXD], smax[SDP_MAXD];
     DevBuf V;
+    // per-call buffers, kept and grown: x_next, g, cell_off, proba, jc, J, idx
+    DevBuf buf[7];
+    size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
+    int reserve(int k, size_t bytes)
+    {
+        if (cap[k] >= bytes) return SDP_OK;
+        int rc = buf[k].alloc(bytes + bytes / 4);
+        cap[k] = rc ? 0 : bytes + bytes / 4;
+        return rc;
+    }
+    int put(int k, const void *host, size_t bytes)
+    {
+        int rc = reserve(k, bytes);
+        if (rc) return rc;
+        if (bytes) HIP_TRY(hipMemcpy(buf[k].p, host, bytes, hipMemcpyHostToDevice));
+        return SDP_OK;
+    }
 };
 
 extern "C" int sdp_tab_create(int d, const double *smin, const double *smax,
@@ -385,15 +402,18 @@ extern "C" int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_o
     const int64_t n_cells = cell_off[n_nodes];
     if (n_cells <= 0 || !x_next || !g) return fail(SDP_EINVAL, "empty lattice");
     if (W > 0 && !proba) return fail(SDP_EINVAL, "perturbation weights missing");
-    DevBuf dx, dg, doff, dp, djc, dJ, didx;
+    // the handle keeps its device buffers from call to call (a caller that backs nodes
+    // up one at a time -- DPSolver._value_at_state_vect -- allocates nothing here)
+    DevBuf &dx = t->buf[0], &dg = t->buf[1], &doff = t->buf[2], &dp = t->buf[3], &djc = t->buf[4],
+           &dJ = t->buf[5], &didx = t->buf[6];
     int rc;
-    if ((rc = upload(dx, x_next, (size_t)t->d * n_cells * 8))) return rc;
-    if ((rc = upload(dg, g, (size_t)n_cells * 8))) return rc;
-    if ((rc = upload(doff, cell_off, (size_t)(n_nodes + 1) * 8))) return rc;
-    if (W > 0 && (rc = upload(dp, proba, (size_t)W * 8))) return rc;
-    if ((rc = djc.alloc((size_t)n_cells * 8))) return rc;
-    if ((rc = dJ.alloc((size_t)n_nodes * 8))) return rc;
-    if ((rc = didx.alloc((size_t)n_nodes * 8))) return rc;
+    if ((rc = t->put(0, x_next, (size_t)t->d * n_cells * 8))) return rc;
+    if ((rc = t->put(1, g, (size_t)n_cells * 8))) return rc;
+    if ((rc = t->put(2, cell_off, (size_t)(n_nodes + 1) * 8))) return rc;
+    if (W > 0 && (rc = t->put(3, proba, (size_t)W * 8))) return rc;
+    if ((rc = t->reserve(4, (size_t)n_cells * 8))) return rc;
+    if ((rc = t->reserve(5, (size_t)n_nodes * 8))) return rc;
+    if ((rc = t->reserve(6, (size_t)n_nodes * 8))) return rc;
     SdpTabArgs a;
     memset(&a, 0, sizeof(a));
     a.V = t->V.p; a.x_next = dx.p; a.g = dg.p; a.cell_off = (const int64_t *)doff.p;
@@ -611,10 +631,12 @@ struct sdp_problem {
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
     DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps;
+    DevBuf stage[3];                       // layout-conversion buffers of the fused host call (J, pol, idx)
+    size_t stage_bytes[3] = {0, 0, 0};
     int64_t stamp_words = 0;
     size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
-    hipFunction_t f_sweep = nullptr, f_evalpol = nullptr;
+    hipFunction_t f_sweep = nullptr, f_evalpol = nullptr, f_simulate = nullptr;
     hipDeviceptr_t prm_dev = nullptr;     // `sdp_model_prm` of the code object (lifted model constants)
     size_t prm_bytes = 0;
     hipStream_t stream = nullptr;
@@ -757,6 +779,10 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
     }
     e = hipModuleGetFunction(&p->f_evalpol, p->mod, k_eval);
     if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no %s kernel: %s", desc->module_path, k_eval, hipGetErrorString(e));
+    if (hipModuleGetFunction(&p->f_simulate, p->mod, "sdp_simulate") != hipSuccess) {
+        (void)hipGetLastError();
+        p->f_simulate = nullptr;
+    }
     // lifted model constants (codegen: `__constant__ sdp_real sdp_model_prm[]`), if any
     if (hipModuleGetGlobal(&p->prm_dev, &p->prm_bytes, p->mod, "sdp_model_prm") != hipSuccess) {
         (void)hipGetLastError();
@@ -1149,6 +1175,133 @@ extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_d
     HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->last_kernel_ms = ms;
     if (rel_dp && J_ref_out) HIP_TRY(hipMemcpy(J_ref_out, p->refs.p, (size_t)n_iter * 8, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pinned host memory for the arrays that cross the API every call
+// (DPSolver.value_iteration takes and returns numpy arrays, stodynprog.py:466,
+// 494-498, 530-533): copies to and from page-locked memory run as one DMA at
+// PCIe rate and asynchronously; pageable memory is staged by the runtime
+// ---------------------------------------------------------------------------
+extern "C" int sdp_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(SDP_EINVAL, "NULL argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 8, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(SDP_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    return SDP_OK;
+}
+
+extern "C" int sdp_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return SDP_OK;
+}
+
+// device buffer in the handle's layout -> host (reference C order), enqueued on the
+// problem stream WITHOUT a synchronisation; `slot` picks the conversion buffer
+static int download_nodes_async(sdp_problem *p, void *host, const void *dev, size_t elem_bytes, int slot)
+{
+    const size_t bytes = (size_t)p->S * elem_bytes;
+    if (p->layout != SDP_LAYOUT_COLUMNS) {
+        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, p->stream));
+        return SDP_OK;
+    }
+    if (p->stage_bytes[slot] < bytes) {
+        int rc = p->stage[slot].alloc(bytes);
+        if (rc) { p->stage_bytes[slot] = 0; return rc; }
+        p->stage_bytes[slot] = bytes;
+    }
+    int rc = launch_transpose(dev, p->stage[slot].p, p->S / p->orders[0], p->orders[0],
+                              (int)(elem_bytes / 4), p->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host, p->stage[slot].p, bytes, hipMemcpyDeviceToHost, p->stream));
+    return SDP_OK;
+}
+
+static int gather_policy(sdp_problem *p);
+
+// One value_iteration call with host arrays in and out (stodynprog.py:466-534):
+// upload of J_next (skipped when host_V is NULL: the device keeps its value buffer),
+// the backup, the relative-DP shift and the downloads of J_k and the policy values
+// are queued back to back on the problem stream; ONE synchronisation at the end.
+extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, double t_k, int rel_dp,
+                                       int64_t ref_index, void *host_J, void *host_pol,
+                                       int32_t *host_idx, double *J_ref_out)
+{
+    if (!p || !host_J) return fail(SDP_EINVAL, "NULL argument");
+    int rc;
+    if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
+    if ((rc = ensure_refs(p, 1))) return rc;
+    const size_t rs = real_size(p->dtype);
+    if (host_V) {
+        const size_t bytes = (size_t)p->S * rs;
+        if (p->layout != SDP_LAYOUT_COLUMNS) {
+            HIP_TRY(hipMemcpyAsync(p->V.p, host_V, bytes, hipMemcpyHostToDevice, p->stream));
+        } else {
+            if ((rc = ensure_scratch(p, bytes))) return rc;
+            HIP_TRY(hipMemcpyAsync(p->scratch.p, host_V, bytes, hipMemcpyHostToDevice, p->stream));
+            if ((rc = launch_transpose(p->scratch.p, p->V.p, p->orders[0], p->S / p->orders[0],
+                                       (int)(rs / 4), p->stream))) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    if ((rc = run_backup(p, false, t_k))) return rc;
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    if ((rc = join_comm(p))) return rc;
+    if (rel_dp && (rc = rel_shift(p, ref_index, 0))) return rc;
+    if ((rc = download_nodes_async(p, host_J, p->J.p, rs, 0))) return rc;
+    if (host_pol || host_idx) {
+        if (p->comm && p->comm->nranks > 1 && (rc = gather_policy(p))) return rc;   // collective, synchronises
+        if (host_pol && (rc = download_nodes_async(p, host_pol, p->pol.p, (size_t)p->nu * rs, 1))) return rc;
+        if (host_idx && (rc = download_nodes_async(p, host_idx, p->idx.p, 4, 2))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->last_kernel_ms = ms;
+    if (rel_dp && J_ref_out) HIP_TRY(hipMemcpy(J_ref_out, p->refs.p, 8, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+// Batched closed-loop simulation on the device (kernel sdp_simulate of the model's code
+// object): see include/sdp_hip.h.
+extern "C" int sdp_problem_simulate(sdp_problem *p, const void *host_pol, int64_t B, int64_t T,
+                                    const void *host_x0, const void *host_w, double t0,
+                                    void *host_x, void *host_u, void *host_g)
+{
+    if (!p || !host_pol || !host_x0 || !host_x || !host_u) return fail(SDP_EINVAL, "NULL argument");
+    if (B < 0 || T < 0) return fail(SDP_EINVAL, "negative size");
+    if (!p->f_simulate) return fail(SDP_EMODULE, "the model's code object has no sdp_simulate kernel");
+    if (p->W > 0 && T > 0 && !host_w) return fail(SDP_EINVAL, "a stochastic system needs the perturbation sequences");
+    if (B == 0) return SDP_OK;
+    const size_t rs = real_size(p->dtype);
+    DevBuf dpol, dx0, dw, dx, du, dg;
+    int rc;
+    if ((rc = upload(dpol, host_pol, (size_t)p->nu * p->S * rs))) return rc;
+    if ((rc = upload(dx0, host_x0, (size_t)p->d * B * rs))) return rc;
+    if (host_w && T > 0 && (rc = upload(dw, host_w, (size_t)T * B * rs))) return rc;
+    if ((rc = dx.alloc((size_t)(T + 1) * p->d * B * rs))) return rc;
+    if ((rc = du.alloc((size_t)T * p->nu * B * rs))) return rc;
+    if (host_g && (rc = dg.alloc((size_t)T * B * rs))) return rc;
+    SdpSimArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pol = dpol.p; a.axes = p->axes.p; a.x0 = dx0.p; a.w = (host_w && T > 0) ? dw.p : nullptr;
+    a.x = dx.p; a.u = du.p; a.g = host_g ? dg.p : nullptr;
+    a.B = B; a.T = T; a.S = p->S; a.t0 = t0;
+    for (int k = 0; k < SDP_MAXD; ++k) { a.orders[k] = p->orders[k]; a.axis_off[k] = p->axis_off[k]; }
+    size_t size = sizeof(a);
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                     HIP_LAUNCH_PARAM_END};
+    int64_t blocks = (B + 63) / 64;
+    if (blocks > (int64_t)p->cus * 32) blocks = (int64_t)p->cus * 32;
+    HIP_TRY(hipStreamSynchronize(p->stream));        // lifted constants set on the problem stream
+    HIP_TRY(hipModuleLaunchKernel(p->f_simulate, (unsigned)blocks, 1, 1, 64, 1, 1, 0, p->stream, nullptr, extra));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(host_x, dx.p, (size_t)(T + 1) * p->d * B * rs, hipMemcpyDeviceToHost));
+    if (T > 0) HIP_TRY(hipMemcpy(host_u, du.p, (size_t)T * p->nu * B * rs, hipMemcpyDeviceToHost));
+    if (host_g && T > 0) HIP_TRY(hipMemcpy(host_g, dg.p, (size_t)T * B * rs, hipMemcpyDeviceToHost));
     return SDP_OK;
 }
 

@@ -46,6 +46,25 @@ struct SdpSweepArgs {
     unsigned long long *stamps;
 };
 
+// Batched closed-loop simulation (the user loop of the reference's examples, e.g.
+// examples/20 Searev storage control/storage_control.py:242-251): per step the
+// policy is looked up by multilinear interpolation and the dynamics advance.
+struct SdpSimArgs {
+    const void *pol;       // [nu][S] policy (control VALUES on the state grid), C order
+    const void *axes;      // concatenated state-grid axes, like SdpSweepArgs
+    const void *x0;        // [d][B] start states
+    const void *w;         // [T][B] perturbation sequences (null: deterministic system)
+    void *x;               // [T+1][d][B] states (x[0] = x0)
+    void *u;               // [T][nu][B] controls applied
+    void *g;               // [T][B] instantaneous costs (may be null)
+    int64_t B;             // trajectories
+    int64_t T;             // steps
+    int64_t S;             // state nodes
+    double t0;             // time index of step 0 (non-stationary systems)
+    int32_t orders[SDP_MAXD];
+    int32_t axis_off[SDP_MAXD];
+};
+
 // Stand-alone multilinear interpolation (multilinear_cython.pyx:17-49).
 struct SdpInterpArgs {
     const void *values;    // [n_v][S]

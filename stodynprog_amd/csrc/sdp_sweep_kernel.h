@@ -226,3 +226,56 @@ extern "C" __global__ void __launch_bounds__(256) sdp_evalpol(SdpSweepArgs a)
         ((sdp_real *)a.J)[node] = sdp_expected_cost<true>(a, grid, V, x, u, t);
     }
 }
+
+// B closed-loop trajectories of T steps, one lane each, without leaving the GPU:
+//     u_k = policy(x_k)          multilinear interpolation of every control component
+//                                (MlinInterpolator.__call__, stodynprog.py:269-289 ->
+//                                multilinear_cython.pyx:51-300: lerp tree in double)
+//     x_k+1 = dyn(x_k, u_k, w_k)  the traced model (stodynprog.py:674 evaluates the same
+//                                callable); g_k = cost(x_k, u_k, w_k)
+// -- the loop every closed-loop example of the reference writes by hand
+// (examples/20 Searev storage control/storage_control.py:242-251).
+extern "C" __global__ void __launch_bounds__(64) sdp_simulate(SdpSimArgs a)
+{
+    SdpGrid<sdp_real, SDP_D> grid;
+    {
+        const sdp_real *axes = (const sdp_real *)a.axes;
+        sdp_real smin[SDP_D], smax[SDP_D];
+#pragma unroll
+        for (int k = 0; k < SDP_D; ++k) {
+            smin[k] = axes[a.axis_off[k]];
+            smax[k] = axes[a.axis_off[k] + a.orders[k] - 1];
+        }
+        sdp_make_grid<sdp_real, SDP_D>(grid, a.orders, smin, smax);
+    }
+    const sdp_real *__restrict__ pol = (const sdp_real *)a.pol;
+    const sdp_real *__restrict__ wseq = (const sdp_real *)a.w;
+    sdp_real *__restrict__ xo = (sdp_real *)a.x;
+    sdp_real *__restrict__ uo = (sdp_real *)a.u;
+    sdp_real *__restrict__ go = (sdp_real *)a.g;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < a.B; b += stride) {
+        sdp_real x[SDP_D];
+#pragma unroll
+        for (int k = 0; k < SDP_D; ++k) {
+            x[k] = ((const sdp_real *)a.x0)[k * a.B + b];
+            xo[k * a.B + b] = x[k];
+        }
+        for (int64_t step = 0; step < a.T; ++step) {
+            sdp_real u[SDP_NU], xn[SDP_D], g;
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c)
+                u[c] = sdp_interp_point<sdp_real, SDP_D, double>(pol + c * a.S, grid, x);
+            const sdp_real w = wseq ? wseq[step * a.B + b] : (sdp_real)0;
+            sdp_model_cell(x, u, w, (sdp_real)(a.t0 + (double)step), xn, g);
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c) uo[(step * SDP_NU + c) * a.B + b] = u[c];
+            if (go) go[step * a.B + b] = g;
+#pragma unroll
+            for (int k = 0; k < SDP_D; ++k) {
+                x[k] = xn[k];
+                xo[((step + 1) * SDP_D + k) * a.B + b] = xn[k];
+            }
+        }
+    }
+}

@@ -152,6 +152,38 @@ class _DeviceValues(object):
             pass
 
 
+class _DeviceTab(object):
+    """sdp_tab handle over an interpolator's values: uploaded once, then any number of
+    tabulated backups (DPSolver._value_at_state_vect, one call per node in user code)."""
+
+    def __init__(self, interp):
+        import ctypes as C
+        V = np.ascontiguousarray(interp.values, dtype=float).ravel()
+        smin = np.ascontiguousarray(interp._xmin, dtype=float)
+        smax = np.ascontiguousarray(interp._xmax, dtype=float)
+        orders = np.ascontiguousarray(interp._xshape, dtype=np.int64)
+        h = C.c_void_p()
+        nat.check(nat.lib().sdp_tab_create(interp.ndim, nat.ptr(smin), nat.ptr(smax),
+                                           nat.ptr(orders), nat.ptr(V), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                nat.lib().sdp_tab_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def device_tab(interp):
+    """the (cached) sdp_tab handle of a MlinInterpolator; dropped by set_values"""
+    tab = interp.__dict__.get('_tab')
+    if tab is None:
+        tab = interp.__dict__['_tab'] = _DeviceTab(interp)
+    return tab
+
+
 class MlinInterpolator:
     """Variadic-coordinate interpolator over grid vectors (reference
     stodynprog.py:255-290).  Only the first entry, last entry and length of
@@ -173,10 +205,12 @@ class MlinInterpolator:
         assert values.shape == tuple(self._xshape)
         self.values = np.ascontiguousarray(np.atleast_2d(values.ravel()))
         self.__dict__.pop('_dev', None)
+        self.__dict__.pop('_tab', None)
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop('_dev', None)                 # device handles do not pickle
+        state.pop('_tab', None)
         return state
 
     def __call__(self, *x_interp):

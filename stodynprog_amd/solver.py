@@ -135,6 +135,29 @@ class _DeviceProblem(object):
                                                     int(ref_index), nat.ptr(refs)))
         return refs[:int(n_iter)]
 
+    def backup_host(self, V, t_k=0.0, rel_dp=False, ref_index=0):
+        """value_iteration's device work with host arrays in and out in ONE library call
+        (sdp_problem_backup_host): upload, sweep, relative-DP shift, download of J and of
+        the policy values, one synchronisation.  Large outputs live in page-locked memory
+        (ordinary writable ndarrays for the caller) so the copies run at PCIe rate; fed
+        back as the next J_next they upload at that rate too.  The lattice indices stay
+        on the device until asked for (get_index)."""
+        V = np.ascontiguousarray(V, dtype=self.dtype)
+        big = self.S * self.dtype.itemsize >= (1 << 20)
+        new = nat.pinned_empty if big else np.empty
+        J = new(self.shape, self.dtype)
+        pol = new(self.shape + (self.nu,), self.dtype)
+        ref = C.c_double(0.0)
+        nat.check(nat.lib().sdp_problem_backup_host(self.h, nat.ptr(V), float(t_k), int(bool(rel_dp)),
+                                                    int(ref_index), nat.ptr(J), nat.ptr(pol), None,
+                                                    C.byref(ref)))
+        return J, pol, ref.value
+
+    def get_index(self):
+        idx = np.empty(self.shape, dtype=np.int32)
+        nat.check(nat.lib().sdp_problem_get_policy(self.h, None, nat.ptr(idx)))
+        return idx
+
     def swap(self):
         nat.check(nat.lib().sdp_problem_swap(self.h))
 
@@ -191,8 +214,25 @@ class DPSolver(object):
         #          operations, J within ~1e-15 relative of 'exact' (opt-in)
         self.arithmetic = 'exact'
         self._cache = {}
-        self.last_policy_index = None      # flat control-lattice index of the last sweep
+        self._idx_cache = None             # see last_policy_index
+        self._idx_source = None
         self.backend_info = {}
+
+    @property
+    def last_policy_index(self):
+        """flat C-order index into the control lattice of the optimal control of every
+        node, from the last sweep (int32, shape of the state grid).  After a
+        value_iteration call the indices stay on the device and are fetched on first
+        access (the reference returns control VALUES only, stodynprog.py:530-533)."""
+        if self._idx_cache is None and self._idx_source is not None:
+            prob, self._idx_source = self._idx_source, None
+            if prob.h:
+                self._idx_cache = prob.get_index()
+        return self._idx_cache
+
+    @last_policy_index.setter
+    def last_policy_index(self, value):
+        self._idx_cache, self._idx_source = value, None
 
     # ------------------------------------------------------------------ grids
     def discretize_perturb(self, *linspace_args):
@@ -321,10 +361,21 @@ class DPSolver(object):
                 else:
                     lo_v[c] = np.broadcast_to(a, shape).ravel()
                     hi_v[c] = np.broadcast_to(b, shape).ravel()
-            # accepted only if it reproduces the scalar calls the reference makes
-            rng = np.random.default_rng(12345)
-            probe = set(rng.integers(0, S, size=min(S, 48)).tolist())
-            probe.update([0, S - 1, S // 2])
+            # accepted only if it reproduces the scalar calls the reference makes: at EVERY
+            # node of a small grid; on a large one along every grid line through the
+            # corners and the centre (every distinct row / column of the open grid shows
+            # up there) plus a random sample
+            if S <= 20000:
+                probe = range(S)
+            else:
+                rng = np.random.default_rng(12345)
+                probe = set(rng.integers(0, S, size=256).tolist())
+                anchors = list(itertools.product(*[(0, n // 2, n - 1) for n in shape]))
+                for k in range(d):
+                    for anc in anchors:
+                        ind = [np.full(shape[k], a) for a in anc]
+                        ind[k] = np.arange(shape[k])
+                        probe.update(np.ravel_multi_index(tuple(ind), shape).tolist())
             for flat in probe:
                 sb = scalar_box(flat)
                 col = 0 if constant else flat
@@ -377,12 +428,14 @@ class DPSolver(object):
         s = self.sys
         # the callables themselves (hashed by identity and kept alive by the cache
         # key, so a recycled id() can never alias a stale entry)
-        parts = [s.dyn, s.cost, s.control_box, repr(sorted(s.params.items())),
+        parts = [s.dyn, s.cost, s.control_box, _params_key(s.params),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
                  id(self.comm), self.comm_phases, self.comm_taper, self.kernel, self.arithmetic]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
-        return hash(tuple(parts))
+        # the tuple itself is the cache key (not its hash): the callables stay alive as
+        # long as the entry does, so a recycled id() can never alias a stale entry
+        return tuple(parts)
 
     def _traced(self):
         key = ('trace', self.sys.dyn, self.sys.cost, repr(sorted(self.sys.params.items())))
@@ -652,7 +705,10 @@ class DPSolver(object):
             node_range = (int(bounds[self.comm.rank]), int(bounds[self.comm.rank + 1]))
         else:
             bounds, node_range = None, (0, S)
-        # drop other cached problems: they hold large device buffers
+        # drop other cached problems: they hold large device buffers (indices of the last
+        # sweep that nobody has looked at yet are fetched first)
+        if self._idx_source is not None:
+            self.last_policy_index
         for k in [k for k in self._cache if k[0] == 'problem']:
             self._cache.pop(k).close()
         prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
@@ -755,6 +811,12 @@ class DPSolver(object):
         if isinstance(model, TraceError):
             return self._backup_tabulated(J_next, t_k, rel_dp)
         prob = self._problem(t_k, model)
+        if self.comm is None:
+            # single GPU: one library call, arrays through page-locked memory
+            J_k, pol_k, J_ref = prob.backup_host(J_next, 0.0 if t_k is None else t_k, rel_dp,
+                                                 self._ref_flat(prob) if rel_dp else 0)
+            self._idx_cache, self._idx_source = None, prob
+            return J_k, pol_k, J_ref
         prob.set_value(J_next)
         # with a host-side (gloo) communicator the slabs are exchanged through
         # host memory after the sweep; with RCCL the library does it on device
@@ -831,6 +893,11 @@ class DPSolver(object):
                     pol_k[flat] = [u_grids[c].ravel()[ind[c]] for c in range(nu)]
                 batch, cells = [], 0
 
+            # one rule in every path (traced or not): the callables of a STATIONARY system
+            # are never handed a time index.  (The reference's bellman_recursion passes t_k
+            # regardless, sdp.py:582, and so raises TypeError on a stationary system.)
+            if self.sys.stationnary:
+                t_k = None
             for flat, x_k in enumerate(itertools.product(*self.state_grid)):
                 u_grids, dims = self.control_grids(x_k, t_k)
                 lattice = dims + ((W,) if W else ())
@@ -879,7 +946,7 @@ class DPSolver(object):
             k = t_k - t_ini
             J_next = J_fin if t_k == (t_fin - 1) else J[k + 1]
             self._check_state_array(np.asarray(J_next))
-            # the reference always passes t_k to the callbacks here (sdp.py:582)
+            # the callables get t_k when the system is time dependent (see _backup_tabulated)
             J[k], pol[k], _ = self._backup(np.asarray(J_next), t_k, False)
         exec_time = (datetime.now() - t_start).total_seconds()
         if report_time:
@@ -910,24 +977,17 @@ class DPSolver(object):
         xn = np.ascontiguousarray(np.vstack(
             [np.broadcast_to(np.asarray(x, dtype=float), lattice).ravel() for x in x_next]))
         gg = np.ascontiguousarray(np.broadcast_to(np.asarray(g_grid, dtype=float), lattice).ravel())
-        it = J_next_interp
-        h = C.c_void_p()
-        V = np.ascontiguousarray(it.values, dtype=float).ravel()
-        smin = np.ascontiguousarray(it._xmin, dtype=float)
-        smax = np.ascontiguousarray(it._xmax, dtype=float)
-        orders = np.ascontiguousarray(it._xshape, dtype=np.int64)
-        nat.check(nat.lib().sdp_tab_create(it.ndim, nat.ptr(smin), nat.ptr(smax),
-                                           nat.ptr(orders), nat.ptr(V), C.byref(h)))
-        try:
-            off = np.array([0, gg.size], dtype=np.int64)
-            Jb = np.zeros(1)
-            ib = np.zeros(1, dtype=np.int64)
-            proba = np.ascontiguousarray(self.perturb_proba[0], dtype=float) if W else None
-            nat.check(nat.lib().sdp_tab_backup(h, 1, nat.ptr(off), W, nat.ptr(proba),
-                                               nat.ptr(xn), nat.ptr(gg), nat.ptr(Jb),
-                                               nat.ptr(ib)))
-        finally:
-            nat.lib().sdp_tab_destroy(h)
+        # the interpolator's values go to the device once (handle cached on the object,
+        # dropped by set_values), not once per node
+        from .interp import device_tab
+        tab = device_tab(J_next_interp)
+        off = np.array([0, gg.size], dtype=np.int64)
+        Jb = np.zeros(1)
+        ib = np.zeros(1, dtype=np.int64)
+        proba = np.ascontiguousarray(self.perturb_proba[0], dtype=float) if W else None
+        nat.check(nat.lib().sdp_tab_backup(tab.h, 1, nat.ptr(off), W, nat.ptr(proba),
+                                           nat.ptr(xn), nat.ptr(gg), nat.ptr(Jb),
+                                           nat.ptr(ib)))
         ind_opt = np.unravel_index(int(ib[0]), dims)
         u_opt = [u_grids[i].flatten()[ind_opt[i]] for i in range(nu)]
         return (Jb[0], u_opt)
@@ -1013,6 +1073,8 @@ class DPSolver(object):
                            for i in range(d))
         u_k = [pol[..., i].reshape(dims + (1,)) for i in range(nu)]
         args = state_grid + tuple(u_k) + (w_k,)
+        if not self.sys.stationnary:
+            args = (0,) + args                  # like the traced path: time index 0
         x_next = self.sys.dyn(*args, **self.sys.params)
         g = self.sys.cost(*args, **self.sys.params)
         lattice = dims + (W,)
@@ -1073,6 +1135,94 @@ class DPSolver(object):
                 J_ref = J_pol[1]
                 print('ref policy cost: {:g}'.format(J_ref))
         return J_pol, pol
+
+    # ------------------------------------------------------------ closed-loop simulation
+    def simulate(self, pol, x0, w=None, n_steps=None, t0=0):
+        """Closed-loop trajectories under the policy `pol` -- the loop every example of the
+        reference writes by hand (examples/20 Searev storage control/
+        storage_control.py:242-251):
+
+            for k in range(T):
+                u[k] = [self.interp_on_state(pol[..., c])(*x[k]) for c in range(nb_control)]
+                x[k+1] = sys.dyn(*x[k], *u[k], w[k])
+
+        run for a BATCH of trajectories on the GPU without a host round trip per step
+        (kernel sdp_simulate: policy lookup by multilinear interpolation + the traced
+        dynamics).  NOT in the reference API.
+
+        pol : policy array on the state grid, shape state_dims + (nb_control,)
+              (as returned by value_iteration / policy_iteration)
+        x0  : start state(s), shape (nb_state,) or (B, nb_state)
+        w   : perturbation sequence(s), shape (T,) or (T, B); None for a deterministic
+              system (then give n_steps)
+        t0  : time index of the first step (non-stationary systems)
+
+        Returns (x, u, g): states (T+1, [B,] nb_state), controls (T, [B,] nb_control) and
+        instantaneous costs (T[, B]).  Same bits as the hand-written loop when the
+        model is `bit_exact` (backend_info)."""
+        dims = self._state_grid_shape
+        d, nu = len(dims), len(self.sys.control)
+        pol = np.asarray(pol)
+        assert pol.shape == dims + (nu,)
+        x0 = np.asarray(x0, dtype=float)
+        single = x0.ndim == 1
+        x0 = np.atleast_2d(x0)
+        assert x0.shape[1] == d
+        B = x0.shape[0]
+        n_w = len(self.sys.perturb)
+        if n_w:
+            assert w is not None, 'a stochastic system needs the perturbation sequence(s) w'
+            w = np.asarray(w, dtype=float)
+            w = w.reshape(-1, 1) if w.ndim == 1 else w
+            assert w.shape[1] == B
+            T = w.shape[0] if n_steps is None else int(n_steps)
+            assert w.shape[0] >= T
+        else:
+            assert n_steps is not None, 'give n_steps for a deterministic system'
+            T = int(n_steps)
+        t_trace = None if self.sys.stationnary else t0
+        model = self._trace_now(t_trace)
+        if isinstance(model, TraceError) or (model.t_value is not None):
+            x, u, g = self._simulate_host(pol, x0, w, T, t0)
+        else:
+            prob = self._problem(t_trace, model)
+            dt = self.dtype
+            pol_d = np.ascontiguousarray(np.moveaxis(pol, -1, 0), dtype=dt)        # [nu][S]
+            x0_d = np.ascontiguousarray(x0.T, dtype=dt)                             # [d][B]
+            w_d = np.ascontiguousarray(w[:T], dtype=dt) if n_w else None            # [T][B]
+            x = np.empty((T + 1, d, B), dtype=dt)
+            u = np.empty((T, nu, B), dtype=dt)
+            g = np.empty((T, B), dtype=dt)
+            nat.check(nat.lib().sdp_problem_simulate(prob.h, nat.ptr(pol_d), B, T, nat.ptr(x0_d),
+                                                     nat.ptr(w_d), float(t0), nat.ptr(x), nat.ptr(u),
+                                                     nat.ptr(g)))
+            x, u = np.moveaxis(x, 1, 2), np.moveaxis(u, 1, 2)
+        if single:
+            return x[:, 0], u[:, 0], g[:, 0]
+        return np.ascontiguousarray(x), np.ascontiguousarray(u), g
+
+    def _simulate_host(self, pol, x0, w, T, t0):
+        """the reference's loop as written (callables on the host, one interpolator call
+        per step, batched over the trajectories): models that cannot be traced"""
+        d, nu = len(self._state_grid_shape), len(self.sys.control)
+        B = x0.shape[0]
+        laws = [self.interp_on_state(np.ascontiguousarray(pol[..., c])) for c in range(nu)]
+        x = np.zeros((T + 1, B, d))
+        u = np.zeros((T, B, nu))
+        g = np.zeros((T, B))
+        x[0] = x0
+        for k in range(T):
+            xs = tuple(x[k, :, i] for i in range(d))
+            for c in range(nu):
+                u[k, :, c] = laws[c](*xs)
+            args = xs + tuple(u[k, :, c] for c in range(nu)) + ((w[k],) if w is not None else ())
+            if not self.sys.stationnary:
+                args = (t0 + k,) + args
+            xn = self.sys.dyn(*args, **self.sys.params)
+            for i in range(d):
+                x[k + 1, :, i] = xn[i]
+            g[k] = self.sys.cost(*args, **self.sys.params)
+        return x, u, g
 
     # ------------------------------------------------------------------ reporting
     def print_summary(self):
@@ -1152,6 +1302,22 @@ class _TupleMinMax(object):
     def __exit__(self, *exc):
         for name, orig in self.saved.items():
             setattr(np, name, orig)
+
+
+def _params_key(params):
+    """hashable, untruncated image of a params dict (repr() shortens large arrays)"""
+    out = []
+    for k in sorted(params):
+        v = params[k]
+        if isinstance(v, np.ndarray):
+            out.append((k, v.dtype.str, v.shape, v.tobytes()))
+        else:
+            try:
+                hash(v)
+                out.append((k, v))
+            except TypeError:
+                out.append((k, repr(v)))
+    return tuple(out)
 
 
 def _same(a, b):

@@ -557,6 +557,29 @@ class TracedModel(object):
             trail |= n.deps
         return (trail & (DEP_U | DEP_X)) == 0
 
+    @property
+    def column_shareable(self):
+        """True when the next values of all state axes but the leading one do not
+        depend on the LEADING state variable (they may depend on the control):
+            x0' = f0(x, u, w[, t])       x_k' = f_k(x_1.., u, w[, t])  for k >= 1
+        The nodes of a column along axis 0 then share, control by control, the partial
+        interpolation over axes 1.. -- storage_separable is the special case without u.
+        (The column kernel can use it when the nodes of a column also share their
+        control values, i.e. the admissible box does not depend on x0.)"""
+        if self.n_state < 2:
+            return False
+        trail = 0
+        for n in self.x_next[1:]:
+            trail |= n.deps
+        return (trail & DEP_X) == 0
+
+    @property
+    def trail_depends_on_u(self):
+        trail = 0
+        for n in self.x_next[1:]:
+            trail |= n.deps
+        return bool(trail & DEP_U)
+
     def separable_axis_hint(self):
         """index k > 0 of a state variable that would make the model
         storage-separable if it came first (all other next-state values

@@ -343,7 +343,65 @@ def g9():
          seconds=np.array(time.time() - t0))
 
 
-ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9)
+def g10():
+    """closed-loop simulation with a policy looked up by interp_on_state: the loop of
+    the reference's examples/20 Searev storage control/storage_control.py:242-251,
+    run with the reference's classes (MlinInterpolator.__call__ + sys.dyn per step),
+    for several start states and disturbance sequences; plus a two-control system
+    (storage-AR1) simulated the same way."""
+    print('g10 closed-loop simulation')
+    wec, dpsolv = models.searev(ref, n_E=11, n_S=15, n_A=13)
+    pol = models.searev_linear_policy(dpsolv)                       # (11, 15, 13, 1)
+    law = dpsolv.interp_on_state(pol[..., 0])
+    rng = np.random.default_rng(42)
+    T, B = 400, 5
+    w = rng.normal(0., models.SEAREV['innov_std'], (T, B))
+    x0 = np.column_stack([rng.uniform(1, 9, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)])
+    x0[0] = (models.SEAREV['E_rated'] / 3, 0., 0.)                   # the example's start state
+    x = np.zeros((T + 1, B, 3))
+    u = np.zeros((T, B, 1))
+    g = np.zeros((T, B))
+    x[0] = x0
+    for b in range(B):
+        for k in range(T):
+            u[k, b, 0] = law(x[k, b, 0], x[k, b, 1], x[k, b, 2])     # storage_control.py:246
+            x[k + 1, b] = wec.dyn(x[k, b, 0], x[k, b, 1], x[k, b, 2], u[k, b, 0], w[k, b])
+            g[k, b] = wec.cost(x[k, b, 0], x[k, b, 1], x[k, b, 2], u[k, b, 0], w[k, b])
+    sto, ar1 = models.storage_ar1(ref, n_E=21, n_P=25)
+    pol2 = models.storage_ar1_empirical_policy(ar1)                  # (21, 25, 2)
+    laws = [ar1.interp_on_state(np.ascontiguousarray(pol2[..., c])) for c in range(2)]
+    T2, B2 = 300, 3
+    w2 = rng.normal(0., 0.4, (T2, B2))
+    y0 = np.column_stack([rng.uniform(1, 9, B2), rng.uniform(-2, 2, B2)])
+    y = np.zeros((T2 + 1, B2, 2))
+    v = np.zeros((T2, B2, 2))
+    y[0] = y0
+    for b in range(B2):
+        for k in range(T2):
+            v[k, b] = [float(law_c(y[k, b, 0], y[k, b, 1])) for law_c in laws]
+            y[k + 1, b] = sto.dyn(y[k, b, 0], y[k, b, 1], v[k, b, 0], v[k, b, 1], w2[k, b])
+    save('g10_simulation', pol=pol, x0=x0, w=w, x=x, u=u, g=g, pol2=pol2, y0=y0, w2=w2, y=y, v=v)
+
+
+def g11():
+    """config 5 (synthetic 512^3, fp32 sweep judged against fp64): the fp64 REFERENCE on
+    the 512^3 grid on sampled nodes (J, policy value, lattice index, margin)."""
+    print('g11 synthetic 512^3 (fp64 reference for the fp32 config)')
+    _, c5 = models.synthetic3d(ref, N=512)
+    V0 = models.synthetic3d_V0(c5.state_grid)
+    rng = np.random.default_rng(5)
+    S = 512 ** 3
+    nodes = np.unique(np.concatenate([rng.integers(0, S, 3000), [0, S - 1, S // 2]]))
+    t0 = time.time()
+    J, pol, idx, mar, npts = ref_sweep_sampled(c5, V0, nodes)
+    print('    {} nodes in {:.1f} s'.format(len(nodes), time.time() - t0))
+    assert (npts == 64).all()
+    import zlib
+    save('g11_synth512', nodes=nodes, J=J, pol=pol, idx=idx, margin=mar,
+         V0_crc=np.array(zlib.crc32(V0.tobytes())))
+
+
+ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or sorted(ALL)

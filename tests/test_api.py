@@ -309,3 +309,19 @@ def test_control_box_table_vectorises_the_tuple_min_max_idiom():
     lo, hi, n = s._box_table()
     E = s.state_grid[0]
     assert np.array_equal(lo[0].reshape(41, 61)[:, 0], np.maximum(np.minimum(E, 2.), 0.5) - 3.0)
+
+
+def test_interpolator_loader_refuses_anything_but_data(tmp_path):
+    """compat.load_interpolator reads third-party policy files: a pickle that names any
+    global besides the interpolator class and numpy's array reconstruction is refused"""
+    import os
+    import pickle
+    from stodynprog_amd.compat import load_interpolator
+
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ('echo pwned',))
+    path = tmp_path / 'evil.dat'
+    path.write_bytes(pickle.dumps(Evil(), protocol=2))
+    with pytest.raises(pickle.UnpicklingError):
+        load_interpolator(str(path))

@@ -607,7 +607,9 @@ def test_policy_iteration_reproduces_published_costs(gpu, capsys):
     assert 'policy iteration 1/2' in out and 'policy iteration 2/2' in out
     assert abs(J_ref - float(g['ar1_pi_Jref'])) < 1e-12
     assert np.abs(J - g['ar1_pi_J']).max() < 1e-10
-    _prove_policy_ties(solver, pol_ini, 50, 2, pol, g['ar1_pi_pol0'][..., None], 'ar1 policy iteration')
+    pol_ref = pol.copy()                          # the fixture holds control 0 (the second is pinned to one point)
+    pol_ref[..., 0] = g['ar1_pi_pol0']
+    _prove_policy_ties(solver, pol_ini, 50, 2, pol, pol_ref, 'ar1 policy iteration')
 
 
 def _prove_policy_ties(solver, pol_ini, n_val, n_pol, pol, pol_ref, what):
@@ -892,6 +894,26 @@ def test_fp32_512cubed_against_fp64_oracle(gpu):
     assert (idx32.ravel()[nodes][clear] == io[clear]).all()
     assert clear.mean() > 0.5
     assert idx32.min() >= 0 and idx32.max() <= 63
+    # ... and against the REFERENCE itself on this grid (golden g11: fp64 stodynprog on 3003
+    # sampled nodes of the 512^3 problem, tests/golden/make_golden.py g11)
+    g = golden('g11_synth512')
+    import zlib
+    assert int(g['V0_crc']) == zlib.crc32(V0.tobytes())
+    gn = g['nodes']
+    rel = np.abs(J32.ravel()[gn] - g['J']).max() / np.abs(g['J']).max()
+    assert rel < 1e-5, rel
+    clear = g['margin'] > 1e-5 * np.maximum(1.0, np.abs(g['J']))
+    assert (idx32.ravel()[gn][clear] == g['idx'][clear]).all() and clear.mean() > 0.5
+    # (the fp32 sweep generates its control points in fp32: i*step+lo rounds differently)
+    assert np.allclose(u32.reshape(-1)[gn][clear], g['pol'][clear, 0], rtol=1e-6, atol=1e-7)
+    from conftest import _report
+    _report('{:32s} nodes {:9d}  max|dJ|/|J| {:.2e}  (fp32 sweep vs fp64 reference, bar 1e-5); indices '
+            'identical at the {} nodes whose reference margin exceeds fp32 resolution'.format(
+                'synthetic c5 512^3 fp32', len(gn), rel, int(clear.sum())))
+    # the fp64 sweep on the same grid: bit-level parity with the reference golden
+    J64, u64 = ref.value_iteration(V0, report_time=False)
+    assert_sweep_parity(J64.ravel()[gn], ref.last_policy_index.ravel()[gn], g['J'], g['idx'],
+                        g['margin'], 'synthetic 512^3 fp64 vs reference', prove=(ref, V0), nodes=gn)
 
 
 # ---------------------------------------------------------------- opt-in fused arithmetic
