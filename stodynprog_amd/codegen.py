@@ -207,14 +207,17 @@ def lanes_for(max_controls):
     return lanes
 
 
-def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None):
+def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
+                     per_control=None):
     """column: None for the generic node-order kernels, or (N0, W) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
     staged: None, or the dict of `staged_config` to also build the LDS-staged
     generic kernel of csrc/sdp_staged_kernel.h (node order, any traceable model).
     window: None, or the tuple of `column_window_config` (column kernel whose
-    table holds a window of rows of axis 0)."""
+    table holds a window of rows of axis 0).
+    per_control: None, or the tuple of `column_percontrol_config` (column kernel
+    that rebuilds its table for every control)."""
     real = {'float64': 'double', 'float32': 'float'}[np.dtype(dtype).name]
     head = [
         '// generated by stodynprog_amd.codegen -- do not edit',
@@ -240,8 +243,12 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
     if column is not None:
         assert model.column_shareable
         wpair = use_wpair(model, dtype) and window is None
-        col_cfg = window if window is not None else column_config(column[0], column[1], model.n_state,
-                                                                  dtype, wpair)
+        if per_control is not None:
+            col_cfg = per_control
+        elif window is not None:
+            col_cfg = window
+        else:
+            col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair)
         assert col_cfg is not None
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
@@ -252,7 +259,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
             '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
             '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
-        ] + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
+        ] + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + (
+            ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
                        'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER')
@@ -418,6 +426,24 @@ def column_config(n0, w, n_state, dtype, wpair=False):
 def _column_lds(tw, w, rows, n_state, rs, threads):
     raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16)
     return (raw + 15) // 16 * 16
+
+
+def column_percontrol_config(n0, w, n_state, dtype):
+    """Shape of the column kernel with a table per control (SDP_TRAIL_HAS_U of
+    csrc/sdp_column_kernel.h): (threads, lds_bytes, w_chunk).  One thread per node of
+    a column (at most 512; longer columns are split over workgroups), and a table of
+    `w_chunk` perturbation points at a time, about 32 KiB: four to five workgroups
+    then share a CU and hide each other's barriers and load latencies."""
+    rs = np.dtype(dtype).itemsize
+    w = max(int(w), 1)
+    threads = min(512, max(64, (int(n0) + 63) // 64 * 64))
+    wchunk = max(1, min(w, (32 * 1024) // (int(n0) * rs)))
+    if os.environ.get('SDP_COL_WCHUNK'):                # A/B runs
+        wchunk = max(1, min(w, int(os.environ['SDP_COL_WCHUNK'])))
+    lds = _column_lds(wchunk, w, n0, n_state, rs, threads)
+    if lds > COLUMN_LDS_MAX:
+        return None
+    return threads, lds, wchunk
 
 
 def column_window_config(n0, w, n_state, dtype, reach_rows):

@@ -115,8 +115,11 @@ struct SdpColShared {
 };
 
 // statically sized LDS image (a single workgroup may use up to 160 KiB)
+#ifndef SDP_COL_WCHUNK
+#define SDP_COL_WCHUNK SDP_COL_W     // per-control table only: perturbation points tabulated at a time
+#endif
 struct __attribute__((aligned(16))) SdpColLds {
-    sdp_real T[SDP_COL_TW * SDP_COL_ROWS];
+    sdp_real T[(SDP_TRAIL_HAS_U ? SDP_COL_WCHUNK : SDP_COL_TW) * SDP_COL_ROWS];
     sdp_real w_lam[SDP_COL_W * SDP_DT];
     sdp_real w_oml[SDP_COL_W * SDP_DT];
     sdp_real pw[SDP_COL_W];                // weight / point copies (SDP_COL_WMODE 2)
@@ -1077,13 +1080,63 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
 // a gather kernel's 2^d scattered reads and full lerp nest (about 15 operations
 // and 2^(d-1) coalesced loads instead of about 100 operations), and nothing else
 // changes: same operations on the same operands in the same order, argmin in
-// control order in-lane.  A unit holds at most blockDim.x nodes (col_splits).
+// control order in-lane.
+// Shape: the workgroup has one thread per node of its unit (blockDim.x = nodes
+// of a column, at most SDP_COL_THREADS; longer columns are split), so every lane
+// works in phase B; the table holds SDP_COL_WCHUNK perturbation points at a time
+// (about 32 KiB), which lets four workgroups share a CU and hide each other's
+// barriers and load latencies.  Measured on the control-coupled benchmark
+// (256^3 x 64 x 32 fp64): 65.6 ms against 92.4 ms for the staged tile kernel and 549 ms
+// for the direct one; 24 vector instructions per cell, but 32 B per cell of strip reads:
+// 2.15e9 vector loads and 315 GB of L2 misses per sweep (60 % L2 hit rate) bound it.
+// (Taking the columns in 16 x 16 blocks of the (axis 1, axis 2) plane instead of
+// row by row changed that by 1 %: not kept.)
+
+// phase A for the perturbation points w_lo .. w_lo+cnt-1: T[(w - w_lo)][r], all rows
+SDP_DEV void sdp_colu_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                              const SdpColShared &s, int w_lo, int cnt)
+{
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int G = SDP_COL_A_GROUP;
+    constexpr int NV = 1 << SDP_DT;
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+    // consecutive threads = consecutive rows (coalesced strips); a thread keeps its row and
+    // takes G consecutive perturbation points per round: their strips overlap (L1 hits)
+    for (int r = threadIdx.x; r < N0; r += blockDim.x) {
+        for (int w0 = 0; w0 < cnt; w0 += G) {
+            sdp_real vals[G][NV];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int w = w_lo + min(w0 + j, cnt - 1);               // clamp: result unused
+                int off[SDP_DT];
+#pragma unroll
+                for (int k = 0; k < SDP_DT; ++k) off[k] = s.w_off[w * SDP_DT + k];
+                SdpColGather<0>::run(V + r, tg, off, 0, vals[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (w0 + j < cnt) {
+                    const int w = w_lo + w0 + j;
+                    sdp_real lam[SDP_DT], oml[SDP_DT];
+#pragma unroll
+                    for (int k = 0; k < SDP_DT; ++k) {
+                        lam[k] = s.w_lam[w * SDP_DT + k];
+                        oml[k] = s.w_oml[w * SDP_DT + k];
+                    }
+                    s.T[(w0 + j) * N0 + r] = SdpColNest<0, false>::run(vals[j], lam, oml, tg.shift);
+                }
+            }
+        }
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
     SDP_STAMP_BEGIN(a);
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
+    constexpr int WC = SDP_COL_WCHUNK;
     if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
     const sdp_real t = (sdp_real)a.t_k;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
@@ -1091,12 +1144,13 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     sdp_col_carve(sdp_lds, s);
     SdpGrid<sdp_real, SDP_DT> tg;
     sdp_col_trailing_grid(a, tg);
-    SdpLeadAxis lead;
-    sdp_col_lead_axis(a, lead);
+    SdpLeadAxis l;
+    sdp_col_lead_axis(a, l);
     SdpColWalk walk;
     sdp_col_walk(a, walk);
-    SdpColWeights wts;
-    sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+    SdpColWeights k;
+    sdp_col_load_weights(a, k, sdp_lds.pw, sdp_lds.gw);
+    const volatile sdp_lds_real *T = (const volatile sdp_lds_real *)s.T;
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
@@ -1114,18 +1168,63 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_real best = INFINITY;
         int ibest = INT_MAX;
         for (int ci = 0; ci < box.total; ++ci) {
-            sdp_real u[1][SDP_NU], jc[1];
-            sdp_controls_at(box, ci, u[0]);
-            sdp_col_phase_w(a, tg, s, x, u[0], t);      // (its inputs x[1..], u, w are workgroup-uniform)
-            __syncthreads();                            // also: phase B of the previous control is done
-            sdp_col_phase_a<false>(a, tg, s);
-            __syncthreads();
-            if (mine) {
-                sdp_col_expected_cost<1>(a, tg, s, wts, lead, x, u, t, jc);
-                if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
+            sdp_real u[SDP_NU];
+            sdp_controls_at(box, ci, u);
+            // (phase W overwrites what phase A of the previous control read: every thread is past
+            // that phase's closing barrier; the table itself is protected by the chunk loop's)
+            sdp_col_phase_w(a, tg, s, x, u, t);         // its inputs x[1..], u, w are workgroup-uniform
+            // what the node's cells share: the cell of x0' and the cost, when they do not depend on w
+            sdp_real lam0 = 0, oml0 = 0, g = 0, acc = (sdp_real)0;
+            int q0 = 0;
+#define SDP_COLU_LOCATE(wval)                                                           \
+            {                                                                          \
+                const sdp_real xn0_ = sdp_model_lead(x, u, (wval), t);                 \
+                const sdp_real sn_ = (xn0_ - l.smin) / l.span;          /* pyx:75 */   \
+                const sdp_real p_ = sn_ * l.nm1;                                       \
+                q0 = max(min(sdp_trunc_i32(p_), l.ordm2), 0);           /* pyx:78 */   \
+                lam0 = p_ - (sdp_real)q0;                               /* pyx:81 */   \
+                oml0 = (sdp_real)1 - lam0;                                             \
             }
+            if (mine) {
+#if !SDP_LEAD_HAS_W || !SDP_HAS_W
+                SDP_COLU_LOCATE((sdp_real)0)
+#endif
+#if !SDP_COST_HAS_W || !SDP_HAS_W
+                g = sdp_model_cost(x, u, (sdp_real)0, t);
+#endif
+            }
+            for (int w_lo = 0; w_lo < Wn; w_lo += WC) {
+                const int cnt = min(WC, Wn - w_lo);
+                __syncthreads();                        // phase W done / previous chunk's readers done
+                sdp_colu_phase_a(a, tg, s, w_lo, cnt);
+                __syncthreads();
+                if (mine) {
+#if SDP_HAS_W
+#pragma unroll 4
+                    for (int j = 0; j < cnt; ++j) {
+                        const int w = w_lo + j;
+#if SDP_LEAD_HAS_W
+                        SDP_COLU_LOCATE(SDP_COL_GW(k, w))
+#endif
+                        const sdp_real lo = T[j * N0 + q0];
+                        const sdp_real hi = T[j * N0 + q0 + 1];
+                        const sdp_real val = oml0 * lo + lam0 * hi;               // pyx:88-300
+#if SDP_COST_HAS_W
+                        g = sdp_model_cost(x, u, SDP_COL_GW(k, w), t);
+#endif
+                        const sdp_real jc = g + val;                              // stodynprog.py:677
+                        acc = acc + jc * SDP_COL_PW(k, w);                        // stodynprog.py:681
+                    }
+#else
+                    const sdp_real lo = T[q0];
+                    const sdp_real hi = T[q0 + 1];
+                    acc = g + (oml0 * lo + lam0 * hi);                            // stodynprog.py:679-680
+#endif
+                }
+            }
+#undef SDP_COLU_LOCATE
+            if (mine && (ibest == INT_MAX || sdp_better_seq(acc, best))) { best = acc; ibest = ci; }
         }
-        __syncthreads();
         if (mine) sdp_col_store(a, col * N0 + i, box, best, ibest);
     }
     SDP_STAMP_END(a);

@@ -298,7 +298,9 @@ def synthetic3d_coupled(api=None, N=256, n_w=32, gain=0.1, cross=0.0):
 
     def coupled_dyn(x0, x1, x2, u, w):
         x0n = x0 + b * u
-        x1n = m1 + a11 * x1 + a12 * x2 + w + gain * u + cross * x0
+        x1n = m1 + a11 * x1 + a12 * x2 + w + gain * u
+        if cross:                               # (a traced `0 * x0` would still count as a dependency)
+            x1n = x1n + cross * x0
         x2n = m2 + a21 * x1 + a22 * x2 + c * w
         return (x0n, x1n, x2n)
     syn.dyn = coupled_dyn

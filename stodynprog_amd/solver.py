@@ -581,15 +581,25 @@ class DPSolver(object):
         column = (self.kernel in ('auto', 'column') and model.storage_separable and
                   codegen.column_config(shape[0], W, len(shape), dt,
                                         codegen.use_wpair(model, dt)) is not None)
+        # trailing next states that depend on the control but not on x0: the nodes of a
+        # column still share a table, control by control, provided they share their control
+        # values (box independent of x0) -- csrc/sdp_column_kernel.h, SDP_TRAIL_HAS_U
+        per_control = (not column and self.kernel in ('auto', 'column') and model.column_shareable
+                       and model.trail_depends_on_u and self.arithmetic == 'exact'
+                       and self._box_constant_along_axis0(bp, shape))
+        per_control_cfg = None
+        if per_control:
+            per_control_cfg = codegen.column_percontrol_config(shape[0], W, len(shape), dt)
+            column = per_control = per_control_cfg is not None
         window = None
-        if (not column and self.kernel in ('auto', 'column') and model.storage_separable
-                and self.arithmetic == 'exact'):
+        if (not column and not per_control and self.kernel in ('auto', 'column')
+                and model.storage_separable and self.arithmetic == 'exact'):
             # the W x N0 table exceeds the LDS of a CU: tabulate a window of rows per
             # segment of the column (csrc/sdp_column_kernel.h, SDP_COL_ROWS)
             window = codegen.column_window_config(shape[0], W, len(shape), dt,
                                                   self._lead_reach_rows(model, bp, box_t))
             column = window is not None
-        if not column and self.kernel in ('auto', 'column'):
+        if (not column or per_control) and self.kernel in ('auto', 'column'):
             k = model.separable_axis_hint()
             if k is not None and not self._cache.get('hinted'):
                 self._cache['hinted'] = True
@@ -613,11 +623,24 @@ class DPSolver(object):
         source = codegen.translation_unit(model, dt, lanes,
                                           column=(shape[0], W) if column else None,
                                           fused=(self.arithmetic == 'fused'), staged=staged,
-                                          window=window)
+                                          window=window, per_control=per_control_cfg if per_control else None)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged,
-                    window=window,
+                    window=window, per_control=per_control,
+                    col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
                     max_u=bp['max_u'], W=W, box_digest=bp['digest'])
+
+    @staticmethod
+    def _box_constant_along_axis0(bp, shape):
+        """do all nodes of every column along axis 0 have the same control box?"""
+        if not bp['per_node']:
+            return True
+        n0 = shape[0]
+        for arr in (bp['lo'], bp['hi'], bp['n']):
+            a = arr.reshape(arr.shape[0], n0, -1)
+            if not (a == a[:, :1, :]).all():
+                return False
+        return True
 
     def _lead_reach_rows(self, model, bp, box_t=None, n_samples=4096):
         """Rows of axis 0 the controls (and perturbation points) of ONE node span:
@@ -714,14 +737,14 @@ class DPSolver(object):
         prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
                               per_node, node_range,
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
-                              bounds, layout, plan['staged'],
-                              plan['window'][3] if plan['window'] else 0)
+                              bounds, layout, plan['staged'], plan['col_seg_nodes'])
         self._cache[fp] = prob
         prob.info = dict(mode='traced',
                          kernel='column' if column else ('staged' if plan['staged'] else 'generic'),
                          staged=plan['staged'],
                          row_window=(dict(rows=plan['window'][2], segment_nodes=plan['window'][3])
                                      if plan['window'] else None),
+                         table_per_control=bool(plan['per_control']),
                          arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),

@@ -1240,7 +1240,11 @@ def test_random_models_match_numpy_bit_for_bit(gpu, seed):
     with np.errstate(all='ignore'):
         J, u = solver.value_iteration(V, report_time=False)
         Jo, uo, io, mo = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
-    assert solver.backend_info['kernel'] == ('column' if model.storage_separable else 'staged')
+    # storage-separable -> column kernel; trailing axes that depend on the control but not on
+    # the leading state -> column kernel with a table per control; anything else -> staged tiles
+    assert solver.backend_info['kernel'] == ('column' if model.column_shareable else 'staged')
+    assert bool(solver.backend_info.get('table_per_control')) == (model.column_shareable
+                                                                 and not model.storage_separable)
     if model.bit_exact:
         assert np.array_equal(J, Jo, equal_nan=True), (lead, trail, cst)
         assert np.array_equal(solver.last_policy_index, io)
