@@ -147,16 +147,20 @@ SDP_DEV void sdp_col_trailing_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_
 {
     const sdp_real *axes = (const sdp_real *)a.axes;
     int m = SDP_COL_N0;
+    g.pow2 = 0;
 #pragma unroll
     for (int k = SDP_DT - 1; k >= 0; --k) {
         const int ax = k + 1;
         g.smin[k] = axes[a.axis_off[ax]];
         g.span[k] = axes[a.axis_off[ax] + a.orders[ax] - 1] - g.smin[k];
+        g.rspan[k] = (sdp_real)1 / g.span[k];
+        if (sdp_is_pow2(g.span[k])) g.pow2 |= 1 << k;
         g.nm1[k] = (sdp_real)(a.orders[ax] - 1);
         g.ordm2[k] = a.orders[ax] - 2;
         g.M[k] = m;
         m *= a.orders[ax];
     }
+    g.pow2 = __builtin_amdgcn_readfirstlane(g.pow2);
     g.shift = (sdp_real)0;
 }
 
@@ -355,8 +359,9 @@ SDP_DEV sdp_real sdp_col_inner_global(const SdpSweepArgs &a, const SdpGrid<sdp_r
 }
 
 struct SdpLeadAxis {
-    sdp_real smin, span, nm1;
+    sdp_real smin, span, nm1, rspan;
     int ordm2;
+    bool pow2;          // span is a power of two: (x - smin) / span == (x - smin) * rspan, bit for bit
 };
 
 SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
@@ -364,6 +369,8 @@ SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
     const sdp_real *axes = (const sdp_real *)a.axes;
     l.smin = axes[a.axis_off[0]];
     l.span = axes[a.axis_off[0] + a.orders[0] - 1] - l.smin;
+    l.rspan = (sdp_real)1 / l.span;
+    l.pow2 = __builtin_amdgcn_readfirstlane((int)sdp_is_pow2(l.span)) != 0;
     l.nm1 = (sdp_real)(a.orders[0] - 1);
     l.ordm2 = a.orders[0] - 2;
 }
@@ -469,7 +476,7 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &, const SdpGrid<sdp_real,
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const sdp_real xn0 = sdp_model_lead(x, u[j], (sdp_real)0, t);
-        const sdp_real sn = (xn0 - l.smin) / l.span;                    /* pyx:75 */
+        const sdp_real sn = sdp_div_span<sdp_real>(xn0 - l.smin, l.span, l.rspan, l.pow2);   /* pyx:75 */
         const sdp_real p = sn * l.nm1;
         const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);          /* pyx:78 */
         lam0[j] = p - (sdp_real)q0;                                     /* pyx:81 */
@@ -586,7 +593,7 @@ SDP_DEV sdp_real sdp_col_cost_global(const SdpSweepArgs &a, const SdpGrid<sdp_re
 #define SDP_COL_LOCATE1(wval)                                                           \
     {                                                                                  \
         const sdp_real xn0_ = sdp_model_lead(x, u, (wval), t);                         \
-        const sdp_real sn_ = (xn0_ - l.smin) / l.span;                  /* pyx:75 */   \
+        const sdp_real sn_ = sdp_div_span<sdp_real>(xn0_ - l.smin, l.span, l.rspan, l.pow2); /* pyx:75 */   \
         const sdp_real p_ = sn_ * l.nm1;                                               \
         q0 = max(min(sdp_trunc_i32(p_), l.ordm2), 0);                   /* pyx:78 */   \
         lam0 = p_ - (sdp_real)q0;                                       /* pyx:81 */   \
@@ -648,7 +655,7 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real
 #define SDP_COL_LOCATE(j, wval)                                                         \
     {                                                                                  \
         const sdp_real xn0_ = sdp_model_lead(x, u[j], (wval), t);                      \
-        const sdp_real sn_ = (xn0_ - l.smin) / l.span;                  /* pyx:75 */   \
+        const sdp_real sn_ = sdp_div_span<sdp_real>(xn0_ - l.smin, l.span, l.rspan, l.pow2); /* pyx:75 */   \
         const sdp_real p_ = sn_ * l.nm1;                                               \
         const int q0_ = max(min(sdp_trunc_i32(p_), l.ordm2), 0);        /* pyx:78 */   \
         lam0[j] = p_ - (sdp_real)q0_;                                   /* pyx:81 */   \
@@ -1179,7 +1186,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #define SDP_COLU_LOCATE(wval)                                                           \
             {                                                                          \
                 const sdp_real xn0_ = sdp_model_lead(x, u, (wval), t);                 \
-                const sdp_real sn_ = (xn0_ - l.smin) / l.span;          /* pyx:75 */   \
+                const sdp_real sn_ = sdp_div_span<sdp_real>(xn0_ - l.smin, l.span, l.rspan, l.pow2); /* pyx:75 */   \
                 const sdp_real p_ = sn_ * l.nm1;                                       \
                 q0 = max(min(sdp_trunc_i32(p_), l.ordm2), 0);           /* pyx:78 */   \
                 lam0 = p_ - (sdp_real)q0;                               /* pyx:81 */   \

@@ -22,11 +22,42 @@
 SDP_DEV int sdp_trunc_i32(double p) { return (fabs(p) < 2147483648.0) ? (int)p : INT_MIN; }
 SDP_DEV int sdp_trunc_i32(float p) { return (fabsf(p) < 2147483648.0f) ? (int)p : INT_MIN; }
 
+// `(s - smin) / span` of pyx:75 when the divisor is a power of two -- grids on [0, 1],
+// [-4, 4], [0, 2^k] -- equals the product with its reciprocal BIT FOR BIT: x / 2^k and
+// x * 2^-k are the same real number and both operations round it correctly (also into the
+// subnormals).  One instruction instead of the ~16 of an IEEE division; any other
+// divisor takes the true division.  `pow2` is wave-uniform: a scalar branch.
+#ifndef SDP_NO_POW2
+#define SDP_NO_POW2 0            // 1: always divide (A/B runs)
+#endif
+SDP_DEV bool sdp_is_pow2(double v)
+{
+    if (SDP_NO_POW2) return false;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned e = (unsigned)(b >> 52);          // sign + exponent
+    return (b & 0x000FFFFFFFFFFFFFull) == 0 && e >= 1 && e <= 2046;
+}
+SDP_DEV bool sdp_is_pow2(float v)
+{
+    if (SDP_NO_POW2) return false;
+    const unsigned b = __float_as_uint(v);
+    const unsigned e = b >> 23;
+    return (b & 0x007FFFFFu) == 0 && e >= 1 && e <= 254;
+}
+template <typename real>
+SDP_DEV real sdp_div_span(real num, real span, real rspan, bool pow2)
+{
+    if (pow2) return num * rspan;
+    return num / span;
+}
+
 // Grid constants of one interpolation problem, kept in registers/SGPRs.
 template <typename real, int D>
 struct SdpGrid {
     real smin[D];
     real span[D];   // smax - smin              (pyx:75, denominator)
+    real rspan[D];  // 1 / span, used only where span is a power of two (exact then)
+    int pow2;       // bit k: span[k] is a power of two
     real nm1[D];    // (real)(order - 1)
     int ordm2[D];   // order - 2
     int M[D];       // C-order strides, M[D-1] = 1 (pyx:164-165)
@@ -50,7 +81,7 @@ struct SdpCell {
 template <typename real, int D, typename wide>
 SDP_DEV void sdp_locate_axis(const SdpGrid<real, D> &g, int k, real s, SdpCell<real, D, wide> &c)
 {
-    const real sn = (s - g.smin[k]) / g.span[k];                   // pyx:75
+    const real sn = sdp_div_span<real>(s - g.smin[k], g.span[k], g.rspan[k], (g.pow2 >> k) & 1);   // pyx:75
     const real p = sn * g.nm1[k];
     const int q = max(min(sdp_trunc_i32(p), g.ordm2[k]), 0);       // pyx:78
     c.lam[k] = p - (real)q;                                        // pyx:81 (unclamped)
@@ -102,15 +133,19 @@ SDP_DEV void sdp_make_grid(SdpGrid<real, D> &g, const int32_t *orders, const rea
 {
     int m = 1;
     g.shift = (real)0;
+    g.pow2 = 0;
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
         g.smin[k] = smin[k];
         g.span[k] = smax[k] - smin[k];
+        g.rspan[k] = (real)1 / g.span[k];
+        if (sdp_is_pow2(g.span[k])) g.pow2 |= 1 << k;
         g.nm1[k] = (real)(orders[k] - 1);
         g.ordm2[k] = orders[k] - 2;
         g.M[k] = m;
         m *= orders[k];
     }
+    g.pow2 = __builtin_amdgcn_readfirstlane(g.pow2);       // the same in every lane: keep it scalar
 }
 
 // ---------------------------------------------------------------------------

@@ -99,7 +99,7 @@ SDP_DEV int sdp_stg_row_stride(int len)
 SDP_DEV int sdp_stg_locate(const SdpGrid<sdp_real, SDP_D> &g, int k, sdp_real s,
                            SdpCell<sdp_real, SDP_D, sdp_real> &c)
 {
-    const sdp_real sn = (s - g.smin[k]) / g.span[k];               // pyx:75
+    const sdp_real sn = sdp_div_span<sdp_real>(s - g.smin[k], g.span[k], g.rspan[k], (g.pow2 >> k) & 1);   // pyx:75
     const sdp_real p = sn * g.nm1[k];
     const int q = max(min(sdp_trunc_i32(p), g.ordm2[k]), 0);       // pyx:78
     c.lam[k] = p - (sdp_real)q;                                    // pyx:81 (unclamped)

@@ -137,3 +137,27 @@ def test_pickled_interpolator_evaluates_after_reload(gpu, tmp_path):
 def pickle_roundtrip(obj):
     import pickle
     return pickle.loads(pickle.dumps(obj))
+
+
+def test_power_of_two_spans_multiply_by_the_reciprocal_bit_exactly(gpu):
+    """`(s - smin) / span` (pyx:75) is computed as a product with 1/span when span is a
+    power of two (sdp_div_span, csrc/sdp_device.h): the same real number, rounded the same
+    way -- checked against the C oracle (true division) on spans 1, 8, 0.5, 2^-30, 2^40 and,
+    for contrast, 10 and 3; queries include huge, tiny, subnormal, infinite and NaN values"""
+    rng = np.random.default_rng(12)
+    for dt in (np.float64, np.float32):
+        tiny = np.finfo(dt).tiny
+        for lo, span in ((0., 1.), (-4., 8.), (0.25, 0.5), (1., 2. ** -30), (-7., 2. ** 40), (0., 10.), (-1., 3.)):
+            smin = np.array([lo, lo], dtype=dt)
+            smax = np.array([lo + span, lo + span], dtype=dt)
+            orders = np.array([7, 5])
+            values = rng.standard_normal((2, 35)).astype(dt)
+            base = lo + span * rng.uniform(-0.5, 1.5, (2, 4000))
+            special = np.array([[lo, lo + span, lo + tiny, lo - tiny * 3, 1e300 if dt == np.float64 else 1e38,
+                                 -1e300 if dt == np.float64 else -1e38, np.inf, -np.inf, np.nan, 5e-324],
+                                [lo + span / 3] * 10])
+            s = np.ascontiguousarray(np.concatenate([base, special], axis=1).astype(dt))
+            with np.errstate(all='ignore'):
+                out = multilinear_interpolation(smin, smax, orders, values, s)
+                ref = c_oracle.mlinterp(smin, smax, orders, values, s)
+            assert np.array_equal(out, ref, equal_nan=True), (dt, lo, span)
