@@ -633,6 +633,9 @@ struct sdp_problem {
     DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps;
     DevBuf stage[3];                       // layout-conversion buffers of the fused host call (J, pol, idx)
     size_t stage_bytes[3] = {0, 0, 0};
+    hipStream_t copy_stream = nullptr;     // downloads of finished phases, under the next phase's kernel
+    hipEvent_t ev_host[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_copy = nullptr;
     int64_t stamp_words = 0;
     size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
@@ -659,6 +662,9 @@ struct sdp_problem {
         if (ev2) (void)hipEventDestroy(ev2);
         if (ev3) (void)hipEventDestroy(ev3);
         if (ev_comm) (void)hipEventDestroy(ev_comm);
+        if (ev_copy) (void)hipEventDestroy(ev_copy);
+        for (auto &e : ev_host) if (e) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto &e : ev_phase) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1222,6 +1228,37 @@ static int download_nodes_async(sdp_problem *p, void *host, const void *dev, siz
 
 static int gather_policy(sdp_problem *p);
 
+// Rows [nb, ne) (device order) of a per-node array -> their place in the host array
+// (reference C order), enqueued on `stream`.  Node layout: one contiguous copy.  Column
+// layout: the rows are whole columns c0 .. c1-1, i.e. the host sub-block [:, c0:c1] of the
+// [N0][P] array: transposed into the dense [N0][c1-c0] part of the conversion buffer, then
+// one strided 2-D copy.
+static int download_range_async(sdp_problem *p, void *host, const void *dev, size_t elem_bytes, int slot,
+                                int64_t nb, int64_t ne, hipStream_t stream)
+{
+    if (ne <= nb) return SDP_OK;
+    if (p->layout != SDP_LAYOUT_COLUMNS) {
+        HIP_TRY(hipMemcpyAsync((char *)host + nb * elem_bytes, (const char *)dev + nb * elem_bytes,
+                               (size_t)(ne - nb) * elem_bytes, hipMemcpyDeviceToHost, stream));
+        return SDP_OK;
+    }
+    const size_t bytes = (size_t)p->S * elem_bytes;
+    if (p->stage_bytes[slot] < bytes) {
+        int rc = p->stage[slot].alloc(bytes);
+        if (rc) { p->stage_bytes[slot] = 0; return rc; }
+        p->stage_bytes[slot] = bytes;
+    }
+    const int64_t n0 = p->orders[0], P = p->S / n0, c0 = nb / n0, c1 = ne / n0;
+    char *dense = (char *)p->stage[slot].p + (size_t)nb * elem_bytes;          // [N0][c1-c0]
+    int rc = launch_transpose((const char *)dev + nb * elem_bytes, dense, c1 - c0, n0,
+                              (int)(elem_bytes / 4), stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync((char *)host + c0 * elem_bytes, (size_t)P * elem_bytes, dense,
+                             (size_t)(c1 - c0) * elem_bytes, (size_t)(c1 - c0) * elem_bytes, (size_t)n0,
+                             hipMemcpyDeviceToHost, stream));
+    return SDP_OK;
+}
+
 // One value_iteration call with host arrays in and out (stodynprog.py:466-534):
 // upload of J_next (skipped when host_V is NULL: the device keeps its value buffer),
 // the backup, the relative-DP shift and the downloads of J_k and the policy values
@@ -1245,6 +1282,43 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
             if ((rc = launch_transpose(p->scratch.p, p->V.p, p->orders[0], p->S / p->orders[0],
                                        (int)(rs / 4), p->stream))) return rc;
         }
+    }
+    // Large single-GPU problems: the backup runs in a few phases of the node range and the
+    // finished rows of a phase go to the host (copy stream) UNDER the kernel of the next
+    // phase, so only the last phase's download is exposed.  J waits for the relative-DP
+    // shift when there is one; the policy never does.
+    const int64_t unit = p->layout == SDP_LAYOUT_COLUMNS ? p->orders[0] : 1;
+    const int64_t units = (p->node_end - p->node_begin) / unit;
+    const int n_ph = 4;
+    if (!p->comm && p->S * (int64_t)rs >= ((int64_t)8 << 20) && units >= 64 * n_ph &&
+        p->node_begin == 0 && p->node_end == p->S && !getenv("SDP_HOST_NO_OVERLAP")) {
+        if (!p->copy_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+            for (auto &e : p->ev_host) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_copy, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(p->ev0, p->stream));
+        for (int ph = 0; ph < n_ph; ++ph) {
+            const int64_t nb = units * ph / n_ph * unit, ne = units * (ph + 1) / n_ph * unit;
+            if ((rc = launch_sweep(p, t_k, nb, ne))) return rc;
+            HIP_TRY(hipEventRecord(p->ev_host[ph], p->stream));
+            HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->ev_host[ph], 0));
+            if (!rel_dp && (rc = download_range_async(p, host_J, p->J.p, rs, 0, nb, ne, p->copy_stream))) return rc;
+            if (host_pol && (rc = download_range_async(p, host_pol, p->pol.p, (size_t)p->nu * rs, 1, nb, ne, p->copy_stream))) return rc;
+            if (host_idx && (rc = download_range_async(p, host_idx, p->idx.p, 4, 2, nb, ne, p->copy_stream))) return rc;
+        }
+        HIP_TRY(hipEventRecord(p->ev1, p->stream));
+        if (rel_dp) {
+            if ((rc = rel_shift(p, ref_index, 0))) return rc;
+            if ((rc = download_nodes_async(p, host_J, p->J.p, rs, 0))) return rc;    // (its own slot-0 buffer use:
+        }                                                                             //  no phase copy of J is in flight)
+        HIP_TRY(hipStreamSynchronize(p->copy_stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        p->last_kernel_ms = ms;
+        if (rel_dp && J_ref_out) HIP_TRY(hipMemcpy(J_ref_out, p->refs.p, 8, hipMemcpyDeviceToHost));
+        return SDP_OK;
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     if ((rc = run_backup(p, false, t_k))) return rc;

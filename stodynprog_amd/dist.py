@@ -255,7 +255,12 @@ def from_env():
     local = int(os.environ.get('LOCAL_RANK', rank))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     from . import _native as nat
-    nat.check(nat.lib().sdp_set_device(local))
+    n_dev = nat.device_count()
+    if n_dev < 1:
+        raise nat.NativeError('rank {}: no HIP device visible'.format(rank))
+    # one GPU per rank; a launcher that narrows each rank's visibility to its own GPU
+    # (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES) leaves device 0 as the only choice
+    nat.check(nat.lib().sdp_set_device(local % n_dev))
     rdv = FileRendezvous(rank, world)
     with _stdout_to_stderr():          # nothing native may write into the caller's stdout
         uid = rdv.exchange(RcclCommunicator.new_unique_id() if rank == 0 else None)

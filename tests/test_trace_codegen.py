@@ -295,3 +295,65 @@ def test_power_follows_numpy_array_ufunc_and_scalar_rules():
     assert m.bit_exact
     m = trace_model(lambda x, u, w: (x + u,), lambda x, u, w: np.square(x - 0.3) + np.power(x, 2) + u, 1, 1, 1)
     assert m.bit_exact                                   # ufunc loops: x*x for scalars too
+
+
+def test_kernel_family_planning_without_a_gpu():
+    """which kernel family a discretised problem gets, and the compile-time shapes the
+    planners hand to the generated unit (no GPU needed: planning is host code)"""
+    from stodynprog_amd import codegen
+    # storage-separable, table fits LDS: full-table column kernel
+    _, s = models.synthetic3d(N=64)
+    plan = s._kernel_plan()
+    assert plan['column'] and not plan['window'] and not plan['per_control'] and plan['staged'] is None
+    assert '#define SDP_TRAIL_HAS_U 0' in plan['source'] and 'SDP_COL_ROWS' not in plan['source']
+    # same model, 1024-point leading axis: 32 x 1024 x 8 B = 256 KiB > LDS -> row window
+    s.discretize_state(0, 1, 1024, 0, 1, 12, 0, 1, 12)
+    plan = s._kernel_plan()
+    threads, lds, rows, seg = plan['window']
+    assert plan['column'] and rows < 1024 and rows % 32 == 0 and seg >= 64 and seg % 64 == 0
+    assert lds * (2 if threads == 512 else 1) <= codegen.COLUMN_LDS_MAX
+    assert '#define SDP_COL_ROWS {}'.format(rows) in plan['source'] and plan['col_seg_nodes'] == seg
+    assert rows >= seg + s._lead_reach_rows(plan['model'], s._box_plan()) + 2
+    # the control also drives x1: a table per control (nodes of a column share their controls)
+    _, c = models.synthetic3d_coupled(N=32)
+    m = c._traced()
+    assert m.column_shareable and m.trail_depends_on_u and not m.storage_separable
+    plan = c._kernel_plan()
+    assert plan['column'] and plan['per_control'] and '#define SDP_TRAIL_HAS_U 1' in plan['source']
+    assert '#define SDP_COL_WCHUNK' in plan['source'] and plan['col_seg_nodes'] in (64, 128, 256, 512)
+    # x1 also depends on x0: nothing to share along a column -> LDS-staged tiles
+    _, f = models.synthetic3d_coupled(N=32, cross=0.3)
+    assert not f._traced().column_shareable
+    plan = f._kernel_plan()
+    st = plan['staged']
+    assert not plan['column'] and st['threads'] == int(np.prod(st['tile'])) == 512
+    assert 1 <= st['cu'] <= 8 and 1 <= st['cw'] <= 32 and st['cap'] * 8 <= codegen.STAGED_LDS_BYTES
+    for macro in ('SDP_STG_THREADS 512', 'SDP_STG_T0 8', 'SDP_STG_CU', 'SDP_STG_CW', 'SDP_STG_CAP'):
+        assert '#define ' + macro in plan['source']
+    # 1-D problems (no column): staged
+    _, inv = models.inventory()
+    plan = inv._kernel_plan()
+    assert not plan['column'] and plan['staged']['tile'] == (512,)
+    # forcing a family
+    c.kernel = 'staged'
+    assert c._kernel_plan()['staged'] is not None
+    c.kernel = 'generic'
+    plan = c._kernel_plan()
+    assert not plan['column'] and plan['staged'] is None
+    c.kernel = 'nonsense'
+    with pytest.raises(ValueError):
+        c._kernel_plan()
+
+
+def test_percontrol_and_window_shapes():
+    from stodynprog_amd import codegen
+    th, lds, wc = codegen.column_percontrol_config(256, 32, 3, np.float64)
+    assert th == 256 and wc == 16 and lds <= 40 * 1024           # four workgroups per CU
+    th, lds, wc = codegen.column_percontrol_config(600, 5, 2, np.float64)
+    assert th == 512 and 1 <= wc <= 5
+    assert codegen.column_percontrol_config(40, 0, 2, np.float32)[0] == 64
+    # window: rows from the LDS budget, segment from the reach
+    assert codegen.column_window_config(1024, 32, 3, np.float64, 66) is not None
+    assert codegen.column_window_config(1024, 32, 3, np.float64, 2000) is None     # one node spans the axis
+    assert codegen.staged_row_stride(19, 8, 3, 8) == 24 and codegen.staged_row_stride(8, 8, 3, 8) == 8
+    assert codegen.staged_row_stride(19, 32, 2, 8) == 19 and codegen.staged_row_stride(20, 8, 3, 4) == 21
