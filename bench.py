@@ -441,8 +441,8 @@ def run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='synth256', choices=sorted(WORKLOADS))
     ap.add_argument('--grid', type=int, default=0,
                     help='synthetic workloads: points per state axis (default: the config\'s)')

@@ -226,8 +226,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         '#define SDP_NU {}'.format(model.n_control),
         '#define SDP_HAS_W {}'.format(1 if model.n_perturb else 0),
         '#define SDP_LANES {}'.format(int(lanes)),
-        ] + (['#define SDP_STAMP 1     // diagnostic build: in-kernel clock stamps (tools/clock_probe.py)']
-             if os.environ.get('SDP_STAMP') == '1' else []) + (
+        ] + (['#define SDP_STAMP {}     // diagnostic build: in-kernel clock stamps (tools/clock_probe.py, '
+              'tools/phase_probe.py)'.format(int(os.environ['SDP_STAMP']))]
+             if os.environ.get('SDP_STAMP') in ('1', '2') else []) + (
             ['#define SDP_NO_POW2 1  // A/B: true division also for power-of-two spans']
             if os.environ.get('SDP_NO_POW2') == '1' else []) + [
         '#include "sdp_device.h"',

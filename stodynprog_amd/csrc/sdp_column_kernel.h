@@ -59,9 +59,6 @@
 #ifndef SDP_COL_THREADS
 #define SDP_COL_THREADS 512
 #endif
-#ifndef SDP_COL_BATCH
-#define SDP_COL_BATCH 2          // perturbation points whose LDS reads are issued together
-#endif
 #ifndef SDP_COL_UNROLL_U
 #define SDP_COL_UNROLL_U 2       // controls evaluated together per lane (independent chains)
 #endif
@@ -84,6 +81,16 @@
 #define SDP_COL_WPAIR 0          // 1 (4-byte reals): the table interleaves perturbation points 2k and
 #endif                           //    2k+1, T2[k][r] = (inner_2k(r), inner_2k+1(r)); one 8-byte LDS read
                                  //    serves two cells and the cell arithmetic runs as packed fp32
+#ifndef SDP_COL_BATCH
+// perturbation points whose LDS reads are issued together (x SDP_COL_UNROLL_U controls).
+// Same-box A/B on MI355X, 256^3 x 64 x 32: plain fp64 table 4 -> 8.96 ms, 2 -> 9.23 ms (Searev
+// 128^3: 0.460 vs 0.481 ms); the pair layout of 4-byte reals spills at 4 (10.3 vs 5.5 ms).
+#if SDP_COL_WPAIR || SDP_LEAD_HAS_W
+#define SDP_COL_BATCH 2
+#else
+#define SDP_COL_BATCH 4
+#endif
+#endif
 #if SDP_COL_WPAIR && (!SDP_HAS_W || SDP_LEAD_HAS_W)
 #error "SDP_COL_WPAIR needs a perturbation and an x0' that does not depend on it"
 #endif
@@ -934,6 +941,12 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     int parity = 0;
+#if SDP_STAMP == 2     // diagnostic: shader clocks thread 0 spends in phases W, A, B (+ idle at barriers)
+    unsigned long long tw = 0, ta = 0, tb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, tstart = __builtin_amdgcn_s_memtime();
+#define SDP_COL_MARK(v) v = __builtin_amdgcn_s_memtime()
+#else
+#define SDP_COL_MARK(v)
+#endif
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
@@ -943,13 +956,16 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
         __syncthreads();                       // readers of the previous table are done
+        SDP_COL_MARK(t0);
         sdp_col_window_predict<false>(a, lead, sdp_lds.win, parity, col, i_lo, i_hi, x, t);
         sdp_col_phase_w(a, tg, s, x, nullptr, t);
         __syncthreads();
+        SDP_COL_MARK(t1);
         s.r0 = sdp_col_window_read(sdp_lds.win, parity);
         parity ^= 1;
         sdp_col_phase_a<false>(a, tg, s);
         __syncthreads();
+        SDP_COL_MARK(t2);
 
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
         // per wavefront: their rows q0 are consecutive, so the LDS reads are
@@ -1019,8 +1035,22 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_store(a, node, box, best, ibest);
             }
         }
+#if SDP_STAMP == 2
+        t3 = __builtin_amdgcn_s_memtime();
+        tw += t1 - t0; ta += t2 - t1; tb += t3 - t2;
+#endif
     }
+#if SDP_STAMP == 2
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[blockIdx.x * 4 + 0] = tw;
+        a.stamps[blockIdx.x * 4 + 1] = ta;
+        a.stamps[blockIdx.x * 4 + 2] = tb;
+        a.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - tstart;
+    }
+#else
     SDP_STAMP_END(a);
+#endif
+#undef SDP_COL_MARK
 }
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)

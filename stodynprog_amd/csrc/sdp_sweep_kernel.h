@@ -33,7 +33,7 @@ typedef SDP_REAL sdp_real;
 #ifndef SDP_STAMP
 #define SDP_STAMP 0
 #endif
-#if SDP_STAMP
+#if SDP_STAMP == 1
 #define SDP_STAMP_BEGIN(a)                                                             \
     if ((a).stamps && threadIdx.x == 0) {                                              \
         (a).stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();                 \
