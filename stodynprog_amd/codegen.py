@@ -262,7 +262,12 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
             '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
             '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
-        ] + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + (
+        ] + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
+                  int(os.environ.get('SDP_COL_A_LW') or _order[1]))]
+             if (not os.environ.get('SDP_COL_A_ORDER') and per_control is None and
+                 (_order := column_build_order(int(col_cfg[0]), column[1],
+                                               int(window[2]) if window is not None else column[0]))[0] == 2)
+             else []) + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + (
             ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
@@ -424,6 +429,25 @@ def column_config(n0, w, n_state, dtype, wpair=False):
         if lds * (2 if threads == 512 else 1) <= COLUMN_LDS_MAX:
             return threads, lds
     return None
+
+
+def column_build_order(threads, w, rows):
+    """How phase A of the column kernel deals the W x rows table entries to the threads
+    (SDP_COL_A_ORDER / SDP_COL_A_LW of csrc/sdp_column_kernel.h): (2, lanes_per_w) when the
+    perturbation points fill the workgroup's thread groups -- a thread then keeps its w, reads
+    the trailing cell once and walks the rows with constant address steps (measured on MI355X:
+    256^3 x 64 x 32 fp64 -2 %, fp32 -3.5 %) -- else (0, 0): entries dealt round-robin (with 9
+    points on 16 groups of 32 lanes the first form leaves 44 % of the threads idle: +3 %)."""
+    w = max(int(w), 1)
+    best = (0, 0, 0.0)
+    for lw in (64, 32, 16, 8):
+        if lw > rows or threads % lw:
+            continue
+        groups = threads // lw
+        util = w / float(-(-w // groups) * groups)
+        if util > best[2] + 1e-9:
+            best = (2, lw, util)
+    return (best[0], best[1]) if best[2] >= 0.85 else (0, 0)
 
 
 def _column_lds(tw, w, rows, n_state, rs, threads):

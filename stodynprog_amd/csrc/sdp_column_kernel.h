@@ -72,7 +72,10 @@
 #define SDP_COL_A_GROUP 4        // table entries per thread whose vertex loads are issued together
 #endif
 #ifndef SDP_COL_A_ORDER
-#define SDP_COL_A_ORDER 0        // table build: 0 entries dealt round-robin, 1 consecutive w per thread
+#define SDP_COL_A_ORDER 0        // table build: 0 entries dealt round-robin; 1 a thread keeps its row and takes
+#endif                           //   consecutive w; 2 a thread keeps its w (SDP_COL_A_LW lanes per w) and walks the rows
+#ifndef SDP_COL_A_LW
+#define SDP_COL_A_LW 16
 #endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
@@ -255,7 +258,54 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
     const sdp_real *__restrict__ V = (const sdp_real *)a.V + s.r0;
     constexpr int G = SDP_COL_A_GROUP;
     constexpr int NV = 1 << SDP_DT;
-#if SDP_COL_A_ORDER == 1
+#if SDP_COL_A_ORDER == 2
+    // a thread keeps its perturbation point w and takes rows r, r + LW, r + 2 LW, ..: the
+    // trailing cell (offsets and weights) is read from LDS ONCE per thread instead of once
+    // per entry, and the addresses of consecutive entries differ by a constant (immediate
+    // offsets of the loads and of the table stores: no address arithmetic per entry).  LW
+    // consecutive lanes read LW consecutive rows (LW x sizeof(real) contiguous bytes).
+    constexpr int LW = SDP_COL_A_LW;                     // lanes (= consecutive rows) per perturbation point
+    const int WPASS = blockDim.x / LW;                   // perturbation points handled side by side (the
+    const int rl = threadIdx.x % LW;                     //  policy-evaluation launch has fewer threads)
+    for (int w = threadIdx.x / LW; w < Wn; w += WPASS) {
+        int off[SDP_DT];
+        sdp_real lam[SDP_DT], oml[SDP_DT];
+#pragma unroll
+        for (int k = 0; k < SDP_DT; ++k) {
+            off[k] = s.w_off[w * SDP_DT + k];
+            lam[k] = s.w_lam[w * SDP_DT + k];
+            oml[k] = s.w_oml[w * SDP_DT + k];
+        }
+#if SDP_COL_FUSED && SDP_HAS_W
+        const sdp_real pw_ = ((const sdp_real *)a.proba)[w];
+#endif
+        for (int j0 = 0; j0 * LW < N0; j0 += G) {
+            sdp_real vals[G][NV];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int r = min((j0 + j) * LW + rl, N0 - 1);           // clamp: result unused
+                SdpColGather<0>::run(V + r, tg, off, 0, vals[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int r = (j0 + j) * LW + rl;
+                if (r < N0) {
+                    const sdp_real val = SdpColNest<0, SHIFT>::run(vals[j], lam, oml, tg.shift);
+#if SDP_COL_FUSED && SDP_HAS_W
+                    const sdp_real entry = val * pw_;
+#else
+                    const sdp_real entry = val;
+#endif
+#if SDP_COL_WPAIR
+                    s.T[((w >> 1) * N0 + r) * 2 + (w & 1)] = entry;
+#else
+                    s.T[w * N0 + r] = entry;
+#endif
+                }
+            }
+        }
+    }
+#elif SDP_COL_A_ORDER == 1
     // a thread keeps its row r and takes G CONSECUTIVE perturbation points per round:
     // neighbouring points share part of their 2^(d-1) vertex strips (the cell of an
     // exogenous process moves by about one grid step per point), so the second read of
