@@ -95,3 +95,27 @@ def test_eval_policy_and_relative_dp(gpu):
     (Ka, ra), _ = one.value_iteration((Vd, 0.), rel_dp=True, report_time=False)
     (Kb, rb), _ = two.value_iteration((Vd, 0.), rel_dp=True, report_time=False)
     assert np.array_equal(Ka, Kb) and ra == rb
+
+
+def test_deterministic_and_float32_per_control_tables(gpu):
+    def make_det():
+        sysd = SysDescription((2, 1, 0), name='deterministic price maker')
+        sysd.dyn = lambda E, P, u: (E + u, 0.8 * P + 0.1 * u)
+        sysd.cost = lambda E, P, u: P * u + 0.2 * u * u + 0.01 * E
+        sysd.control_box = lambda E, P: ((-1., 1.),)
+        s = DPSolver(sysd)
+        s.discretize_state(0, 10, 70, -2, 2, 9)
+        s.control_steps = (0.125,)
+        return sysd, s
+    auto = _run(make_det, 'auto')
+    assert auto[3].backend_info['table_per_control']
+    _check_same(auto, _run(make_det, 'generic'))
+
+    def make32():
+        sysd, s = models.synthetic3d_coupled(N=20)
+        s.dtype = np.dtype(np.float32)
+        return sysd, s
+    V = models.synthetic3d_V0(make32()[1].state_grid, np.float32)
+    auto = _run(make32, 'auto', V=V)
+    assert auto[3].backend_info['table_per_control'] and auto[0].dtype == np.float32
+    _check_same(auto, _run(make32, 'generic', V=V))

@@ -92,3 +92,11 @@ def test_untraceable_model_runs_the_host_loop(gpu):
     pol = (0.1 * s.state_grid[0])[:, None]
     x, u, g = s.simulate(pol, [[0.5], [-0.5]], np.zeros((4, 2)))
     assert x.shape == (5, 2, 1) and np.allclose(x[1, :, 0], [0.55, -0.45])
+
+
+def test_empty_batch_and_zero_steps(gpu):
+    wec, solver = models.searev(n_E=5, n_S=5, n_A=5)
+    pol = models.searev_linear_policy(solver)
+    x, u, g = solver.simulate(pol, np.zeros((3, 3)) + [[5., 0., 0.]], np.zeros((0, 3)))
+    assert x.shape == (1, 3, 3) and u.shape == (0, 3, 1) and g.shape == (0, 3)
+    assert np.array_equal(x[0], np.zeros((3, 3)) + [[5., 0., 0.]])

@@ -141,3 +141,37 @@ def test_staged_relative_dp_and_eval_policy(gpu):
     Ea = one.eval_policy(pa, 3, report_time=False)
     Eb = two.eval_policy(pb, 3, report_time=False)
     assert np.array_equal(Ea, Eb)
+
+
+def test_staged_float32_and_large_grid_through_the_host_path(gpu):
+    """float32 staging (odd row stride rule) and a grid large enough for the host-array
+    path to run the backup in phases (downloads under the next phase's kernel): node
+    sub-ranges of a tile-walking kernel"""
+    for dtype, N in ((np.float32, 24), (np.float64, 112)):
+        res = []
+        for kernel in ('generic', 'staged'):
+            _, s = models.synthetic3d_coupled(N=N, cross=0.2)
+            s.dtype = np.dtype(dtype)
+            s.kernel = kernel
+            V = models.synthetic3d_V0(s.state_grid, dtype)
+            J, pol = s.value_iteration(V, report_time=False)
+            assert s.backend_info['kernel'] == kernel and J.dtype == dtype
+            res.append((J, pol, s.last_policy_index))
+        _same(res[0], res[1])
+
+
+def test_staged_minimal_axes(gpu):
+    """axes of two points (one cell), fewer nodes than a tile"""
+    def make():
+        sysd = SysDescription((3, 1, 1), name='tiny')
+        sysd.dyn = lambda a, b, c, u, w: (0.5 * a + u * b, b + w, 0.9 * c - 0.1 * u * a)
+        sysd.cost = lambda a, b, c, u, w: a * a + u * u + c * w
+        sysd.control_box = lambda a, b, c: ((0., 1.),)
+        sysd.perturb_laws = [NormalLaw(0, 0.2)]
+        s = DPSolver(sysd)
+        s.discretize_state(0, 1, 2, -1, 1, 3, 0, 2, 2)
+        s.discretize_perturb(-0.4, 0.4, 3)
+        s.control_steps = (0.5,)
+        return sysd, s
+    a, b = _both(make)
+    _same(a, b)

@@ -90,3 +90,9 @@ def test_window_eval_policy_and_relative_dp(gpu):
     (Ka, ra), _ = one.value_iteration((Vd, 0.), rel_dp=True, report_time=False)
     (Kb, rb), _ = two.value_iteration((Vd, 0.), rel_dp=True, report_time=False)
     assert np.array_equal(Ka, Kb) and ra == rb
+
+
+def test_window_with_a_ragged_leading_axis(gpu):
+    """1000 rows: not a multiple of the segment or of the wavefront"""
+    a, b = _pair(lambda: _long_lead(N0=1000, n1=7, n2=9))
+    _check(a, b)
