@@ -938,11 +938,8 @@ SDP_DEV void sdp_col_window_predict(const SdpSweepArgs &a, const SdpLeadAxis &l,
 #endif
         }
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        qmin = min(qmin, __shfl_xor(qmin, m, 64));
-        nqmax = min(nqmax, __shfl_xor(nqmax, m, 64));
-    }
+    qmin = sdp_wave_min(qmin);
+    nqmax = sdp_wave_min(nqmax);
     if ((threadIdx.x & 63) == 0 && qmin != INT_MAX) {
         atomicMin(&win[parity][0], qmin);
         atomicMin(&win[parity][1], nqmax);

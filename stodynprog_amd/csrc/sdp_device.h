@@ -208,6 +208,12 @@ SDP_DEV bool sdp_better_idx(real cv, int ci, real bv, int bi)
     return (cv < bv) || (cv == bv && ci < bi);
 }
 
+// wavefront-wide integer min / max (DPP row operations, no LDS traffic); every lane gets the result
+extern "C" __device__ int __ockl_wfred_min_i32(int);
+extern "C" __device__ int __ockl_wfred_max_i32(int);
+SDP_DEV int sdp_wave_min(int v) { return __ockl_wfred_min_i32(v); }
+SDP_DEV int sdp_wave_max(int v) { return __ockl_wfred_max_i32(v); }
+
 SDP_DEV double sdp_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 SDP_DEV float sdp_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 

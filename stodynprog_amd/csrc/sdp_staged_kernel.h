@@ -188,9 +188,7 @@ extern "C" __global__ void __launch_bounds__(SDP_STG_THREADS, SDP_STG_THREADS / 
         if (tid == 0) sh.n_ctrl = 0;
         __syncthreads();
         {
-            int m = total;
-#pragma unroll
-            for (int s = 1; s < 64; s <<= 1) m = max(m, __shfl_xor(m, s, 64));
+            const int m = sdp_wave_max(total);
             if (lane == 0 && m > 0) atomicMax(&sh.n_ctrl, m);
         }
         __syncthreads();
@@ -234,11 +232,8 @@ extern "C" __global__ void __launch_bounds__(SDP_STG_THREADS, SDP_STG_THREADS / 
                 }
 #pragma unroll
                 for (int k = 0; k < SDP_D; ++k) {
-#pragma unroll
-                    for (int s = 1; s < 64; s <<= 1) {
-                        lo[k] = min(lo[k], __shfl_xor(lo[k], s, 64));
-                        nhi[k] = min(nhi[k], __shfl_xor(nhi[k], s, 64));
-                    }
+                    lo[k] = sdp_wave_min(lo[k]);
+                    nhi[k] = sdp_wave_min(nhi[k]);
                 }
                 if (lane == 0) {
 #pragma unroll
