@@ -247,13 +247,15 @@ class _PinnedBlock(object):
 
 _pinned_free = {}            # nbytes -> [ptr, ...]
 _pinned_live = {}            # ptr -> nbytes of blocks currently viewed by arrays
-PINNED_KEEP = 6              # free blocks kept per size
+PINNED_KEEP = 4              # free blocks kept per size ...
+PINNED_KEEP_BYTES = 4 << 30  # ... and in total (page-locked memory is a scarce resource)
 
 
 def _pinned_release(ptr, nbytes):
     _pinned_live.pop(ptr, None)
     free = _pinned_free.setdefault(nbytes, [])
-    if len(free) < PINNED_KEEP:
+    pooled = sum(n * len(v) for n, v in _pinned_free.items())
+    if len(free) < PINNED_KEEP and pooled + nbytes <= PINNED_KEEP_BYTES:
         free.append(ptr)
     elif _lib is not None:
         _lib.sdp_host_free(C.c_void_p(ptr))

@@ -1253,3 +1253,42 @@ def test_random_models_match_numpy_bit_for_bit(gpu, seed):
         assert np.allclose(J, Jo, rtol=1e-13, atol=1e-15, equal_nan=True), (lead, trail, cst)
         clear = mo > 1e-12 * max(1.0, np.nanmax(np.abs(Jo)))
         assert np.array_equal(solver.last_policy_index[clear], io[clear])
+
+
+def test_host_array_path_in_phases_equals_the_plain_downloads(gpu):
+    """value_iteration on a large grid runs the backup in phases and downloads the finished
+    rows under the next phase's kernel (strided 2-D copies of transposed sub-blocks in the
+    column layout; sdp_problem_backup_host).  Same arrays as the step-by-step entry points
+    -- two controls (16-byte policy rows), relative DP, float32, a node-layout problem"""
+    def pair(make, rel_dp=False):
+        _, a = make()
+        _, b = make()
+        V = np.random.default_rng(21).standard_normal(a._state_grid_shape).astype(a.dtype)
+        if rel_dp:
+            V = V - V[a._state_ref_ind]
+        arg = (V, 0.) if rel_dp else V
+        Ja, pa = quiet(a.value_iteration, arg, rel_dp)
+        Jb, pb = quiet(b.value_iterations, arg, 1, rel_dp)          # set_value / sweep / get_value / get_policy
+        if rel_dp:
+            assert Ja[1] == Jb[1]
+            Ja, Jb = Ja[0], Jb[0]
+        assert a._state_grid_shape == Ja.shape and Ja.nbytes >= 8 << 20
+        assert np.array_equal(Ja, Jb) and np.array_equal(pa, pb)
+        assert np.array_equal(a.last_policy_index, b.last_policy_index)
+        return a
+    s = pair(lambda: models.storage_ar1(n_E=1200, n_P=1000, steps=(1.0, 0.1)))
+    assert s.backend_info['kernel'] == 'column' and len(s.sys.control) == 2
+    pair(lambda: models.storage_ar1(n_E=1200, n_P=1000, steps=(1.0, 0.1)), rel_dp=True)
+
+    def f32():
+        sysd, ref = models.synthetic3d(N=144)
+        ref.dtype = np.dtype(np.float32)
+        return sysd, ref
+    pair(f32)
+
+    def staged():
+        sysd, ref = models.synthetic3d_coupled(N=104, cross=0.1)
+        ref.control_steps = (0.5,)
+        return sysd, ref
+    s = pair(staged)
+    assert s.backend_info['kernel'] == 'staged'
