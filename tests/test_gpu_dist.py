@@ -261,3 +261,36 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
     import glob
     for leftover in glob.glob('/dev/shm/sdp_mock_*'):      # bench.py leaves its communicator to the OS
         os.unlink(leftover)
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_the_real_launcher(gpu, tmp_path):
+    """The driver's exact command line for N > 1 -- `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`
+    -- on the one GPU of the test box (both ranks on device 0, collectives through the
+    stand-in): the launcher owns MASTER_PORT, sets TORCHELASTIC_* and is the parent of both
+    workers, which is what dist.FileRendezvous keys its file on; the workers never import torch."""
+    import json
+    if importlib.util.find_spec('torch') is None:
+        pytest.skip('torch (the launcher) not installed')
+    mock = _build_mock(tmp_path)
+    port = _free_port()
+    env = dict(os.environ, SDP_RCCL_LIBRARY=mock, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--grid', '48', '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850,
+                         cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True and d['value'] > 0, d
+    assert d['config']['torch_imported'] is False
+    import glob
+    for leftover in glob.glob('/dev/shm/sdp_mock_*'):
+        os.unlink(leftover)
+    assert not glob.glob('/dev/shm/sdp_rccl_uid_{}_*'.format(port))      # rank 0 removed its file
