@@ -59,9 +59,6 @@
 #ifndef SDP_COL_THREADS
 #define SDP_COL_THREADS 512
 #endif
-#ifndef SDP_COL_UNROLL_U
-#define SDP_COL_UNROLL_U 2       // controls evaluated together per lane (independent chains)
-#endif
 #ifndef SDP_COL_UNROLL_W
 #define SDP_COL_UNROLL_W 4       // unroll factor of the perturbation loop (in batches)
 #endif
@@ -92,6 +89,15 @@
 #define SDP_COL_BATCH 2
 #else
 #define SDP_COL_BATCH 4
+#endif
+#endif
+#ifndef SDP_COL_UNROLL_U
+// controls evaluated together per lane (independent chains).  Same-box A/B, 256^3 x 64 x 32:
+// fp64 plain table 2 -> 8.96 ms, 4 -> 9.08 ms; fp32 pair layout 2 -> 5.35 ms, 4 -> 5.19 ms
+#if SDP_COL_WPAIR
+#define SDP_COL_UNROLL_U 4
+#else
+#define SDP_COL_UNROLL_U 2
 #endif
 #endif
 #if SDP_COL_WPAIR && (!SDP_HAS_W || SDP_LEAD_HAS_W)
