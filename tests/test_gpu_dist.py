@@ -35,7 +35,9 @@ rng = np.random.default_rng(11)                     # same stream on both ranks
 CASES = [('synthetic3d', dict(N=20), 'column'),
          ('storage_ar1', dict(), 'column'),          # 61 column planes: uneven slabs
          ('nas_demo', dict(), None),
-         ('inventory', dict(), None)]
+         ('inventory', dict(), None),
+         ('synthetic3d_coupled', dict(N=20), 'column'),              # table per control
+         ('synthetic3d_coupled', dict(N=18, cross=0.2), 'staged')]   # LDS-staged tiles
 for name, kw, kernel in CASES:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
@@ -195,7 +197,9 @@ def quiet(fn, *a, **k):
 
 CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3), ('synthetic3d', dict(N=20), -4),
          ('storage_ar1', dict(), 4),                  # 61 columns: uneven parts -> broadcasts
-         ('nas_demo', dict(), 4), ('inventory', dict(), 4)]
+         ('nas_demo', dict(), 4), ('inventory', dict(), 4),          # inventory: LDS-staged tiles, node ranges
+         ('synthetic3d_coupled', dict(N=20), 4),                     # column kernel, table per control
+         ('synthetic3d_coupled', dict(N=18, cross=0.2), 3)]          # staged tiles in 3-D, ragged
 for name, kw, phases in CASES:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
