@@ -394,7 +394,8 @@ def run(args):
         'lattice_cells_per_sec': cells * sweeps_per_s,
         'roofline': roof,
     }
-    if world == 1 and kernel_family == 'column' and args.fused:
+    if world == 1 and kernel_family == 'column' and args.fused and not solver.backend_info.get('row_window') \
+            and not solver.backend_info.get('table_per_control'):
         # secondary figure (never the headline `value`): the opt-in fused-arithmetic
         # variant of the same kernel (weight-scaled LDS table + FMAs; J within
         # ~1e-15 relative of the exact kernel)
@@ -408,7 +409,11 @@ def run(args):
             fprob.swap()
             _, fk = fprob.bench_sweeps(args.steps)
             out['fused_arithmetic'] = {'kernel_ms': fk / args.steps, 'sweeps_per_s': 1e3 * args.steps / fk,
-                                       'note': 'opt-in DPSolver.arithmetic="fused"; not the reference rounding sequence'}
+                                       'note': 'SECONDARY figure, never the headline `value`: opt-in '
+                                               'DPSolver.arithmetic="fused" (weight-scaled LDS table + 2 FMAs per '
+                                               'cell instead of the reference\'s 6 separately rounded operations; J '
+                                               'within ~1e-15 relative of the exact kernel, inside the 1e-10 parity '
+                                               'bar but not the reference rounding sequence); LDS-read bound'}
         except Exception as e:
             out['fused_arithmetic'] = {'error': repr(e)}
     if world > 1 or os.environ.get('SDP_BENCH_SELFCHECK'):
@@ -451,7 +456,8 @@ def main():
                     help='kernel family (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fused', action='store_true',
-                    help='also time the opt-in fused-arithmetic variant (secondary figure)')
+                    help='also time the opt-in fused-arithmetic variant (secondary figure; off by default so '
+                         'that a profile of the default command holds ONE flavour of sdp_sweep_col)')
     ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))
