@@ -37,6 +37,7 @@ import json
 import os
 import sys
 import time
+import warnings
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -250,7 +251,7 @@ def run(args):
             dev_comm.barrier()
             nat.check(nat.lib().sdp_synchronize())
 
-    phase_times = None
+    phase_times, peer_note = None, None
     if dev_comm is not None:
         # Untimed tuning of the comm/compute overlap: how many phases a backup is cut
         # into (each phase's all-gather runs under the next phase's kernel).  Few
@@ -258,24 +259,52 @@ def run(args):
         # collectives; the best count depends on the rank count and the fabric.
         # Every rank times the same candidates; the max over ranks decides, so all
         # ranks pick the same count.
+        exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,peer').split(',') if e]
         if os.environ.get('SDP_COMM_PHASES'):
             solver.comm_phases = int(os.environ['SDP_COMM_PHASES'])
+            solver.comm_exchange = exchanges[0]
         else:
-            phase_times = {}
-            for ph, taper in ((2, False), (4, False), (8, False), (16, False), (4, True), (8, True)):
-                solver.comm_phases, solver.comm_taper = ph, taper
-                trial = solver._problem()
-                trial.set_value(V0)
-                trial.bench_sweeps(2)
-                trial.swap()
-                sync_all()
-                t0 = time.perf_counter()
-                trial.bench_sweeps(3)
-                sync_all()
-                phase_times['{}{}'.format(ph, 't' if taper else '')] = \
-                    dev_comm.allreduce_max(time.perf_counter() - t0) / 3 * 1e3
+            # Second dimension: how the rows travel.  'rccl' = all-gather kernels of the
+            # collective library; 'peer' = every rank copies its rows into the peers' buffers
+            # (HIP IPC mappings, copy engines, no compute units).  'peer' is a candidate only
+            # where every rank can map every peer, and only if its J equals the RCCL one bit
+            # for bit on every rank after the same sweeps.
+            phase_times, J_check = {}, None
+            for exch in exchanges:
+                if dev_comm.nranks == 1 and exch != 'rccl':
+                    continue
+                for ph, taper in ((2, False), (4, False), (8, False), (16, False), (4, True), (8, True)):
+                    solver.comm_phases, solver.comm_taper, solver.comm_exchange = ph, taper, exch
+                    with warnings.catch_warnings():
+                        warnings.simplefilter('ignore')
+                        trial = solver._problem()
+                    if solver.backend_info.get('exchange', 'rccl') != exch:
+                        peer_note = 'peer exchange unavailable on this node (buffers not mappable)'
+                        break
+                    trial.set_value(V0)
+                    trial.bench_sweeps(2)
+                    trial.swap()
+                    sync_all()
+                    t0 = time.perf_counter()
+                    trial.bench_sweeps(3)
+                    sync_all()
+                    t = dev_comm.allreduce_max(time.perf_counter() - t0) / 3 * 1e3
+                    key = '{}{}{}'.format(ph, 't' if taper else '', '' if exch == 'rccl' else '/' + exch)
+                    if (ph, taper) == (4, False):           # one result check per exchange
+                        J_now = trial.get_value()
+                        if J_check is None:
+                            J_check = J_now
+                        elif dev_comm.allreduce_max(0.0 if np.array_equal(J_now, J_check) else 1.0) > 0:
+                            peer_note = '{} exchange rejected: J differs from the RCCL result'.format(exch)
+                            phase_times = {k: v for k, v in phase_times.items() if '/' + exch not in k}
+                            break
+                        del J_now
+                    phase_times[key] = t
             best = min(phase_times, key=lambda k: (phase_times[k], k))
-            solver.comm_phases, solver.comm_taper = int(best.rstrip('t')), best.endswith('t')
+            plan, _, exch = best.partition('/')
+            solver.comm_phases, solver.comm_taper = int(plan.rstrip('t')), plan.endswith('t')
+            solver.comm_exchange = exch or 'rccl'
+            del J_check
 
     prob = solver._problem()
     assert solver.backend_info['max_controls'] == U_max
@@ -384,10 +413,13 @@ def run(args):
                    'lattice_cells_per_sweep': cells,
                    'kernel_family': kernel_family,
                    'sharding': ('single GPU' if dev_comm is None else
-                                'columns dealt in {} {}phases x {} ranks; RCCL all-gather of each phase '
-                                'of J under the kernel of the next phase'.format(
-                                    int(prob.parts.shape[0]), 'tapered ' if solver.comm_taper else '',
-                                    world)),
+                                'columns dealt in {} {}phases x {} ranks; {} of each phase of J under the '
+                                'kernel of the next phase'.format(
+                                    int(prob.parts.shape[0]), 'tapered ' if solver.comm_taper else '', world,
+                                    'peer writes (HIP IPC, copy engines)'
+                                    if solver.backend_info.get('exchange') == 'peer' else 'RCCL all-gather')),
+                   'comm_exchange': None if dev_comm is None else solver.backend_info.get('exchange'),
+                   'comm_exchange_note': peer_note,
                    'comm_phase_tuning_ms_per_sweep': phase_times,
                    'torch_imported': 'torch' in sys.modules},
         'state_cells_per_sec': S * sweeps_per_s,

@@ -267,6 +267,17 @@ const char *sdp_comm_library(void);      /* path/name the nccl* symbols came fro
  */
 int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
                             const int64_t *part_bounds /* [n_phases][nranks+1] */);
+/*
+ * Alternative exchange for the sharded backups: every rank maps the other ranks' value / J
+ * buffers (HIP IPC) and, phase by phase, WRITES its rows into them with device-to-device
+ * copies on one stream per peer -- copy engines over xGMI, no compute units, all links of the
+ * fully connected node at once -- instead of an RCCL all-gather per phase.  The writes are
+ * one-sided, so two 1-word all-reduces bracket them: one before the first write of an API call
+ * (every peer has returned from its previous call, i.e. finished reading its J), one at the end
+ * of every backup (all rows have landed everywhere).  Same results.  Collective (all ranks
+ * call it, after sdp_problem_attach_comm); on failure the handle keeps the RCCL exchange.
+ */
+int sdp_problem_enable_peer_exchange(sdp_problem *p);
 int sdp_comm_allreduce_max(sdp_comm *c, double *inout);    /* host scalar, for timing */
 int sdp_comm_barrier(sdp_comm *c);
 

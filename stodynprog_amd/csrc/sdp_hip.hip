@@ -499,7 +499,7 @@ static int launch_transpose(const void *in, void *out, int64_t R, int64_t C, int
 // ---------------------------------------------------------------------------
 typedef struct { char internal[128]; } nccl_uid;
 typedef void *nccl_comm_t;
-enum { NCCL_INT8 = 0, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_MAX = 2 };
+enum { NCCL_INT8 = 0, NCCL_INT32 = 2, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_MAX = 2 };
 
 struct RcclApi {
     void *h = nullptr;
@@ -633,6 +633,15 @@ struct sdp_problem {
     DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps;
     DevBuf stage[3];                       // layout-conversion buffers of the fused host call (J, pol, idx)
     size_t stage_bytes[3] = {0, 0, 0};
+    // peer-write exchange (sdp_problem_enable_peer_exchange): the other ranks' value / J buffers
+    // mapped into this process, one copy stream per peer
+    bool peer_exchange = false;
+    std::vector<void *> peer_V, peer_J;    // [nranks] (own entry: the local buffer)
+    std::vector<hipStream_t> peer_stream;  // [nranks] (own entry unused)
+    std::vector<hipEvent_t> peer_done;     // [nranks]
+    int *d_flag = nullptr;                 // word for the rendezvous all-reduces
+    hipEvent_t ev_enter = nullptr, ev_fence = nullptr;
+    bool peer_fence = true;                // next backup is the first of an API call: see open_pushes
     hipStream_t copy_stream = nullptr;     // downloads of finished phases, under the next phase's kernel
     hipEvent_t ev_host[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_copy = nullptr;
@@ -654,6 +663,23 @@ struct sdp_problem {
     int cus = 256;
     int refs_cap = 0;
     int col_threads = 512;
+    void release_peers()
+    {
+        const int me = comm ? comm->rank : -1;
+        for (size_t r = 0; r < peer_V.size(); ++r) {
+            if ((int)r == me) continue;
+            if (peer_V[r]) (void)hipIpcCloseMemHandle(peer_V[r]);
+            if (peer_J[r]) (void)hipIpcCloseMemHandle(peer_J[r]);
+        }
+        peer_V.clear(); peer_J.clear();
+        for (auto &st : peer_stream) if (st) (void)hipStreamDestroy(st);
+        for (auto &e : peer_done) if (e) (void)hipEventDestroy(e);
+        peer_stream.clear(); peer_done.clear();
+        if (d_flag) { (void)hipFree(d_flag); d_flag = nullptr; }
+        if (ev_enter) { (void)hipEventDestroy(ev_enter); ev_enter = nullptr; }
+        if (ev_fence) { (void)hipEventDestroy(ev_fence); ev_fence = nullptr; }
+        peer_exchange = false;
+    }
     ~sdp_problem()
     {
         if (mod) (void)hipModuleUnload(mod);
@@ -662,6 +688,7 @@ struct sdp_problem {
         if (ev2) (void)hipEventDestroy(ev2);
         if (ev3) (void)hipEventDestroy(ev3);
         if (ev_comm) (void)hipEventDestroy(ev_comm);
+        release_peers();
         if (ev_copy) (void)hipEventDestroy(ev_copy);
         for (auto &e : ev_host) if (e) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -1032,6 +1059,62 @@ static int gather_phase_of(sdp_problem *p, int phase, void *buffer, size_t elem_
     return SDP_OK;
 }
 
+// Peer-write form of the exchange of one phase of J: this rank's rows of the phase go straight
+// into every other rank's J buffer (mapped through HIP IPC) as device-to-device copies on one
+// stream per peer -- copy engines over xGMI, no compute units, all links at once -- ordered
+// behind the phase's kernel by `after`.
+static int push_phase(sdp_problem *p, int phase, hipEvent_t after)
+{
+    const int n = p->comm->nranks, me = p->comm->rank;
+    const int64_t *b = p->parts.data() + (size_t)phase * (n + 1);
+    const size_t rs = real_size(p->dtype);
+    const size_t off = (size_t)b[me] * rs, bytes = (size_t)(b[me + 1] - b[me]) * rs;
+    if (!bytes) return SDP_OK;
+    for (int k = 1; k < n; ++k) {
+        const int q = (me + k) % n;                       // start with a different peer on every rank
+        HIP_TRY(hipStreamWaitEvent(p->peer_stream[q], after, 0));
+        HIP_TRY(hipMemcpyAsync((char *)p->peer_J[q] + off, (const char *)p->J.p + off, bytes,
+                               hipMemcpyDeviceToDevice, p->peer_stream[q]));
+    }
+    return SDP_OK;
+}
+
+// Start of the first peer-write backup of an API call.  Writes into a peer's J are one-sided:
+// nothing in them waits for the peer, which may still be reading that buffer on behalf of its
+// PREVIOUS call (relative-DP shift, download to the host) when a faster rank starts the next
+// one.  So the first pushes of a call wait behind a tiny all-reduce that every rank joins only
+// once its previous call has returned.  It runs on the communicator stream under the first
+// phase's kernel.  Inside a chain of backups the end-of-backup rendezvous is enough (pushes of
+// step k+1 go to the buffer step k only read, and every rank's step-k kernels precede it).
+static int open_pushes(sdp_problem *p)
+{
+    const int n = p->comm->nranks, me = p->comm->rank;
+    hipStream_t cs = p->comm->stream;
+    HIP_TRY(hipEventRecord(p->ev_enter, p->stream));
+    HIP_TRY(hipStreamWaitEvent(cs, p->ev_enter, 0));
+    NCCL_TRY(g_rccl.AllReduce(p->d_flag, p->d_flag, 1, NCCL_INT32, NCCL_MAX, p->comm->comm, cs));
+    HIP_TRY(hipEventRecord(p->ev_fence, cs));
+    for (int q = 0; q < n; ++q)
+        if (q != me) HIP_TRY(hipStreamWaitEvent(p->peer_stream[q], p->ev_fence, 0));
+    p->peer_fence = false;
+    return SDP_OK;
+}
+
+// End of a peer-write backup: when the tiny all-reduce below completes on this rank, every
+// rank has passed its own copies (stream order), so all rows have landed everywhere.
+static int finish_pushes(sdp_problem *p)
+{
+    const int n = p->comm->nranks, me = p->comm->rank;
+    hipStream_t cs = p->comm->stream;
+    for (int q = 0; q < n; ++q) {
+        if (q == me) continue;
+        HIP_TRY(hipEventRecord(p->peer_done[q], p->peer_stream[q]));
+        HIP_TRY(hipStreamWaitEvent(cs, p->peer_done[q], 0));
+    }
+    NCCL_TRY(g_rccl.AllReduce(p->d_flag, p->d_flag, 1, NCCL_INT32, NCCL_MAX, p->comm->comm, cs));
+    return SDP_OK;
+}
+
 static int gather_phase(sdp_problem *p, int phase)
 {
     return gather_phase_of(p, phase, p->J.p, real_size(p->dtype));
@@ -1052,6 +1135,7 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
                        : launch_sweep(p, t_k, p->node_begin, p->node_end);
     }
     const int n = p->comm->nranks, rank = p->comm->rank;
+    if (n > 1 && p->peer_exchange && p->peer_fence && (rc = open_pushes(p))) return rc;
     for (int ph = 0; ph < p->n_phases; ++ph) {
         const int64_t *b = p->parts.data() + (size_t)ph * (n + 1);
         rc = evalpol ? launch_evalpol(p, t_k, b[rank], b[rank + 1], shift_index, ref_out)
@@ -1059,11 +1143,16 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
         if (rc) return rc;
         if (n > 1) {
             HIP_TRY(hipEventRecord(p->ev_phase[ph], p->stream));
-            HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
-            if ((rc = gather_phase(p, ph))) return rc;
+            if (p->peer_exchange) {
+                if ((rc = push_phase(p, ph, p->ev_phase[ph]))) return rc;
+            } else {
+                HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
+                if ((rc = gather_phase(p, ph))) return rc;
+            }
         }
     }
     if (n > 1) {
+        if (p->peer_exchange && (rc = finish_pushes(p))) return rc;
         HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
         p->comm_pending = true;
     }
@@ -1123,6 +1212,7 @@ extern "C" int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int6
                                     double *J_ref_out)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
+    p->peer_fence = true;                // first backup of a call (open_pushes)
     int rc;
     if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
     if ((rc = ensure_refs(p, 1))) return rc;
@@ -1139,10 +1229,17 @@ extern "C" int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int6
     return SDP_OK;
 }
 
+// V <-> J ping-pong.  Every rank swaps in lockstep, so the mapped peer buffers swap too.
+static void swap_buffers(sdp_problem *p)
+{
+    std::swap(p->V.p, p->J.p);
+    if (p->peer_exchange) p->peer_V.swap(p->peer_J);
+}
+
 extern "C" int sdp_problem_swap(sdp_problem *p)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
-    std::swap(p->V.p, p->J.p);
+    swap_buffers(p);
     return SDP_OK;
 }
 
@@ -1150,6 +1247,7 @@ extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_d
                                        int64_t ref_index, double *J_ref_out)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
+    p->peer_fence = true;                // first backup of a call (open_pushes)
     if (n_iter < 0) return fail(SDP_EINVAL, "negative iteration count");
     if (!p->pol_in.p) return fail(SDP_EINVAL, "no policy set (sdp_problem_set_policy)");
     int rc;
@@ -1169,7 +1267,7 @@ extern "C" int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_d
     // instead of three.
     double *refs = (double *)p->refs.p;
     for (int k = 0; k < n_iter; ++k) {
-        if (k > 0) std::swap(p->V.p, p->J.p);
+        if (k > 0) swap_buffers(p);
         const bool fused = rel_dp && k > 0;
         if ((rc = run_backup(p, true, 0.0, fused ? ref_index : -1, fused ? refs + (k - 1) : nullptr))) return rc;
         if ((rc = join_comm(p))) return rc;
@@ -1268,6 +1366,7 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
                                        int32_t *host_idx, double *J_ref_out)
 {
     if (!p || !host_J) return fail(SDP_EINVAL, "NULL argument");
+    p->peer_fence = true;                // first backup of a call (open_pushes)
     int rc;
     if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
     if ((rc = ensure_refs(p, 1))) return rc;
@@ -1443,6 +1542,7 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
                                         int64_t ref_index, double *loop_ms, double *kernel_ms)
 {
     if (!p || reps < 1) return fail(SDP_EINVAL, "bad arguments");
+    p->peer_fence = true;                // first backup of a call (open_pushes)
     int rc;
     if ((rc = check_ref(p, rel_dp, ref_index))) return rc;
     if ((rc = ensure_refs(p, 1))) return rc;
@@ -1455,7 +1555,7 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(p->ev2, p->stream));
     for (int r = 0; r < reps; ++r) {
-        if (r > 0) std::swap(p->V.p, p->J.p);
+        if (r > 0) swap_buffers(p);
         HIP_TRY(hipEventRecord(ev[2 * r], p->stream));
         if ((rc = run_backup(p, false, 0.0))) return rc;
         HIP_TRY(hipEventRecord(ev[2 * r + 1], p->stream));
@@ -1477,11 +1577,78 @@ extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp
     return SDP_OK;
 }
 
+// Map every other rank's value / J buffer into this process (HIP IPC) and switch the exchange
+// of the backups from RCCL all-gathers to peer writes (push_phase).  Collective: every rank of
+// the communicator calls it, after sdp_problem_attach_comm.  The handles travel through the
+// communicator itself (one all-gather of 2 x 64 bytes per rank).
+extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
+{
+    if (!p || !p->comm) return fail(SDP_EINVAL, "no communicator attached");
+    const int n = p->comm->nranks, me = p->comm->rank;
+    if (n == 1) return SDP_OK;
+    p->release_peers();
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+    std::vector<hipIpcMemHandle_t> all((size_t)2 * n);
+    HIP_TRY(hipIpcGetMemHandle(&all[2 * me], p->V.p));
+    HIP_TRY(hipIpcGetMemHandle(&all[2 * me + 1], p->J.p));
+    DevBuf stage;
+    int rc = stage.alloc(sizeof(hipIpcMemHandle_t) * 2 * n);
+    if (rc) return rc;
+    hipStream_t cs = p->comm->stream;
+    HIP_TRY(hipMemcpyAsync((char *)stage.p + (size_t)me * 128, &all[2 * me], 128, hipMemcpyHostToDevice, cs));
+    NCCL_TRY(g_rccl.AllGather((char *)stage.p + (size_t)me * 128, stage.p, 128, NCCL_INT8, p->comm->comm, cs));
+    HIP_TRY(hipMemcpyAsync(all.data(), stage.p, (size_t)n * 128, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    p->peer_V.assign(n, nullptr); p->peer_J.assign(n, nullptr);
+    p->peer_stream.assign(n, nullptr); p->peer_done.assign(n, nullptr);
+    p->peer_V[me] = p->V.p; p->peer_J[me] = p->J.p;
+    int failed = 0;
+    char why[256] = "";
+    for (int r = 0; r < n && !failed; ++r) {
+        if (r == me) continue;
+        hipError_t e = hipIpcOpenMemHandle(&p->peer_V[r], all[2 * r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) p->peer_V[r] = nullptr;
+        if (e == hipSuccess) {
+            e = hipIpcOpenMemHandle(&p->peer_J[r], all[2 * r + 1], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) p->peer_J[r] = nullptr;
+        }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->peer_stream[r], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->peer_done[r], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            failed = 1;
+            snprintf(why, sizeof(why), "mapping rank %d's buffers: %s", r, hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
+    if (!failed && hipMalloc((void **)&p->d_flag, 8) != hipSuccess) { failed = 1; snprintf(why, sizeof(why), "hipMalloc"); }
+    if (!failed && (hipEventCreateWithFlags(&p->ev_enter, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&p->ev_fence, hipEventDisableTiming) != hipSuccess)) {
+        failed = 1; snprintf(why, sizeof(why), "hipEventCreate");
+    }
+    // all ranks or none: the ranks agree on the outcome before anybody writes into a peer
+    // (this also guarantees that every rank has mapped everything before the first write)
+    int *d_fail = (int *)stage.p;
+    HIP_TRY(hipMemcpyAsync(d_fail, &failed, sizeof(int), hipMemcpyHostToDevice, cs));
+    NCCL_TRY(g_rccl.AllReduce(d_fail, d_fail, 1, NCCL_INT32, NCCL_MAX, p->comm->comm, cs));
+    int any_failed = 0;
+    HIP_TRY(hipMemcpyAsync(&any_failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    if (any_failed) {
+        p->release_peers();
+        return fail(SDP_ECOMM, "peer exchange not available (%s): the RCCL exchange stays in place",
+                    failed ? why : "another rank could not map its peers");
+    }
+    HIP_TRY(hipMemset(p->d_flag, 0, 8));
+    p->peer_exchange = true;
+    p->peer_fence = true;
+    return SDP_OK;
+}
+
 extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
                                        const int64_t *part_bounds)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
-    if (!c) { p->comm = nullptr; p->parts.clear(); p->n_phases = 0; return SDP_OK; }
+    if (!c) { p->release_peers(); p->comm = nullptr; p->parts.clear(); p->n_phases = 0; return SDP_OK; }
     if (!part_bounds || n_phases < 1) return fail(SDP_EINVAL, "phase partition missing");
     const int n = c->nranks;
     std::vector<int64_t> parts(part_bounds, part_bounds + (size_t)n_phases * (n + 1));

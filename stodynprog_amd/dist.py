@@ -160,26 +160,38 @@ class RcclCommunicator(_Base):
             self.handle = None
 
 
+def _proc_start_time(pid):
+    """start time of process `pid` in clock ticks since boot (/proc/<pid>/stat, field 22), or
+    None when there is no such process"""
+    try:
+        with open('/proc/{}/stat'.format(int(pid)), 'rb') as f:
+            raw = f.read()
+        return int(raw[raw.rindex(b')') + 2:].split()[19])
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 class FileRendezvous(object):
     """Hand-off of the 128-byte RCCL unique id between the ranks of ONE node
     through a file (default directory /dev/shm), with nothing but the Python
     standard library: a process that shards sweeps never imports torch.
 
-    Rank 0 writes the id atomically (temp file + rename); the others poll for
-    it.  The file name is built from what the launcher gives every rank of one
-    job and no rank of another: MASTER_PORT, the launcher's pid (the workers
-    of `python -m torch.distributed.run` are children of one agent process),
-    torchelastic's run id and restart count.  A file older than this process
-    minus `stale_s` seconds is ignored (left behind by a crashed job), rank 0
-    replaces any such file and removes its own once every rank has joined the
-    communicator.  SDP_RENDEZVOUS_FILE overrides the path (ranks started by
-    hand from different shells)."""
+    Rank 0 writes the id atomically (temp file + rename) together with its own
+    pid and process start time; the others poll for the file and accept it
+    only while THAT process is alive (same pid, same start time in
+    /proc/<pid>/stat) -- a file left behind by a crashed job names a dead
+    process and is ignored, however recent it is.  The file name is built from
+    what a launcher gives every rank of a job: MASTER_PORT (one job per port on
+    a node), WORLD_SIZE, torchelastic's run id and restart count; rank 0
+    removes the file once every rank has joined the communicator.
+    SDP_RENDEZVOUS_FILE overrides the path."""
 
-    def __init__(self, rank, world, timeout_s=None, stale_s=180.0):
+    MAGIC = b'SDPUID1\n'
+
+    def __init__(self, rank, world, timeout_s=None):
         self.rank, self.world = int(rank), int(world)
         self.timeout_s = float(os.environ.get('SDP_RENDEZVOUS_TIMEOUT', 600)
                                if timeout_s is None else timeout_s)
-        self.stale_s = float(stale_s)
         self.path = os.environ.get('SDP_RENDEZVOUS_FILE') or self.default_path()
 
     @staticmethod
@@ -189,21 +201,43 @@ class FileRendezvous(object):
             '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK)
             else tempfile.gettempdir())
         key = '_'.join(str(v) for v in (
-            os.environ.get('MASTER_PORT', '0'), os.getppid(),
+            os.environ.get('MASTER_PORT', '0'), os.environ.get('WORLD_SIZE', '1'),
             os.environ.get('TORCHELASTIC_RUN_ID', 'none'),
-            os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'),
-            os.environ.get('WORLD_SIZE', '1')))
+            os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')))
         key = ''.join(c if (c.isalnum() or c in '_-') else '-' for c in key)
         return os.path.join(base, 'sdp_rccl_uid_' + key)
 
     def publish(self, payload):
         """rank 0: make `payload` (bytes) visible to the other ranks"""
-        tmp = '{}.tmp.{}'.format(self.path, os.getpid())
+        pid = os.getpid()
+        head = '{} {} {}\n'.format(pid, _proc_start_time(pid) or 0, len(payload)).encode()
+        tmp = '{}.tmp.{}'.format(self.path, pid)
         with open(tmp, 'wb') as f:
-            f.write(len(payload).to_bytes(4, 'little') + payload)
+            f.write(self.MAGIC + head + payload)
             f.flush()
             os.fsync(f.fileno())
-        os.replace(tmp, self.path)          # atomic: readers see nothing or everything
+        os.replace(tmp, self.path)          # atomic: readers see the old file, or all of the new one
+
+    def _read(self):
+        """payload of the file if it is complete and its writer is alive, else None"""
+        try:
+            with open(self.path, 'rb') as f:
+                raw = f.read()
+        except OSError:
+            return None
+        if not raw.startswith(self.MAGIC):
+            return None
+        try:
+            head, rest = raw[len(self.MAGIC):].split(b'\n', 1)
+            pid, start, size = (int(x) for x in head.split())
+        except ValueError:
+            return None
+        if len(rest) != size:
+            return None
+        alive = _proc_start_time(pid)
+        if alive is None or (start and alive != start):
+            return None                      # written by a process that is gone: a crashed job's file
+        return rest
 
     def fetch(self):
         """other ranks: wait for rank 0's payload"""
@@ -211,17 +245,11 @@ class FileRendezvous(object):
         t0 = time.time()
         delay = 0.002
         while True:
-            try:
-                st = os.stat(self.path)
-                if st.st_mtime >= t0 - self.stale_s:
-                    with open(self.path, 'rb') as f:
-                        raw = f.read()
-                    if len(raw) >= 4 and len(raw) == 4 + int.from_bytes(raw[:4], 'little'):
-                        return raw[4:]
-            except OSError:
-                pass
+            payload = self._read()
+            if payload is not None:
+                return payload
             if time.time() - t0 > self.timeout_s:
-                raise TimeoutError('rank {}: no RCCL unique id from rank 0 at {} after {:.0f} s'
+                raise TimeoutError('rank {}: no RCCL unique id from a live rank 0 at {} after {:.0f} s'
                                    .format(self.rank, self.path, self.timeout_s))
             time.sleep(delay)
             delay = min(delay * 1.5, 0.1)

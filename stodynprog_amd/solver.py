@@ -208,6 +208,11 @@ class DPSolver(object):
         # vertex, the first kernel) force a family.  All give the same bits.
         self.kernel = 'auto'
         self.comm_phases = 4               # multi-GPU: phases per backup (comm/compute overlap)
+        # multi-GPU: how the J rows of a phase reach the other ranks -- 'rccl': in-place all-gather;
+        # 'peer': every rank writes its rows straight into the others' buffers (HIP IPC mappings,
+        # device-to-device copies over xGMI, no compute units); falls back to 'rccl' when the
+        # buffers cannot be mapped (backend_info['exchange'] tells which one runs)
+        self.comm_exchange = 'rccl'
         self.comm_taper = False            # multi-GPU: shrinking phases (smallest gather exposed)
         # 'exact': every floating-point operation of the reference, same order (default);
         # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
@@ -430,7 +435,8 @@ class DPSolver(object):
         # key, so a recycled id() can never alias a stale entry)
         parts = [s.dyn, s.cost, s.control_box, _params_key(s.params),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
-                 id(self.comm), self.comm_phases, self.comm_taper, self.kernel, self.arithmetic]
+                 id(self.comm), self.comm_phases, self.comm_taper, self.comm_exchange, self.kernel,
+                 self.arithmetic]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         # the tuple itself is the cache key (not its hash): the callables stay alive as
@@ -739,7 +745,19 @@ class DPSolver(object):
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
                               bounds, layout, plan['staged'], plan['col_seg_nodes'])
         self._cache[fp] = prob
-        prob.info = dict(mode='traced',
+        exchange = None
+        if self.comm is not None and self.comm.is_device and self.comm.nranks > 1:
+            exchange = 'rccl'
+            if self.comm_exchange == 'peer':
+                try:                                        # collective: all ranks succeed or none
+                    nat.check(nat.lib().sdp_problem_enable_peer_exchange(prob.h))
+                    exchange = 'peer'
+                except RuntimeError as e:
+                    import warnings
+                    warnings.warn('peer exchange unavailable, using the RCCL all-gather: {}'.format(e))
+            elif self.comm_exchange != 'rccl':
+                raise ValueError("comm_exchange must be 'rccl' or 'peer'")
+        prob.info = dict(mode='traced', exchange=exchange,
                          kernel='column' if column else ('staged' if plan['staged'] else 'generic'),
                          staged=plan['staged'],
                          row_window=(dict(rows=plan['window'][2], segment_nodes=plan['window'][3])

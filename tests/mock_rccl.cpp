@@ -131,8 +131,19 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int roo
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, void *h, hipStream_t stream)
 {
     Comm *c = (Comm *)h;
-    if (dtype != 8 || op != 2 || count != 1) return 4;              // float64 max of one value
+    if ((dtype != 8 && dtype != 2) || op != 2 || count != 1) return 4;   // max of one float64 / int32
     if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    if (dtype == 2) {
+        int v;
+        if (hipMemcpy(&v, send, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        memcpy(slot(c, c->rank), &v, 4);
+        barrier(c);
+        int best = v;
+        for (int r = 0; r < c->n; ++r) { int o; memcpy(&o, slot(c, r), 4); if (o > best) best = o; }
+        barrier(c);
+        if (hipMemcpy(recv, &best, 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        return 0;
+    }
     double v;
     if (hipMemcpy(&v, send, 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     memcpy(slot(c, c->rank), &v, 8);

@@ -154,8 +154,9 @@ def test_library_load_never_imports_torch():
 
 
 def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
-    """dist.FileRendezvous: atomic publish by rank 0, polling readers, stale
-    files of a crashed job ignored, rank 0 removes its file."""
+    """dist.FileRendezvous: atomic publish by rank 0, polling readers; a file whose
+    writer is no longer alive (a crashed job, however recent) is ignored; rank 0
+    removes its file"""
     import threading
     import time
     monkeypatch.setenv('SDP_RENDEZVOUS_DIR', str(tmp_path))
@@ -163,12 +164,12 @@ def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
     monkeypatch.setenv('WORLD_SIZE', '4')
     payload = bytes(range(128))
     path = dist.FileRendezvous.default_path()
-    assert path.startswith(str(tmp_path)) and '29123' in path and str(os.getppid()) in path
-    # a stale file (previous crashed job, same key) must not be taken for the new id
+    assert path.startswith(str(tmp_path)) and '29123' in path
+    # a FRESH file of a dead writer (a job that crashed a moment ago, same port) must not be taken
+    dead = subprocess.Popen([sys.executable, '-c', 'pass'])
+    dead.wait()
     with open(path, 'wb') as f:
-        f.write((128).to_bytes(4, 'little') + b'x' * 128)
-    old = time.time() - 3600
-    os.utime(path, (old, old))
+        f.write(dist.FileRendezvous.MAGIC + '{} {} 128\n'.format(dead.pid, 12345).encode() + b'x' * 128)
     got = {}
 
     def reader(r):
@@ -178,7 +179,7 @@ def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
     for t in threads:
         t.start()
     time.sleep(0.3)
-    assert not got                                     # still waiting: the stale file is ignored
+    assert not got                                     # still waiting: the writer of that file is gone
     r0 = dist.FileRendezvous(0, 4)
     assert r0.exchange(payload) == payload
     for t in threads:
@@ -186,11 +187,22 @@ def test_file_rendezvous_hands_the_id_to_every_rank(tmp_path, monkeypatch):
     assert got == {1: payload, 2: payload, 3: payload}
     r0.cleanup()
     assert not os.path.exists(path)
-    # a truncated file (writer died mid-way; cannot happen with rename, but be strict)
-    with open(path, 'wb') as f:
-        f.write((128).to_bytes(4, 'little') + b'short')
-    with pytest.raises(TimeoutError):
-        dist.FileRendezvous(1, 4, timeout_s=0.3).exchange()
+    # a live pid with the wrong start time (a recycled pid) and a truncated file are refused too
+    for content in (dist.FileRendezvous.MAGIC + '{} {} 128\n'.format(os.getpid(), 1).encode() + b'y' * 128,
+                    dist.FileRendezvous.MAGIC + '{} {} 128\n'.format(os.getpid(), 0).encode() + b'short'):
+        with open(path, 'wb') as f:
+            f.write(content)
+        with pytest.raises(TimeoutError):
+            dist.FileRendezvous(1, 4, timeout_s=0.3).exchange()
+    # the ranks need not share a parent process (a launcher may wrap each of them)
+    os.unlink(path)
+    code = ("import sys; sys.path.insert(0, {!r}); from stodynprog_amd import dist; "
+            "print(dist.FileRendezvous(1, 4, timeout_s=20).exchange().hex())").format(ROOT)
+    child = subprocess.Popen(['sh', '-c', 'exec "$0" -c "$1"', sys.executable, code],
+                             stdout=subprocess.PIPE, env=dict(os.environ))
+    time.sleep(0.5)
+    dist.FileRendezvous(0, 4).exchange(payload)
+    assert child.communicate(timeout=60)[0].decode().strip() == payload.hex()
 
 
 def test_tapered_phase_partition_covers_every_unit_once():

@@ -200,16 +200,19 @@ CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3), ('synth
          ('nas_demo', dict(), 4), ('inventory', dict(), 4),          # inventory: LDS-staged tiles, node ranges
          ('synthetic3d_coupled', dict(N=20), 4),                     # column kernel, table per control
          ('synthetic3d_coupled', dict(N=18, cross=0.2), 3)]          # staged tiles in 3-D, ragged
-for name, kw, phases in CASES:
+EXCHANGES = os.environ.get('SDP_TEST_EXCHANGES', 'rccl,peer').split(',')
+for (name, kw, phases), exchange in [(c, e) for c in CASES for e in EXCHANGES]:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
     two.comm = dev
+    two.comm_exchange = exchange                     # 'peer': rows written into the peers' buffers (HIP IPC)
     two.comm_phases, two.comm_taper = abs(phases), phases < 0          # negative: tapered phases
     V0 = rng.standard_normal(one._state_grid_shape)
     J1, p1 = one.value_iteration(V0, report_time=False); i1 = one.last_policy_index
     J2, p2 = two.value_iteration(V0, report_time=False); i2 = two.last_policy_index
     prob = [v for k, v in two._cache.items() if k[0] == 'problem'][0]
     assert prob.parts is not None and prob.parts.shape[1] == dev.nranks + 1
+    assert two.backend_info['exchange'] == exchange, two.backend_info
     assert np.array_equal(J1, J2), name
     assert np.array_equal(p1, p2) and np.array_equal(i1, i2), name      # get_policy gathers
     ref = one._state_ref_ind
@@ -224,7 +227,7 @@ for name, kw, phases in CASES:
     Ka, _ = quiet(one.value_iterations, V0, 3)
     Kb, _ = quiet(two.value_iterations, V0, 3)
     assert np.array_equal(Ka, Kb), name
-    print('rank', rank, name, phases, 'ok', flush=True)
+    print('rank', rank, name, phases, exchange, 'ok', flush=True)
 dev.barrier()
 for k in [k for k in list(two._cache) if k[0] == 'problem']:
     two._cache.pop(k).close()
@@ -260,7 +263,9 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
     assert len(lines) == 1, outs[0]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True, d
-    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == {'2', '4', '8', '16', '4t', '8t'}
+    plans = {'2', '4', '8', '16', '4t', '8t'}
+    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == plans | {p + '/peer' for p in plans}, d['config']
+    assert d['config']['comm_exchange'] in ('rccl', 'peer') and d['config']['comm_exchange_note'] is None
     assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
     import glob
     for leftover in glob.glob('/dev/shm/sdp_mock_*'):      # bench.py leaves its communicator to the OS
