@@ -235,6 +235,8 @@ def run(args):
     sysd, ref_solver, solver, V0, dtype, cfg, label, model_name = build_solver(args, models, DPSolver, dev_comm)
     if args.kernel:
         solver.kernel = args.kernel
+    if args.no_filter:
+        solver.certified_filter = False
     S = V0.size
     d = V0.ndim
     nu = len(sysd.control)
@@ -340,12 +342,22 @@ def run(args):
     k_s = k_ms * 1e-3
     kname = {'column': 'sdp_sweep_col', 'generic': 'sdp_sweep', 'staged': 'sdp_sweep_lds'}.get(
         kernel_family, 'sdp_sweep')
-    pmc_key = '{}_{}_{}'.format(args.config if not args.grid else '{}{}'.format(model_name, args.grid),
-                                'f64' if rb == 8 else 'f32', kernel_family)
+    filtered = bool(solver.backend_info.get('certified_filter'))
+    pmc_key = '{}_{}_{}{}'.format(args.config if not args.grid else '{}{}'.format(model_name, args.grid),
+                                  'f64' if rb == 8 else 'f32', kernel_family, '_filter' if filtered else '')
     pmc, pmc_path = load_pmc(pmc_key)
-    issue_peak = FP64_ISSUE_PEAK if rb == 8 else FP32_ISSUE_PEAK
+    issue_peak = FP64_ISSUE_PEAK if (rb == 8 or filtered) else FP32_ISSUE_PEAK
     analytic = cells * 6 / 64.0                        # 6 operations per lattice cell, never fusable
-    if pmc and pmc.get('valu_wave_instr'):
+    if filtered and pmc and pmc.get('counters_mean_per_dispatch', {}).get('SQ_INSTS_VALU'):
+        # the filter leaves a mix of fp64 and 32-bit VALU work (cell location, comparisons,
+        # selects), all of it issued at 4 clk per wave64 instruction on the same port
+        counted = float(pmc['counters_mean_per_dispatch']['SQ_INSTS_VALU'])
+        count_source = ('{}: SQ_INSTS_VALU per {} dispatch (rocprofv3 --pmc of this command); of which fp64 '
+                        'arithmetic {:.3g}'.format(pmc_path, kname, float(pmc.get('valu_wave_instr') or 0)))
+    elif filtered:
+        counted = None
+        count_source = 'no PMC summary committed for this workload'
+    elif pmc and pmc.get('valu_wave_instr'):
         counted = float(pmc['valu_wave_instr'])
         count_source = ('{}: {} per {} dispatch (rocprofv3 --pmc of this command)'
                         .format(pmc_path, pmc.get('valu_wave_instr_counters', 'SQ_INSTS_VALU_*'), kname))
@@ -354,8 +366,8 @@ def run(args):
         count_source = ('analytic lower bound: 6 {} operations per lattice cell (2 mul + add of the outer '
                         'lerp, cost add, weight mul, accumulate); no PMC summary committed for this '
                         'workload'.format('fp64' if rb == 8 else 'fp32'))
-    instr_launch = counted * share
-    achieved = instr_launch / k_s
+    instr_launch = counted * share if counted is not None else None
+    achieved = instr_launch / k_s if counted is not None else None
     traffic = None
     traffic_source = None
     if pmc and pmc.get('hbm_bytes') and world == 1:
@@ -363,30 +375,45 @@ def run(args):
         traffic_source = '{}: {}'.format(pmc_path, pmc.get('hbm_bytes_formula', '2 x FETCH_SIZE + WRITE_SIZE'))
     clock = load_clock()
     roof = {
-        'bound': 'fp64_valu' if rb == 8 else 'fp32_valu',
-        'achieved': achieved, 'peak': issue_peak, 'unit': 'wave-instr/s', 'frac': achieved / issue_peak,
+        'bound': 'valu_issue' if filtered else ('fp64_valu' if rb == 8 else 'fp32_valu'),
+        'achieved': achieved, 'peak': issue_peak, 'unit': 'wave-instr/s',
+        'frac': achieved / issue_peak if achieved is not None else None,
         'traffic': traffic, 'traffic_source': traffic_source,
         'kernel': kname, 'kernel_ms': k_ms,
         'valu_wave_instr_per_launch': instr_launch, 'count_source': count_source,
         'analytic_min_wave_instr_per_launch': analytic * share,
         'peak_source': 'spec: 256 CU x 4 SIMD x 2.4 GHz / {} clk per wave64 {} VALU instruction '
                        '(MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s, fp64 half of it)'.format(
-                           4 if rb == 8 else 2, 'fp64' if rb == 8 else 'fp32'),
-        'why_not_hbm': 'the column kernel tabulates the inner lerps of a column in LDS, so the 2^d-vertex '
+                           4 if (rb == 8 or filtered) else 2,
+                           'fp64 or unpacked 32-bit' if filtered else ('fp64' if rb == 8 else 'fp32')),
+        'why_not_hbm': 'certified expectation-first filter (DESIGN.md section 3): the expectation over w commutes '
+                       'with the lerp along axis 0, so one lerp on a w-reduced table plus a proven error radius '
+                       'decides every control but the near-minimal ones; only those run the reference\'s W x 6 '
+                       'operations, and J / policy / index keep the same bits.  What is left is VALU issue (cell '
+                       'location, cost, bounds per control) on top of the LDS table build; HBM is a few % '
+                       'utilised (hbm block).  `reference_operations` prices the sweep at the 6 operations per '
+                       'lattice cell the reference spends: above the fp64 peak by design' if filtered else
+                       'the column kernel tabulates the inner lerps of a column in LDS, so the 2^d-vertex '
                        'gather per lattice cell never reaches L2/HBM; HBM is a few % utilised (hbm block) '
                        'and the 6 separately rounded operations per cell that bit-exactness forbids to '
                        'fuse bind the kernel' if kernel_family == 'column' else
                        'per-cell gathers: bound by vector-memory/LDS gather issue, see DESIGN.md section 4',
     }
-    if clock and clock.get('sweep_kernel_ghz'):
+    if filtered:
+        roof['reference_operations'] = {
+            'wave_instr_per_launch': analytic * share, 'per_s': analytic * share / k_s,
+            'over_fp64_issue_peak': analytic * share / k_s / FP64_ISSUE_PEAK,
+            'note': 'NOT a utilisation: 6 separately rounded operations per lattice cell (what the reference, the '
+                    'oracle and `--no-filter` execute) divided by this kernel\'s time'}
+    if clock and clock.get('sweep_kernel_ghz') and achieved is not None:
         ghz = float(clock['sweep_kernel_ghz'])
-        peak_clk = N_SIMD * ghz * 1e9 / (4 if rb == 8 else 2)
+        peak_clk = N_SIMD * ghz * 1e9 / (4 if (rb == 8 or filtered) else 2)
         roof['measured_clock_ghz'] = ghz
         roof['peak_at_measured_clock'] = peak_clk
         roof['frac_at_measured_clock'] = achieved / peak_clk
         roof['clock_source'] = 'profiles/clock.json (s_memtime / s_memrealtime stamps, diagnostic build)'
         cpi = clock.get('fp64_clk_per_wave_instr_measured')
-        if cpi and rb == 8:
+        if cpi and rb == 8 and not filtered:
             # the ubench does not reach 4 clk per fp64 wave-instruction either (8 waves/SIMD,
             # independent chains): what the pipe sustains at the clock the sweep kernel holds
             roof['fp64_clk_per_wave_instr_measured'] = cpi
@@ -411,7 +438,7 @@ def run(args):
                                 else '{} (not a BASELINE config)'.format(label)),
                    'state_nodes': S, 'controls_max': U_max, 'perturbations': W,
                    'lattice_cells_per_sweep': cells,
-                   'kernel_family': kernel_family,
+                   'kernel_family': kernel_family, 'certified_filter': filtered,
                    'sharding': ('single GPU' if dev_comm is None else
                                 'columns dealt in {} {}phases x {} ranks; {} of each phase of J under the '
                                 'kernel of the next phase'.format(
@@ -453,7 +480,8 @@ def run(args):
         # the same chain of sweeps on its GPU alone and compares J bit for bit
         try:
             J_sharded = prob.get_value()
-            single = clone_solver(DPSolver, sysd, solver, dtype, kernel=solver.kernel)
+            single = clone_solver(DPSolver, sysd, solver, dtype, kernel=solver.kernel,
+                                  certified_filter=solver.certified_filter)
             sprob = single._problem()
             sprob.set_value(V0)
             if args.warmup > 0:
@@ -487,6 +515,9 @@ def main():
     ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged'],
                     help='kernel family (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-filter', action='store_true',
+                    help='column kernel: evaluate every control with the reference\'s W x 6 operations instead '
+                         'of the certified expectation-first filter (same bits either way; A/B runs)')
     ap.add_argument('--fused', action='store_true',
                     help='also time the opt-in fused-arithmetic variant (secondary figure; off by default so '
                          'that a profile of the default command holds ONE flavour of sdp_sweep_col)')

@@ -208,7 +208,7 @@ def lanes_for(max_controls):
 
 
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
-                     per_control=None):
+                     per_control=None, filtered=False):
     """column: None for the generic node-order kernels, or (N0, W) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
@@ -217,7 +217,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
     window: None, or the tuple of `column_window_config` (column kernel whose
     table holds a window of rows of axis 0).
     per_control: None, or the tuple of `column_percontrol_config` (column kernel
-    that rebuilds its table for every control)."""
+    that rebuilds its table for every control).
+    filtered: column kernel with the certified expectation-first filter (SDP_COL_FILTER of
+    csrc/sdp_column_kernel.h; see `column_filter_applies`)."""
     real = {'float64': 'double', 'float32': 'float'}[np.dtype(dtype).name]
     head = [
         '// generated by stodynprog_amd.codegen -- do not edit',
@@ -228,7 +230,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         '#define SDP_LANES {}'.format(int(lanes)),
         ] + (['#define SDP_STAMP {}     // diagnostic build: in-kernel clock stamps (tools/clock_probe.py, '
               'tools/phase_probe.py)'.format(int(os.environ['SDP_STAMP']))]
-             if os.environ.get('SDP_STAMP') in ('1', '2') else []) + (
+             if os.environ.get('SDP_STAMP') in ('1', '2', '3') else []) + (
             ['#define SDP_NO_POW2 1  // A/B: true division also for power-of-two spans']
             if os.environ.get('SDP_NO_POW2') == '1' else []) + [
         '#include "sdp_device.h"',
@@ -262,7 +264,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
             '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
             '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
-        ] + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
+        ] + (['#define SDP_COL_FILTER 1'] + (
+            ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
+            if os.environ.get('SDP_COL_FILTER_SCALE') else []) if filtered else []) + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
                   int(os.environ.get('SDP_COL_A_LW') or _order[1]))]
              if (not os.environ.get('SDP_COL_A_ORDER') and per_control is None and
                  (_order := column_build_order(int(col_cfg[0]), column[1],
@@ -271,7 +275,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             '',
@@ -414,6 +418,21 @@ def use_wpair(model, dtype):
             and not model.lead_depends_on_w and not model.trail_depends_on_u)
 
 
+def column_filter_applies(model, fused=False, window=None, per_control=None):
+    """Can phase B of the column kernel run the certified expectation-first filter
+    (SDP_COL_FILTER of csrc/sdp_column_kernel.h)?  It needs a perturbation that reaches
+    neither x0' nor the cost -- then the expectation commutes with the lerp along axis 0 and
+    all but the surviving controls of a node are decided on a table reduced over w -- and the
+    plain full-column table with the reference's arithmetic.  Same bits as without it
+    (the survivors are re-evaluated with the reference's operations).  SDP_COL_FILTER=0 in
+    the environment switches it off (A/B runs)."""
+    if os.environ.get('SDP_COL_FILTER', '1') == '0':
+        return False
+    return bool(model.n_perturb > 0 and not model.lead_depends_on_w and not model.cost_depends_on_w
+                and not model.trail_depends_on_u and not fused and window is None
+                and per_control is None)
+
+
 def column_config(n0, w, n_state, dtype, wpair=False):
     """Compile-time shape of the column kernel for a grid with n0 points along
     axis 0 and w perturbation points: (threads, lds_bytes), or None if the
@@ -425,7 +444,7 @@ def column_config(n0, w, n_state, dtype, wpair=False):
     w = max(int(w), 1)
     tw = w + (w & 1) if wpair else w
     for threads in (512, 1024):
-        lds = _column_lds(tw, w, n0, n_state, rs, threads)
+        lds = _column_lds(tw, w, n0, n_state, rs, threads, reduced=True)   # (whether or not it is compiled in)
         if lds * (2 if threads == 512 else 1) <= COLUMN_LDS_MAX:
             return threads, lds
     return None
@@ -450,8 +469,10 @@ def column_build_order(threads, w, rows):
     return (best[0], best[1]) if best[2] >= 0.85 else (0, 0)
 
 
-def _column_lds(tw, w, rows, n_state, rs, threads):
-    raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16)
+def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False):
+    # reduced: + the (A[r], D[r]) table of the certified filter (full-column table only)
+    raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16
+           + (2 * rows * rs if reduced else 0))
     return (raw + 15) // 16 * 16
 
 

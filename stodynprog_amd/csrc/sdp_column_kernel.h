@@ -109,6 +109,19 @@
 #ifndef SDP_COL_ROWS
 #define SDP_COL_ROWS SDP_COL_N0
 #endif
+#ifndef SDP_COL_FILTER
+#define SDP_COL_FILTER 0         // 1: certified expectation-first filter in phase B (see sdp_col_filter_*)
+#endif
+#ifndef SDP_COL_FILTER_UNROLL
+#define SDP_COL_FILTER_UNROLL 4  // controls per round of the filter's first pass
+#endif
+#ifndef SDP_COL_FILTER_SCALE
+#define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
+#endif
+#if SDP_COL_FILTER && (!SDP_HAS_W || SDP_LEAD_HAS_W || SDP_COST_HAS_W || SDP_TRAIL_HAS_U || SDP_COL_FUSED || \
+                       SDP_COL_ROWS < SDP_COL_N0)
+#error "SDP_COL_FILTER needs a perturbation that reaches neither x0' nor the cost, and the plain full-column table"
+#endif
 #if SDP_TRAIL_HAS_U && (SDP_COL_WPAIR || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
 #error "control-dependent trailing dynamics: plain full table, exact arithmetic only"
 #endif
@@ -144,6 +157,10 @@ struct __attribute__((aligned(16))) SdpColLds {
     int part_i[SDP_COL_THREADS];
     int w_off[SDP_COL_W * SDP_DT];
     int win[2][2];                         // row window: per parity (min row, minus max row) of the unit
+#if SDP_COL_FILTER
+    // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
+    sdp_real ad[2 * SDP_COL_ROWS] __attribute__((aligned(16)));
+#endif
 };
 static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
 
@@ -967,6 +984,186 @@ SDP_DEV int sdp_col_window_read(int (*win)[2], int parity)
     return max(min(r0, SDP_COL_N0 - SDP_COL_ROWS), 0);
 }
 
+#if SDP_COL_FILTER
+// ---------------------------------------------------------------------------
+// Certified expectation-first filter for phase B.
+//
+// When the perturbation reaches neither x0' nor the cost, a control's expected
+// cost is, in real arithmetic,
+//     R(u) = sum_w p_w (g + oml0 T[w][q0] + lam0 T[w][q0+1])
+//          = g sum_w p_w + oml0 A[q0] + lam0 A[q0+1],      A[r] = sum_w p_w T[w][r],
+// i.e. ONE lerp on a table reduced over w instead of W of them.  The reference's
+// value E(u) (the W x 6 separately rounded operations of sdp_col_expected_cost)
+// and the short form F(u) (sdp_col_filter_eval) are both roundings of R(u) --
+// same q0, lam0, oml0, g and table entries, which are computed once -- so with
+// u = the unit roundoff and S(u) = sum_w |p_w| (|g| + |oml0 T[w][q0]| + |lam0 T[w][q0+1]|):
+//     |E - R| <= gamma_{W+4} S,   |F - R| <= gamma_{W+3} S,   gamma_n = n u / (1 - n u)
+// (a vertex value passes through at most W+4 roundings on the long path: two of
+// the lerp, the add of g, the weight, and at most W accumulations; W+3 on the
+// short one).  With the computable bound
+//     S^(u) = Pcap |g| + (|oml0| + |lam0|) max(D[q0], D[q0+1]),   D[r] = Pcap max_w |T[w][r]|,
+//     Pcap = max(1, sum_w |p_w|)  >=  S(u),
+// the radius  delta(u) = 4 (W + 8) u S^(u) (+ tiny)  covers |E - F| with a factor
+// ~1.8 to spare (the spare absorbs the roundings of S^, of F +- delta and of the
+// sums of the weights; `tiny` = the smallest normal number covers the absolute
+// errors of operations that underflow -- it enters through D[r], which carries 2 tiny / (4 (W+8) u)
+// on top, and |oml0| + |lam0| >= 1 - u).  Nothing overflows on the long path as
+// long as |F| + S^ < 2^1000 (2^100 for 4-byte reals) and sum |p_w| <= 1024:
+// anything else -- infinities, NaNs, huge values -- marks the node `bad`.
+//
+// Per node, with ONE radius delta = the largest delta(u) of its controls (it covers each
+// of them):  m = min_u F + delta  bounds the minimum of E from above, so a
+// control with F - delta > m is strictly worse than the best one and can be
+// neither the argmin nor tied with it.  If exactly one control survives it IS
+// the first-occurrence argmin of the reference and J = E of that control,
+// evaluated with the reference's operations: same bits.  If several survive
+// (near-ties), or the node is bad, the survivors (all controls of a bad node)
+// are evaluated with the reference's operations in lattice order and compared
+// like the reference does.  The outcome never depends on F or delta beyond
+// "which controls were skipped", and skipped controls are provably not minimal:
+// J, policy and index are bit-identical to the plain kernel for every input.
+// ---------------------------------------------------------------------------
+// v_min / v_max as single instructions (the compiler's fmin/fmax may add canonicalising
+// operations); only used on values that are not NaN, or on nodes the NaN sends the long way
+SDP_DEV double sdp_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SDP_DEV double sdp_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SDP_DEV float sdp_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SDP_DEV float sdp_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+struct SdpColFilter {
+    sdp_real psum;      // fl(sum_w p_w), accumulated in w order
+    sdp_real pcap;      // max(1, sum_w |p_w|)
+    sdp_real cu;        // 4 (W + 8) u  (x SDP_COL_FILTER_SCALE)
+    sdp_real floor;     // 2 tiny / cu, added to every D[r]: cu S^ >= tiny whatever the values
+    bool ok;            // weights are finite and of ordinary size
+};
+template <typename R> struct SdpFilterConst;
+template <> struct SdpFilterConst<double> {
+    static constexpr double tiny = 2.2250738585072014e-308, limit = 0x1p1000, eps = 0x1p-52;
+};
+template <> struct SdpFilterConst<float> {
+    static constexpr float tiny = 1.17549435e-38f, limit = 0x1p100f, eps = 0x1p-23f;
+};
+constexpr sdp_real SDP_COL_FILTER_TINY = SdpFilterConst<sdp_real>::tiny;      // smallest normal number
+constexpr sdp_real SDP_COL_FILTER_LIMIT = SdpFilterConst<sdp_real>::limit;
+constexpr sdp_real SDP_COL_FILTER_EPS = SdpFilterConst<sdp_real>::eps;        // 2 u
+
+SDP_DEV void sdp_col_filter_setup(const SdpSweepArgs &a, SdpColFilter &f)
+{
+    const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
+    sdp_real ps = (sdp_real)0, pa = (sdp_real)0;
+    for (int w = 0; w < SDP_COL_W; ++w) {
+        ps = ps + p[w];
+        pa = pa + (p[w] < (sdp_real)0 ? -p[w] : p[w]);
+    }
+    f.psum = ps;
+    f.pcap = pa > (sdp_real)1 ? pa : (sdp_real)1;
+    f.cu = (sdp_real)SDP_COL_FILTER_SCALE * (sdp_real)(2 * (SDP_COL_W + 8)) * SDP_COL_FILTER_EPS;   // u = eps / 2
+    f.floor = (sdp_real)2 * SDP_COL_FILTER_TINY / f.cu;
+    f.ok = pa <= (sdp_real)1024;                           // false for NaN
+}
+
+// after phase A (and a barrier): the reduced table, one thread per row
+SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const SdpColFilter &f)
+{
+    constexpr int N0 = SDP_COL_ROWS;
+    const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
+    for (int r = threadIdx.x; r < N0; r += blockDim.x) {
+        sdp_real acc = (sdp_real)0, big = (sdp_real)0;
+#pragma unroll 8
+        for (int w = 0; w < SDP_COL_W; ++w) {
+#if SDP_COL_WPAIR
+            const sdp_real v = m.T[((w >> 1) * N0 + r) * 2 + (w & 1)];
+#else
+            const sdp_real v = m.T[w * N0 + r];
+#endif
+            acc = acc + p[w] * v;
+            big = sdp_vmax(big, fabs(v));
+        }
+        m.ad[2 * r] = acc;
+        // (>= tiny / cu: the radius never drops below `tiny`; a NaN entry, which the max skips,
+        // shows in acc and makes the row's bound infinite)
+        m.ad[2 * r + 1] = acc == acc ? f.pcap * big + f.floor : (sdp_real)INFINITY;
+    }
+}
+
+// F(u) and S^(u) of one control (x0' cell and cost exactly as sdp_col_expected_cost computes them;
+// POW2 = l.pow2, a template argument so that the loop of the first pass carries no branch)
+template <bool POW2>
+SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, const SdpLeadAxis &l,
+                                 const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &S)
+{
+    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+    const sdp_real sn = POW2 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span;       // sdp_div_span
+    const sdp_real p = sn * l.nm1;
+    const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);
+    const sdp_real lam0 = p - (sdp_real)q0;
+    const sdp_real oml0 = (sdp_real)1 - lam0;
+    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    const sdp_real *ad = m.ad + 2 * q0;
+    const sdp_real a0 = ad[0], d0 = ad[1], a1 = ad[2], d1 = ad[3];
+    F = g * f.psum + (oml0 * a0 + lam0 * a1);
+    S = fma(fabs(g), f.pcap, (fabs(oml0) + fabs(lam0)) * sdp_vmax(d0, d1));
+}
+
+// What the first pass keeps of a node's controls: the two smallest F (and whose the smallest
+// is), the largest S^ -- one radius cu * s_max then covers every control of the node -- and the
+// sum of the S^, in which a NaN or an infinity of any control sticks (|F| <~ S^, and a NaN of
+// F comes with a NaN or an infinity of S^: through D[r] -- sdp_col_filter_reduce --, |g|, |lam0|).
+struct SdpColBounds {
+    sdp_real f1, f2, s_max, s_sum;
+    int i1;
+};
+
+// first pass over the controls [c_lo, c_hi) of one node.  PLAIN: a one-dimensional lattice that
+// is an ordinary linspace (n > 1, step != 0): sdp_control_value without its rare branches, the
+// last point (`stop`, numpy.linspace) taken out of the loop.
+template <bool PLAIN, bool POW2>
+SDP_DEV void sdp_col_filter_pass1(const SdpColLds &m, const SdpColFilter &f, const SdpLeadAxis &l,
+                                  const SdpBox &box, sdp_real *x, sdp_real t, int c_lo, int c_hi,
+                                  SdpColBounds &b)
+{
+    auto eval = [&](int ci, const sdp_real *u) {
+        sdp_real F, S;
+        sdp_col_filter_eval<POW2>(m, f, l, x, u, t, F, S);
+        b.s_sum = b.s_sum + S;
+        b.s_max = sdp_vmax(b.s_max, S);
+        b.f2 = sdp_vmin(b.f2, sdp_vmax(b.f1, F));
+        b.i1 = F < b.f1 ? ci : b.i1;
+        b.f1 = sdp_vmin(b.f1, F);
+    };
+    auto one = [&](int ci) {
+        sdp_real u[SDP_NU];
+        if (PLAIN) u[0] = (sdp_real)ci * box.step[0] + box.lo[0];
+        else sdp_controls_at(box, ci, u);
+        eval(ci, u);
+    };
+    const int last = PLAIN ? box.n[0] - 1 : INT_MAX;
+    const int c_main = min(c_hi, last);
+    constexpr int K = SDP_COL_FILTER_UNROLL;
+    int ci = c_lo;
+    for (; ci + K <= c_main; ci += K) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) one(ci + j);
+    }
+    for (; ci < c_main; ++ci) one(ci);
+    if (PLAIN && c_hi > last && c_lo <= last) eval(last, box.hi);
+}
+
+SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
+{
+    const sdp_real o_f1 = sdp_shfl_xor(b.f1, d), o_f2 = sdp_shfl_xor(b.f2, d);
+    const sdp_real o_max = sdp_shfl_xor(b.s_max, d), o_sum = sdp_shfl_xor(b.s_sum, d);
+    const int o_i1 = __shfl_xor(b.i1, d, 64);
+    const sdp_real mx = o_f1 > b.f1 ? o_f1 : b.f1;
+    b.f2 = o_f2 < b.f2 ? o_f2 : b.f2;
+    b.f2 = mx < b.f2 ? mx : b.f2;
+    if (o_f1 < b.f1) { b.f1 = o_f1; b.i1 = o_i1; }         // (equal: f2 = f1, the node keeps both)
+    b.s_max = o_max > b.s_max ? o_max : b.s_max;
+    b.s_sum = b.s_sum + o_sum;
+}
+#endif  // SDP_COL_FILTER
+
 #if !SDP_TRAIL_HAS_U
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
@@ -992,13 +1189,22 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     sdp_col_walk(a, walk);
     SdpColWeights wts;
     sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+#if SDP_COL_FILTER
+    SdpColFilter filt;
+    sdp_col_filter_setup(a, filt);
+#endif
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     int parity = 0;
 #if SDP_STAMP == 2     // diagnostic: shader clocks thread 0 spends in phases W, A, B (+ idle at barriers)
     unsigned long long tw = 0, ta = 0, tb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, tstart = __builtin_amdgcn_s_memtime();
+    unsigned long long tr = 0, tp1 = 0, tp2 = 0, m0 = 0, m1 = 0, m2 = 0;   // filter: reduce, first pass, second pass
+    (void)tr; (void)tp1; (void)tp2; (void)m0; (void)m1; (void)m2;
 #define SDP_COL_MARK(v) v = __builtin_amdgcn_s_memtime()
 #else
 #define SDP_COL_MARK(v)
+#endif
+#if SDP_STAMP == 3 && SDP_COL_FILTER   // diagnostic: how often the filter leaves more than one control
+    unsigned long long n_slow = 0, n_exact = 0, n_all = 0;
 #endif
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
@@ -1008,7 +1214,10 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
-        __syncthreads();                       // readers of the previous table are done
+        // Phase W only writes the trailing cells, which nothing reads after phase A; the barrier
+        // that follows it also tells that every wave has left phase B of the previous unit, i.e.
+        // that the table may be overwritten.  (The row window publishes through win[] first.)
+        if (SDP_COL_WINDOW) __syncthreads();
         SDP_COL_MARK(t0);
         sdp_col_window_predict<false>(a, lead, sdp_lds.win, parity, col, i_lo, i_hi, x, t);
         sdp_col_phase_w(a, tg, s, x, nullptr, t);
@@ -1020,6 +1229,96 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         __syncthreads();
         SDP_COL_MARK(t2);
 
+#if SDP_COL_FILTER
+        sdp_col_filter_reduce(a, sdp_lds, filt);
+        __syncthreads();
+        SDP_COL_MARK(m0);
+#if SDP_STAMP == 2
+        tr += m0 - t2;
+#endif
+        // ---- phase B, filtered (see SdpColFilter).  A wave takes 64 / chunks consecutive
+        // nodes; the lanes l, l + npw, l + 2 npw, .. of a node share its control lattice in
+        // `chunks` consecutive ranges and meet through lane shuffles.  Lanes past the end of
+        // the unit repeat its last node (they must stay active for the shuffles) and store
+        // nothing.
+        {
+            const int n_nodes = i_hi - i_lo;
+            const int groups = (n_nodes + 63) >> 6;
+            int chunks = groups < waves ? waves / groups : 1;
+            chunks = 1 << (31 - __builtin_clz(chunks < 64 ? chunks : 64));     // power of two <= 64
+            const int npw = 64 / chunks;                                        // nodes per wave
+            const int items = (n_nodes + npw - 1) / npw;
+            for (int item = wave; item < items; item += waves) {
+                const int chunk = lane / npw;
+                const int i_raw = i_lo + item * npw + (lane - chunk * npw);
+                const bool live = i_raw < i_hi;
+                const int i = live ? i_raw : i_hi - 1;
+                const int64_t node = col * N0 + i;
+                SdpBox box;
+                x[0] = axis0[i];
+                sdp_load_box(a, node, box);
+                const int c_lo = (int)((int64_t)box.total * chunk / chunks);
+                const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
+                // pass 1: bounds of every control of this lane's range
+                SDP_COL_MARK(m1);
+                SdpColBounds bd;
+                bd.f1 = bd.f2 = INFINITY;
+                bd.s_max = bd.s_sum = (sdp_real)0;
+                bd.i1 = INT_MAX;
+                const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
+                if (__all(plain)) {
+                    if (lead.pow2) sdp_col_filter_pass1<true, true>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    else sdp_col_filter_pass1<true, false>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                } else {
+                    if (lead.pow2) sdp_col_filter_pass1<false, true>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    else sdp_col_filter_pass1<false, false>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                }
+                for (int d = npw; d < 64; d <<= 1) sdp_col_bounds_merge(bd, d);
+                // pass 2: the reference's operations on the survivors
+                SDP_COL_MARK(m2);
+#if SDP_STAMP == 2
+                tp1 += m2 - m1;
+#endif
+                const bool bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT);
+                const sdp_real radius = filt.cu * bd.s_max;
+                const sdp_real m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
+                const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
+                const int first = single ? bd.i1 : c_lo, last = single ? bd.i1 + 1 : c_hi;
+                sdp_real best = INFINITY;
+                int ibest = INT_MAX;
+                for (int ci = first; ci < last; ++ci) {
+                    sdp_real u[1][SDP_NU], jc[1];
+                    sdp_controls_at(box, ci, u[0]);
+                    bool cand = single || bad;
+                    if (!cand) {
+                        sdp_real F, S;
+                        if (lead.pow2) sdp_col_filter_eval<true>(sdp_lds, filt, lead, x, u[0], t, F, S);
+                        else sdp_col_filter_eval<false>(sdp_lds, filt, lead, x, u[0], t, F, S);
+                        cand = !(F - radius > m_hi);
+                    }
+                    if (cand) {
+#if SDP_STAMP == 3
+                        if (live) ++n_exact;
+#endif
+                        sdp_col_expected_cost<1>(a, tg, s, wts, lead, x, u, t, jc);
+                        if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
+                    }
+                }
+                for (int d = npw; d < 64; d <<= 1) {       // ranges are in lattice order: lower index wins ties
+                    const sdp_real ov = sdp_shfl_xor(best, d);
+                    const int oi = __shfl_xor(ibest, d, 64);
+                    if (oi != INT_MAX && (ibest == INT_MAX || sdp_better_idx(ov, oi, best, ibest))) { best = ov; ibest = oi; }
+                }
+#if SDP_STAMP == 3
+                if (live && chunk == 0) { ++n_all; if (!single) ++n_slow; }
+#endif
+                if (live && chunk == 0) sdp_col_store(a, node, box, best, ibest);
+#if SDP_STAMP == 2
+                tp2 += __builtin_amdgcn_s_memtime() - m2;
+#endif
+            }
+        }
+#else
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
         // per wavefront: their rows q0 are consecutive, so the LDS reads are
         // conflict-free), the control loop and the argmin run in-lane with no
@@ -1088,17 +1387,29 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_store(a, node, box, best, ibest);
             }
         }
+#endif  // SDP_COL_FILTER
 #if SDP_STAMP == 2
         t3 = __builtin_amdgcn_s_memtime();
         tw += t1 - t0; ta += t2 - t1; tb += t3 - t2;
 #endif
     }
-#if SDP_STAMP == 2
+#if SDP_STAMP == 3 && SDP_COL_FILTER
+    if (a.stamps) {
+        atomicAdd((unsigned long long *)&a.stamps[0], n_slow);
+        atomicAdd((unsigned long long *)&a.stamps[1], n_exact);
+        atomicAdd((unsigned long long *)&a.stamps[2], n_all);
+    }
+#elif SDP_STAMP == 2
     if (a.stamps && threadIdx.x == 0) {
         a.stamps[blockIdx.x * 4 + 0] = tw;
         a.stamps[blockIdx.x * 4 + 1] = ta;
         a.stamps[blockIdx.x * 4 + 2] = tb;
         a.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - tstart;
+#if SDP_COL_FILTER
+        a.stamps[(gridDim.x + blockIdx.x) * 4 + 0] = tr;
+        a.stamps[(gridDim.x + blockIdx.x) * 4 + 1] = tp1;
+        a.stamps[(gridDim.x + blockIdx.x) * 4 + 2] = tp2;
+#endif
     }
 #else
     SDP_STAMP_END(a);

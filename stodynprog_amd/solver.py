@@ -218,6 +218,11 @@ class DPSolver(object):
         # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
         #          operations, J within ~1e-15 relative of 'exact' (opt-in)
         self.arithmetic = 'exact'
+        # column kernel, 'exact' arithmetic: decide all but the near-minimal controls of a node on
+        # a table reduced over the perturbation (rigorous error radius) and evaluate only the
+        # survivors with the reference's operations -- same bits, ~W times less work per control
+        # (csrc/sdp_column_kernel.h, SdpColFilter).  False: every control the long way.
+        self.certified_filter = True
         self._cache = {}
         self._idx_cache = None             # see last_policy_index
         self._idx_source = None
@@ -436,7 +441,7 @@ class DPSolver(object):
         parts = [s.dyn, s.cost, s.control_box, _params_key(s.params),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
                  id(self.comm), self.comm_phases, self.comm_taper, self.comm_exchange, self.kernel,
-                 self.arithmetic]
+                 self.arithmetic, getattr(self, 'certified_filter', True)]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         # the tuple itself is the cache key (not its hash): the callables stay alive as
@@ -626,11 +631,14 @@ class DPSolver(object):
                 staged = codegen.staged_config(model, self.state_grid, self.perturb_grid, bp, dt,
                                                0.0 if box_t is None else float(box_t))
                 self._cache[key] = staged
+        filtered = bool(column and getattr(self, 'certified_filter', True) and codegen.column_filter_applies(
+            model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None))
         source = codegen.translation_unit(model, dt, lanes,
                                           column=(shape[0], W) if column else None,
                                           fused=(self.arithmetic == 'fused'), staged=staged,
-                                          window=window, per_control=per_control_cfg if per_control else None)
-        return dict(model=model, source=source, column=column, lanes=lanes, staged=staged,
+                                          window=window, per_control=per_control_cfg if per_control else None,
+                                          filtered=filtered)
+        return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
                     window=window, per_control=per_control,
                     col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
@@ -763,6 +771,7 @@ class DPSolver(object):
                          row_window=(dict(rows=plan['window'][2], segment_nodes=plan['window'][3])
                                      if plan['window'] else None),
                          table_per_control=bool(plan['per_control']),
+                         certified_filter=bool(plan.get('filtered')),
                          arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),

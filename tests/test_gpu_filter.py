@@ -1,0 +1,172 @@
+"""Certified expectation-first filter of the column kernel (csrc/sdp_column_kernel.h,
+SdpColFilter).  When the perturbation reaches neither x0' nor the cost, the first pass
+decides all but the near-minimal controls of a node on a table reduced over w, with a
+rigorous error radius, and only the survivors are evaluated with the reference's
+operations.  The claim under test: J, policy and policy index are BIT-IDENTICAL to the
+kernel that evaluates every control the long way -- for ordinary inputs (one survivor
+per node), for exact ties, for NaN / infinite / huge / subnormal values (the node then
+takes the long way), and for any error radius >= the proven one (SDP_COL_FILTER_SCALE
+blows it up until every control survives)."""
+import numpy as np
+import pytest
+
+from stodynprog_amd import models, SysDescription, DPSolver
+from stodynprog_amd.models import NormalLaw
+
+pytestmark = pytest.mark.gpu
+
+
+def _sweep(make, filt, V, dtype=np.float64, kernel='auto', rel=False):
+    _, s = make()
+    s.dtype = np.dtype(dtype)
+    s.kernel = kernel
+    s.certified_filter = filt
+    with np.errstate(all='ignore'):
+        J, pol = s.value_iteration(np.asarray(V, dtype=float), report_time=False)
+    return J, pol, s.last_policy_index, s
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0], equal_nan=True), 'J differs'
+    assert np.array_equal(a[2], b[2]), 'policy index differs'
+    assert np.array_equal(a[1], b[1], equal_nan=True), 'policy differs'
+
+
+def _stock(n_x=96, n_y=9, n_w=7, cost_has_u=True, box_on_state=False):
+    """stock x0 driven by the control, exogenous AR(1) y, perturbation on y only"""
+    sysd = SysDescription((2, 1, 1), name='stock')
+    sysd.dyn = lambda x, y, u, w: (x + 0.7 * u, 0.8 * y + w)
+    if cost_has_u:
+        sysd.cost = lambda x, y, u, w: (y - 0.3) * u + 0.2 * u * u + 0.05 * x
+    else:
+        sysd.cost = lambda x, y, u, w: 0.05 * x + y * y + 0.0 * u
+    if box_on_state:
+        sysd.control_box = lambda x, y: ((-1.0, 1.0 + 0.5 * y * y + 0.01 * x),)
+    else:
+        sysd.control_box = lambda x, y: ((-1.0, 1.0),)
+    sysd.perturb_laws = [NormalLaw(0, 0.2)]
+    s = DPSolver(sysd)
+    s.discretize_state(0, 3, n_x, -1, 1, n_y)
+    s.discretize_perturb(-0.5, 0.5, n_w)
+    s.control_steps = (0.0625,)
+    return sysd, s
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('N', [20, 33])
+def test_benchmark_model_same_bits_with_and_without(gpu, N, dtype):
+    make = lambda: models.synthetic3d(N=N)
+    V = models.synthetic3d_V0(make()[1].state_grid)
+    on, off = _sweep(make, True, V, dtype), _sweep(make, False, V, dtype)
+    assert on[3].backend_info['certified_filter'] and not off[3].backend_info['certified_filter']
+    assert on[3].backend_info['kernel'] == off[3].backend_info['kernel'] == 'column'
+    _same(on, off)
+    _same(on, _sweep(make, True, V, dtype, kernel='generic'))      # and the direct kernel
+
+
+def test_against_the_numpy_oracle(gpu):
+    from oracle import vi_numpy
+    make = lambda: models.synthetic3d(N=20)
+    V = np.random.default_rng(3).standard_normal((20, 20, 20))
+    J, pol, idx, s = _sweep(make, True, V)
+    assert s.backend_info['certified_filter']
+    nodes = np.arange(0, V.size, 7)
+    Jo, polo, idxo, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(s), V, nodes=nodes)
+    assert np.array_equal(J.ravel()[nodes], Jo) and np.array_equal(idx.ravel()[nodes], idxo)
+
+
+@pytest.mark.parametrize('box_on_state', [False, True])
+def test_two_dimensional_stock_per_node_boxes_and_ragged_columns(gpu, box_on_state):
+    make = lambda: _stock(box_on_state=box_on_state)
+    V = np.random.default_rng(11).standard_normal(make()[1]._state_grid_shape)
+    on, off = _sweep(make, True, V), _sweep(make, False, V)
+    assert on[3].backend_info['certified_filter']
+    _same(on, off)
+
+
+def test_exact_ties_keep_the_first_control(gpu):
+    """a constant cost-to-go and a cost without the control: every control of a node has the
+    same expected cost, bit for bit -- all survive, the lowest index wins (numpy argmin)"""
+    make = lambda: _stock(cost_has_u=False)
+    V = np.full(make()[1]._state_grid_shape, 2.5)
+    on, off = _sweep(make, True, V), _sweep(make, False, V)
+    _same(on, off)
+    assert (on[2] == 0).all()
+
+
+@pytest.mark.parametrize('case', ['nan', 'inf', '-inf', 'huge', 'subnormal', 'mixed_scales'])
+def test_special_values_take_the_long_way(gpu, case):
+    make = lambda: _stock()
+    shape = make()[1]._state_grid_shape
+    V = np.random.default_rng(5).standard_normal(shape)
+    if case == 'nan':
+        V[10:14, 2:5] = np.nan
+    elif case == 'inf':
+        V[40:, :] = np.inf                       # a forbidden region
+    elif case == '-inf':
+        V[::7, 3] = -np.inf
+    elif case == 'huge':
+        V *= 1e302                               # the long path overflows here and there
+    elif case == 'subnormal':
+        V *= 1e-310
+    else:
+        V[30:50] *= 1e12                         # a penalty region next to ordinary values
+    on, off = _sweep(make, True, V), _sweep(make, False, V)
+    assert on[3].backend_info['certified_filter']
+    _same(on, off)
+
+
+def test_weights_that_do_not_sum_to_one(gpu):
+    def make():
+        sysd, s = _stock()
+        s.perturb_proba = [np.asarray(s.perturb_proba[0]) * 3.7]
+        return sysd, s
+    V = np.random.default_rng(2).standard_normal(make()[1]._state_grid_shape)
+    _same(_sweep(make, True, V), _sweep(make, False, V))
+
+
+@pytest.mark.parametrize('scale', ['1e6', '1e11', '1e18'])
+def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
+    """SDP_COL_FILTER_SCALE multiplies the error radius: more and more controls survive the
+    first pass (all of them at 1e18) and go through the second; the result cannot change"""
+    make = lambda: models.synthetic3d(N=24)
+    V = models.synthetic3d_V0(make()[1].state_grid)
+    ref = _sweep(make, False, V)
+    monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+    on = _sweep(make, True, V)
+    assert 'SDP_COL_FILTER_SCALE' in on[3]._kernel_plan()['source']
+    _same(on, ref)
+
+
+def test_chained_sweeps_and_relative_dp(gpu):
+    make = lambda: models.synthetic3d(N=24)
+    _, a = make()
+    _, b = make()
+    b.certified_filter = False
+    V = models.synthetic3d_V0(a.state_grid)
+    V = V - V[a._state_ref_ind]
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        Ja, pa = a.value_iterations((V, 0.), 6, rel_dp=True)
+        Jb, pb = b.value_iterations((V, 0.), 6, rel_dp=True)
+    assert np.array_equal(Ja[0], Jb[0]) and Ja[1] == Jb[1] and np.array_equal(pa, pb)
+    assert np.array_equal(a.last_policy_index, b.last_policy_index)
+
+
+def test_where_the_filter_does_not_apply(gpu):
+    """a cost or an x0' that sees the perturbation: every control the long way"""
+    sysd, s = _stock()
+    sysd.cost = lambda x, y, u, w: (y + w) * u + 0.2 * u * u
+    s._cache.clear()
+    s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
+    assert s.backend_info['kernel'] == 'column' and not s.backend_info['certified_filter']
+    sysd, s = _stock()
+    sysd.dyn = lambda x, y, u, w: (x + 0.7 * u + 0.1 * w, 0.8 * y + w)
+    s._cache.clear()
+    s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
+    assert s.backend_info['kernel'] == 'column' and not s.backend_info['certified_filter']
+    _, s = models.synthetic3d(N=16)
+    s.arithmetic = 'fused'
+    s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
+    assert not s.backend_info['certified_filter']

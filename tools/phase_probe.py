@@ -22,7 +22,9 @@ _, k = prob.bench_sweeps(5)
 st = np.zeros(65536 * 4, dtype=np.uint64)
 nat.check(nat.lib().sdp_problem_debug_stamps(prob.h, 1, st.ctypes.data_as(C.c_void_p), st.size))
 st = st.reshape(-1, 4).astype(float)
-st = st[st[:, 3] > 0]
+n_wg = int((st[:, 3] > 0).sum())
+extra = st[n_wg:2 * n_wg]                 # filter builds: reduce, first pass, second pass of phase B
+st = st[:n_wg]
 tot = st[:, 3]
 print('kernel {:.3f} ms; {} workgroups; lifetime of a workgroup: median {:.3e} clk'.format(k / 5, len(st), np.median(tot)))
 for name, col in (('W (trailing cells + barrier)', 0), ('A (table build + barrier)', 1), ('B (cells, argmin, stores + barrier)', 2)):
@@ -30,3 +32,7 @@ for name, col in (('W (trailing cells + barrier)', 0), ('A (table build + barrie
         name, 100 * np.median(st[:, col] / tot), 100 * np.percentile(st[:, col] / tot, 10),
         100 * np.percentile(st[:, col] / tot, 90)))
 print('unaccounted (column bookkeeping, kernel prologue) {:.2f} %'.format(100 * np.median(1 - st[:, :3].sum(axis=1) / tot)))
+if s.backend_info.get('certified_filter'):
+    for name, col in (('B: reduction of the table over w + barrier', 0), ('B: first pass (bounds of every control)', 1),
+                      ('B: second pass (survivors, merge, stores)', 2)):
+        print('{:40s} {:6.2f} %'.format(name, 100 * np.median(extra[:, col] / tot)))
