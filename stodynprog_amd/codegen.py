@@ -233,6 +233,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
              if os.environ.get('SDP_STAMP') in ('1', '2', '3') else []) + (
             ['#define SDP_NO_POW2 1  // A/B: true division also for power-of-two spans']
             if os.environ.get('SDP_NO_POW2') == '1' else []) + [
+            '#define {} {}   // SDP_EXTRA_DEFINES (diagnostic builds)'.format(*kv.split('='))
+            for kv in os.environ.get('SDP_EXTRA_DEFINES', '').split(',') if '=' in kv] + [
         '#include "sdp_device.h"',
         'typedef SDP_REAL sdp_real;',
         ''] + ([
@@ -275,7 +277,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             '',

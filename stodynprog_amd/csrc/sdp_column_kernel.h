@@ -115,6 +115,9 @@
 #ifndef SDP_COL_FILTER_UNROLL
 #define SDP_COL_FILTER_UNROLL 4  // controls per round of the filter's first pass
 #endif
+#ifndef SDP_COL_B_PRIO
+#define SDP_COL_B_PRIO 3         // wave priority (s_setprio) while in phase B
+#endif
 #ifndef SDP_COL_FILTER_SCALE
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
@@ -240,14 +243,17 @@ struct SdpColNest<SDP_DT - 1, SHIFT> {
 };
 
 // phase W for column `c`: trailing cell of every perturbation point -> s.w_*
+// (`first`: the threads from `first` on do it, the others pass)
 SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
-                             const SdpColShared &s, const sdp_real *x, const sdp_real *u, sdp_real t)
+                             const SdpColShared &s, const sdp_real *x, const sdp_real *u, sdp_real t,
+                             int first = 0)
 {
     constexpr int Wn = SDP_COL_W;
 #if SDP_HAS_W
     const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
 #endif
-    for (int w = threadIdx.x; w < Wn; w += blockDim.x) {
+    if ((int)threadIdx.x < first) return;
+    for (int w = (int)threadIdx.x - first; w < Wn; w += (int)blockDim.x - first) {
         sdp_real xn[SDP_D];
 #if SDP_HAS_W
         sdp_model_trail(x, u, wgrid[w], t, xn);
@@ -307,7 +313,11 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
 #pragma unroll
             for (int j = 0; j < G; ++j) {
                 const int r = min((j0 + j) * LW + rl, N0 - 1);           // clamp: result unused
+#ifdef SDP_DIAG_NO_A_LOADS
+                for (int q = 0; q < NV; ++q) vals[j][q] = (sdp_real)(r + q);
+#else
                 SdpColGather<0>::run(V + r, tg, off, 0, vals[j]);
+#endif
             }
 #pragma unroll
             for (int j = 0; j < G; ++j) {
@@ -1207,6 +1217,13 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     unsigned long long n_slow = 0, n_exact = 0, n_all = 0;
 #endif
 
+#if SDP_COL_FILTER
+    if (walk.unit < walk.end) {                            // trailing cells of the first unit
+        sdp_real xn[SDP_D];
+        sdp_col_coords(a, a.col_begin + walk.unit / a.col_splits, xn);
+        sdp_col_phase_w(a, tg, s, xn, nullptr, t);
+    }
+#endif
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = a.col_begin + unit / a.col_splits;
         const int part = (int)(unit % a.col_splits);
@@ -1214,6 +1231,23 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
+#if SDP_COL_FILTER
+        // The trailing cells of this unit were computed during the previous one (by its last
+        // wave, next to the reduction of the table; before the loop for the first unit): phase W
+        // is off the critical path.  This barrier publishes them and tells that every wave has
+        // left phase B of the previous unit, i.e. that the table may be overwritten.
+        SDP_COL_MARK(t0);
+        __syncthreads();
+        SDP_COL_MARK(t1);
+        sdp_col_phase_a<false>(a, tg, s);
+        __syncthreads();
+        SDP_COL_MARK(t2);
+        if (unit + walk.stride < walk.end) {               // nothing reads the cells after phase A
+            sdp_real xn[SDP_D];
+            sdp_col_coords(a, a.col_begin + (unit + walk.stride) / a.col_splits, xn);
+            sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
+        }
+#else
         // Phase W only writes the trailing cells, which nothing reads after phase A; the barrier
         // that follows it also tells that every wave has left phase B of the previous unit, i.e.
         // that the table may be overwritten.  (The row window publishes through win[] first.)
@@ -1228,6 +1262,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_phase_a<false>(a, tg, s);
         __syncthreads();
         SDP_COL_MARK(t2);
+#endif
 
 #if SDP_COL_FILTER
         sdp_col_filter_reduce(a, sdp_lds, filt);
@@ -1248,6 +1283,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             chunks = 1 << (31 - __builtin_clz(chunks < 64 ? chunks : 64));     // power of two <= 64
             const int npw = 64 / chunks;                                        // nodes per wave
             const int items = (n_nodes + npw - 1) / npw;
+            // the issue-bound phase goes first: the co-resident workgroup's table build mostly
+            // waits for memory and fills the gaps (measured: 2.79 -> 2.57 ms)
+            __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
             for (int item = wave; item < items; item += waves) {
                 const int chunk = lane / npw;
                 const int i_raw = i_lo + item * npw + (lane - chunk * npw);
@@ -1266,6 +1304,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 bd.s_max = bd.s_sum = (sdp_real)0;
                 bd.i1 = INT_MAX;
                 const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
+#ifdef SDP_DIAG_NO_PASS1
+                if (t == (sdp_real)123.456)
+#endif
                 if (__all(plain)) {
                     if (lead.pow2) sdp_col_filter_pass1<true, true>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
                     else sdp_col_filter_pass1<true, false>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
@@ -1286,6 +1327,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 const int first = single ? bd.i1 : c_lo, last = single ? bd.i1 + 1 : c_hi;
                 sdp_real best = INFINITY;
                 int ibest = INT_MAX;
+#ifdef SDP_DIAG_NO_PASS2
+                if (bd.f1 == (sdp_real)123.456)
+#endif
                 for (int ci = first; ci < last; ++ci) {
                     sdp_real u[1][SDP_NU], jc[1];
                     sdp_controls_at(box, ci, u[0]);
@@ -1317,6 +1361,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 tp2 += __builtin_amdgcn_s_memtime() - m2;
 #endif
             }
+            __builtin_amdgcn_s_setprio(0);
         }
 #else
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
@@ -1329,6 +1374,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         const int n_nodes = i_hi - i_lo;
         const int groups = (n_nodes + 63) >> 6;
         const int chunks = groups < waves ? waves / groups : 1;
+        __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
         for (int item = wave; item < groups * chunks; item += waves) {
             const int grp = item / chunks;
             const int chunk = item - grp * chunks;
@@ -1367,6 +1413,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (chunks > 1) {
             __syncthreads();
             for (int n = threadIdx.x; n < n_nodes; n += blockDim.x) {

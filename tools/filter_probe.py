@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How selective the certified filter of the column kernel is (diagnostic SDP_STAMP=3 build):
 nodes that keep more than one control after the first pass, and controls evaluated with the
-reference's operations, per sweep.  usage: python tools/filter_probe.py [N] [sweeps]  (through gpurun)"""
+reference's operations, per sweep.  usage: python tools/filter_probe.py [N] [sweeps] [dtype]  (through gpurun)"""
 import ctypes as C
 import os
 import sys
@@ -13,10 +13,12 @@ from stodynprog_amd import models, _native as nat
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dtype = np.dtype(sys.argv[3]) if len(sys.argv) > 3 else np.dtype('float64')
 _, s = models.synthetic3d(N=N)
+s.dtype = dtype
 prob = s._problem()
 assert s.backend_info['certified_filter']
-prob.set_value(models.synthetic3d_V0(s.state_grid))
+prob.set_value(models.synthetic3d_V0(s.state_grid, dtype))
 for k in range(sweeps):
     nat.check(nat.lib().sdp_problem_debug_stamps(prob.h, 0, None, 0))
     nat.check(nat.lib().sdp_problem_debug_stamps(prob.h, 1, None, 0))
