@@ -908,6 +908,13 @@ SDP_DEV void sdp_col_walk(const SdpSweepArgs &a, SdpColWalk &w)
     w.stride = gridDim.x >> 3;
 }
 
+// column of a unit (tried and not kept, no gain on MI355X: taking the columns in 8 x 8 tiles of
+// (x1, x2), and cutting the XCDs' shares along x2 so that the chip works on one band of strips)
+SDP_DEV int64_t sdp_col_of_unit(const SdpSweepArgs &a, int64_t unit)
+{
+    return a.col_begin + unit / a.col_splits;
+}
+
 SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
 {
     const sdp_real *axes = (const sdp_real *)a.axes;
@@ -1120,10 +1127,31 @@ SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, cons
 // is), the largest S^ -- one radius cu * s_max then covers every control of the node -- and the
 // sum of the S^, in which a NaN or an infinity of any control sticks (|F| <~ S^, and a NaN of
 // F comes with a NaN or an infinity of S^: through D[r] -- sdp_col_filter_reduce --, |g|, |lam0|).
+// With TOP2 also the third smallest F and whose the second is: when exactly two controls
+// survive -- the usual near-tie, the lattice points either side of the continuous optimum --
+// the second pass takes those two without looking at the lattice again.  Worth its five
+// instructions per control where near-ties are common (4-byte reals: ~5 % of the nodes of the
+// benchmark problem; 8-byte reals: none).
+#ifndef SDP_COL_FILTER_TOP2
+#define SDP_COL_FILTER_TOP2 -1   // -1: for 4-byte reals only
+#endif
+constexpr bool SDP_COL_TOP2 = SDP_COL_FILTER_TOP2 < 0 ? sizeof(sdp_real) == 4 : SDP_COL_FILTER_TOP2 != 0;
 struct SdpColBounds {
-    sdp_real f1, f2, s_max, s_sum;
-    int i1;
+    sdp_real f1, f2, f3, s_max, s_sum;
+    int i1, i2;
 };
+// one more value (of control ci) into the running two / three smallest
+SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_real F, int ci)
+{
+    if (SDP_COL_TOP2) {
+        b.f3 = sdp_vmin(b.f3, sdp_vmax(b.f2, F));
+        const bool c1 = F < b.f1, c2 = F < b.f2;
+        b.i2 = c1 ? b.i1 : (c2 ? ci : b.i2);
+    }
+    b.f2 = sdp_vmin(b.f2, sdp_vmax(b.f1, F));
+    b.i1 = F < b.f1 ? ci : b.i1;
+    b.f1 = sdp_vmin(b.f1, F);
+}
 
 // first pass over the controls [c_lo, c_hi) of one node.  PLAIN: a one-dimensional lattice that
 // is an ordinary linspace (n > 1, step != 0): sdp_control_value without its rare branches, the
@@ -1138,9 +1166,7 @@ SDP_DEV void sdp_col_filter_pass1(const SdpColLds &m, const SdpColFilter &f, con
         sdp_col_filter_eval<POW2>(m, f, l, x, u, t, F, S);
         b.s_sum = b.s_sum + S;
         b.s_max = sdp_vmax(b.s_max, S);
-        b.f2 = sdp_vmin(b.f2, sdp_vmax(b.f1, F));
-        b.i1 = F < b.f1 ? ci : b.i1;
-        b.f1 = sdp_vmin(b.f1, F);
+        sdp_col_bounds_insert(b, F, ci);
     };
     auto one = [&](int ci) {
         sdp_real u[SDP_NU];
@@ -1165,10 +1191,20 @@ SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
     const sdp_real o_f1 = sdp_shfl_xor(b.f1, d), o_f2 = sdp_shfl_xor(b.f2, d);
     const sdp_real o_max = sdp_shfl_xor(b.s_max, d), o_sum = sdp_shfl_xor(b.s_sum, d);
     const int o_i1 = __shfl_xor(b.i1, d, 64);
-    const sdp_real mx = o_f1 > b.f1 ? o_f1 : b.f1;
-    b.f2 = o_f2 < b.f2 ? o_f2 : b.f2;
-    b.f2 = mx < b.f2 ? mx : b.f2;
-    if (o_f1 < b.f1) { b.f1 = o_f1; b.i1 = o_i1; }         // (equal: f2 = f1, the node keeps both)
+    if (SDP_COL_TOP2) {
+        // the other lane's three smallest, one after the other (its third cannot end up among
+        // the two smallest of the union unless it ties with them -- and then f3 says so)
+        const sdp_real o_f3 = sdp_shfl_xor(b.f3, d);
+        const int o_i2 = __shfl_xor(b.i2, d, 64);
+        sdp_col_bounds_insert(b, o_f1, o_i1);
+        sdp_col_bounds_insert(b, o_f2, o_i2);
+        sdp_col_bounds_insert(b, o_f3, INT_MAX);
+    } else {
+        const sdp_real mx = o_f1 > b.f1 ? o_f1 : b.f1;
+        b.f2 = o_f2 < b.f2 ? o_f2 : b.f2;
+        b.f2 = mx < b.f2 ? mx : b.f2;
+        if (o_f1 < b.f1) { b.f1 = o_f1; b.i1 = o_i1; }     // (equal: f2 = f1, the node keeps both)
+    }
     b.s_max = o_max > b.s_max ? o_max : b.s_max;
     b.s_sum = b.s_sum + o_sum;
 }
@@ -1220,12 +1256,12 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_FILTER
     if (walk.unit < walk.end) {                            // trailing cells of the first unit
         sdp_real xn[SDP_D];
-        sdp_col_coords(a, a.col_begin + walk.unit / a.col_splits, xn);
+        sdp_col_coords(a, sdp_col_of_unit(a, walk.unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
     }
 #endif
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
-        const int64_t col = a.col_begin + unit / a.col_splits;
+        const int64_t col = sdp_col_of_unit(a, unit);
         const int part = (int)(unit % a.col_splits);
         const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
         const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
@@ -1244,7 +1280,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         SDP_COL_MARK(t2);
         if (unit + walk.stride < walk.end) {               // nothing reads the cells after phase A
             sdp_real xn[SDP_D];
-            sdp_col_coords(a, a.col_begin + (unit + walk.stride) / a.col_splits, xn);
+            sdp_col_coords(a, sdp_col_of_unit(a, unit + walk.stride), xn);
             sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
         }
 #else
@@ -1300,9 +1336,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 // pass 1: bounds of every control of this lane's range
                 SDP_COL_MARK(m1);
                 SdpColBounds bd;
-                bd.f1 = bd.f2 = INFINITY;
+                bd.f1 = bd.f2 = bd.f3 = INFINITY;
                 bd.s_max = bd.s_sum = (sdp_real)0;
-                bd.i1 = INT_MAX;
+                bd.i1 = bd.i2 = INT_MAX;
                 const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
 #ifdef SDP_DIAG_NO_PASS1
                 if (t == (sdp_real)123.456)
@@ -1324,16 +1360,24 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 const sdp_real radius = filt.cu * bd.s_max;
                 const sdp_real m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
                 const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
-                const int first = single ? bd.i1 : c_lo, last = single ? bd.i1 + 1 : c_hi;
+                // exactly two survivors (TOP2): the lanes of the node take one each (a lane alone takes both)
+                const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
+                const int p_lo = min(bd.i1, bd.i2), p_hi = max(bd.i1, bd.i2);
+                int first = c_lo, last = c_hi, stride = 1;
+                if (single) { first = bd.i1; last = bd.i1 + 1; }
+                if (pair) {
+                    if (chunks == 1) { first = p_lo; last = p_hi + 1; stride = max(p_hi - p_lo, 1); }
+                    else { first = (chunk & 1) ? p_hi : p_lo; last = chunk < 2 ? first + 1 : first; }
+                }
                 sdp_real best = INFINITY;
                 int ibest = INT_MAX;
 #ifdef SDP_DIAG_NO_PASS2
                 if (bd.f1 == (sdp_real)123.456)
 #endif
-                for (int ci = first; ci < last; ++ci) {
+                for (int ci = first; ci < last; ci += stride) {
                     sdp_real u[1][SDP_NU], jc[1];
                     sdp_controls_at(box, ci, u[0]);
-                    bool cand = single || bad;
+                    bool cand = single || pair || bad;
                     if (!cand) {
                         sdp_real F, S;
                         if (lead.pow2) sdp_col_filter_eval<true>(sdp_lds, filt, lead, x, u[0], t, F, S);
@@ -1354,7 +1398,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                     if (oi != INT_MAX && (ibest == INT_MAX || sdp_better_idx(ov, oi, best, ibest))) { best = ov; ibest = oi; }
                 }
 #if SDP_STAMP == 3
-                if (live && chunk == 0) { ++n_all; if (!single) ++n_slow; }
+                if (live && chunk == 0) { ++n_all; if (!single && !pair) ++n_slow; }
 #endif
                 if (live && chunk == 0) sdp_col_store(a, node, box, best, ibest);
 #if SDP_STAMP == 2
@@ -1488,7 +1532,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     int parity = 0;
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
-        const int64_t col = a.col_begin + unit / a.col_splits;
+        const int64_t col = sdp_col_of_unit(a, unit);
         const int part = (int)(unit % a.col_splits);
         const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
         const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
@@ -1601,7 +1645,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     const volatile sdp_lds_real *T = (const volatile sdp_lds_real *)s.T;
 
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
-        const int64_t col = a.col_begin + unit / a.col_splits;
+        const int64_t col = sdp_col_of_unit(a, unit);
         const int part = (int)(unit % a.col_splits);
         const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
         const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);

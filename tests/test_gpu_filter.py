@@ -139,6 +139,25 @@ def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
     _same(on, ref)
 
 
+@pytest.mark.parametrize('n_x', [96, 600])
+def test_two_survivors_take_the_short_cut(gpu, monkeypatch, n_x):
+    """SDP_COL_FILTER_TOP2 (default for 4-byte reals): the first pass also keeps the second
+    best control, and a node with exactly two survivors evaluates those two -- one per lane
+    of the node, or both on a lane that has the node to itself (600 nodes per column)"""
+    make = lambda: _stock(n_x=n_x)
+    V = np.random.default_rng(4).standard_normal(make()[1]._state_grid_shape)
+    on, off = _sweep(make, True, V, np.float32), _sweep(make, False, V, np.float32)
+    assert on[3].backend_info['certified_filter']
+    _same(on, off)
+    # the same path in 8-byte reals, with a radius wide enough to leave pairs
+    monkeypatch.setenv('SDP_COL_FILTER_TOP2', '1')
+    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '3e10')
+    on = _sweep(make, True, V)
+    monkeypatch.delenv('SDP_COL_FILTER_TOP2')
+    monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+    _same(on, _sweep(make, False, V))
+
+
 def test_chained_sweeps_and_relative_dp(gpu):
     make = lambda: models.synthetic3d(N=24)
     _, a = make()
