@@ -6,8 +6,16 @@
 // ranks on one device, and the test box has one.  Loaded through
 // SDP_RCCL_LIBRARY; lets tests/test_gpu_dist.py drive the library's multi-rank
 // code path (phase partition, in-place gather addresses, events, policy
-// gather) with nranks = 2 on real kernels.  Not a collective library: every
-// call synchronises the stream and the ranks.
+// gather) with nranks = 2 on real kernels.  Not a collective library.
+//
+// Two builds.  Default: every call synchronises the stream and the ranks (the
+// host blocks until the collective is complete).  -DSDP_MOCK_ASYNC: like the
+// real library the call only ENQUEUES work on the stream and returns -- the
+// staging copies are hipMemcpyAsync to / from the page-locked shared segment
+// and the rendezvous between the ranks are host functions in stream order
+// (hipLaunchHostFunc) -- so a missing event / stream dependency in the caller
+// (a kernel that reads J before the gather has landed, a host read before the
+// communicator stream was joined) is no longer hidden by the stand-in.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
@@ -21,7 +29,11 @@
 #include <sched.h>
 
 namespace {
+#ifdef SDP_MOCK_ASYNC
+constexpr size_t SLOT = (size_t)16 << 20;          // staging bytes per rank (the segment is page-locked)
+#else
 constexpr size_t SLOT = (size_t)96 << 20;          // staging bytes per rank
+#endif
 constexpr int MAXR = 8;
 struct Header {
     std::atomic<int> arrived;
@@ -78,6 +90,10 @@ int ncclCommInitRank(void **out, int nranks, uid128 id, int rank)
     if (m == MAP_FAILED) { delete c; return 2; }
     c->hdr = (Header *)m;                 // a fresh segment is zero-filled: counters start at 0
     c->slots = (char *)m + 4096;
+#ifdef SDP_MOCK_ASYNC
+    // page-locked: the staging copies are truly asynchronous
+    if (hipHostRegister(m, c->bytes, hipHostRegisterDefault) != hipSuccess) { munmap(m, c->bytes); delete c; return 1; }
+#endif
     c->hdr->attached.fetch_add(1);
     while (c->hdr->attached.load() < nranks) sched_yield();
     *out = c;
@@ -88,12 +104,84 @@ int ncclCommDestroy(void *h)
 {
     Comm *c = (Comm *)h;
     if (!c) return 0;
+#ifdef SDP_MOCK_ASYNC
+    (void)hipDeviceSynchronize();
+    (void)hipHostUnregister((void *)c->hdr);
+#endif
     munmap((void *)c->hdr, c->bytes);
     shm_unlink(c->name);
     delete c;
     return 0;
 }
 
+#ifdef SDP_MOCK_ASYNC
+// ---- asynchronous build ----------------------------------------------------
+namespace {
+void barrier_cb(void *h) { barrier((Comm *)h); }
+struct ReduceJob { Comm *c; int dtype; };
+void reduce_cb(void *p)
+{
+    ReduceJob *j = (ReduceJob *)p;
+    Comm *c = j->c;
+    char *out = slot(c, c->rank) + 64;                       // result next to this rank's operand
+    if (j->dtype == 2) {
+        int best; memcpy(&best, slot(c, 0), 4);
+        for (int r = 1; r < c->n; ++r) { int o; memcpy(&o, slot(c, r), 4); if (o > best) best = o; }
+        memcpy(out, &best, 4);
+    } else {
+        double best; memcpy(&best, slot(c, 0), 8);
+        for (int r = 1; r < c->n; ++r) { double o; memcpy(&o, slot(c, r), 8); if (o > best) best = o; }
+        memcpy(out, &best, 8);
+    }
+    delete j;
+}
+#define TRY(e) do { if ((e) != hipSuccess) return 1; } while (0)
+}  // namespace
+
+int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *h, hipStream_t stream)
+{
+    Comm *c = (Comm *)h;
+    const size_t bytes = count * dtype_size[dtype];
+    if (bytes > SLOT) return 4;
+    TRY(hipMemcpyAsync(slot(c, c->rank), send, bytes, hipMemcpyDeviceToHost, stream));
+    TRY(hipLaunchHostFunc(stream, barrier_cb, c));            // every rank has staged its part
+    for (int r = 0; r < c->n; ++r) {
+        char *dst = (char *)recv + (size_t)r * bytes;
+        if (r == c->rank && dst == (const char *)send) continue;      // in place
+        TRY(hipMemcpyAsync(dst, slot(c, r), bytes, hipMemcpyHostToDevice, stream));
+    }
+    TRY(hipLaunchHostFunc(stream, barrier_cb, c));            // every rank has read: the slots are free
+    return 0;
+}
+
+int ncclBroadcast(const void *send, void *recv, size_t count, int dtype, int root, void *h, hipStream_t stream)
+{
+    Comm *c = (Comm *)h;
+    const size_t bytes = count * dtype_size[dtype];
+    if (bytes > SLOT) return 4;
+    if (c->rank == root) TRY(hipMemcpyAsync(slot(c, root), send, bytes, hipMemcpyDeviceToHost, stream));
+    TRY(hipLaunchHostFunc(stream, barrier_cb, c));
+    if (c->rank != root) TRY(hipMemcpyAsync(recv, slot(c, root), bytes, hipMemcpyHostToDevice, stream));
+    else if (recv != send) TRY(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, stream));
+    TRY(hipLaunchHostFunc(stream, barrier_cb, c));
+    return 0;
+}
+
+int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, void *h, hipStream_t stream)
+{
+    Comm *c = (Comm *)h;
+    if ((dtype != 8 && dtype != 2) || op != 2 || count != 1) return 4;   // max of one float64 / int32
+    const size_t bytes = dtype_size[dtype];
+    TRY(hipMemcpyAsync(slot(c, c->rank), send, bytes, hipMemcpyDeviceToHost, stream));
+    TRY(hipLaunchHostFunc(stream, barrier_cb, c));
+    TRY(hipLaunchHostFunc(stream, reduce_cb, new ReduceJob{c, dtype}));
+    TRY(hipMemcpyAsync(recv, slot(c, c->rank) + 64, bytes, hipMemcpyHostToDevice, stream));
+    TRY(hipLaunchHostFunc(stream, barrier_cb, c));            // operands may be overwritten
+    return 0;
+}
+#undef TRY
+#else
+// ---- synchronous build -----------------------------------------------------
 int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *h, hipStream_t stream)
 {
     Comm *c = (Comm *)h;
@@ -154,6 +242,8 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
     if (hipMemcpy(recv, &best, 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
     return 0;
 }
+
+#endif  // SDP_MOCK_ASYNC
 
 int ncclGroupStart(void) { return 0; }
 int ncclGroupEnd(void) { return 0; }

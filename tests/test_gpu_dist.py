@@ -154,13 +154,16 @@ def test_real_rccl_without_torch_and_two_runtime_guard(gpu, tmp_path):
 # blocking) through SDP_RCCL_LIBRARY.  Everything above the collective calls is
 # the product code that runs on the multi-GPU node.
 # ---------------------------------------------------------------------------
-def _build_mock(tmp_path):
+def _build_mock(tmp_path, asynchronous=False):
+    """the collective stand-in (tests/mock_rccl.cpp); `asynchronous`: the build whose calls only
+    enqueue work on the stream, like the real library"""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available to build the collective stand-in')
-    out = str(tmp_path / 'libmock_rccl.so')
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17',
-                           '-o', out, os.path.join(ROOT, 'tests', 'mock_rccl.cpp'), '-lrt'])
+    out = str(tmp_path / ('libmock_rccl_async.so' if asynchronous else 'libmock_rccl.so'))
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17']
+                          + (['-DSDP_MOCK_ASYNC'] if asynchronous else [])
+                          + ['-o', out, os.path.join(ROOT, 'tests', 'mock_rccl.cpp'), '-lrt'])
     return out
 
 
@@ -237,9 +240,11 @@ print('rank', rank, 'all ok', flush=True)
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('world', [2, 3, 8])
-def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world):
-    mock = _build_mock(tmp_path)
+@pytest.mark.parametrize('world,asynchronous', [(2, False), (3, False), (8, False), (2, True), (3, True)])
+def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world, asynchronous):
+    """asynchronous: the stand-in only enqueues (staging copies + host-function rendezvous in
+    stream order), so the library's events and stream joins carry the ordering, as with RCCL"""
+    mock = _build_mock(tmp_path, asynchronous)
     script = tmp_path / 'lib_worker.py'
     script.write_text(LIB_WORKER.format(root=ROOT))
     outs = _run_ranks(script, world, dict(SDP_RCCL_LIBRARY=mock))
@@ -248,13 +253,14 @@ def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, worl
 
 
 @pytest.mark.timeout(900)
-def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path):
+@pytest.mark.parametrize('asynchronous', [False, True])
+def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path, asynchronous):
     """bench.py exactly as the driver launches it for N > 1 (env of
     torch.distributed.run), two ranks on the one GPU through the stand-in:
     phase tuning, timed region, max over ranks, one JSON line on rank 0, and the
     sharded result checked against a single-GPU chain of sweeps"""
     import json
-    mock = _build_mock(tmp_path)
+    mock = _build_mock(tmp_path, asynchronous)
     outs = _run_ranks(os.path.join(ROOT, 'bench.py'), 2, dict(SDP_RCCL_LIBRARY=mock),
                       argv=['--gpus', '2', '--grid', '48', '--steps', '3', '--warmup', '1',
                             '--no-cpu-baseline'])
