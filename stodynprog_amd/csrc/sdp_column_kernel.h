@@ -160,6 +160,7 @@ struct __attribute__((aligned(16))) SdpColLds {
     int part_i[SDP_COL_THREADS];
     int w_off[SDP_COL_W * SDP_DT];
     int win[2][2];                         // row window: per parity (min row, minus max row) of the unit
+    int next_unit;                         // filtered kernel: the unit claimed for the next round
 #if SDP_COL_FILTER
     // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
     sdp_real ad[2 * SDP_COL_ROWS] __attribute__((aligned(16)));
@@ -908,11 +909,33 @@ SDP_DEV void sdp_col_walk(const SdpSweepArgs &a, SdpColWalk &w)
     w.stride = gridDim.x >> 3;
 }
 
-// column of a unit (tried and not kept, no gain on MI355X: taking the columns in 8 x 8 tiles of
-// (x1, x2), and cutting the XCDs' shares along x2 so that the chip works on one band of strips)
+// Column of a unit.  The filtered kernel hands its units out IN ORDER (SdpSweepArgs.claim), so the
+// workgroups resident on an XCD are always at ~64 consecutive units; with two trailing axes
+// those are taken as an 8 x 8 tile of (x1, x2) instead of 64 columns along x2: the cells of
+// 8 x 8 neighbouring columns overlap almost entirely, and the strips their tables are built
+// from (a ~40 x 25 patch of 2 KiB strips for the benchmark dynamics) stay in the XCD's
+// 4 MiB L2, where 64 columns in a row reach over three times as many.  A bijection on every
+// aligned block of 8 rows of columns inside the launch's range (identity elsewhere); the
+// results do not depend on the order.  (With the static striding of the other kernels the
+// workgroups drift apart and the order made no difference: measured.)
+#ifndef SDP_COL_TILE
+#define SDP_COL_TILE 1
+#endif
 SDP_DEV int64_t sdp_col_of_unit(const SdpSweepArgs &a, int64_t unit)
 {
-    return a.col_begin + unit / a.col_splits;
+    const int64_t col = a.col_begin + unit / a.col_splits;
+#if SDP_D == 3 && SDP_COL_FILTER && SDP_COL_TILE
+    const int64_t n2 = a.orders[2];
+    if ((n2 & 7) == 0) {
+        const int64_t blk = 8 * n2;
+        const int64_t b0 = col / blk * blk;
+        if (b0 >= a.col_begin && b0 + blk <= a.col_end) {
+            const int64_t local = col - b0, tile = local >> 6, within = local & 63;
+            return b0 + (within >> 3) * n2 + (tile << 3) + (within & 7);
+        }
+    }
+#endif
+    return col;
 }
 
 SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
@@ -1104,16 +1127,22 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
     }
 }
 
-// F(u) and S^(u) of one control (x0' cell and cost exactly as sdp_col_expected_cost computes them;
-// POW2 = l.pow2, a template argument so that the loop of the first pass carries no branch)
-template <bool POW2>
+// F(u) and S^(u) of one control (x0' cell and cost exactly as sdp_col_expected_cost computes them).
+// AXIS, a template argument so that the loop of the first pass carries no branch: 0 the true
+// division of pyx:75; 1 a power-of-two span (product with the reciprocal: sdp_div_span); 2 the
+// axis [0, 1] (x - 0.0 and x * 1.0 are x, bit for bit).  `pmax` collects |p|: the truncation
+// to an int has x86 semantics beyond 2^31 (sdp_trunc_i32) -- a node that gets there takes the
+// long way instead of paying for the check on every control.
+template <int AXIS>
 SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, const SdpLeadAxis &l,
-                                 const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &S)
+                                 const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &S,
+                                 sdp_real &pmax)
 {
     const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
-    const sdp_real sn = POW2 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span;       // sdp_div_span
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
     const sdp_real p = sn * l.nm1;
-    const int q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);
+    pmax = sdp_vmax(pmax, fabs(p));
+    const int q0 = max(min((int)p, l.ordm2), 0);            // (saturating conversion; NaN -> 0)
     const sdp_real lam0 = p - (sdp_real)q0;
     const sdp_real oml0 = (sdp_real)1 - lam0;
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
@@ -1121,6 +1150,11 @@ SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, cons
     const sdp_real a0 = ad[0], d0 = ad[1], a1 = ad[2], d1 = ad[3];
     F = g * f.psum + (oml0 * a0 + lam0 * a1);
     S = fma(fabs(g), f.pcap, (fabs(oml0) + fabs(lam0)) * sdp_vmax(d0, d1));
+}
+SDP_DEV int sdp_col_axis_mode(const SdpLeadAxis &l)
+{
+    if (!l.pow2) return 0;
+    return (l.smin == (sdp_real)0 && l.span == (sdp_real)1) ? 2 : 1;
 }
 
 // What the first pass keeps of a node's controls: the two smallest F (and whose the smallest
@@ -1137,9 +1171,12 @@ SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, cons
 #endif
 constexpr bool SDP_COL_TOP2 = SDP_COL_FILTER_TOP2 < 0 ? sizeof(sdp_real) == 4 : SDP_COL_FILTER_TOP2 != 0;
 struct SdpColBounds {
-    sdp_real f1, f2, f3, s_max, s_sum;
+    sdp_real f1, f2, f3, s_max, s_sum, p_max;
     int i1, i2;
 };
+// 8-byte reals: the SUM of the S^ serves as the node's bound (no running maximum; a radius
+// U times the necessary one, ~1e-12 relative, still leaves one survivor); 4-byte reals keep the maximum
+constexpr bool SDP_COL_RADIUS_FROM_SUM = sizeof(sdp_real) == 8;
 // one more value (of control ci) into the running two / three smallest
 SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_real F, int ci)
 {
@@ -1156,16 +1193,16 @@ SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_real F, int ci)
 // first pass over the controls [c_lo, c_hi) of one node.  PLAIN: a one-dimensional lattice that
 // is an ordinary linspace (n > 1, step != 0): sdp_control_value without its rare branches, the
 // last point (`stop`, numpy.linspace) taken out of the loop.
-template <bool PLAIN, bool POW2>
+template <bool PLAIN, int AXIS>
 SDP_DEV void sdp_col_filter_pass1(const SdpColLds &m, const SdpColFilter &f, const SdpLeadAxis &l,
                                   const SdpBox &box, sdp_real *x, sdp_real t, int c_lo, int c_hi,
                                   SdpColBounds &b)
 {
     auto eval = [&](int ci, const sdp_real *u) {
         sdp_real F, S;
-        sdp_col_filter_eval<POW2>(m, f, l, x, u, t, F, S);
+        sdp_col_filter_eval<AXIS>(m, f, l, x, u, t, F, S, b.p_max);
         b.s_sum = b.s_sum + S;
-        b.s_max = sdp_vmax(b.s_max, S);
+        if (!SDP_COL_RADIUS_FROM_SUM) b.s_max = sdp_vmax(b.s_max, S);
         sdp_col_bounds_insert(b, F, ci);
     };
     auto one = [&](int ci) {
@@ -1207,6 +1244,8 @@ SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
     }
     b.s_max = o_max > b.s_max ? o_max : b.s_max;
     b.s_sum = b.s_sum + o_sum;
+    const sdp_real o_p = sdp_shfl_xor(b.p_max, d);
+    b.p_max = o_p > b.p_max ? o_p : b.p_max;
 }
 #endif  // SDP_COL_FILTER
 
@@ -1238,6 +1277,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_FILTER
     SdpColFilter filt;
     sdp_col_filter_setup(a, filt);
+    const int axis_mode = __builtin_amdgcn_readfirstlane(sdp_col_axis_mode(lead));
 #endif
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     int parity = 0;
@@ -1254,13 +1294,23 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
 
 #if SDP_COL_FILTER
-    if (walk.unit < walk.end) {                            // trailing cells of the first unit
+    // The units of this XCD's share are handed out in order (one atomic per unit, claimed a
+    // round ahead): whatever their speeds, the workgroups of an XCD work on neighbouring units.
+    const int64_t u_base = walk.unit - (blockIdx.x >> 3), u_end = walk.end;
+    unsigned int *claim = a.claim + 32 * (blockIdx.x & 7);
+    if (threadIdx.x == 0) sdp_lds.next_unit = (int)atomicAdd(claim, 1u);
+    __syncthreads();
+    int64_t unit = u_base + sdp_lds.next_unit;
+    if (unit < u_end) {                                    // trailing cells of the first unit
         sdp_real xn[SDP_D];
-        sdp_col_coords(a, sdp_col_of_unit(a, walk.unit), xn);
+        sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
     }
-#endif
+    while (unit < u_end) {
+        int64_t next_unit;
+#else
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
+#endif
         const int64_t col = sdp_col_of_unit(a, unit);
         const int part = (int)(unit % a.col_splits);
         const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
@@ -1278,10 +1328,16 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_phase_a<false>(a, tg, s);
         __syncthreads();
         SDP_COL_MARK(t2);
-        if (unit + walk.stride < walk.end) {               // nothing reads the cells after phase A
-            sdp_real xn[SDP_D];
-            sdp_col_coords(a, sdp_col_of_unit(a, unit + walk.stride), xn);
-            sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
+        if (wave == waves - 1) {                           // nothing reads the cells after phase A
+            int nx = 0;
+            if (lane == 0) nx = (int)atomicAdd(claim, 1u);
+            nx = __builtin_amdgcn_readfirstlane(nx);
+            if (lane == 0) sdp_lds.next_unit = nx;
+            if (u_base + nx < u_end) {
+                sdp_real xn[SDP_D];
+                sdp_col_coords(a, sdp_col_of_unit(a, u_base + nx), xn);
+                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
+            }
         }
 #else
         // Phase W only writes the trailing cells, which nothing reads after phase A; the barrier
@@ -1303,6 +1359,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_FILTER
         sdp_col_filter_reduce(a, sdp_lds, filt);
         __syncthreads();
+        next_unit = u_base + sdp_lds.next_unit;
         SDP_COL_MARK(m0);
 #if SDP_STAMP == 2
         tr += m0 - t2;
@@ -1337,18 +1394,20 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 SDP_COL_MARK(m1);
                 SdpColBounds bd;
                 bd.f1 = bd.f2 = bd.f3 = INFINITY;
-                bd.s_max = bd.s_sum = (sdp_real)0;
+                bd.s_max = bd.s_sum = bd.p_max = (sdp_real)0;
                 bd.i1 = bd.i2 = INT_MAX;
                 const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
 #ifdef SDP_DIAG_NO_PASS1
                 if (t == (sdp_real)123.456)
 #endif
                 if (__all(plain)) {
-                    if (lead.pow2) sdp_col_filter_pass1<true, true>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                    else sdp_col_filter_pass1<true, false>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    else sdp_col_filter_pass1<true, 0>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
                 } else {
-                    if (lead.pow2) sdp_col_filter_pass1<false, true>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                    else sdp_col_filter_pass1<false, false>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
+                    else sdp_col_filter_pass1<false, 0>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
                 }
                 for (int d = npw; d < 64; d <<= 1) sdp_col_bounds_merge(bd, d);
                 // pass 2: the reference's operations on the survivors
@@ -1356,8 +1415,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_STAMP == 2
                 tp1 += m2 - m1;
 #endif
-                const bool bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT);
-                const sdp_real radius = filt.cu * bd.s_max;
+                const bool bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)2147483648.0);
+                const sdp_real radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? bd.s_sum : bd.s_max);
                 const sdp_real m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
                 const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
                 // exactly two survivors (TOP2): the lanes of the node take one each (a lane alone takes both)
@@ -1380,8 +1439,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                     bool cand = single || pair || bad;
                     if (!cand) {
                         sdp_real F, S;
-                        if (lead.pow2) sdp_col_filter_eval<true>(sdp_lds, filt, lead, x, u[0], t, F, S);
-                        else sdp_col_filter_eval<false>(sdp_lds, filt, lead, x, u[0], t, F, S);
+                        sdp_real pm = (sdp_real)0;
+                        if (lead.pow2) sdp_col_filter_eval<1>(sdp_lds, filt, lead, x, u[0], t, F, S, pm);
+                        else sdp_col_filter_eval<0>(sdp_lds, filt, lead, x, u[0], t, F, S, pm);
                         cand = !(F - radius > m_hi);
                     }
                     if (cand) {
@@ -1483,7 +1543,20 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         t3 = __builtin_amdgcn_s_memtime();
         tw += t1 - t0; ta += t2 - t1; tb += t3 - t2;
 #endif
+#if SDP_COL_FILTER
+        unit = next_unit;
+#endif
     }
+#if SDP_COL_FILTER
+    // the last workgroup to run out of units leaves the counters at zero for the next launch
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(a.claim + 256, 1u) == gridDim.x - 1) {
+            for (int k = 0; k < 8; ++k) atomicExch(a.claim + 32 * k, 0u);
+            atomicExch(a.claim + 256, 0u);
+        }
+    }
+#endif
 #if SDP_STAMP == 3 && SDP_COL_FILTER
     if (a.stamps) {
         atomicAdd((unsigned long long *)&a.stamps[0], n_slow);

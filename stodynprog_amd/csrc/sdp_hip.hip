@@ -630,7 +630,7 @@ struct sdp_problem {
     int64_t S = 0, node_begin = 0, node_end = 0;
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
-    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps;
+    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps, claim;
     DevBuf stage[3];                       // layout-conversion buffers of the fused host call (J, pol, idx)
     size_t stage_bytes[3] = {0, 0, 0};
     // peer-write exchange (sdp_problem_enable_peer_exchange): the other ranks' value / J buffers
@@ -800,6 +800,11 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         int mt = 0;
         if (hipFuncGetAttribute(&mt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, p->f_sweep) == hipSuccess && mt >= 64)
             p->col_threads = mt > 1024 ? 1024 : mt;
+        // unit counters of the filtered column kernel (SdpSweepArgs.claim): zero once, the kernel
+        // leaves them zero
+        int rc = p->claim.alloc(4 * (8 * 32 + 32));
+        if (rc) return rc;
+        HIP_TRY(hipMemset(p->claim.p, 0, 4 * (8 * 32 + 32)));
     }
     if (p->variant == SDP_VARIANT_STAGED) {
         int mt = 0;
@@ -924,6 +929,7 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     a.W = p->W; a.box_per_node = p->box_per_node;
     a.shift_index = -1; a.ref_out = nullptr;
     a.stamps = (unsigned long long *)p->stamps.p;
+    a.claim = (unsigned int *)p->claim.p;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
         a.col_begin = nb / p->orders[0];

@@ -44,6 +44,10 @@ struct SdpSweepArgs {
     // [gridDim.x][4] words: s_memtime / s_memrealtime of thread 0 at kernel entry and exit
     // (in-kernel clock = d memtime / d memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS item 6)
     unsigned long long *stamps;
+    // ---- filtered column kernel: units handed out in order (sdp_column_kernel.h) ----
+    // claim[32 * k], k = 0..7: next unit of XCD k's share (relative); claim[256]: workgroups that
+    // have finished (the last one zeroes everything for the next launch).  Zero before the first launch.
+    unsigned int *claim;
 };
 
 // Batched closed-loop simulation (the user loop of the reference's examples, e.g.

@@ -589,9 +589,11 @@ class DPSolver(object):
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         if self.kernel not in ('auto', 'generic', 'column', 'staged'):
             raise ValueError("kernel must be 'auto', 'column', 'staged' or 'generic'")
+        may_filter = (getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'
+                      and codegen.column_filter_applies(model))
         column = (self.kernel in ('auto', 'column') and model.storage_separable and
                   codegen.column_config(shape[0], W, len(shape), dt,
-                                        codegen.use_wpair(model, dt)) is not None)
+                                        codegen.use_wpair(model, dt), may_filter) is not None)
         # trailing next states that depend on the control but not on x0: the nodes of a
         # column still share a table, control by control, provided they share their control
         # values (box independent of x0) -- csrc/sdp_column_kernel.h, SDP_TRAIL_HAS_U
