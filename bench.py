@@ -346,14 +346,21 @@ def run(args):
     pmc_key = '{}_{}_{}{}'.format(args.config if not args.grid else '{}{}'.format(model_name, args.grid),
                                   'f64' if rb == 8 else 'f32', kernel_family, '_filter' if filtered else '')
     pmc, pmc_path = load_pmc(pmc_key)
-    issue_peak = FP64_ISSUE_PEAK if (rb == 8 or filtered) else FP32_ISSUE_PEAK
+    issue_peak = (N_SIMD * 2.4e9) if filtered else (FP64_ISSUE_PEAK if rb == 8 else FP32_ISSUE_PEAK)
     analytic = cells * 6 / 64.0                        # 6 operations per lattice cell, never fusable
+    valu_all = valu_f64 = None
     if filtered and pmc and pmc.get('counters_mean_per_dispatch', {}).get('SQ_INSTS_VALU'):
-        # the filter leaves a mix of fp64 and 32-bit VALU work (cell location, comparisons,
-        # selects), all of it issued at 4 clk per wave64 instruction on the same port
-        counted = float(pmc['counters_mean_per_dispatch']['SQ_INSTS_VALU'])
-        count_source = ('{}: SQ_INSTS_VALU per {} dispatch (rocprofv3 --pmc of this command); of which fp64 '
-                        'arithmetic {:.3g}'.format(pmc_path, kname, float(pmc.get('valu_wave_instr') or 0)))
+        # the filter leaves a mix of fp64 arithmetic (4 clk per wave64 instruction) and 32-bit /
+        # conversion / select work (2 clk: MI355X_MICROARCH.md, cycle constants): priced in SIMD
+        # issue cycles, fp64 ADD/MUL/FMA at 4 and EVERYTHING else at 2 (the 64-bit min / max /
+        # compare / convert instructions among "everything else" cost 4: the figure is a floor)
+        cm = pmc['counters_mean_per_dispatch']
+        valu_all = float(cm['SQ_INSTS_VALU'])
+        valu_f64 = float(sum(cm.get('SQ_INSTS_VALU_{}_F64'.format(k), 0.0) for k in ('ADD', 'MUL', 'FMA'))) if rb == 8 else 0.0
+        counted = 4.0 * valu_f64 + 2.0 * (valu_all - valu_f64)
+        count_source = ('{}: per {} dispatch (rocprofv3 --pmc of this command) SQ_INSTS_VALU {:.4g}, of which fp64 '
+                        'ADD/MUL/FMA {:.4g}; issue cycles = 4 x fp64 + 2 x the rest'.format(
+                            pmc_path, kname, valu_all, valu_f64))
     elif filtered:
         counted = None
         count_source = 'no PMC summary committed for this workload'
@@ -376,16 +383,17 @@ def run(args):
     clock = load_clock()
     roof = {
         'bound': 'valu_issue' if filtered else ('fp64_valu' if rb == 8 else 'fp32_valu'),
-        'achieved': achieved, 'peak': issue_peak, 'unit': 'wave-instr/s',
+        'achieved': achieved, 'peak': issue_peak, 'unit': 'SIMD issue cycles/s' if filtered else 'wave-instr/s',
         'frac': achieved / issue_peak if achieved is not None else None,
         'traffic': traffic, 'traffic_source': traffic_source,
         'kernel': kname, 'kernel_ms': k_ms,
-        'valu_wave_instr_per_launch': instr_launch, 'count_source': count_source,
+        'valu_wave_instr_per_launch': (valu_all * share if valu_all is not None else instr_launch),
+        'issue_cycles_per_launch': instr_launch if filtered else None, 'count_source': count_source,
         'analytic_min_wave_instr_per_launch': analytic * share,
-        'peak_source': 'spec: 256 CU x 4 SIMD x 2.4 GHz / {} clk per wave64 {} VALU instruction '
-                       '(MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s, fp64 half of it)'.format(
-                           4 if (rb == 8 or filtered) else 2,
-                           'fp64 or unpacked 32-bit' if filtered else ('fp64' if rb == 8 else 'fp32')),
+        'peak_source': ('spec: 256 CU x 4 SIMD x 2.4 GHz issue cycles per second' if filtered else
+                        'spec: 256 CU x 4 SIMD x 2.4 GHz / {} clk per wave64 {} VALU instruction '
+                        '(MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s, fp64 half of it)'.format(
+                            4 if rb == 8 else 2, 'fp64' if rb == 8 else 'fp32')),
         'why_not_hbm': 'certified expectation-first filter (DESIGN.md section 3): the expectation over w commutes '
                        'with the lerp along axis 0, so one lerp on a w-reduced table plus a proven error radius '
                        'decides every control but the near-minimal ones; only those run the reference\'s W x 6 '
@@ -399,6 +407,9 @@ def run(args):
                        'fuse bind the kernel' if kernel_family == 'column' else
                        'per-cell gathers: bound by vector-memory/LDS gather issue, see DESIGN.md section 4',
     }
+    if filtered and valu_all is not None:
+        roof['valu_wave_instr_fp64_arith'] = valu_f64 * share
+        roof['frac_if_every_instr_took_4clk'] = 4.0 * valu_all * share / k_s / issue_peak
     if filtered:
         roof['reference_operations'] = {
             'wave_instr_per_launch': analytic * share, 'per_s': analytic * share / k_s,
@@ -406,8 +417,11 @@ def run(args):
             'note': 'NOT a utilisation: 6 separately rounded operations per lattice cell (what the reference, the '
                     'oracle and `--no-filter` execute) divided by this kernel\'s time'}
     if clock and clock.get('sweep_kernel_ghz') and achieved is not None:
-        ghz = float(clock['sweep_kernel_ghz'])
-        peak_clk = N_SIMD * ghz * 1e9 / (4 if (rb == 8 or filtered) else 2)
+        # (the filtered kernel draws less power and holds a higher clock than the long-way kernel)
+        ghz = float(clock['sweep_kernel_ghz'] if filtered else
+                    clock.get('long_way_kernel', {}).get('sweep_kernel_ghz', clock['sweep_kernel_ghz']))
+        ghz = min(ghz, 2.4)      # (the stamps of the filtered kernel read 2.43 GHz, 1 % above the part's peak clock)
+        peak_clk = N_SIMD * ghz * 1e9 / (1 if filtered else (4 if rb == 8 else 2))
         roof['measured_clock_ghz'] = ghz
         roof['peak_at_measured_clock'] = peak_clk
         roof['frac_at_measured_clock'] = achieved / peak_clk

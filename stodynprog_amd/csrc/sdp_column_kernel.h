@@ -118,6 +118,9 @@
 #ifndef SDP_COL_B_PRIO
 #define SDP_COL_B_PRIO 3         // wave priority (s_setprio) while in phase B
 #endif
+#ifndef SDP_COL_FILTER_RUNROLL
+#define SDP_COL_FILTER_RUNROLL 16   // table entries in flight per thread in the reduction over w
+#endif
 #ifndef SDP_COL_FILTER_SCALE
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
@@ -1110,7 +1113,7 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
     const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
     for (int r = threadIdx.x; r < N0; r += blockDim.x) {
         sdp_real acc = (sdp_real)0, big = (sdp_real)0;
-#pragma unroll 8
+#pragma unroll SDP_COL_FILTER_RUNROLL
         for (int w = 0; w < SDP_COL_W; ++w) {
 #if SDP_COL_WPAIR
             const sdp_real v = m.T[((w >> 1) * N0 + r) * 2 + (w & 1)];
@@ -1325,12 +1328,12 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         SDP_COL_MARK(t0);
         __syncthreads();
         SDP_COL_MARK(t1);
+        int nx = 0;                                        // the next unit: claimed here, the atomic's
+        if (wave == waves - 1 && lane == 0) nx = (int)atomicAdd(claim, 1u);   // round trip hides under phase A
         sdp_col_phase_a<false>(a, tg, s);
         __syncthreads();
         SDP_COL_MARK(t2);
         if (wave == waves - 1) {                           // nothing reads the cells after phase A
-            int nx = 0;
-            if (lane == 0) nx = (int)atomicAdd(claim, 1u);
             nx = __builtin_amdgcn_readfirstlane(nx);
             if (lane == 0) sdp_lds.next_unit = nx;
             if (u_base + nx < u_end) {
@@ -1357,6 +1360,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
 
 #if SDP_COL_FILTER
+        __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);        // (see phase B)
         sdp_col_filter_reduce(a, sdp_lds, filt);
         __syncthreads();
         next_unit = u_base + sdp_lds.next_unit;

@@ -25,6 +25,8 @@ st = st.reshape(-1, 4).astype(float)
 n_wg = int((st[:, 3] > 0).sum())
 extra = st[n_wg:2 * n_wg]                 # filter builds: reduce, first pass, second pass of phase B
 st = st[:n_wg]
+busy = st[:, 2] > 0                       # (units are claimed in order: late workgroups find nothing left)
+st, extra = st[busy], extra[busy[:len(extra)]] if len(extra) else extra
 tot = st[:, 3]
 print('kernel {:.3f} ms; {} workgroups; lifetime of a workgroup: median {:.3e} clk'.format(k / 5, len(st), np.median(tot)))
 for name, col in (('W (trailing cells + barrier)', 0), ('A (table build + barrier)', 1), ('B (cells, argmin, stores + barrier)', 2)):
