@@ -357,3 +357,33 @@ def test_percontrol_and_window_shapes():
     assert codegen.column_window_config(1024, 32, 3, np.float64, 2000) is None     # one node spans the axis
     assert codegen.staged_row_stride(19, 8, 3, 8) == 24 and codegen.staged_row_stride(8, 8, 3, 8) == 8
     assert codegen.staged_row_stride(19, 32, 2, 8) == 19 and codegen.staged_row_stride(20, 8, 3, 4) == 21
+
+
+def test_certified_filter_planning_without_a_gpu():
+    """where the column kernel gets the certified expectation-first filter (SDP_COL_FILTER of
+    csrc/sdp_column_kernel.h) and the workgroup shape that goes with it: one lane per node"""
+    from stodynprog_amd import codegen
+    _, s = models.synthetic3d(N=256)
+    plan = s._kernel_plan()
+    assert plan['column'] and plan['filtered']
+    src = plan['source']
+    assert '#define SDP_COL_FILTER 1' in src and '#define SDP_COL_THREADS 256' in src
+    assert '#define SDP_COL_MIN_WAVES 1' in src
+    s.certified_filter = False                           # every control the long way: the round-1 shape
+    src = s._kernel_plan()['source']
+    assert 'SDP_COL_FILTER' not in src and '#define SDP_COL_THREADS 512' in src
+    s.certified_filter = True
+    s.arithmetic = 'fused'                               # not the reference's operations: no filter
+    assert not s._kernel_plan()['filtered']
+    # 512 nodes per column: 512 lanes; beyond that the lanes of a wave share nodes as before
+    _, s = models.synthetic3d(N=64)
+    s.discretize_state(0, 1, 512, 0, 1, 16, 0, 1, 16)
+    s.dtype = np.dtype('float32')
+    assert '#define SDP_COL_THREADS 512' in s._kernel_plan()['source']
+    # a perturbation in x0' or in the cost: the expectation no longer commutes with the lerp
+    m = trace_model(lambda x, y, u, w: (x + u + 0.1 * w, 0.5 * y + w), lambda x, y, u, w: u * u, 2, 1, 1)
+    assert m.storage_separable and not codegen.column_filter_applies(m)
+    m = trace_model(lambda x, y, u, w: (x + u, 0.5 * y + w), lambda x, y, u, w: u * w, 2, 1, 1)
+    assert m.storage_separable and not codegen.column_filter_applies(m)
+    m = trace_model(lambda x, y, u, w: (x + u, 0.5 * y + w), lambda x, y, u, w: u * y, 2, 1, 1)
+    assert codegen.column_filter_applies(m)
