@@ -261,27 +261,35 @@ def run(args):
         # collectives; the best count depends on the rank count and the fabric.
         # Every rank times the same candidates; the max over ranks decides, so all
         # ranks pick the same count.
-        exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,peer').split(',') if e]
+        exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,peer,sparse').split(',') if e]
         if os.environ.get('SDP_COMM_PHASES'):
             solver.comm_phases = int(os.environ['SDP_COMM_PHASES'])
-            solver.comm_exchange = exchanges[0]
+            solver.comm_exchange = 'peer' if exchanges[0] == 'sparse' else exchanges[0]
+            solver.comm_sparse = exchanges[0] == 'sparse'
         else:
             # Second dimension: how the rows travel.  'rccl' = all-gather kernels of the
             # collective library; 'peer' = every rank copies its rows into the peers' buffers
-            # (HIP IPC mappings, copy engines, no compute units).  'peer' is a candidate only
-            # where every rank can map every peer, and only if its J equals the RCCL one bit
-            # for bit on every rank after the same sweeps.
+            # (HIP IPC mappings, copy engines, no compute units); 'sparse' = 'peer' with one
+            # slab of columns per rank and only the rows a peer reads sent to it.  'peer' /
+            # 'sparse' are candidates only where every rank can map every peer, and only if
+            # their J equals the RCCL one bit for bit on every rank after the same sweeps.
             phase_times, J_check = {}, None
             for exch in exchanges:
                 if dev_comm.nranks == 1 and exch != 'rccl':
                     continue
                 for ph, taper in ((2, False), (4, False), (8, False), (16, False), (4, True), (8, True)):
-                    solver.comm_phases, solver.comm_taper, solver.comm_exchange = ph, taper, exch
+                    if exch == 'sparse' and taper:
+                        continue                            # (slabs are cut evenly)
+                    solver.comm_phases, solver.comm_taper = ph, taper
+                    solver.comm_exchange = 'peer' if exch == 'sparse' else exch
+                    solver.comm_sparse = exch == 'sparse'
                     with warnings.catch_warnings():
                         warnings.simplefilter('ignore')
                         trial = solver._problem()
-                    if solver.backend_info.get('exchange', 'rccl') != exch:
-                        peer_note = 'peer exchange unavailable on this node (buffers not mappable)'
+                    got = solver.backend_info.get('exchange', 'rccl')
+                    if got != {'sparse': 'peer-sparse'}.get(exch, exch):
+                        peer_note = ('peer exchange unavailable on this node (buffers not mappable)'
+                                     if got == 'rccl' else 'sparse exchange does not apply to this kernel family')
                         break
                     trial.set_value(V0)
                     trial.bench_sweeps(2)
@@ -305,7 +313,8 @@ def run(args):
             best = min(phase_times, key=lambda k: (phase_times[k], k))
             plan, _, exch = best.partition('/')
             solver.comm_phases, solver.comm_taper = int(plan.rstrip('t')), plan.endswith('t')
-            solver.comm_exchange = exch or 'rccl'
+            solver.comm_exchange = {'': 'rccl', 'sparse': 'peer'}.get(exch, exch)
+            solver.comm_sparse = exch == 'sparse'
             del J_check
 
     prob = solver._problem()
@@ -457,8 +466,11 @@ def run(args):
                                 'columns dealt in {} {}phases x {} ranks; {} of each phase of J under the '
                                 'kernel of the next phase'.format(
                                     int(prob.parts.shape[0]), 'tapered ' if solver.comm_taper else '', world,
-                                    'peer writes (HIP IPC, copy engines)'
-                                    if solver.backend_info.get('exchange') == 'peer' else 'RCCL all-gather')),
+                                    {'peer': 'peer writes (HIP IPC, copy engines)',
+                                     'peer-sparse': 'peer writes of the rows each rank reads (one slab of columns '
+                                                    'per rank; {:.0%} of the array received per rank)'.format(
+                                                        getattr(prob, 'need_fraction', 0.0))}.get(
+                                        solver.backend_info.get('exchange'), 'RCCL all-gather'))),
                    'comm_exchange': None if dev_comm is None else solver.backend_info.get('exchange'),
                    'comm_exchange_note': peer_note,
                    'comm_phase_tuning_ms_per_sweep': phase_times,

@@ -278,6 +278,18 @@ int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
  * call it, after sdp_problem_attach_comm); on failure the handle keeps the RCCL exchange.
  */
 int sdp_problem_enable_peer_exchange(sdp_problem *p);
+/*
+ * Sparse peer exchange (after sdp_problem_enable_peer_exchange): a backup sends a peer only the
+ * rows of J that peer READS in its own backups -- for a column q of need_off, the sorted,
+ * disjoint node ranges ranges[2k], ranges[2k+1], k in [need_off[q], need_off[q+1]) (whole columns
+ * in the column layout; the relative-DP reference node must be in every list).  The host
+ * computes them from the model: the cells the trailing next states of a rank's columns fall in.
+ * A rank's J is then complete only there; sdp_problem_get_value completes it first (every rank
+ * sends all its rows: collective), sdp_problem_backup_host sends all rows to begin with.
+ * NULL, NULL switches back to sending everything.
+ */
+int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_off /* [nranks+1] */,
+                               const int64_t *ranges /* [need_off[nranks]][2] */);
 int sdp_comm_allreduce_max(sdp_comm *c, double *inout);    /* host scalar, for timing */
 int sdp_comm_barrier(sdp_comm *c);
 

@@ -11,6 +11,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <utility>
 
 #include "../../include/sdp_hip.h"
 #include "sdp_device.h"
@@ -660,6 +662,10 @@ struct sdp_problem {
     hipEvent_t ev_comm = nullptr;
     int n_phases = 0;
     bool comm_pending = false;
+    // sparse peer exchange (sdp_problem_set_peer_needs): need[q] = sorted, disjoint node ranges of J
+    // that rank q reads in a backup; J / V are then complete on a rank only there
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> need;
+    bool sparse = false, J_partial = false, V_partial = false;
     int cus = 256;
     int refs_cap = 0;
     int col_threads = 512;
@@ -905,6 +911,7 @@ static int download_nodes(sdp_problem *p, void *host, const void *dev, size_t el
 extern "C" int sdp_problem_set_value(sdp_problem *p, const void *host_V)
 {
     if (!p || !host_V) return fail(SDP_EINVAL, "NULL argument");
+    p->V_partial = false;
     return upload_nodes(p, p->V.p, host_V, real_size(p->dtype));
 }
 
@@ -1069,18 +1076,33 @@ static int gather_phase_of(sdp_problem *p, int phase, void *buffer, size_t elem_
 // into every other rank's J buffer (mapped through HIP IPC) as device-to-device copies on one
 // stream per peer -- copy engines over xGMI, no compute units, all links at once -- ordered
 // behind the phase's kernel by `after`.
-static int push_phase(sdp_problem *p, int phase, hipEvent_t after)
+static int push_phase(sdp_problem *p, int phase, hipEvent_t after, bool everything)
 {
     const int n = p->comm->nranks, me = p->comm->rank;
     const int64_t *b = p->parts.data() + (size_t)phase * (n + 1);
     const size_t rs = real_size(p->dtype);
-    const size_t off = (size_t)b[me] * rs, bytes = (size_t)(b[me + 1] - b[me]) * rs;
-    if (!bytes) return SDP_OK;
+    const int64_t lo = b[me], hi = b[me + 1];
+    if (hi <= lo) return SDP_OK;
     for (int k = 1; k < n; ++k) {
         const int q = (me + k) % n;                       // start with a different peer on every rank
-        HIP_TRY(hipStreamWaitEvent(p->peer_stream[q], after, 0));
-        HIP_TRY(hipMemcpyAsync((char *)p->peer_J[q] + off, (const char *)p->J.p + off, bytes,
-                               hipMemcpyDeviceToDevice, p->peer_stream[q]));
+        if (!p->sparse || everything) {
+            HIP_TRY(hipStreamWaitEvent(p->peer_stream[q], after, 0));
+            HIP_TRY(hipMemcpyAsync((char *)p->peer_J[q] + (size_t)lo * rs, (const char *)p->J.p + (size_t)lo * rs,
+                                   (size_t)(hi - lo) * rs, hipMemcpyDeviceToDevice, p->peer_stream[q]));
+            continue;
+        }
+        // only the rows the peer reads (sdp_problem_set_peer_needs)
+        const auto &iv = p->need[q];
+        auto it = std::lower_bound(iv.begin(), iv.end(), lo,
+                                   [](const std::pair<int64_t, int64_t> &r, int64_t v) { return r.second <= v; });
+        bool waited = false;
+        for (; it != iv.end() && it->first < hi; ++it) {
+            const int64_t s0 = it->first > lo ? it->first : lo, s1 = it->second < hi ? it->second : hi;
+            if (s1 <= s0) continue;
+            if (!waited) { HIP_TRY(hipStreamWaitEvent(p->peer_stream[q], after, 0)); waited = true; }
+            HIP_TRY(hipMemcpyAsync((char *)p->peer_J[q] + (size_t)s0 * rs, (const char *)p->J.p + (size_t)s0 * rs,
+                                   (size_t)(s1 - s0) * rs, hipMemcpyDeviceToDevice, p->peer_stream[q]));
+        }
     }
     return SDP_OK;
 }
@@ -1133,7 +1155,7 @@ static int gather_phase(sdp_problem *p, int phase)
 // (problem stream); the problem stream then waits for the last gather, so
 // whatever follows (relative-DP shift, next sweep) sees the complete J.
 static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_index = -1,
-                      double *ref_out = nullptr)
+                      double *ref_out = nullptr, bool everything = false)
 {
     int rc;
     if (!p->comm) {
@@ -1150,7 +1172,7 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
         if (n > 1) {
             HIP_TRY(hipEventRecord(p->ev_phase[ph], p->stream));
             if (p->peer_exchange) {
-                if ((rc = push_phase(p, ph, p->ev_phase[ph]))) return rc;
+                if ((rc = push_phase(p, ph, p->ev_phase[ph], everything))) return rc;
             } else {
                 HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
                 if ((rc = gather_phase(p, ph))) return rc;
@@ -1161,6 +1183,7 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
         if (p->peer_exchange && (rc = finish_pushes(p))) return rc;
         HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
         p->comm_pending = true;
+        p->J_partial = p->peer_exchange && p->sparse && !everything;
     }
     return SDP_OK;
 }
@@ -1172,6 +1195,26 @@ static int join_comm(sdp_problem *p)
         HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_comm, 0));
         p->comm_pending = false;
     }
+    return SDP_OK;
+}
+
+// Sparse peer exchange: before J leaves the device (or is read whole), every rank sends the rows
+// it computed to every peer.  Collective, like the backups.
+static int complete_J(sdp_problem *p)
+{
+    if (!p->comm || p->comm->nranks == 1 || !p->peer_exchange || !p->J_partial) return SDP_OK;
+    int rc;
+    if ((rc = join_comm(p))) return rc;
+    p->peer_fence = true;                                  // nobody may still be reading its J
+    if ((rc = open_pushes(p))) return rc;
+    HIP_TRY(hipEventRecord(p->ev_enter, p->stream));
+    for (int ph = 0; ph < p->n_phases; ++ph)
+        if ((rc = push_phase(p, ph, p->ev_enter, true))) return rc;
+    if ((rc = finish_pushes(p))) return rc;
+    HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
+    p->comm_pending = true;
+    if ((rc = join_comm(p))) return rc;
+    p->J_partial = false;
     return SDP_OK;
 }
 
@@ -1239,6 +1282,7 @@ extern "C" int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int6
 static void swap_buffers(sdp_problem *p)
 {
     std::swap(p->V.p, p->J.p);
+    std::swap(p->V_partial, p->J_partial);
     if (p->peer_exchange) p->peer_V.swap(p->peer_J);
 }
 
@@ -1426,7 +1470,7 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
         return SDP_OK;
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
-    if ((rc = run_backup(p, false, t_k))) return rc;
+    if ((rc = run_backup(p, false, t_k, -1, nullptr, true))) return rc;    // J goes to the host: all rows to all ranks
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     if ((rc = join_comm(p))) return rc;
     if (rel_dp && (rc = rel_shift(p, ref_index, 0))) return rc;
@@ -1487,6 +1531,8 @@ extern "C" int sdp_problem_simulate(sdp_problem *p, const void *host_pol, int64_
 extern "C" int sdp_problem_get_value(sdp_problem *p, void *host_J)
 {
     if (!p || !host_J) return fail(SDP_EINVAL, "NULL argument");
+    int rc;
+    if ((rc = complete_J(p))) return rc;                   // (sparse exchange: collective)
     return download_nodes(p, host_J, p->J.p, real_size(p->dtype));
 }
 
@@ -1650,6 +1696,31 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     return SDP_OK;
 }
 
+extern "C" int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_off, const int64_t *ranges)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (!need_off || !ranges) { p->sparse = false; p->need.clear(); return SDP_OK; }
+    if (!p->comm || !p->peer_exchange) return fail(SDP_EINVAL, "sparse exchange needs the peer exchange (sdp_problem_enable_peer_exchange)");
+    if (p->J_partial || p->V_partial) return fail(SDP_EINVAL, "the value arrays are incomplete: fetch or set them first");
+    const int n = p->comm->nranks;
+    const int64_t unit = p->layout == SDP_LAYOUT_COLUMNS ? p->orders[0] : 1;
+    std::vector<std::vector<std::pair<int64_t, int64_t>>> need((size_t)n);
+    for (int q = 0; q < n; ++q) {
+        int64_t at = 0;
+        for (int64_t k = need_off[q]; k < need_off[q + 1]; ++k) {
+            const int64_t b = ranges[2 * k], e = ranges[2 * k + 1];
+            if (b < at || e <= b || e > p->S || b % unit || e % unit)
+                return fail(SDP_EINVAL, "peer needs: ranges must be sorted, disjoint, inside the grid%s",
+                            unit > 1 ? " and made of whole columns" : "");
+            need[(size_t)q].emplace_back(b, e);
+            at = e;
+        }
+    }
+    p->need.swap(need);
+    p->sparse = true;
+    return SDP_OK;
+}
+
 extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
                                        const int64_t *part_bounds)
 {
@@ -1678,5 +1749,7 @@ extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_ph
     p->n_phases = n_phases;
     p->comm = c;
     p->comm_pending = false;
+    p->sparse = false;                     // (a new partition: the need lists no longer apply)
+    p->need.clear();
     return SDP_OK;
 }

@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-__all__ = ['slab_bounds', 'phase_partition', 'RcclCommunicator', 'GlooCommunicator',
+__all__ = ['slab_bounds', 'phase_partition', 'slab_partition', 'RcclCommunicator', 'GlooCommunicator',
            'FileRendezvous', 'from_env']
 
 
@@ -60,6 +60,30 @@ def phase_partition(n_units, unit, nranks, n_phases, taper=False):
         for r in range(nranks + 1):
             bounds[ph, r] = (lo + (hi - lo) * r // nranks) * unit
     return bounds
+
+
+def slab_partition(n_units, unit, nranks, n_phases):
+    """Node bounds for the SPARSE peer exchange, in the same [phases][nranks+1] form: every
+    rank owns ONE contiguous slab of the units (so that the rows its backups read are few and
+    near its own), cut into `n_phases` pieces for the overlap.  Expressed as nranks * n_phases
+    "phases" in node order in each of which a single rank has work: phase r * n_phases + k is
+    piece k of rank r's slab (bounds equal to its begin for ranks <= r, to its end above)."""
+    n_phases = max(1, min(int(n_phases), max(1, n_units // max(nranks, 1))))
+    bounds = np.zeros((nranks * n_phases, nranks + 1), dtype=np.int64)
+    for r in range(nranks):
+        lo, hi = n_units * r // nranks, n_units * (r + 1) // nranks
+        for k in range(n_phases):
+            a, b = lo + (hi - lo) * k // n_phases, lo + (hi - lo) * (k + 1) // n_phases
+            bounds[r * n_phases + k, :r + 1] = a * unit
+            bounds[r * n_phases + k, r + 1:] = b * unit
+    return bounds
+
+
+def intervals_of(mask):
+    """sorted [begin, end) runs of the True entries of a 1-D boolean array"""
+    m = np.concatenate(([False], np.asarray(mask, dtype=bool), [False]))
+    d = np.flatnonzero(m[1:] != m[:-1])
+    return d.reshape(-1, 2)
 
 
 class _Base(object):

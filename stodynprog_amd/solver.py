@@ -214,6 +214,11 @@ class DPSolver(object):
         # buffers cannot be mapped (backend_info['exchange'] tells which one runs)
         self.comm_exchange = 'rccl'
         self.comm_taper = False            # multi-GPU: shrinking phases (smallest gather exposed)
+        # peer exchange only: every rank owns one slab of columns and is sent only the rows of J its
+        # own backups read (computed from the model: the cells its trailing next states fall in) --
+        # for a contracting exogenous process a fraction of the array.  J is completed on every
+        # rank when the host asks for it.  Plain column kernel, stationary systems.
+        self.comm_sparse = False
         # 'exact': every floating-point operation of the reference, same order (default);
         # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
         #          operations, J within ~1e-15 relative of 'exact' (opt-in)
@@ -440,7 +445,8 @@ class DPSolver(object):
         # key, so a recycled id() can never alias a stale entry)
         parts = [s.dyn, s.cost, s.control_box, _params_key(s.params),
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
-                 id(self.comm), self.comm_phases, self.comm_taper, self.comm_exchange, self.kernel,
+                 id(self.comm), self.comm_phases, self.comm_taper, self.comm_exchange,
+                 getattr(self, 'comm_sparse', False), self.kernel,
                  self.arithmetic, getattr(self, 'certified_filter', True)]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
@@ -734,10 +740,17 @@ class DPSolver(object):
         if self.comm is not None and self.comm.is_device:
             # RCCL: the library shares out phases of the node range and overlaps
             # each phase's all-gather with the next phase's kernel
-            from .dist import phase_partition
+            from .dist import phase_partition, slab_partition
             unit = shape[0] if column else 1
             bounds = phase_partition(S // unit, unit, self.comm.nranks, self.comm_phases,
                                      self.comm_taper)
+            sparse = (getattr(self, 'comm_sparse', False) and self.comm_exchange == 'peer'
+                      and self.comm.nranks > 1 and column and not plan['per_control']
+                      and not plan['window'] and model.storage_separable and self.sys.stationnary
+                      and len(shape) >= 2)
+            if sparse:
+                dense_bounds = bounds
+                bounds = slab_partition(S // unit, unit, self.comm.nranks, self.comm_phases)
             node_range = (0, S)
         elif self.comm is not None:
             bounds = self.comm.slab_bounds(dev_shape)
@@ -765,6 +778,15 @@ class DPSolver(object):
                 except RuntimeError as e:
                     import warnings
                     warnings.warn('peer exchange unavailable, using the RCCL all-gather: {}'.format(e))
+                    if sparse:                              # back to interleaved phases for the gathers
+                        prob.parts = np.ascontiguousarray(dense_bounds, dtype=np.int64)
+                        nat.check(nat.lib().sdp_problem_attach_comm(prob.h, self.comm.handle,
+                                                                    int(prob.parts.shape[0]), nat.ptr(prob.parts)))
+                if exchange == 'peer' and sparse:
+                    off, ranges = self._peer_needs(model, prob.parts, shape)
+                    nat.check(nat.lib().sdp_problem_set_peer_needs(prob.h, nat.ptr(off), nat.ptr(ranges)))
+                    exchange = 'peer-sparse'
+                    prob.need_fraction = float((ranges[:, 1] - ranges[:, 0]).sum()) / S / self.comm.nranks
             elif self.comm_exchange != 'rccl':
                 raise ValueError("comm_exchange must be 'rccl' or 'peer'")
         prob.info = dict(mode='traced', exchange=exchange,
@@ -780,6 +802,63 @@ class DPSolver(object):
                          bit_exact_model=model.bit_exact,
                          inexact_ops=model.inexact_ops())
         return prob
+
+    def _peer_needs(self, model, parts, shape):
+        """For the sparse peer exchange: per rank the node ranges (device order, whole columns) of
+        the cost-to-go array its backups READ -- the 2^(d-1) vertex columns of the cell each
+        perturbation point sends each of its columns to, one more cell on every side (the device
+        locates the cells itself; a next state on a cell boundary may round the other way there),
+        and the column of the relative-DP reference node.  Returns (offsets[nranks+1], ranges[:, 2])."""
+        from .trace import evaluate
+        from .dist import intervals_of
+        n0, trail = shape[0], shape[1:]
+        nranks = parts.shape[1] - 1
+        grids = [np.asarray(g, dtype=float) for g in self.state_grid]
+        wg = (np.asarray(self.perturb_grid[0], dtype=float)
+              if (self.perturb_grid and model.n_perturb) else None)
+        ws = [None] if wg is None else list(wg)
+        n_cols = int(np.prod(trail))
+        idx = np.unravel_index(np.arange(n_cols), trail)
+        xcols = [grids[k + 1][idx[k]] for k in range(len(trail))]
+        owner = np.empty(n_cols, dtype=np.int64)
+        for r in range(nranks):
+            for ph in range(parts.shape[0]):
+                owner[parts[ph, r] // n0:parts[ph, r + 1] // n0] = r
+        nu = len(self.sys.control)
+        u0 = [np.zeros(n_cols) for _ in range(nu)]
+        x0 = np.full(n_cols, grids[0][0])
+        cells = []
+        for w in ws:
+            with np.errstate(all='ignore'):
+                xn, _ = evaluate(model, [x0] + xcols, u0, [] if w is None else [np.full(n_cols, w)], 0.0)
+            q = []
+            for k, g in enumerate(grids[1:]):
+                nk = len(g)
+                p = (np.broadcast_to(np.asarray(xn[k + 1], dtype=float), (n_cols,)) - g[0]) / (g[-1] - g[0]) * (nk - 1)
+                p = np.nan_to_num(p, nan=0.0, posinf=0.0, neginf=0.0)
+                p = np.where(np.abs(p) < 2147483648.0, p, 0.0)        # sdp_trunc_i32
+                q.append(np.clip(np.trunc(p).astype(np.int64), 0, nk - 2))
+            cells.append(q)
+        ref_col = int(np.ravel_multi_index(self._state_ref_ind[1:], trail)) if len(trail) else 0
+        offs, out = [0], []
+        span = (-1, 0, 1, 2)
+        for r in range(nranks):
+            mine = owner == r
+            need = np.zeros(trail, dtype=bool)
+            for q in cells:
+                for delta in np.ndindex(*([len(span)] * len(trail))):
+                    at = tuple(np.clip(q[k][mine] + span[delta[k]], 0, trail[k] - 1) for k in range(len(trail)))
+                    need[at] = True
+            need = need.reshape(-1)
+            need[ref_col] = True
+            need[mine] = False                               # its own rows never travel
+            iv = intervals_of(need) * n0
+            out.append(iv)
+            offs.append(offs[-1] + len(iv))
+        ranges = (np.concatenate(out) if out else np.zeros((0, 2))).astype(np.int64).reshape(-1, 2)
+        if not len(ranges):
+            ranges = np.zeros((1, 2), dtype=np.int64)        # (a valid pointer for the C call)
+        return np.ascontiguousarray(offs, dtype=np.int64), np.ascontiguousarray(ranges)
 
     def _ref_flat(self, prob=None):
         """flat C-order index of the relative-DP reference node (sdp.py:384)"""

@@ -217,3 +217,36 @@ def test_tapered_phase_partition_covers_every_unit_once():
                 assert (np.diff(sizes) <= 0).all() and sizes[-1] < sizes[0]
     b = dist.phase_partition(65536, 256, 8, 4, True)
     assert [int(x) for x in (b[:, -1] - b[:, 0]) // 256] == [26214, 19661, 13107, 6554]
+
+
+def test_slab_partition_and_peer_needs_on_the_host():
+    """the sparse peer exchange: one slab of columns per rank (as nranks x phases single-owner
+    phases in node order) and, per rank, the rows of J its backups read"""
+    import numpy as np
+    from stodynprog_amd import models, dist
+    b = dist.slab_partition(100, 7, 3, 4)
+    assert b.shape == (12, 4) and b[0, 0] == 0 and b[-1, -1] == 700
+    assert (b[1:, 0] == b[:-1, -1]).all()                 # phases tile the node range in order
+    for mp in range(12):
+        r = mp // 4
+        sizes = np.diff(b[mp])
+        assert (sizes[np.arange(3) != r] == 0).all() and sizes[r] > 0 and (b[mp] % 7 == 0).all()
+    assert dist.intervals_of([0, 1, 1, 0, 1]).tolist() == [[1, 3], [4, 5]]
+    _, s = models.synthetic3d(N=32)
+    m = s._traced()
+    shape = s._shape()
+    for nranks in (2, 5):
+        parts = dist.slab_partition(32 * 32, 32, nranks, 3)
+        off, ranges = s._peer_needs(m, parts, shape)
+        assert off[0] == 0 and len(off) == nranks + 1 and off[-1] == len(ranges)
+        ref_node = int(np.ravel_multi_index(s._state_ref_ind[1:], shape[1:])) * 32
+        for r in range(nranks):
+            iv = ranges[off[r]:off[r + 1]]
+            assert (iv[:, 0] < iv[:, 1]).all() and (iv[1:, 0] >= iv[:-1, 1]).all() and (iv % 32 == 0).all()
+            own_lo, own_hi = parts[r * 3, r], parts[r * 3 + 2, r + 1]
+            assert all(e <= own_lo or b0 >= own_hi for b0, e in iv)          # its own rows never travel
+            inside_own = own_lo <= ref_node < own_hi
+            assert inside_own or any(b0 <= ref_node < e for b0, e in iv)      # the reference node is read
+            assert 0 < (iv[:, 1] - iv[:, 0]).sum() < 32 ** 3
+        # the dynamics contract towards the middle: far less than everybody else's rows
+        assert (ranges[:, 1] - ranges[:, 0]).sum() / nranks < 0.5 * 32 ** 3 * (nranks - 1) / nranks

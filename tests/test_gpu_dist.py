@@ -203,12 +203,17 @@ CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3), ('synth
          ('nas_demo', dict(), 4), ('inventory', dict(), 4),          # inventory: LDS-staged tiles, node ranges
          ('synthetic3d_coupled', dict(N=20), 4),                     # column kernel, table per control
          ('synthetic3d_coupled', dict(N=18, cross=0.2), 3)]          # staged tiles in 3-D, ragged
-EXCHANGES = os.environ.get('SDP_TEST_EXCHANGES', 'rccl,peer').split(',')
+EXCHANGES = os.environ.get('SDP_TEST_EXCHANGES', 'rccl,peer,sparse').split(',')
 for (name, kw, phases), exchange in [(c, e) for c in CASES for e in EXCHANGES]:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
     two.comm = dev
-    two.comm_exchange = exchange                     # 'peer': rows written into the peers' buffers (HIP IPC)
+    # 'peer': rows written into the peers' buffers (HIP IPC); 'sparse': one slab per rank, and a
+    # peer is sent only the rows it reads (plain column kernel; the others keep the full exchange)
+    two.comm_exchange = 'peer' if exchange == 'sparse' else exchange
+    two.comm_sparse = exchange == 'sparse'
+    if exchange == 'sparse':
+        exchange = 'peer-sparse' if name in ('synthetic3d', 'storage_ar1', 'nas_demo') else 'peer'
     two.comm_phases, two.comm_taper = abs(phases), phases < 0          # negative: tapered phases
     V0 = rng.standard_normal(one._state_grid_shape)
     J1, p1 = one.value_iteration(V0, report_time=False); i1 = one.last_policy_index
@@ -216,6 +221,9 @@ for (name, kw, phases), exchange in [(c, e) for c in CASES for e in EXCHANGES]:
     prob = [v for k, v in two._cache.items() if k[0] == 'problem'][0]
     assert prob.parts is not None and prob.parts.shape[1] == dev.nranks + 1
     assert two.backend_info['exchange'] == exchange, two.backend_info
+    if exchange == 'peer-sparse':                        # strictly less than everybody else's rows
+        assert 0.0 < prob.need_fraction < (dev.nranks - 1.0) / dev.nranks + 1e-12, prob.need_fraction
+        assert prob.parts.shape[0] == dev.nranks * min(abs(phases), prob.parts.shape[0])
     assert np.array_equal(J1, J2), name
     assert np.array_equal(p1, p2) and np.array_equal(i1, i2), name      # get_policy gathers
     ref = one._state_ref_ind
@@ -270,8 +278,9 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path, asynchronous):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True, d
     plans = {'2', '4', '8', '16', '4t', '8t'}
-    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == plans | {p + '/peer' for p in plans}, d['config']
-    assert d['config']['comm_exchange'] in ('rccl', 'peer') and d['config']['comm_exchange_note'] is None
+    assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == (
+        plans | {p + '/peer' for p in plans} | {p + '/sparse' for p in plans if not p.endswith('t')}), d['config']
+    assert d['config']['comm_exchange'] in ('rccl', 'peer', 'peer-sparse') and d['config']['comm_exchange_note'] is None
     assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
     import glob
     for leftover in glob.glob('/dev/shm/sdp_mock_*'):      # bench.py leaves its communicator to the OS
