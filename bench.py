@@ -329,6 +329,8 @@ def run(args):
     sync_all()
     t0 = time.perf_counter()
     loop_ms, kernel_ms = prob.bench_sweeps(args.steps)       # K sweeps (+ all-gathers)
+    if dev_comm is not None:
+        prob.complete()      # sparse exchange: the timed region ends, like the others, with J complete everywhere
     sync_all()
     elapsed = time.perf_counter() - t0
     if dev_comm is not None:

@@ -290,6 +290,9 @@ int sdp_problem_enable_peer_exchange(sdp_problem *p);
  */
 int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_off /* [nranks+1] */,
                                const int64_t *ranges /* [need_off[nranks]][2] */);
+/* Sparse peer exchange: make the last backup's J complete on every rank (collective; a no-op
+ * otherwise) -- what sdp_problem_get_value does before it downloads. */
+int sdp_problem_complete_value(sdp_problem *p);
 int sdp_comm_allreduce_max(sdp_comm *c, double *inout);    /* host scalar, for timing */
 int sdp_comm_barrier(sdp_comm *c);
 

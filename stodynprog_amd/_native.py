@@ -110,6 +110,7 @@ def _declare(lib):
         'sdp_comm_destroy': (C.c_int, [vp]),
         'sdp_problem_attach_comm': (C.c_int, [vp, vp, i32, vp]),
         'sdp_problem_set_peer_needs': (C.c_int, [vp, vp, vp]),
+        'sdp_problem_complete_value': (C.c_int, [vp]),
         'sdp_problem_enable_peer_exchange': (C.c_int, [vp]),
         'sdp_comm_allreduce_max': (C.c_int, [vp, P(dbl)]),
         'sdp_comm_barrier': (C.c_int, [vp]),

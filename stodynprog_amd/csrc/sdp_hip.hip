@@ -1696,6 +1696,15 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     return SDP_OK;
 }
 
+extern "C" int sdp_problem_complete_value(sdp_problem *p)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    int rc;
+    if ((rc = complete_J(p))) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDP_OK;
+}
+
 extern "C" int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_off, const int64_t *ranges)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");

@@ -161,6 +161,10 @@ class _DeviceProblem(object):
     def swap(self):
         nat.check(nat.lib().sdp_problem_swap(self.h))
 
+    def complete(self):
+        """sparse peer exchange: make J complete on every rank (collective; no-op otherwise)"""
+        nat.check(nat.lib().sdp_problem_complete_value(self.h))
+
     def get_value(self):
         J = np.empty(self.shape, dtype=self.dtype)
         nat.check(nat.lib().sdp_problem_get_value(self.h, nat.ptr(J)))
