@@ -503,6 +503,30 @@ def run(args):
                                                'bar but not the reference rounding sequence); LDS-read bound'}
         except Exception as e:
             out['fused_arithmetic'] = {'error': repr(e)}
+    if world == 1 and filtered and not args.no_filter_check:
+        # The filter's claim, checked in this very run (outside the timed region): the same chain of
+        # sweeps with every control evaluated the long way -- the reference's W x 6 operations per
+        # control -- gives the same J and the same policy indices, bit for bit; its time stands beside.
+        try:
+            J_f = prob.get_value()
+            _, idx_f = prob.get_policy()
+            long_way = clone_solver(DPSolver, sysd, solver, dtype, kernel=solver.kernel, certified_filter=False)
+            lprob = long_way._problem()
+            lprob.set_value(V0)
+            if args.warmup > 0:
+                lprob.bench_sweeps(args.warmup)
+                lprob.swap()
+            _, lk = lprob.bench_sweeps(args.steps)
+            _, idx_l = lprob.get_policy()
+            out['every_control_the_long_way'] = {
+                'kernel_ms': lk / args.steps, 'sweeps_per_s': 1e3 * args.steps / lk,
+                'J_identical': bool(np.array_equal(J_f, lprob.get_value(), equal_nan=True)),
+                'policy_index_identical': bool(np.array_equal(idx_f, idx_l)),
+                'note': 'DPSolver.certified_filter = False (bench.py --no-filter): same chain of {} sweeps, '
+                        'compared after the last one over all {} nodes'.format(args.warmup + args.steps, S)}
+            del lprob, J_f, idx_f, idx_l
+        except Exception as e:
+            out['every_control_the_long_way'] = {'error': repr(e)}
     if world > 1 or os.environ.get('SDP_BENCH_SELFCHECK'):
         # self-check of the sharded path (outside the timed region): rank 0 repeats
         # the same chain of sweeps on its GPU alone and compares J bit for bit
@@ -543,6 +567,8 @@ def main():
     ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged'],
                     help='kernel family (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-filter-check', action='store_true',
+                    help='skip the untimed re-run of the chain with every control the long way and its comparison')
     ap.add_argument('--no-filter', action='store_true',
                     help='column kernel: evaluate every control with the reference\'s W x 6 operations instead '
                          'of the certified expectation-first filter (same bits either way; A/B runs)')
