@@ -213,6 +213,11 @@ def clone_solver(DPSolver, sysd, solver, dtype, **attrs):
     return s
 
 
+def _trace(*a):
+    if os.environ.get('SDP_BENCH_TRACE'):
+        print('[bench r{}]'.format(os.environ.get('RANK', '0')), *a, file=sys.stderr, flush=True)
+
+
 def run(args):
     """everything but the final print; returns the result dict on rank 0, else None"""
     from stodynprog_amd import models, dist, _native as nat
@@ -288,7 +293,9 @@ def run(args):
                         trial = solver._problem()
                     got = solver.backend_info.get('exchange', 'rccl')
                     if got != {'sparse': 'peer-sparse'}.get(exch, exch):
-                        peer_note = ('peer exchange unavailable on this node (buffers not mappable)'
+                        _trace('exchange', exch, 'not available:', got, getattr(trial, 'peer_failure', ''))
+                        peer_note = ('peer exchange unavailable on this node: {}'.format(
+                                         getattr(trial, 'peer_failure', 'buffers not mappable'))
                                      if got == 'rccl' else 'sparse exchange does not apply to this kernel family')
                         break
                     trial.set_value(V0)
@@ -310,6 +317,7 @@ def run(args):
                             break
                         del J_now
                     phase_times[key] = t
+                    _trace('candidate', key, round(t, 3))
             best = min(phase_times, key=lambda k: (phase_times[k], k))
             plan, _, exch = best.partition('/')
             solver.comm_phases, solver.comm_taper = int(plan.rstrip('t')), plan.endswith('t')
@@ -322,6 +330,7 @@ def run(args):
     prob.set_value(V0)
     kernel_family = solver.backend_info.get('kernel')
 
+    _trace('tuned', solver.comm_phases if dev_comm is not None else None)
     # warm-up sweeps (untimed), ping-pong like the timed ones
     if args.warmup > 0:
         prob.bench_sweeps(args.warmup)
@@ -333,10 +342,12 @@ def run(args):
         prob.complete()      # sparse exchange: the timed region ends, like the others, with J complete everywhere
     sync_all()
     elapsed = time.perf_counter() - t0
+    _trace('timed region done')
     if dev_comm is not None:
         elapsed = dev_comm.allreduce_max(elapsed)
         kernel_ms = dev_comm.allreduce_max(kernel_ms)
 
+    _trace('reduced')
     if rank != 0:
         return None
     ms_per_step = elapsed * 1e3 / args.steps

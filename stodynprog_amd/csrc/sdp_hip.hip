@@ -1641,8 +1641,21 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     p->release_peers();
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
     std::vector<hipIpcMemHandle_t> all((size_t)2 * n);
-    HIP_TRY(hipIpcGetMemHandle(&all[2 * me], p->V.p));
-    HIP_TRY(hipIpcGetMemHandle(&all[2 * me + 1], p->J.p));
+    memset(all.data(), 0, all.size() * sizeof(hipIpcMemHandle_t));
+    // From here to the agreement below every rank takes part in the same two collectives whatever
+    // happens locally: a failure only raises `failed` (a rank that left early would leave the
+    // others waiting in a collective).
+    int failed = 0;
+    char why[256] = "";
+    {
+        hipError_t e = hipIpcGetMemHandle(&all[2 * me], p->V.p);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&all[2 * me + 1], p->J.p);
+        if (e != hipSuccess) {
+            failed = 1;
+            snprintf(why, sizeof(why), "exporting this rank's buffers: %s", hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
     DevBuf stage;
     int rc = stage.alloc(sizeof(hipIpcMemHandle_t) * 2 * n);
     if (rc) return rc;
@@ -1654,8 +1667,6 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     p->peer_V.assign(n, nullptr); p->peer_J.assign(n, nullptr);
     p->peer_stream.assign(n, nullptr); p->peer_done.assign(n, nullptr);
     p->peer_V[me] = p->V.p; p->peer_J[me] = p->J.p;
-    int failed = 0;
-    char why[256] = "";
     for (int r = 0; r < n && !failed; ++r) {
         if (r == me) continue;
         hipError_t e = hipIpcOpenMemHandle(&p->peer_V[r], all[2 * r], hipIpcMemLazyEnablePeerAccess);

@@ -765,7 +765,17 @@ class DPSolver(object):
         # sweep that nobody has looked at yet are fetched first)
         if self._idx_source is not None:
             self.last_policy_index
-        for k in [k for k in self._cache if k[0] == 'problem']:
+        old = [k for k in self._cache if k[0] == 'problem']
+        if old and self.comm is not None and self.comm.is_device and self.comm.nranks > 1:
+            # peer exchange: the other ranks may have this rank's old buffers mapped (HIP IPC).  Every
+            # rank first closes ITS mappings, then all meet, and only then are the buffers freed -- a
+            # freed buffer that is still mapped elsewhere poisons the export of the next one
+            # allocated at its address (hipIpcGetMemHandle: invalid argument, seen with 8 ranks).
+            for k in old:
+                if self._cache[k].h:
+                    nat.check(nat.lib().sdp_problem_attach_comm(self._cache[k].h, None, 0, None))
+            self.comm.barrier()
+        for k in old:
             self._cache.pop(k).close()
         prob = _DeviceProblem(arrays, module, dt, shape, len(self.sys.control), W, lanes,
                               per_node, node_range,
@@ -780,8 +790,13 @@ class DPSolver(object):
                     nat.check(nat.lib().sdp_problem_enable_peer_exchange(prob.h))
                     exchange = 'peer'
                 except RuntimeError as e:
+                    # only the outcome the ranks AGREED on is a reason to fall back (all of them
+                    # do); anything else is this rank's problem alone and must not be papered over
+                    if 'peer exchange not available' not in str(e):
+                        raise
                     import warnings
                     warnings.warn('peer exchange unavailable, using the RCCL all-gather: {}'.format(e))
+                    prob.peer_failure = str(e)
                     if sparse:                              # back to interleaved phases for the gathers
                         prob.parts = np.ascontiguousarray(dense_bounds, dtype=np.int64)
                         nat.check(nat.lib().sdp_problem_attach_comm(prob.h, self.comm.handle,
