@@ -257,6 +257,10 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         else:
             col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair, filtered)
         assert col_cfg is not None
+        pipe = (column_pipe_config(column[0], column[1], model.n_state, dtype, wpair)
+                if filtered and per_control is None and window is None else None)
+        if pipe is not None:
+            col_cfg = pipe[:2]
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
             '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
@@ -269,6 +273,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         ] + (['#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap']
              if filtered and int(col_cfg[0]) <= 256 and not os.environ.get('SDP_COL_MIN_WAVES') else []) + (
             ['#define SDP_COL_FILTER 1'] + (
+            ['#define SDP_COL_PIPE 1', '#define SDP_PIPE_PRODUCERS {}'.format(pipe[2])] + [
+                '#define {} {}'.format(k, int(os.environ[k])) for k in ('SDP_PIPE_G', 'SDP_PIPE_PRIO_P')
+                if os.environ.get(k)] if pipe is not None else []) + (
             ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
             if os.environ.get('SDP_COL_FILTER_SCALE') else []) if filtered else []) + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
                   int(os.environ.get('SDP_COL_A_LW') or _order[1]))]
@@ -279,7 +286,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             '',
@@ -463,6 +470,34 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False):
     return None
 
 
+PIPE_PRODUCERS = 4        # producer waves of the pipelined filtered kernel (one per SIMD)
+PIPE_CONSUMERS = 8        # consumer waves (two per SIMD: their vector issue interleaves)
+
+
+def column_pipe_config(n0, w, n_state, dtype, wpair=False):
+    """Shape of the filtered column kernel as a producer / consumer pipeline inside one
+    workgroup per CU (SDP_COL_PIPE, csrc/sdp_column_pipe.h): (threads, lds_bytes, producers),
+    or None where it does not apply -- two tables must fit the LDS of a CU, and the table
+    build must be worth waves of its own (W >= 16 perturbation points on a column of >= 128
+    nodes; the small tables of storage-AR1 / Searev keep the one-workgroup-does-both form,
+    of which a CU holds many).  SDP_COL_PIPE=0/1 in the environment forces it (A/B runs)."""
+    rs = np.dtype(dtype).itemsize
+    w = max(int(w), 1)
+    tw = w + (w & 1) if wpair else w
+    force = os.environ.get('SDP_COL_PIPE')
+    if force != '1':
+        return None
+    producers = int(os.environ.get('SDP_PIPE_PRODUCERS') or PIPE_PRODUCERS)
+    consumers = int(os.environ.get('SDP_PIPE_CONSUMERS') or PIPE_CONSUMERS)
+    lds = 2 * ((tw * n0 * rs + 15) // 16 * 16 + 2 * n0 * rs) + 16
+    lds = (lds + 15) // 16 * 16
+    if lds > COLUMN_LDS_MAX or (consumers + producers) * 64 > 1024 or w > 64:
+        return None
+    if force != '1' and (w < 16 or n0 < 128):
+        return None
+    return (consumers + producers) * 64, lds, producers
+
+
 def column_build_order(threads, w, rows):
     """How phase A of the column kernel deals the W x rows table entries to the threads
     (SDP_COL_A_ORDER / SDP_COL_A_LW of csrc/sdp_column_kernel.h): (2, lanes_per_w) when the
@@ -540,7 +575,7 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
 
 
 _HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h',
-            'sdp_staged_kernel.h')
+            'sdp_column_pipe.h', 'sdp_staged_kernel.h')
 _digest_cache = {}
 
 

@@ -121,6 +121,12 @@
 #ifndef SDP_COL_FILTER_RUNROLL
 #define SDP_COL_FILTER_RUNROLL 16   // table entries in flight per thread in the reduction over w
 #endif
+#ifndef SDP_COL_LEAN
+// Lean first pass of the filter (8-byte reals by default): ONE error bound per node -- from the
+// largest |lam0| and the sum of the |F| of its controls and a bound D of the whole column -- instead
+// of one per control, F as two fused multiply-adds on a table of A[r] alone.  See SdpColFilter.
+#define SDP_COL_LEAN -1          // -1: for 8-byte reals; 0 / 1 force it (A/B runs)
+#endif
 #ifndef SDP_COL_FILTER_SCALE
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
@@ -164,12 +170,23 @@ struct __attribute__((aligned(16))) SdpColLds {
     int w_off[SDP_COL_W * SDP_DT];
     int win[2][2];                         // row window: per parity (min row, minus max row) of the unit
     int next_unit;                         // filtered kernel: the unit claimed for the next round
+    unsigned long long dcol[2];            // lean filter: per parity of the unit, bits of max_r D[r] (>= 0: ordered as integers)
 #if SDP_COL_FILTER
     // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
     sdp_real ad[2 * SDP_COL_ROWS] __attribute__((aligned(16)));
 #endif
 };
 static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
+
+// diagnostic builds only (SDP_STAMP 2 / 3): clocks of the two passes, survivor counts
+struct SdpColDiag {
+    unsigned long long m1 = 0, m2 = 0, tp1 = 0, tp2 = 0, n_slow = 0, n_exact = 0, n_all = 0;
+};
+#if SDP_STAMP == 2
+#define SDP_COL_MARK(v) v = __builtin_amdgcn_s_memtime()
+#else
+#define SDP_COL_MARK(v)
+#endif
 
 SDP_DEV void sdp_col_carve(SdpColLds &m, SdpColShared &s)
 {
@@ -1078,8 +1095,10 @@ struct SdpColFilter {
     sdp_real pcap;      // max(1, sum_w |p_w|)
     sdp_real cu;        // 4 (W + 8) u  (x SDP_COL_FILTER_SCALE)
     sdp_real floor;     // 2 tiny / cu, added to every D[r]: cu S^ >= tiny whatever the values
+    sdp_real ratio;     // pcap / |psum| (lean first pass: |g| pcap <= ratio (|F| + |h|))
     bool ok;            // weights are finite and of ordinary size
 };
+constexpr bool SDP_COL_LEAN_ON = SDP_COL_LEAN < 0 ? sizeof(sdp_real) == 8 : SDP_COL_LEAN != 0;
 template <typename R> struct SdpFilterConst;
 template <> struct SdpFilterConst<double> {
     static constexpr double tiny = 2.2250738585072014e-308, limit = 0x1p1000, eps = 0x1p-52;
@@ -1103,14 +1122,18 @@ SDP_DEV void sdp_col_filter_setup(const SdpSweepArgs &a, SdpColFilter &f)
     f.pcap = pa > (sdp_real)1 ? pa : (sdp_real)1;
     f.cu = (sdp_real)SDP_COL_FILTER_SCALE * (sdp_real)(2 * (SDP_COL_W + 8)) * SDP_COL_FILTER_EPS;   // u = eps / 2
     f.floor = (sdp_real)2 * SDP_COL_FILTER_TINY / f.cu;
+    f.ratio = f.pcap / fabs(ps);                           // (psum = 0: infinite -> every node takes the long way)
     f.ok = pa <= (sdp_real)1024;                           // false for NaN
 }
 
-// after phase A (and a barrier): the reduced table, one thread per row
-SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const SdpColFilter &f)
+// after phase A (and a barrier): the reduced table, one thread per row.
+// Lean form: ad[r] = A[r] alone, and ONE bound for the column, dcol[parity] = max_r D[r] (an
+// integer maximum of the bit patterns: D >= 0), which the caller reads after the next barrier.
+SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const SdpColFilter &f, int parity)
 {
     constexpr int N0 = SDP_COL_ROWS;
     const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
+    sdp_real dmax = (sdp_real)0;
     for (int r = threadIdx.x; r < N0; r += blockDim.x) {
         sdp_real acc = (sdp_real)0, big = (sdp_real)0;
 #pragma unroll SDP_COL_FILTER_RUNROLL
@@ -1123,11 +1146,34 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
             acc = acc + p[w] * v;
             big = sdp_vmax(big, fabs(v));
         }
-        m.ad[2 * r] = acc;
         // (>= tiny / cu: the radius never drops below `tiny`; a NaN entry, which the max skips,
         // shows in acc and makes the row's bound infinite)
-        m.ad[2 * r + 1] = acc == acc ? f.pcap * big + f.floor : (sdp_real)INFINITY;
+        const sdp_real d = acc == acc ? f.pcap * big + f.floor : (sdp_real)INFINITY;
+        if (SDP_COL_LEAN_ON) {
+            m.ad[r] = acc;
+            dmax = sdp_vmax(dmax, d);
+        } else {
+            m.ad[2 * r] = acc;
+            m.ad[2 * r + 1] = d;
+        }
     }
+    if (SDP_COL_LEAN_ON) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong((double)dmax);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_xor((long long)bits, d, 64);
+            bits = o > bits ? o : bits;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&m.dcol[parity], bits);
+    }
+}
+// after the barrier that follows the reduction: the column's bound; the slot of the next unit is cleared
+SDP_DEV sdp_real sdp_col_filter_dcol(SdpColLds &m, int parity)
+{
+    if (!SDP_COL_LEAN_ON) return (sdp_real)0;
+    const unsigned long long bits = m.dcol[parity];
+    if (threadIdx.x == 0) m.dcol[parity ^ 1] = 0ull;
+    return (sdp_real)__longlong_as_double((long long)bits);
 }
 
 // F(u) and S^(u) of one control (x0' cell and cost exactly as sdp_col_expected_cost computes them).
@@ -1137,7 +1183,7 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
 // to an int has x86 semantics beyond 2^31 (sdp_trunc_i32) -- a node that gets there takes the
 // long way instead of paying for the check on every control.
 template <int AXIS>
-SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, const SdpLeadAxis &l,
+SDP_DEV void sdp_col_filter_eval(const sdp_real *ad_tab, const SdpColFilter &f, const SdpLeadAxis &l,
                                  const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &S,
                                  sdp_real &pmax)
 {
@@ -1149,7 +1195,7 @@ SDP_DEV void sdp_col_filter_eval(const SdpColLds &m, const SdpColFilter &f, cons
     const sdp_real lam0 = p - (sdp_real)q0;
     const sdp_real oml0 = (sdp_real)1 - lam0;
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
-    const sdp_real *ad = m.ad + 2 * q0;
+    const sdp_real *ad = ad_tab + 2 * q0;
     const sdp_real a0 = ad[0], d0 = ad[1], a1 = ad[2], d1 = ad[3];
     F = g * f.psum + (oml0 * a0 + lam0 * a1);
     S = fma(fabs(g), f.pcap, (fabs(oml0) + fabs(lam0)) * sdp_vmax(d0, d1));
@@ -1158,6 +1204,48 @@ SDP_DEV int sdp_col_axis_mode(const SdpLeadAxis &l)
 {
     if (!l.pow2) return 0;
     return (l.smin == (sdp_real)0 && l.span == (sdp_real)1) ? 2 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// Lean first pass (SDP_COL_LEAN).  Vector issue is what binds the first pass, and on gfx950
+// every vector instruction of a mixed stream costs ~4.2-4.4 clocks of its SIMD whatever its
+// type (profiles/r03_ubench_valu_rate.txt), so the pass is as fast as it is short.  Per control
+// it keeps only what must be per control:
+//     q0, lam0, g       exactly as the reference computes them (they are inputs of E too)
+//     F = fma(g, psum, fma(lam0, A[q0+1] - A[q0], A[q0]))      (3 operations; free to fuse: F is a
+//                        filter value, not a result)
+//     L = max |lam0|,   Fs = sum |F|                             (2 operations)
+// and bounds the error ONCE per node.  With R(u) = g P + oml0 A0* + lam0 A1* the real number both
+// E (the reference's W x 6 roundings) and F approximate, D >= sum_w |p_w T[w][r]| for every row r
+// of the column (dcol), P = sum |p_w|, u the unit roundoff, first order in u:
+//     |E - R| <= (W+4) u [ |g| P + (|oml0| + |lam0|) D ]                        (as before)
+//     |F - R| <= u [ (W+1) |g| P + D ((W+1) |1 - lam0| + (W+6) |lam0| + 2) ]
+//       (g (psum - P*): W-1 additions;  A0, A1: W roundings per term;  oml0 = fl(1 - lam0) of the
+//        reference against the exact 1 - lam0 inside the fma: u |1 - lam0| |A0*|;  the difference
+//        A1 - A0: u (|A0| + |A1|) |lam0|;  the two fma roundings: u (|h| + |g psum + h|))
+//     |E - F| <= (2W+8) u [ |g| P + (1 + 2 |lam0|) D ]        since |oml0|, |1 - lam0| <= 1 + |lam0| (1 + u)
+// |g| is not tracked: F = (g psum + h)(1 + d) gives |g| Pcap <= ratio (|F| (1 + u) + |h|), ratio =
+// Pcap / |psum|, |h| <= (1 + 2 |lam0|) D (1 + 3u).  So with
+//     S_node = ratio (Fs + (1 + 2L) D) + (1 + 2L) D   >=   |g| Pcap + (1 + 2 |lam0|) D   for every control
+// the radius cu S_node, cu = 4 (W+8) u, covers |E - F| with a factor 2 to spare for the second-order
+// terms and the roundings of S_node itself.  A NaN anywhere (g, lam0, the table) makes F a NaN, which
+// sticks in Fs; an infinity makes Fs or D infinite; |p| >= 2^31 (where the truncation of the
+// reference has x86 semantics, sdp_trunc_i32) makes |lam0| >= 2^30: all of them mark the node
+// `bad`, and a bad node evaluates every control the long way.
+template <int AXIS>
+SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
+                               const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &lmax)
+{
+    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
+    const sdp_real p = sn * l.nm1;
+    int q0 = (int)p;                                        // (saturating conversion; NaN -> 0)
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // max(min(q0, ordm2), 0): ordm2 >= 0
+    const sdp_real lam0 = p - (sdp_real)q0;
+    lmax = sdp_vmax(lmax, fabs(lam0));
+    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    const sdp_real a0 = A[q0], a1 = A[q0 + 1];
+    F = fma(g, f.psum, fma(lam0, a1 - a0, a0));
 }
 
 // What the first pass keeps of a node's controls: the two smallest F (and whose the smallest
@@ -1197,15 +1285,21 @@ SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_real F, int ci)
 // is an ordinary linspace (n > 1, step != 0): sdp_control_value without its rare branches, the
 // last point (`stop`, numpy.linspace) taken out of the loop.
 template <bool PLAIN, int AXIS>
-SDP_DEV void sdp_col_filter_pass1(const SdpColLds &m, const SdpColFilter &f, const SdpLeadAxis &l,
+SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const SdpColFilter &f, const SdpLeadAxis &l,
                                   const SdpBox &box, sdp_real *x, sdp_real t, int c_lo, int c_hi,
                                   SdpColBounds &b)
 {
     auto eval = [&](int ci, const sdp_real *u) {
         sdp_real F, S;
-        sdp_col_filter_eval<AXIS>(m, f, l, x, u, t, F, S, b.p_max);
-        b.s_sum = b.s_sum + S;
-        if (!SDP_COL_RADIUS_FROM_SUM) b.s_max = sdp_vmax(b.s_max, S);
+        if (SDP_COL_LEAN_ON) {
+            // (p_max holds the largest |lam0|, s_sum the sum of the |F|: see sdp_col_lean_eval)
+            sdp_col_lean_eval<AXIS>(ad_tab, f, l, x, u, t, F, b.p_max);
+            b.s_sum = b.s_sum + fabs(F);
+        } else {
+            sdp_col_filter_eval<AXIS>(ad_tab, f, l, x, u, t, F, S, b.p_max);
+            b.s_sum = b.s_sum + S;
+            if (!SDP_COL_RADIUS_FROM_SUM) b.s_max = sdp_vmax(b.s_max, S);
+        }
         sdp_col_bounds_insert(b, F, ci);
     };
     auto one = [&](int ci) {
@@ -1250,9 +1344,141 @@ SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
     const sdp_real o_p = sdp_shfl_xor(b.p_max, d);
     b.p_max = o_p > b.p_max ? o_p : b.p_max;
 }
+
+
+// Phase B with the filter for the nodes i_lo .. i_hi-1 of column `col`, by the `waves` waves
+// that call it (this one is number `wave`); `ad_tab` = the (A[r], D[r]) pairs, s.T the table.
+// A wave takes 64 / chunks consecutive nodes; the lanes l, l + npw, l + 2 npw, .. of a node
+// share its control lattice in `chunks` consecutive ranges and meet through lane shuffles.
+// Lanes past the end of the unit repeat its last node (they must stay active for the
+// shuffles) and store nothing.
+SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
+                                  const SdpColShared &s, const SdpColWeights &wts, const SdpLeadAxis &lead,
+                                  const SdpColFilter &filt, int axis_mode, const sdp_real *ad_tab, sdp_real dcol,
+                                  int64_t col, int i_lo, int i_hi, int wave, int waves,
+                                  sdp_real *x, sdp_real t, SdpColDiag &diag)
+{
+    constexpr int N0 = SDP_COL_N0;
+    const int lane = threadIdx.x & 63;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+    (void)diag;
+    const int n_nodes = i_hi - i_lo;
+    const int groups = (n_nodes + 63) >> 6;
+    int chunks = groups < waves ? waves / groups : 1;
+    chunks = 1 << (31 - __builtin_clz(chunks < 64 ? chunks : 64));     // power of two <= 64
+    const int npw = 64 / chunks;                                        // nodes per wave
+    const int items = (n_nodes + npw - 1) / npw;
+    // the issue-bound phase goes first: the co-resident workgroup's table build mostly
+    // waits for memory and fills the gaps (measured: 2.79 -> 2.57 ms)
+    __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
+    for (int item = wave; item < items; item += waves) {
+        const int chunk = lane / npw;
+        const int i_raw = i_lo + item * npw + (lane - chunk * npw);
+        const bool live = i_raw < i_hi;
+        const int i = live ? i_raw : i_hi - 1;
+        const int64_t node = col * N0 + i;
+        SdpBox box;
+        x[0] = axis0[i];
+        sdp_load_box(a, node, box);
+        const int c_lo = (int)((int64_t)box.total * chunk / chunks);
+        const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
+        // pass 1: bounds of every control of this lane's range
+        SDP_COL_MARK(diag.m1);
+        SdpColBounds bd;
+        bd.f1 = bd.f2 = bd.f3 = INFINITY;
+        bd.s_max = bd.s_sum = bd.p_max = (sdp_real)0;
+        bd.i1 = bd.i2 = INT_MAX;
+        const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
+#ifdef SDP_DIAG_NO_PASS1
+        if (t == (sdp_real)123.456)
+#endif
+        if (__all(plain)) {
+            if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else sdp_col_filter_pass1<true, 0>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+        } else {
+            if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else sdp_col_filter_pass1<false, 0>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+        }
+        for (int d = npw; d < 64; d <<= 1) sdp_col_bounds_merge(bd, d);
+        // pass 2: the reference's operations on the survivors
+        SDP_COL_MARK(diag.m2);
+#if SDP_STAMP == 2
+        diag.tp1 += diag.m2 - diag.m1;
+#endif
+        bool bad;
+        sdp_real radius;
+        if (SDP_COL_LEAN_ON) {
+            const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
+            const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
+            bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
+            radius = filt.cu * s_node;
+        } else {
+            bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)2147483648.0);
+            radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? bd.s_sum : bd.s_max);
+        }
+        const sdp_real m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
+        const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
+        // exactly two survivors (TOP2): the lanes of the node take one each (a lane alone takes both)
+        const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
+        const int p_lo = min(bd.i1, bd.i2), p_hi = max(bd.i1, bd.i2);
+        int first = c_lo, last = c_hi, stride = 1;
+        if (single) { first = bd.i1; last = bd.i1 + 1; }
+        if (pair) {
+            if (chunks == 1) { first = p_lo; last = p_hi + 1; stride = max(p_hi - p_lo, 1); }
+            else { first = (chunk & 1) ? p_hi : p_lo; last = chunk < 2 ? first + 1 : first; }
+        }
+        sdp_real best = INFINITY;
+        int ibest = INT_MAX;
+#ifdef SDP_DIAG_NO_PASS2
+        if (bd.f1 == (sdp_real)123.456)
+#endif
+        for (int ci = first; ci < last; ci += stride) {
+            sdp_real u[1][SDP_NU], jc[1];
+            sdp_controls_at(box, ci, u[0]);
+            bool cand = single || pair || bad;
+            if (!cand) {
+                sdp_real F, S;
+                sdp_real pm = (sdp_real)0;
+                if (SDP_COL_LEAN_ON) {
+                    if (lead.pow2) sdp_col_lean_eval<1>(ad_tab, filt, lead, x, u[0], t, F, pm);
+                    else sdp_col_lean_eval<0>(ad_tab, filt, lead, x, u[0], t, F, pm);
+                } else if (lead.pow2) sdp_col_filter_eval<1>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
+                else sdp_col_filter_eval<0>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
+                cand = !(F - radius > m_hi);
+            }
+            if (cand) {
+#if SDP_STAMP == 3
+                if (live) ++diag.n_exact;
+#endif
+                sdp_col_expected_cost<1>(a, tg, s, wts, lead, x, u, t, jc);
+                if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
+            }
+        }
+        for (int d = npw; d < 64; d <<= 1) {       // ranges are in lattice order: lower index wins ties
+            const sdp_real ov = sdp_shfl_xor(best, d);
+            const int oi = __shfl_xor(ibest, d, 64);
+            if (oi != INT_MAX && (ibest == INT_MAX || sdp_better_idx(ov, oi, best, ibest))) { best = ov; ibest = oi; }
+        }
+#if SDP_STAMP == 3
+        if (live && chunk == 0) { ++diag.n_all; if (!single && !pair) ++diag.n_slow; }
+#endif
+        if (live && chunk == 0) sdp_col_store(a, node, box, best, ibest);
+#if SDP_STAMP == 2
+        diag.tp2 += __builtin_amdgcn_s_memtime() - diag.m2;
+#endif
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
 #endif  // SDP_COL_FILTER
 
 #if !SDP_TRAIL_HAS_U
+#ifndef SDP_COL_PIPE
+#define SDP_COL_PIPE 0           // 1: producer / consumer pipeline in one workgroup (sdp_column_pipe.h)
+#endif
+#include "sdp_column_pipe.h"
+#if !SDP_COL_PIPE
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
@@ -1262,8 +1488,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     const int waves = blockDim.x >> 6;
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
-    // the table dimensions are compiled in: refuse a launch on any other grid
-    if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
+    // the table dimensions are compiled in (the host checks `sdp_meta` against the problem
+    // before the first launch: sdp_problem_create); a launch on any other grid is a bug
+    sdp_trap_unless(a.n_lead == N0 && (SDP_HAS_W ? a.W : 1) == Wn);
     const sdp_real t = (sdp_real)a.t_k;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
 
@@ -1283,18 +1510,15 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     const int axis_mode = __builtin_amdgcn_readfirstlane(sdp_col_axis_mode(lead));
 #endif
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
+    if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
     int parity = 0;
 #if SDP_STAMP == 2     // diagnostic: shader clocks thread 0 spends in phases W, A, B (+ idle at barriers)
     unsigned long long tw = 0, ta = 0, tb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, tstart = __builtin_amdgcn_s_memtime();
-    unsigned long long tr = 0, tp1 = 0, tp2 = 0, m0 = 0, m1 = 0, m2 = 0;   // filter: reduce, first pass, second pass
-    (void)tr; (void)tp1; (void)tp2; (void)m0; (void)m1; (void)m2;
-#define SDP_COL_MARK(v) v = __builtin_amdgcn_s_memtime()
-#else
-#define SDP_COL_MARK(v)
+    unsigned long long tr = 0, m0 = 0;   // filter: reduce
+    (void)tr; (void)m0;
 #endif
-#if SDP_STAMP == 3 && SDP_COL_FILTER   // diagnostic: how often the filter leaves more than one control
-    unsigned long long n_slow = 0, n_exact = 0, n_all = 0;
-#endif
+    SdpColDiag diag;                     // filter: first pass, second pass, survivor counts (SDP_STAMP 2 / 3)
+    (void)diag;
 
 #if SDP_COL_FILTER
     // The units of this XCD's share are handed out in order (one atomic per unit, claimed a
@@ -1361,116 +1585,17 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 
 #if SDP_COL_FILTER
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);        // (see phase B)
-        sdp_col_filter_reduce(a, sdp_lds, filt);
+        sdp_col_filter_reduce(a, sdp_lds, filt, parity);
         __syncthreads();
+        const sdp_real dcol = sdp_col_filter_dcol(sdp_lds, parity);
+        parity ^= 1;
         next_unit = u_base + sdp_lds.next_unit;
         SDP_COL_MARK(m0);
 #if SDP_STAMP == 2
         tr += m0 - t2;
 #endif
-        // ---- phase B, filtered (see SdpColFilter).  A wave takes 64 / chunks consecutive
-        // nodes; the lanes l, l + npw, l + 2 npw, .. of a node share its control lattice in
-        // `chunks` consecutive ranges and meet through lane shuffles.  Lanes past the end of
-        // the unit repeat its last node (they must stay active for the shuffles) and store
-        // nothing.
-        {
-            const int n_nodes = i_hi - i_lo;
-            const int groups = (n_nodes + 63) >> 6;
-            int chunks = groups < waves ? waves / groups : 1;
-            chunks = 1 << (31 - __builtin_clz(chunks < 64 ? chunks : 64));     // power of two <= 64
-            const int npw = 64 / chunks;                                        // nodes per wave
-            const int items = (n_nodes + npw - 1) / npw;
-            // the issue-bound phase goes first: the co-resident workgroup's table build mostly
-            // waits for memory and fills the gaps (measured: 2.79 -> 2.57 ms)
-            __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
-            for (int item = wave; item < items; item += waves) {
-                const int chunk = lane / npw;
-                const int i_raw = i_lo + item * npw + (lane - chunk * npw);
-                const bool live = i_raw < i_hi;
-                const int i = live ? i_raw : i_hi - 1;
-                const int64_t node = col * N0 + i;
-                SdpBox box;
-                x[0] = axis0[i];
-                sdp_load_box(a, node, box);
-                const int c_lo = (int)((int64_t)box.total * chunk / chunks);
-                const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
-                // pass 1: bounds of every control of this lane's range
-                SDP_COL_MARK(m1);
-                SdpColBounds bd;
-                bd.f1 = bd.f2 = bd.f3 = INFINITY;
-                bd.s_max = bd.s_sum = bd.p_max = (sdp_real)0;
-                bd.i1 = bd.i2 = INT_MAX;
-                const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
-#ifdef SDP_DIAG_NO_PASS1
-                if (t == (sdp_real)123.456)
-#endif
-                if (__all(plain)) {
-                    if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                    else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                    else sdp_col_filter_pass1<true, 0>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                } else {
-                    if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                    else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                    else sdp_col_filter_pass1<false, 0>(sdp_lds, filt, lead, box, x, t, c_lo, c_hi, bd);
-                }
-                for (int d = npw; d < 64; d <<= 1) sdp_col_bounds_merge(bd, d);
-                // pass 2: the reference's operations on the survivors
-                SDP_COL_MARK(m2);
-#if SDP_STAMP == 2
-                tp1 += m2 - m1;
-#endif
-                const bool bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)2147483648.0);
-                const sdp_real radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? bd.s_sum : bd.s_max);
-                const sdp_real m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
-                const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
-                // exactly two survivors (TOP2): the lanes of the node take one each (a lane alone takes both)
-                const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
-                const int p_lo = min(bd.i1, bd.i2), p_hi = max(bd.i1, bd.i2);
-                int first = c_lo, last = c_hi, stride = 1;
-                if (single) { first = bd.i1; last = bd.i1 + 1; }
-                if (pair) {
-                    if (chunks == 1) { first = p_lo; last = p_hi + 1; stride = max(p_hi - p_lo, 1); }
-                    else { first = (chunk & 1) ? p_hi : p_lo; last = chunk < 2 ? first + 1 : first; }
-                }
-                sdp_real best = INFINITY;
-                int ibest = INT_MAX;
-#ifdef SDP_DIAG_NO_PASS2
-                if (bd.f1 == (sdp_real)123.456)
-#endif
-                for (int ci = first; ci < last; ci += stride) {
-                    sdp_real u[1][SDP_NU], jc[1];
-                    sdp_controls_at(box, ci, u[0]);
-                    bool cand = single || pair || bad;
-                    if (!cand) {
-                        sdp_real F, S;
-                        sdp_real pm = (sdp_real)0;
-                        if (lead.pow2) sdp_col_filter_eval<1>(sdp_lds, filt, lead, x, u[0], t, F, S, pm);
-                        else sdp_col_filter_eval<0>(sdp_lds, filt, lead, x, u[0], t, F, S, pm);
-                        cand = !(F - radius > m_hi);
-                    }
-                    if (cand) {
-#if SDP_STAMP == 3
-                        if (live) ++n_exact;
-#endif
-                        sdp_col_expected_cost<1>(a, tg, s, wts, lead, x, u, t, jc);
-                        if (ibest == INT_MAX || sdp_better_seq(jc[0], best)) { best = jc[0]; ibest = ci; }
-                    }
-                }
-                for (int d = npw; d < 64; d <<= 1) {       // ranges are in lattice order: lower index wins ties
-                    const sdp_real ov = sdp_shfl_xor(best, d);
-                    const int oi = __shfl_xor(ibest, d, 64);
-                    if (oi != INT_MAX && (ibest == INT_MAX || sdp_better_idx(ov, oi, best, ibest))) { best = ov; ibest = oi; }
-                }
-#if SDP_STAMP == 3
-                if (live && chunk == 0) { ++n_all; if (!single && !pair) ++n_slow; }
-#endif
-                if (live && chunk == 0) sdp_col_store(a, node, box, best, ibest);
-#if SDP_STAMP == 2
-                tp2 += __builtin_amdgcn_s_memtime() - m2;
-#endif
-            }
-            __builtin_amdgcn_s_setprio(0);
-        }
+        // ---- phase B, filtered: sdp_col_filter_nodes
+        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, dcol, col, i_lo, i_hi, wave, waves, x, t, diag);
 #else
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
         // per wavefront: their rows q0 are consecutive, so the LDS reads are
@@ -1563,9 +1688,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
 #if SDP_STAMP == 3 && SDP_COL_FILTER
     if (a.stamps) {
-        atomicAdd((unsigned long long *)&a.stamps[0], n_slow);
-        atomicAdd((unsigned long long *)&a.stamps[1], n_exact);
-        atomicAdd((unsigned long long *)&a.stamps[2], n_all);
+        atomicAdd((unsigned long long *)&a.stamps[0], diag.n_slow);
+        atomicAdd((unsigned long long *)&a.stamps[1], diag.n_exact);
+        atomicAdd((unsigned long long *)&a.stamps[2], diag.n_all);
     }
 #elif SDP_STAMP == 2
     if (a.stamps && threadIdx.x == 0) {
@@ -1575,22 +1700,23 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         a.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - tstart;
 #if SDP_COL_FILTER
         a.stamps[(gridDim.x + blockIdx.x) * 4 + 0] = tr;
-        a.stamps[(gridDim.x + blockIdx.x) * 4 + 1] = tp1;
-        a.stamps[(gridDim.x + blockIdx.x) * 4 + 2] = tp2;
+        a.stamps[(gridDim.x + blockIdx.x) * 4 + 1] = diag.tp1;
+        a.stamps[(gridDim.x + blockIdx.x) * 4 + 2] = diag.tp2;
 #endif
     }
 #else
     SDP_STAMP_END(a);
 #endif
-#undef SDP_COL_MARK
 }
+
+#endif  // !SDP_COL_PIPE
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
-    if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
+    sdp_trap_unless(a.n_lead == N0 && (SDP_HAS_W ? a.W : 1) == Wn);
     const sdp_real t = (sdp_real)a.t_k;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
     SdpColShared s;
@@ -1707,7 +1833,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     constexpr int N0 = SDP_COL_N0;
     constexpr int Wn = SDP_COL_W;
     constexpr int WC = SDP_COL_WCHUNK;
-    if (a.n_lead != N0 || (SDP_HAS_W ? a.W : 1) != Wn) return;
+    sdp_trap_unless(a.n_lead == N0 && (SDP_HAS_W ? a.W : 1) == Wn);
     const sdp_real t = (sdp_real)a.t_k;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
     SdpColShared s;
@@ -1822,7 +1948,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)
 {
     constexpr int N0 = SDP_COL_N0;
-    if (a.n_lead != N0) return;
+    sdp_trap_unless(a.n_lead == N0);
     const sdp_real *__restrict__ V = (const sdp_real *)a.V;
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
     SdpGrid<sdp_real, SDP_D> grid;

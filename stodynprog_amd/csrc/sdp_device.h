@@ -15,6 +15,10 @@
 
 #define SDP_DEV __device__ __forceinline__
 
+// a launch the code object was not built for (the host validates `sdp_meta` first, so this
+// never fires in a correct program): abort the kernel instead of returning stale results
+SDP_DEV void sdp_trap_unless(bool ok) { if (!ok) __builtin_trap(); }
+
 // ---------------------------------------------------------------------------
 // <int>(p) of the Cython source is cvttsd2si / cvttss2si on the reference's
 // x86-64 build: NaN and out-of-range values give INT_MIN (then clamped to 0).

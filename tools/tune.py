@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for cfg in sys.argv[1:]:
     env = dict(os.environ)
     for kv in cfg.split():
-        k, v = kv.split('=')
+        k, v = kv.split('=', 1)
         env[k] = v
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '10', '--warmup', '3',
                         '--no-cpu-baseline', '--no-fused'] + os.environ.get('TUNE_BENCH_ARGS', '').split(),
