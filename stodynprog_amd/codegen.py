@@ -133,9 +133,10 @@ def interp_tables_source(model):
     return '\n'.join(out) + '\n'
 
 
-def _emit_body(model, nodes, lines):
-    """statements for `nodes` (topological order); returns the name map"""
-    names = {}
+def _emit_body(model, nodes, lines, names=None):
+    """statements for `nodes` (topological order); returns the name map
+    (`names`: nodes that already have a name -- leaves of a partial evaluation)"""
+    names = dict(names or {})
 
     def name(n):
         return names[n.id]
@@ -198,6 +199,48 @@ def separable_functions_source(model):
     return '\n\n'.join(out)
 
 
+UTAB_MAX_VALUES = 4          # tabulated sub-expressions per control
+UTAB_MAX_BYTES = 4096        # per parity buffer of the table in LDS
+
+
+def control_table_plan(model, dtype, per_node, max_controls):
+    """Can the column-uniform sub-expressions of x0' and of the cost be tabulated once per
+    (column, control) (SDP_COL_UTAB of csrc/sdp_column_kernel.h)?  Needs a control lattice that
+    is the same at every node (constant box) and small enough for LDS.  Returns the frontier
+    nodes (TracedModel.control_uniform_frontier) or None.  SDP_COL_UTAB=0 in the environment
+    switches it off (A/B runs)."""
+    if os.environ.get('SDP_COL_UTAB', '1') == '0' or per_node:
+        return None
+    fr = model.control_uniform_frontier()
+    if fr is None or len(fr) > UTAB_MAX_VALUES:
+        return None
+    if len(fr) * int(max_controls) * np.dtype(dtype).itemsize > UTAB_MAX_BYTES:
+        return None
+    return fr
+
+
+def control_table_source(model, frontier):
+    """C++ text of sdp_model_utab (the tabulated values of one control) and of
+    sdp_model_lead_tab / sdp_model_cost_tab (x0' and the cost from them)."""
+    slot = {n.id: k for k, n in enumerate(frontier)}
+    out = []
+    lines = ['SDP_DEV void sdp_model_utab(const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real *tab)',
+             '{', '    (void)x; (void)u; (void)t;']
+    names = _emit_body(model, model.slice_nodes(frontier), lines)
+    for n in frontier:
+        lines.append('    tab[{}] = {};'.format(slot[n.id], names[n.id]))
+    lines.append('}')
+    out.append('\n'.join(lines))
+    pre = {n.id: 'tab[{}]'.format(slot[n.id]) for n in frontier}
+    for fname, node in (('sdp_model_lead_tab', model.x_next[0]), ('sdp_model_cost_tab', model.cost)):
+        lines = ['SDP_DEV sdp_real {}(const sdp_real *x, const sdp_real *tab, sdp_real t)'.format(fname),
+                 '{', '    (void)x; (void)tab; (void)t;']
+        names = _emit_body(model, model.slice_nodes_until([node], set(slot)), lines, pre)
+        lines += ['    return {};'.format(names[node.id]), '}']
+        out.append('\n'.join(lines))
+    return '\n\n'.join(out)
+
+
 def lanes_for(max_controls):
     """Lanes per state node: the power of two covering the largest control
     lattice, capped at the 64 lanes of a wavefront."""
@@ -208,7 +251,7 @@ def lanes_for(max_controls):
 
 
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
-                     per_control=None, filtered=False):
+                     per_control=None, filtered=False, utab=None):
     """column: None for the generic node-order kernels, or (N0, W) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
@@ -219,7 +262,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
     per_control: None, or the tuple of `column_percontrol_config` (column kernel
     that rebuilds its table for every control).
     filtered: column kernel with the certified expectation-first filter (SDP_COL_FILTER of
-    csrc/sdp_column_kernel.h; see `column_filter_applies`)."""
+    csrc/sdp_column_kernel.h; see `column_filter_applies`).
+    utab: None, or (frontier nodes, controls of the lattice) of `control_table_plan` (filtered
+    kernel only): the first pass reads the column-uniform sub-expressions from a table."""
     real = {'float64': 'double', 'float32': 'float'}[np.dtype(dtype).name]
     head = [
         '// generated by stodynprog_amd.codegen -- do not edit',
@@ -257,10 +302,6 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         else:
             col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair, filtered)
         assert col_cfg is not None
-        pipe = (column_pipe_config(column[0], column[1], model.n_state, dtype, wpair)
-                if filtered and per_control is None and window is None else None)
-        if pipe is not None:
-            col_cfg = pipe[:2]
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
             '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
@@ -273,9 +314,6 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         ] + (['#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap']
              if filtered and int(col_cfg[0]) <= 256 and not os.environ.get('SDP_COL_MIN_WAVES') else []) + (
             ['#define SDP_COL_FILTER 1'] + (
-            ['#define SDP_COL_PIPE 1', '#define SDP_PIPE_PRODUCERS {}'.format(pipe[2])] + [
-                '#define {} {}'.format(k, int(os.environ[k])) for k in ('SDP_PIPE_G', 'SDP_PIPE_PRIO_P')
-                if os.environ.get(k)] if pipe is not None else []) + (
             ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
             if os.environ.get('SDP_COL_FILTER_SCALE') else []) if filtered else []) + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
                   int(os.environ.get('SDP_COL_A_LW') or _order[1]))]
@@ -289,7 +327,10 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
                        'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN')
              if os.environ.get(k)] + [
             separable_functions_source(model),
-            '',
+            ''] + (['#define SDP_COL_UTAB {}'.format(len(utab[0])),
+                    '#define SDP_COL_UTAB_N {}'.format(int(utab[1])),
+                    control_table_source(model, utab[0]), '']
+                   if utab is not None and filtered else []) + [
             '#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h',
             '',
         ]
@@ -470,34 +511,6 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False):
     return None
 
 
-PIPE_PRODUCERS = 4        # producer waves of the pipelined filtered kernel (one per SIMD)
-PIPE_CONSUMERS = 8        # consumer waves (two per SIMD: their vector issue interleaves)
-
-
-def column_pipe_config(n0, w, n_state, dtype, wpair=False):
-    """Shape of the filtered column kernel as a producer / consumer pipeline inside one
-    workgroup per CU (SDP_COL_PIPE, csrc/sdp_column_pipe.h): (threads, lds_bytes, producers),
-    or None where it does not apply -- two tables must fit the LDS of a CU, and the table
-    build must be worth waves of its own (W >= 16 perturbation points on a column of >= 128
-    nodes; the small tables of storage-AR1 / Searev keep the one-workgroup-does-both form,
-    of which a CU holds many).  SDP_COL_PIPE=0/1 in the environment forces it (A/B runs)."""
-    rs = np.dtype(dtype).itemsize
-    w = max(int(w), 1)
-    tw = w + (w & 1) if wpair else w
-    force = os.environ.get('SDP_COL_PIPE')
-    if force != '1':
-        return None
-    producers = int(os.environ.get('SDP_PIPE_PRODUCERS') or PIPE_PRODUCERS)
-    consumers = int(os.environ.get('SDP_PIPE_CONSUMERS') or PIPE_CONSUMERS)
-    lds = 2 * ((tw * n0 * rs + 15) // 16 * 16 + 2 * n0 * rs) + 16
-    lds = (lds + 15) // 16 * 16
-    if lds > COLUMN_LDS_MAX or (consumers + producers) * 64 > 1024 or w > 64:
-        return None
-    if force != '1' and (w < 16 or n0 < 128):
-        return None
-    return (consumers + producers) * 64, lds, producers
-
-
 def column_build_order(threads, w, rows):
     """How phase A of the column kernel deals the W x rows table entries to the threads
     (SDP_COL_A_ORDER / SDP_COL_A_LW of csrc/sdp_column_kernel.h): (2, lanes_per_w) when the
@@ -575,7 +588,7 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
 
 
 _HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h',
-            'sdp_column_pipe.h', 'sdp_staged_kernel.h')
+            'sdp_staged_kernel.h')
 _digest_cache = {}
 
 

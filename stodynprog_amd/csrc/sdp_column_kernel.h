@@ -127,6 +127,17 @@
 // of one per control, F as two fused multiply-adds on a table of A[r] alone.  See SdpColFilter.
 #define SDP_COL_LEAN -1          // -1: for 8-byte reals; 0 / 1 force it (A/B runs)
 #endif
+#ifndef SDP_COL_UTAB
+// K > 0: the generated unit provides sdp_model_utab / sdp_model_lead_tab / sdp_model_cost_tab
+// (codegen.control_table_source): the K sub-expressions of x0' and of the cost that depend on the
+// control but not on x0 are tabulated once per (column, control) -- SDP_COL_UTAB_N controls, the
+// same lattice at every node -- and the first pass of the filter reads them from LDS instead of
+// recomputing them at every node: the same operations on the same operands, the same bits.
+#define SDP_COL_UTAB 0
+#endif
+#ifndef SDP_COL_UTAB_N
+#define SDP_COL_UTAB_N 1
+#endif
 #ifndef SDP_COL_FILTER_SCALE
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
@@ -171,6 +182,8 @@ struct __attribute__((aligned(16))) SdpColLds {
     int win[2][2];                         // row window: per parity (min row, minus max row) of the unit
     int next_unit;                         // filtered kernel: the unit claimed for the next round
     unsigned long long dcol[2];            // lean filter: per parity of the unit, bits of max_r D[r] (>= 0: ordered as integers)
+    // per parity of the unit: the tabulated values of every control of the column (SDP_COL_UTAB)
+    sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N : 2] __attribute__((aligned(16)));
 #if SDP_COL_FILTER
     // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
     sdp_real ad[2 * SDP_COL_ROWS] __attribute__((aligned(16)));
@@ -1089,6 +1102,9 @@ SDP_DEV double sdp_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %
 SDP_DEV double sdp_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 SDP_DEV float sdp_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 SDP_DEV float sdp_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max(a, |b|) with the absolute value as an operand modifier (no separate instruction)
+SDP_DEV double sdp_vmax_abs(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SDP_DEV float sdp_vmax_abs(float a, float b) { float r; asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 struct SdpColFilter {
     sdp_real psum;      // fl(sum_w p_w), accumulated in w order
@@ -1144,7 +1160,7 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
             const sdp_real v = m.T[w * N0 + r];
 #endif
             acc = acc + p[w] * v;
-            big = sdp_vmax(big, fabs(v));
+            big = sdp_vmax_abs(big, v);
         }
         // (>= tiny / cu: the radius never drops below `tiny`; a NaN entry, which the max skips,
         // shows in acc and makes the row's bound infinite)
@@ -1233,20 +1249,55 @@ SDP_DEV int sdp_col_axis_mode(const SdpLeadAxis &l)
 // reference has x86 semantics, sdp_trunc_i32) makes |lam0| >= 2^30: all of them mark the node
 // `bad`, and a bad node evaluates every control the long way.
 template <int AXIS>
-SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
-                               const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &lmax)
+SDP_DEV void sdp_col_lean_core(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
+                               sdp_real xn0, sdp_real g, sdp_real &F, sdp_real &lmax)
 {
-    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
     const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
     const sdp_real p = sn * l.nm1;
     int q0 = (int)p;                                        // (saturating conversion; NaN -> 0)
     asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // max(min(q0, ordm2), 0): ordm2 >= 0
     const sdp_real lam0 = p - (sdp_real)q0;
-    lmax = sdp_vmax(lmax, fabs(lam0));
-    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    lmax = sdp_vmax_abs(lmax, lam0);
     const sdp_real a0 = A[q0], a1 = A[q0 + 1];
     F = fma(g, f.psum, fma(lam0, a1 - a0, a0));
 }
+template <int AXIS>
+SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
+                               const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &lmax)
+{
+    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax);
+}
+#if SDP_COL_UTAB
+// the same with the column-uniform parts of x0' and of the cost read from the control table
+template <int AXIS>
+SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f,
+                                   const SdpLeadAxis &l, const sdp_real *x, int ci, sdp_real t,
+                                   sdp_real &F, sdp_real &lmax)
+{
+    sdp_real tab[SDP_COL_UTAB];
+#pragma unroll
+    for (int k = 0; k < SDP_COL_UTAB; ++k) tab[k] = utab[ci * SDP_COL_UTAB + k];
+    const sdp_real xn0 = sdp_model_lead_tab(x, tab, t);
+    const sdp_real g = sdp_model_cost_tab(x, tab, t);
+    sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax);
+}
+// the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
+SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0)
+{
+    if ((int)threadIdx.x < first) return;
+    SdpBox box;
+    sdp_load_box(a, 0, box);                                // (one box for every node: checked at launch)
+    for (int ci = (int)threadIdx.x - first; ci < SDP_COL_UTAB_N; ci += (int)blockDim.x - first) {
+        sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
+        sdp_controls_at(box, ci, u);
+        sdp_model_utab(x, u, t, tab);
+#pragma unroll
+        for (int k = 0; k < SDP_COL_UTAB; ++k) utab[ci * SDP_COL_UTAB + k] = tab[k];
+    }
+}
+#endif
 
 // What the first pass keeps of a node's controls: the two smallest F (and whose the smallest
 // is), the largest S^ -- one radius cu * s_max then covers every control of the node -- and the
@@ -1285,10 +1336,30 @@ SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_real F, int ci)
 // is an ordinary linspace (n > 1, step != 0): sdp_control_value without its rare branches, the
 // last point (`stop`, numpy.linspace) taken out of the loop.
 template <bool PLAIN, int AXIS>
-SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const SdpColFilter &f, const SdpLeadAxis &l,
-                                  const SdpBox &box, sdp_real *x, sdp_real t, int c_lo, int c_hi,
-                                  SdpColBounds &b)
+SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, const SdpColFilter &f,
+                                  const SdpLeadAxis &l, const SdpBox &box, sdp_real *x, sdp_real t,
+                                  int c_lo, int c_hi, SdpColBounds &b)
 {
+#if SDP_COL_UTAB
+    if (SDP_COL_LEAN_ON) {
+        (void)box;
+        auto one = [&](int ci) {
+            sdp_real F;
+            sdp_col_lean_eval_tab<AXIS>(ad_tab, utab, f, l, x, ci, t, F, b.p_max);
+            b.s_sum = b.s_sum + fabs(F);
+            sdp_col_bounds_insert(b, F, ci);
+        };
+        constexpr int K = SDP_COL_FILTER_UNROLL;
+        int ci = c_lo;
+        for (; ci + K <= c_hi; ci += K) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) one(ci + j);
+        }
+        for (; ci < c_hi; ++ci) one(ci);
+        return;
+    }
+#endif
+    (void)utab;
     auto eval = [&](int ci, const sdp_real *u) {
         sdp_real F, S;
         if (SDP_COL_LEAN_ON) {
@@ -1354,7 +1425,8 @@ SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
 // shuffles) and store nothing.
 SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
                                   const SdpColShared &s, const SdpColWeights &wts, const SdpLeadAxis &lead,
-                                  const SdpColFilter &filt, int axis_mode, const sdp_real *ad_tab, sdp_real dcol,
+                                  const SdpColFilter &filt, int axis_mode, const sdp_real *ad_tab,
+                                  const sdp_real *utab, sdp_real dcol,
                                   int64_t col, int i_lo, int i_hi, int wave, int waves,
                                   sdp_real *x, sdp_real t, SdpColDiag &diag)
 {
@@ -1393,13 +1465,13 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         if (t == (sdp_real)123.456)
 #endif
         if (__all(plain)) {
-            if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else sdp_col_filter_pass1<true, 0>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else sdp_col_filter_pass1<true, 0>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
         } else {
-            if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else sdp_col_filter_pass1<false, 0>(ad_tab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            else sdp_col_filter_pass1<false, 0>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
         }
         for (int d = npw; d < 64; d <<= 1) sdp_col_bounds_merge(bd, d);
         // pass 2: the reference's operations on the survivors
@@ -1474,11 +1546,6 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
 #endif  // SDP_COL_FILTER
 
 #if !SDP_TRAIL_HAS_U
-#ifndef SDP_COL_PIPE
-#define SDP_COL_PIPE 0           // 1: producer / consumer pipeline in one workgroup (sdp_column_pipe.h)
-#endif
-#include "sdp_column_pipe.h"
-#if !SDP_COL_PIPE
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
@@ -1528,10 +1595,17 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     if (threadIdx.x == 0) sdp_lds.next_unit = (int)atomicAdd(claim, 1u);
     __syncthreads();
     int64_t unit = u_base + sdp_lds.next_unit;
+    int upar = 0;                                          // parity buffer of the control table
+#if SDP_COL_UTAB
+    sdp_trap_unless(!a.box_per_node);                      // (and SDP_COL_UTAB_N controls: sdp_meta, checked by the host)
+#endif
     if (unit < u_end) {                                    // trailing cells of the first unit
         sdp_real xn[SDP_D];
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
+#if SDP_COL_UTAB
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t);
+#endif
     }
     while (unit < u_end) {
         int64_t next_unit;
@@ -1564,6 +1638,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_real xn[SDP_D];
                 sdp_col_coords(a, sdp_col_of_unit(a, u_base + nx), xn);
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
+#if SDP_COL_UTAB
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, (int)blockDim.x - 64);
+#endif
             }
         }
 #else
@@ -1595,7 +1672,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         tr += m0 - t2;
 #endif
         // ---- phase B, filtered: sdp_col_filter_nodes
-        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, dcol, col, i_lo, i_hi, wave, waves, x, t, diag);
+        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, sdp_lds.utab[upar], dcol, col, i_lo, i_hi, wave, waves, x, t, diag);
+        upar ^= 1;
 #else
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
         // per wavefront: their rows q0 are consecutive, so the LDS reads are
@@ -1708,8 +1786,6 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     SDP_STAMP_END(a);
 #endif
 }
-
-#endif  // !SDP_COL_PIPE
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)
 {

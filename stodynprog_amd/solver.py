@@ -645,11 +645,15 @@ class DPSolver(object):
                 self._cache[key] = staged
         filtered = bool(column and getattr(self, 'certified_filter', True) and codegen.column_filter_applies(
             model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None))
+        utab = None
+        if filtered:
+            fr = codegen.control_table_plan(model, dt, bp['per_node'], bp['max_u'])
+            utab = (fr, bp['max_u']) if fr is not None else None
         source = codegen.translation_unit(model, dt, lanes,
                                           column=(shape[0], W) if column else None,
                                           fused=(self.arithmetic == 'fused'), staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
-                                          filtered=filtered)
+                                          filtered=filtered, utab=utab)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
                     window=window, per_control=per_control,
                     col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),

@@ -539,6 +539,43 @@ class TracedModel(object):
             stack.extend(n.args)
         return [n for n in self.graph.nodes if n.id in seen]
 
+    def slice_nodes_until(self, outputs, stop_ids):
+        """Nodes reachable from `outputs` without passing through a node of `stop_ids`
+        (those nodes themselves excluded), in topological order."""
+        seen = set()
+        stack = [n for n in outputs if n.id not in stop_ids]
+        while stack:
+            n = stack.pop()
+            if n.id in seen:
+                continue
+            seen.add(n.id)
+            stack.extend(a for a in n.args if a.id not in stop_ids)
+        return [n for n in self.graph.nodes if n.id in seen]
+
+    def control_uniform_frontier(self):
+        """Sub-expressions of x0' and of the cost that depend on the control (and possibly on
+        x_1.., t) but neither on the leading state variable x0 nor on w -- so they take the same
+        value at every node of a column along axis 0 -- and feed an expression that does depend on
+        x0 (or are x0' / the cost themselves).  With a control lattice shared by the nodes of a
+        column they can be evaluated once per (column, control) instead of once per (node,
+        control): the same operations on the same operands, hence the same bits
+        (csrc/sdp_column_kernel.h, SDP_COL_UTAB).  Returns the nodes in recording order, or None
+        when there is none or a boolean is among them."""
+        outs = [self.x_next[0], self.cost]
+        nodes = self.slice_nodes(outs)
+
+        def uniform(n):
+            return (n.deps & (DEP_X | DEP_W)) == 0 and (n.deps & DEP_U) != 0
+        front = set()
+        for n in nodes:
+            if not uniform(n):
+                front.update(a.id for a in n.args if uniform(a))
+        front.update(o.id for o in outs if uniform(o))
+        fr = [n for n in nodes if n.id in front]
+        if not fr or any(n.kind != 'r' for n in fr):
+            return None
+        return fr
+
     @property
     def storage_separable(self):
         """True when the next values of all state axes but the LEADING one
