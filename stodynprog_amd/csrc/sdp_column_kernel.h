@@ -113,7 +113,9 @@
 #define SDP_COL_FILTER 0         // 1: certified expectation-first filter in phase B (see sdp_col_filter_*)
 #endif
 #ifndef SDP_COL_FILTER_UNROLL
-#define SDP_COL_FILTER_UNROLL 4  // controls per round of the filter's first pass
+// controls per round of the filter's first pass.  Same-box A/B, 256^3 x 64 x 32 fp64 with the lean
+// pass and the control table: 2 -> 2.05 ms, 4 -> 1.94, 8 -> 1.89, 16 -> 1.90; 4-byte reals keep 4
+#define SDP_COL_FILTER_UNROLL (sizeof(SDP_REAL) == 8 ? 8 : 4)
 #endif
 #ifndef SDP_COL_B_PRIO
 #define SDP_COL_B_PRIO 3         // wave priority (s_setprio) while in phase B
@@ -312,6 +314,11 @@ SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
 // whole group are issued first -- only the loaded values live in registers
 // meanwhile; the interpolation weights are re-read from LDS afterwards -- so one
 // memory round trip serves SDP_COL_A_GROUP entries.
+extern "C" __device__ double __ockl_wfred_max_f64(double);
+extern "C" __device__ float __ockl_wfred_max_f32(float);
+SDP_DEV double sdp_wave_max(double v) { return __ockl_wfred_max_f64(v); }      // DPP row operations, no LDS traffic
+SDP_DEV float sdp_wave_max(float v) { return __ockl_wfred_max_f32(v); }
+
 template <bool SHIFT = false>
 SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
                              const SdpColShared &s)
@@ -1174,13 +1181,9 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
         }
     }
     if (SDP_COL_LEAN_ON) {
-        unsigned long long bits = (unsigned long long)__double_as_longlong((double)dmax);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = (unsigned long long)__shfl_xor((long long)bits, d, 64);
-            bits = o > bits ? o : bits;
-        }
-        if ((threadIdx.x & 63) == 0) atomicMax(&m.dcol[parity], bits);
+        dmax = sdp_wave_max(dmax);                          // (>= 0, or +inf; never a NaN)
+        if ((threadIdx.x & 63) == 0)
+            atomicMax(&m.dcol[parity], (unsigned long long)__double_as_longlong((double)dmax));
     }
 }
 // after the barrier that follows the reduction: the column's bound; the slot of the next unit is cleared
