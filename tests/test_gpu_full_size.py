@@ -22,3 +22,46 @@ def test_full_256cubed_sweep_matches_the_oracle_on_every_node(gpu):
     text = out.stdout.decode()
     assert out.returncode == 0, text
     assert 'nodes: 16777216   J bit-identical: True' in text and 'index mismatches: 0' in text, text
+
+
+@pytest.mark.timeout(900)
+def test_chained_sweeps_at_full_size_match_the_oracle_on_sampled_nodes(gpu):
+    """What bench.py times are sweeps 5..25 of a chain, not the sweep from the closed-form V0:
+    sweep 6 of the chain at 256^3, from the device's own J_5, against the C oracle on 20 000
+    sampled nodes -- J bit for bit, indices exact."""
+    import io
+    import contextlib
+    import numpy as np
+    from stodynprog_amd import models
+    from oracle import c_oracle
+    _, s = models.synthetic3d(N=256)
+    V0 = models.synthetic3d_V0(s.state_grid)
+    with contextlib.redirect_stdout(io.StringIO()):
+        J5, _ = s.value_iterations(V0, 5)
+        J6, _ = s.value_iteration(J5)
+    idx6 = s.last_policy_index
+    assert s.backend_info['certified_filter']
+    nodes = np.random.default_rng(6).choice(V0.size, size=20000, replace=False)
+    Jo, io_, _ = c_oracle.vi_synth3d(s.state_grid, J5, models.SYNTH_PAR, -1., 1., 64,
+                                     s.perturb_grid[0], s.perturb_proba[0], node_ids=nodes,
+                                     n_threads=min(c_oracle.max_threads(), 64))
+    assert np.array_equal(J6.ravel()[nodes], Jo)
+    assert np.array_equal(idx6.ravel()[nodes], io_)
+
+
+@pytest.mark.timeout(900)
+def test_every_node_through_the_multi_survivor_pass_at_full_size(gpu, monkeypatch):
+    """At the benchmark size no node keeps a second control in 8-byte reals, so the second pass's
+    walk over several survivors never runs there: force it (radius x 1e12: every node keeps
+    several) once at 256^3 and compare all 16.7 M nodes with the ordinary run."""
+    import numpy as np
+    from stodynprog_amd import models
+    _, a = models.synthetic3d(N=256)
+    V0 = models.synthetic3d_V0(a.state_grid)
+    Ja, _ = a.value_iteration(V0, report_time=False)
+    ia = a.last_policy_index
+    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '1e12')
+    _, b = models.synthetic3d(N=256)
+    Jb, _ = b.value_iteration(V0, report_time=False)
+    assert 'SDP_COL_FILTER_SCALE' in b._kernel_plan()['source']
+    assert np.array_equal(Ja, Jb) and np.array_equal(ia, b.last_policy_index)
