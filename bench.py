@@ -17,15 +17,18 @@ over the ranks and the J slabs are all-gathered with RCCL after every sweep,
 inside the timed region.
 
 Prints ONE JSON line on rank 0.
-  roofline      the column kernel removes the 2^d-vertex gather per lattice cell
-                (LDS table), so its binding resource is fp64 VALU issue:
-                achieved = fp64 wave-instructions per launch (rocprofv3 PMC counts
-                of this very command, profiles/pmc_<workload>.json) / kernel
-                duration (HIP events on the kernel's stream, measured here);
-                peak = 256 CU x 4 SIMD x 2.4 GHz / 4 clk = 6.144e11 /s (the 78.6
-                TFLOP/s fp64-vector spec expressed in wave64 instructions).  The
-                gather-accounted contract figure of SURVEY.md 8(d) and the HBM
-                utilisation from the measured traffic are reported beside it.
+  roofline      the column kernel removes the 2^d-vertex gather per lattice cell (LDS table) and, by
+                default, all but the near-minimal controls of a node (certified expectation-first
+                filter), so what binds it is vector-instruction issue: bound = "valu_issue",
+                achieved = 4 SIMD clocks x the vector wave-instructions of one launch (rocprofv3 PMC
+                counts of this very command, profiles/pmc_<workload>.json; every instruction type
+                costs 4.2-4.4 clocks in a mixed stream, profiles/r03_ubench_valu_rate.txt) / kernel
+                duration (HIP events on the kernel's stream, measured here); peak = 256 CU x 4 SIMD x
+                2.4 GHz issue clocks per second.  `count_source_stale` is true when the committed
+                counts were taken from another version of the kernel.  With --no-filter the bound is
+                "fp64_valu" (fp64 wave-instructions against the 78.6 TFLOP/s spec rate, 6.144e11 /s).
+                The gather-accounted contract figure of SURVEY.md 8(d) and the HBM utilisation from
+                the measured traffic are reported beside it.
   cpu_baseline  the C oracle (oracle/sdp_oracle.c, a port of the reference
                 algorithm) timed on this box's host cores on a bounded sample of
                 the same workload: single thread (faithful to the reference
@@ -213,6 +216,9 @@ def clone_solver(DPSolver, sysd, solver, dtype, **attrs):
     return s
 
 
+_REAL_STDOUT = []          # the program's real stdout while descriptor 1 is fenced (main)
+
+
 def _trace(*a):
     if os.environ.get('SDP_BENCH_TRACE'):
         print('[bench r{}]'.format(os.environ.get('RANK', '0')), *a, file=sys.stderr, flush=True)
@@ -258,46 +264,99 @@ def run(args):
             dev_comm.barrier()
             nat.check(nat.lib().sdp_synchronize())
 
-    phase_times, peer_note = None, None
-    if dev_comm is not None:
-        # Untimed tuning of the comm/compute overlap: how many phases a backup is cut
-        # into (each phase's all-gather runs under the next phase's kernel).  Few
-        # phases leave a long last gather exposed, many add launches and small
-        # collectives; the best count depends on the rank count and the fabric.
-        # Every rank times the same candidates; the max over ranks decides, so all
-        # ranks pick the same count.
-        exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,peer,sparse').split(',') if e]
-        if os.environ.get('SDP_COMM_PHASES'):
-            solver.comm_phases = int(os.environ['SDP_COMM_PHASES'])
-            solver.comm_exchange = 'peer' if exchanges[0] == 'sparse' else exchanges[0]
-            solver.comm_sparse = exchanges[0] == 'sparse'
-        else:
-            # Second dimension: how the rows travel.  'rccl' = all-gather kernels of the
-            # collective library; 'peer' = every rank copies its rows into the peers' buffers
-            # (HIP IPC mappings, copy engines, no compute units); 'sparse' = 'peer' with one
-            # slab of columns per rank and only the rows a peer reads sent to it.  'peer' /
-            # 'sparse' are candidates only where every rank can map every peer, and only if
-            # their J equals the RCCL one bit for bit on every rank after the same sweeps.
-            phase_times, J_check = {}, None
-            for exch in exchanges:
-                if dev_comm.nranks == 1 and exch != 'rccl':
-                    continue
-                for ph, taper in ((2, False), (4, False), (8, False), (16, False), (4, True), (8, True)):
-                    if exch == 'sparse' and taper:
-                        continue                            # (slabs are cut evenly)
-                    solver.comm_phases, solver.comm_taper = ph, taper
-                    solver.comm_exchange = 'peer' if exch == 'sparse' else exch
-                    solver.comm_sparse = exch == 'sparse'
-                    with warnings.catch_warnings():
-                        warnings.simplefilter('ignore')
-                        trial = solver._problem()
-                    got = solver.backend_info.get('exchange', 'rccl')
-                    if got != {'sparse': 'peer-sparse'}.get(exch, exch):
-                        _trace('exchange', exch, 'not available:', got, getattr(trial, 'peer_failure', ''))
-                        peer_note = ('peer exchange unavailable on this node: {}'.format(
-                                         getattr(trial, 'peer_failure', 'buffers not mappable'))
-                                     if got == 'rccl' else 'sparse exchange does not apply to this kernel family')
-                        break
+    def timed_region(prob):
+        """W untimed + EXACTLY K timed sweeps from V0, bracketed by barriers and device
+        synchronisations; (seconds, kernel ms), both the maximum over the ranks"""
+        prob.set_value(V0)
+        if args.warmup > 0:
+            prob.bench_sweeps(args.warmup)
+            prob.swap()
+        sync_all()
+        t0 = time.perf_counter()
+        loop_ms, kernel_ms = prob.bench_sweeps(args.steps)       # K sweeps (+ exchanges)
+        if dev_comm is not None:
+            prob.complete()  # sparse exchange: the timed region ends, like the others, with J complete everywhere
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dev_comm is not None:
+            elapsed = dev_comm.allreduce_max(elapsed)
+            kernel_ms = dev_comm.allreduce_max(kernel_ms)
+        return elapsed, kernel_ms
+
+    if dev_comm is None:
+        prob = solver._problem()
+        assert solver.backend_info['max_controls'] == U_max
+        elapsed, kernel_ms = timed_region(prob)
+        if rank != 0:
+            return None
+        out = report(args, locals())
+        return finish_single(args, locals(), out)
+    return run_sharded(args, locals())
+
+
+def run_sharded(args, env):
+    """N > 1 (or the one-rank test hook): the RCCL exchange is tuned, TIMED and reported first;
+    the optional exchanges (peer writes, sparse peer writes) are tried afterwards, each under a
+    watchdog, and can only replace the RCCL result by a faster, bit-identical one.  Whatever
+    happens to an optional candidate -- an error on any rank, a rejected result, a hang -- the
+    line printed is at least the RCCL one and the exit status is 0; only a failure of the RCCL
+    path itself is an error."""
+    import threading
+    solver, dev_comm, V0, rank, nat = (env[k] for k in ('solver', 'dev_comm', 'V0', 'rank', 'nat'))
+    sync_all, timed_region = env['sync_all'], env['timed_region']
+    exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,peer,sparse').split(',') if e]
+    if 'rccl' not in exchanges:
+        exchanges.insert(0, 'rccl')
+    # phases per backup: each phase's exchange runs under the next phase's kernel.  Few phases leave
+    # a long last exchange exposed, many add launches (measured on one GPU: ~0.03 ms per extra phase,
+    # profiles/r03_fixed_cost_sharded.txt); sparse / peer writes need few.  `t`: tapered phases.
+    PLANS = {'rccl': ((4, False), (2, False), (1, False), (8, False), (16, False), (4, True), (8, True)),
+             'peer': ((2, False), (1, False), (4, False), (8, False)),
+             'sparse': ((1, False), (2, False), (4, False))}
+    if os.environ.get('SDP_COMM_PHASES'):
+        forced = (int(os.environ['SDP_COMM_PHASES']), False)
+        PLANS = {k: (forced,) for k in PLANS}
+    fault = os.environ.get('SDP_BENCH_FAULT', '')          # test hook: '<exchange>:<raise|hang|reject>:<rank>'
+    f_exch, f_kind, f_rank = (fault.split(':') + ['', '', ''])[:3]
+    phase_times, notes = {}, []
+    state = {'J_check': None}
+
+    def key_of(exch, ph, taper):
+        return '{}{}{}'.format(ph, 't' if taper else '', '' if exch == 'rccl' else '/' + exch)
+
+    def configure(exch, ph, taper):
+        solver.comm_phases, solver.comm_taper = ph, taper
+        solver.comm_exchange = 'peer' if exch == 'sparse' else exch
+        solver.comm_sparse = exch == 'sparse'
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            return solver._problem()
+
+    def tune(exch):
+        """3 sweeps per plan, the maximum over the ranks decides; the J of the first plan must equal
+        the RCCL one bit for bit on every rank.  Returns (best plan, its time) or (None, reason)."""
+        best = (None, 'no plan timed')
+        # pre-flight: a rank that cannot even start says so BEFORE anybody enters the collective set-up
+        pre_error = None
+        try:
+            if f_exch == exch and f_kind == 'raise' and str(rank) == f_rank:
+                raise RuntimeError('injected failure (SDP_BENCH_FAULT)')
+        except Exception as e:
+            pre_error = '{}: {}'.format(type(e).__name__, e)
+        if dev_comm.allreduce_max(1.0 if pre_error else 0.0) > 0:
+            return None, pre_error or 'another rank failed before the set-up'
+        for n, (ph, taper) in enumerate(PLANS[exch]):
+            local_error = None
+            t = 0.0
+            try:
+                if f_exch == exch and f_kind == 'hang' and str(rank) == f_rank:
+                    time.sleep(1e6)
+                trial = configure(exch, ph, taper)
+                got = solver.backend_info.get('exchange', 'rccl')
+                if got != {'sparse': 'peer-sparse'}.get(exch, exch):
+                    local_error = ('not available on this node: {}'.format(getattr(trial, 'peer_failure', 'buffers not mappable'))
+                                   if got == 'rccl' else 'does not apply to this kernel family')
+                else:
                     trial.set_value(V0)
                     trial.bench_sweeps(2)
                     trial.swap()
@@ -305,51 +364,91 @@ def run(args):
                     t0 = time.perf_counter()
                     trial.bench_sweeps(3)
                     sync_all()
-                    t = dev_comm.allreduce_max(time.perf_counter() - t0) / 3 * 1e3
-                    key = '{}{}{}'.format(ph, 't' if taper else '', '' if exch == 'rccl' else '/' + exch)
-                    if (ph, taper) == (4, False):           # one result check per exchange
+                    t = time.perf_counter() - t0
+                    if n == 0:                                  # one result check per exchange
                         J_now = trial.get_value()
-                        if J_check is None:
-                            J_check = J_now
-                        elif dev_comm.allreduce_max(0.0 if np.array_equal(J_now, J_check) else 1.0) > 0:
-                            peer_note = '{} exchange rejected: J differs from the RCCL result'.format(exch)
-                            phase_times = {k: v for k, v in phase_times.items() if '/' + exch not in k}
-                            break
-                        del J_now
-                    phase_times[key] = t
-                    _trace('candidate', key, round(t, 3))
-            best = min(phase_times, key=lambda k: (phase_times[k], k))
-            plan, _, exch = best.partition('/')
-            solver.comm_phases, solver.comm_taper = int(plan.rstrip('t')), plan.endswith('t')
-            solver.comm_exchange = {'': 'rccl', 'sparse': 'peer'}.get(exch, exch)
-            solver.comm_sparse = exch == 'sparse'
-            del J_check
+                        if f_exch == exch and f_kind == 'reject' and str(rank) == f_rank:
+                            J_now = J_now + 1.0
+                        if state['J_check'] is None:
+                            state['J_check'] = J_now
+                        elif not np.array_equal(J_now, state['J_check']):
+                            local_error = 'rejected: J differs from the RCCL result'
+            except Exception as e:                              # this rank's trouble: the ranks agree below
+                local_error = '{}: {}'.format(type(e).__name__, e)
+            # every rank gets here for every plan (a rank stuck inside a collective does not: watchdog)
+            failed = dev_comm.allreduce_max(1.0 if local_error else 0.0) > 0
+            if failed:
+                return None, local_error or 'another rank failed'
+            t = dev_comm.allreduce_max(t) / 3 * 1e3
+            phase_times[key_of(exch, ph, taper)] = t
+            _trace('candidate', key_of(exch, ph, taper), round(t, 3))
+            if best[0] is None or t < best[1]:
+                best = ((ph, taper), t)
+        return best
 
-    prob = solver._problem()
-    assert solver.backend_info['max_controls'] == U_max
-    prob.set_value(V0)
+    def measure(exch, plan):
+        prob = configure(exch, *plan)
+        elapsed, kernel_ms = timed_region(prob)
+        e = dict(env, prob=prob, elapsed=elapsed, kernel_ms=kernel_ms, phase_times=dict(phase_times),
+                 peer_note='; '.join(notes) or None)
+        out = report(args, e) if rank == 0 else None
+        if rank == 0:
+            out = self_check(args, e, out)
+        sync_all()
+        return out, elapsed
+
+    # ---- 1. the RCCL exchange: tuned, timed, reported.  A failure here is a failure of the run.
+    plan, t_rccl = tune('rccl')
+    if plan is None:
+        raise RuntimeError('RCCL exchange failed: {}'.format(t_rccl))
+    best_out, best_elapsed = measure('rccl', plan)
+    _trace('rccl timed', best_elapsed)
+
+    # ---- 2. optional exchanges, each under a watchdog that prints the best result so far
+    budget = float(os.environ.get('SDP_BENCH_OPTIONAL_TIMEOUT', '180'))
+    for exch in [e for e in exchanges if e != 'rccl' and dev_comm.nranks > 1]:
+        box = {'out': best_out}
+
+        def bail(exch=exch, box=box):
+            if rank == 0 and box['out'] is not None:
+                o = box['out']
+                o['config']['comm_exchange_note'] = '; '.join(notes + [
+                    '{} exchange abandoned: no answer within {:.0f} s (a rank hung)'.format(exch, budget)])
+                o['config']['comm_phase_tuning_ms_per_sweep'] = dict(phase_times)
+                # (file descriptor 1 is fenced off while run() executes: write to the real one)
+                os.write(_REAL_STDOUT[0] if _REAL_STDOUT else 1, (json.dumps(o) + '\n').encode())
+            os._exit(0)
+        dog = threading.Timer(budget, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            plan, t_opt = tune(exch)
+            if plan is None:
+                notes.append('{} exchange not used: {}'.format(exch, t_opt))
+            elif t_opt >= t_rccl:
+                notes.append('{} exchange not faster in tuning ({:.3f} vs {:.3f} ms per sweep)'.format(exch, t_opt, t_rccl))
+            else:
+                out, elapsed = measure(exch, plan)
+                if dev_comm.allreduce_max(1.0 if (rank == 0 and out.get('sharded_matches_single_gpu') is not True) else 0.0) > 0:
+                    notes.append('{} exchange rejected: the sharded chain differs from the single-GPU one'.format(exch))
+                elif elapsed < best_elapsed:
+                    best_out, best_elapsed = out, elapsed
+        finally:
+            dog.cancel()
+    if rank == 0:
+        best_out['config']['comm_exchange_note'] = '; '.join(notes) or None
+        best_out['config']['comm_phase_tuning_ms_per_sweep'] = dict(phase_times)
+    return best_out
+
+
+def report(args, env):
+    """the JSON line of one timed region (rank 0); `env`: the locals of run()"""
+    (models, solver, sysd, prob, dev_comm, V0, dtype, cfg, label, model_name, world, rank, S, d, nu, W, cells,
+     U_max, elapsed, kernel_ms) = (env[k] for k in (
+         'models', 'solver', 'sysd', 'prob', 'dev_comm', 'V0', 'dtype', 'cfg', 'label', 'model_name', 'world',
+         'rank', 'S', 'd', 'nu', 'W', 'cells', 'U_max', 'elapsed', 'kernel_ms'))
+    phase_times, peer_note = env.get('phase_times'), env.get('peer_note')
     kernel_family = solver.backend_info.get('kernel')
-
-    _trace('tuned', solver.comm_phases if dev_comm is not None else None)
-    # warm-up sweeps (untimed), ping-pong like the timed ones
-    if args.warmup > 0:
-        prob.bench_sweeps(args.warmup)
-        prob.swap()
-    sync_all()
-    t0 = time.perf_counter()
-    loop_ms, kernel_ms = prob.bench_sweeps(args.steps)       # K sweeps (+ all-gathers)
-    if dev_comm is not None:
-        prob.complete()      # sparse exchange: the timed region ends, like the others, with J complete everywhere
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    _trace('timed region done')
-    if dev_comm is not None:
-        elapsed = dev_comm.allreduce_max(elapsed)
-        kernel_ms = dev_comm.allreduce_max(kernel_ms)
-
-    _trace('reduced')
-    if rank != 0:
-        return None
     ms_per_step = elapsed * 1e3 / args.steps
     sweeps_per_s = args.steps / elapsed
     rb = dtype.itemsize
@@ -368,20 +467,28 @@ def run(args):
     pmc_key = '{}_{}_{}{}'.format(args.config if not args.grid else '{}{}'.format(model_name, args.grid),
                                   'f64' if rb == 8 else 'f32', kernel_family, '_filter' if filtered else '')
     pmc, pmc_path = load_pmc(pmc_key)
+    # the counts belong to ONE version of the kernel: the summary records the key of the generated
+    # source + kernel headers it was taken from (codegen.source_key, written by tools/summarize_prof.py)
+    from stodynprog_amd import codegen
+    source_key = codegen.source_key(solver._kernel_plan()['source'])
+    count_stale = bool(pmc) and pmc.get('kernel_source_key') != source_key
     issue_peak = (N_SIMD * 2.4e9) if filtered else (FP64_ISSUE_PEAK if rb == 8 else FP32_ISSUE_PEAK)
     analytic = cells * 6 / 64.0                        # 6 operations per lattice cell, never fusable
     valu_all = valu_f64 = None
     if filtered and pmc and pmc.get('counters_mean_per_dispatch', {}).get('SQ_INSTS_VALU'):
-        # the filter leaves a mix of fp64 arithmetic (4 clk per wave64 instruction) and 32-bit /
-        # conversion / select work (2 clk: MI355X_MICROARCH.md, cycle constants): priced in SIMD
-        # issue cycles, fp64 ADD/MUL/FMA at 4 and EVERYTHING else at 2 (the 64-bit min / max /
-        # compare / convert instructions among "everything else" cost 4: the figure is a floor)
+        # Priced in SIMD issue cycles at 4 clocks per wave64 vector instruction WHATEVER its type:
+        # in a mixed stream every vector instruction of this kernel's kind -- fp64 arithmetic, fp64
+        # min / max / compare / convert, 32-bit integer and select work -- occupies its SIMD for
+        # 4.2-4.4 clocks (tools/ubench/valu_rate.hip, profiles/r03_ubench_valu_rate.txt: the 2-clock
+        # rate of plain 32-bit operations does not survive the mix), so 4 is the floor and the spec
+        # rate of the fp64 instructions that make up most of the stream.  (Round 2 charged the
+        # non-fp64 instructions 2 clocks: kept beside it as `frac_r02_accounting`.)
         cm = pmc['counters_mean_per_dispatch']
         valu_all = float(cm['SQ_INSTS_VALU'])
         valu_f64 = float(sum(cm.get('SQ_INSTS_VALU_{}_F64'.format(k), 0.0) for k in ('ADD', 'MUL', 'FMA'))) if rb == 8 else 0.0
-        counted = 4.0 * valu_f64 + 2.0 * (valu_all - valu_f64)
-        count_source = ('{}: per {} dispatch (rocprofv3 --pmc of this command) SQ_INSTS_VALU {:.4g}, of which fp64 '
-                        'ADD/MUL/FMA {:.4g}; issue cycles = 4 x fp64 + 2 x the rest'.format(
+        counted = 4.0 * valu_all
+        count_source = ('{}: per {} dispatch (rocprofv3 --pmc of this command) SQ_INSTS_VALU {:.4g} (fp64 ADD/MUL/FMA '
+                        '{:.4g} of them); issue cycles = 4 x all vector instructions'.format(
                             pmc_path, kname, valu_all, valu_f64))
     elif filtered:
         counted = None
@@ -411,7 +518,8 @@ def run(args):
         'kernel': kname, 'kernel_ms': k_ms,
         'valu_wave_instr_per_launch': (valu_all * share if valu_all is not None else instr_launch),
         'issue_cycles_per_launch': instr_launch if filtered else None, 'count_source': count_source,
-        'analytic_min_wave_instr_per_launch': analytic * share,
+        'count_source_stale': count_stale, 'kernel_source_key': source_key,
+        'every_control_the_long_way_wave_instr_per_launch': analytic * share,
         'peak_source': ('spec: 256 CU x 4 SIMD x 2.4 GHz issue cycles per second' if filtered else
                         'spec: 256 CU x 4 SIMD x 2.4 GHz / {} clk per wave64 {} VALU instruction '
                         '(MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s, fp64 half of it)'.format(
@@ -431,7 +539,14 @@ def run(args):
     }
     if filtered and valu_all is not None:
         roof['valu_wave_instr_fp64_arith'] = valu_f64 * share
-        roof['frac_if_every_instr_took_4clk'] = 4.0 * valu_all * share / k_s / issue_peak
+        roof['frac_r02_accounting'] = (4.0 * valu_f64 + 2.0 * (valu_all - valu_f64)) * share / k_s / issue_peak
+        # what the filtered algorithm cannot do without, in wave64 instructions per launch: per control
+        # the rounding-exact chain to its cell (u, x0', p, q0, lam0: 8), F (3) and the running minima (3);
+        # per table entry the 2^(d-1)-vertex lerp nest (3 per lerp) and its share of the reduction (1); per
+        # node one control evaluated with the reference's 6 operations per perturbation point
+        floor_instr = (S * (cells / max(W, 1) / S) * 14.0 + S * max(W, 1) * (3.0 * (2 ** (d - 1) - 1) + 1.0)
+                       + S * max(W, 1) * 6.0) / 64.0
+        roof['filter_floor_wave_instr_per_launch'] = floor_instr * share
     if filtered:
         roof['reference_operations'] = {
             'wave_instr_per_launch': analytic * share, 'per_s': analytic * share / k_s,
@@ -492,6 +607,16 @@ def run(args):
         'lattice_cells_per_sec': cells * sweeps_per_s,
         'roofline': roof,
     }
+    return out
+
+
+def finish_single(args, env, out):
+    """single GPU, outside the timed region: the secondary figures and the CPU baseline"""
+    (models, DPSolver, solver, ref_solver, sysd, prob, dev_comm, V0, dtype, model_name, world, S, cells, U_max) = (
+        env[k] for k in ('models', 'DPSolver', 'solver', 'ref_solver', 'sysd', 'prob', 'dev_comm', 'V0', 'dtype',
+                         'model_name', 'world', 'S', 'cells', 'U_max'))
+    kernel_family = solver.backend_info.get('kernel')
+    filtered = bool(solver.backend_info.get('certified_filter'))
     if world == 1 and kernel_family == 'column' and args.fused and not solver.backend_info.get('row_window') \
             and not solver.backend_info.get('table_per_control'):
         # secondary figure (never the headline `value`): the opt-in fused-arithmetic
@@ -538,7 +663,28 @@ def run(args):
             del lprob, J_f, idx_f, idx_l
         except Exception as e:
             out['every_control_the_long_way'] = {'error': repr(e)}
-    if world > 1 or os.environ.get('SDP_BENCH_SELFCHECK'):
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            if model_name == 'synthetic3d':
+                out['cpu_baseline'] = cpu_baseline_synth(ref_solver, np.asarray(V0, dtype=np.float64),
+                                                         models, U_max)
+            else:
+                out['cpu_baseline'] = cpu_baseline_numpy(ref_solver, np.asarray(V0, dtype=np.float64), cells)
+        except Exception as e:                       # the baseline must never hide the GPU number
+            out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+    return out
+
+
+
+
+def self_check(args, env, out):
+    """sharded run, outside the timed region: rank 0 repeats the chain on its GPU alone"""
+    (models, DPSolver, solver, ref_solver, sysd, prob, dev_comm, V0, dtype, model_name, world, S, cells, U_max) = (
+        env[k] for k in ('models', 'DPSolver', 'solver', 'ref_solver', 'sysd', 'prob', 'dev_comm', 'V0', 'dtype',
+                         'model_name', 'world', 'S', 'cells', 'U_max'))
+    kernel_family = solver.backend_info.get('kernel')
+    filtered = bool(solver.backend_info.get('certified_filter'))
+    if True:
         # self-check of the sharded path (outside the timed region): rank 0 repeats
         # the same chain of sweeps on its GPU alone and compares J bit for bit
         try:
@@ -554,15 +700,6 @@ def run(args):
             out['sharded_matches_single_gpu'] = bool(np.array_equal(J_sharded, sprob.get_value()))
         except Exception as e:
             out['sharded_matches_single_gpu'] = repr(e)
-    if not args.no_cpu_baseline and world == 1:
-        try:
-            if model_name == 'synthetic3d':
-                out['cpu_baseline'] = cpu_baseline_synth(ref_solver, np.asarray(V0, dtype=np.float64),
-                                                         models, U_max)
-            else:
-                out['cpu_baseline'] = cpu_baseline_numpy(ref_solver, np.asarray(V0, dtype=np.float64), cells)
-        except Exception as e:                       # the baseline must never hide the GPU number
-            out['cpu_baseline'] = {'value': None, 'error': repr(e)}
     return out
 
 
@@ -593,8 +730,11 @@ def main():
     # write into stdout: it carries exactly ONE line, the JSON result of rank 0
     from stodynprog_amd.dist import _stdout_to_stderr
     try:
-        with _stdout_to_stderr():
+        fence = _stdout_to_stderr()
+        with fence:
+            _REAL_STDOUT[:] = [fence._saved]
             out = run(args)
+        _REAL_STDOUT[:] = []
     except BaseException as e:                        # a failed run still prints ONE JSON line
         import traceback
         traceback.print_exc()

@@ -27,7 +27,7 @@ extern "C" {
 #define SDP_EHIP       -3   /* HIP runtime error (RuntimeError) */
 #define SDP_ENOMEM     -4   /* device allocation failed (MemoryError) */
 #define SDP_ECOMM      -5   /* RCCL error or librccl not loadable */
-#define SDP_EMODULE    -6   /* model code object could not be loaded */
+#define SDP_EMODULE    -6   /* model code object could not be loaded, or was not built for this problem */
 
 #define SDP_F64 0
 #define SDP_F32 1
@@ -129,6 +129,13 @@ typedef struct sdp_problem_desc {
     int32_t reserved;           /* must be 0 */
 } sdp_problem_desc;
 
+/* The code object must have been generated for THIS problem: it declares
+ *     extern "C" __constant__ int32_t sdp_meta[SDP_META_WORDS]      (csrc/sdp_kernel_args.h)
+ * -- real type, d, nu, perturbation or not, layout / kernel variant, the axis-0 length and the
+ * perturbation count its column table is sized for, the control lattice of its control table --
+ * and sdp_problem_create compares every field with `desc`.  A mismatch, or a code object
+ * without `sdp_meta`, is refused with SDP_EMODULE and a message naming the field (the reference
+ * raises on a bad shape too, multilinear_cython.pyx:46-47; it never returns stale values). */
 int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **out);
 int sdp_problem_destroy(sdp_problem *p);
 
@@ -247,12 +254,14 @@ int sdp_tab_backup(sdp_tab *t, int64_t n_nodes, const int64_t *cell_off, int64_t
                    int64_t *idx_out /* [n_nodes] */);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------
- * librccl.so is dlopen()ed on first use.  TEST HOOK: when the environment variable
- * SDP_RCCL_LIBRARY names a shared object, the nccl* entry points are taken from it
- * instead (tests/mock_rccl.cpp: a host-staged stand-in that lets several ranks
- * share the ONE GPU of the test box, which RCCL itself refuses).  Never set it in
- * production; sdp_comm_create reports the library it bound through
- * sdp_comm_library(). */
+ * librccl.so is dlopen()ed on first use.  The product library binds librccl and nothing
+ * else.  A TEST build of the same source (-DSDP_TEST_HOOKS, made by the test-suite into a
+ * file of its own; sdp_test_hooks() returns 1 there, 0 in the product) additionally honours
+ * the environment variable SDP_RCCL_LIBRARY: the nccl* entry points are then taken from
+ * that shared object (tests/mock_rccl.cpp: a host-staged stand-in that lets several ranks
+ * share the ONE GPU of the test box, which RCCL itself refuses).  sdp_comm_library()
+ * reports the library the nccl* symbols came from. */
+int sdp_test_hooks(void);
 int sdp_comm_unique_id(char id[128]);                       /* rank 0 */
 int sdp_comm_create(int rank, int nranks, const char id[128], sdp_comm **out);
 int sdp_comm_destroy(sdp_comm *c);

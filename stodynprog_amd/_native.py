@@ -60,17 +60,21 @@ def _sources():
            [os.path.join(REPO, 'include', 'sdp_hip.h')]
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/sdp_hip.hip for gfx950 into csrc/libsdp_hip.so (in-tree)."""
+def build_library(force=False, verbose=False, test_hooks_to=None):
+    """Compile csrc/sdp_hip.hip for gfx950 into csrc/libsdp_hip.so (in-tree).
+    `test_hooks_to`: build the TEST variant (-DSDP_TEST_HOOKS: honours SDP_RCCL_LIBRARY, the
+    collective stand-in of tests/) to that path instead -- never the product library."""
     srcs = _sources()
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
-        return LIB_PATH
-    cmd = [HIPCC] + LIB_FLAGS + ['-o', LIB_PATH, os.path.join(CSRC, 'sdp_hip.hip')]
+    out = test_hooks_to or LIB_PATH
+    if (not force and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs)):
+        return out
+    cmd = [HIPCC] + LIB_FLAGS + (['-DSDP_TEST_HOOKS'] if test_hooks_to else []) + [
+        '-o', out, os.path.join(CSRC, 'sdp_hip.hip')]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 def _declare(lib):
@@ -105,6 +109,7 @@ def _declare(lib):
         'sdp_host_alloc': (C.c_int, [C.c_size_t, P(vp)]),
         'sdp_host_free': (C.c_int, [vp]),
         'sdp_comm_library': (C.c_char_p, []),
+        'sdp_test_hooks': (C.c_int, []),
         'sdp_comm_unique_id': (C.c_int, [C.c_char_p]),
         'sdp_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_char_p, P(vp)]),
         'sdp_comm_destroy': (C.c_int, [vp]),
@@ -252,6 +257,10 @@ _pinned_free = {}            # nbytes -> [ptr, ...]
 _pinned_live = {}            # ptr -> nbytes of blocks currently viewed by arrays
 PINNED_KEEP = 4              # free blocks kept per size ...
 PINNED_KEEP_BYTES = 4 << 30  # ... and in total (page-locked memory is a scarce resource)
+# page-locked bytes in arrays the caller still holds: a user loop that keeps every J_k / pol_k
+# (as the reference allows) must not pin host RAM without bound -- beyond this, and whenever
+# hipHostMalloc refuses, results come in ordinary pageable arrays (slower copies, same values)
+PINNED_LIVE_BYTES = 8 << 30
 
 
 def _pinned_release(ptr, nbytes):
@@ -275,8 +284,11 @@ def pinned_empty(shape, dtype):
     if free:
         ptr = free.pop()
     else:
+        if sum(_pinned_live.values()) + nbytes_alloc > PINNED_LIVE_BYTES:
+            return np.empty(shape, dtype=dt)
         p = C.c_void_p()
-        check(lib().sdp_host_alloc(nbytes_alloc, C.byref(p)))
+        if lib().sdp_host_alloc(nbytes_alloc, C.byref(p)) != 0 or not p.value:
+            return np.empty(shape, dtype=dt)          # (sdp_problem_backup_host takes any host memory)
         ptr = p.value
     _pinned_live[ptr] = nbytes_alloc
     buf = (C.c_char * nbytes_alloc).from_address(ptr)

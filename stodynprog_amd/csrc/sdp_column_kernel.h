@@ -2054,4 +2054,22 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
 }
 #endif  // SDP_TRAIL_HAS_U
 
+extern "C" {
+__constant__ int32_t sdp_meta[SDP_META_WORDS] = {
+    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 1, SDP_COL_N0, SDP_COL_W,
+    (SDP_COL_FILTER ? SDP_META_F_FILTER : 0) | (SDP_COL_ROWS < SDP_COL_N0 ? SDP_META_F_WINDOW : 0) |
+        (SDP_TRAIL_HAS_U ? SDP_META_F_TRAIL_HAS_U : 0) | (SDP_COL_WPAIR ? SDP_META_F_WPAIR : 0) |
+#if SDP_COL_FILTER
+        (SDP_COL_LEAN_ON ? SDP_META_F_LEAN : 0) |
+#endif
+        ((SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? SDP_META_F_CLAIMS : 0),
+    SDP_COL_FILTER ? SDP_COL_UTAB : 0, SDP_COL_FILTER ? SDP_COL_UTAB_N : 0, SDP_COL_THREADS, SDP_COL_ROWS,
+    0, 0, 0};
+}
+
+#else   // SDP_D < 2: no column kernels; the unit is a node-order one after all
+extern "C" {
+__constant__ int32_t sdp_meta[SDP_META_WORDS] = {
+    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1, 0, 0, 0, 256, 0, 0, 0, 0};
+}
 #endif  // SDP_D >= 2

@@ -519,13 +519,26 @@ static RcclApi g_rccl;
 static std::string g_rccl_name;
 
 extern "C" const char *sdp_comm_library(void) { return g_rccl_name.c_str(); }
+extern "C" int sdp_test_hooks(void)
+{
+#ifdef SDP_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 static int rccl_load()
 {
     if (g_rccl.h) return SDP_OK;
-    // SDP_RCCL_LIBRARY: another library with the same nccl* entry points (the tests
-    // load a host-staged stand-in to run several ranks on the one GPU of the test box)
+#ifdef SDP_TEST_HOOKS
+    // TEST BUILD ONLY (-DSDP_TEST_HOOKS, never the product library): SDP_RCCL_LIBRARY names another
+    // library with the same nccl* entry points (the tests load a host-staged stand-in to run
+    // several ranks on the one GPU of the test box)
     const char *override_path = getenv("SDP_RCCL_LIBRARY");
+#else
+    const char *override_path = nullptr;
+#endif
     const char *names[] = {override_path && *override_path ? override_path : "librccl.so",
                            "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
@@ -669,9 +682,13 @@ struct sdp_problem {
     int cus = 256;
     int refs_cap = 0;
     int col_threads = 512;
+    int32_t meta[SDP_META_WORDS] = {0};    // `sdp_meta` of the code object
+    int peer_me = -1;                      // this rank, as of sdp_problem_enable_peer_exchange
     void release_peers()
     {
-        const int me = comm ? comm->rank : -1;
+        // (the rank is the one recorded when the mappings were made: the communicator is not
+        // owned by the problem and may already be gone)
+        const int me = peer_me;
         for (size_t r = 0; r < peer_V.size(); ++r) {
             if ((int)r == me) continue;
             if (peer_V[r]) (void)hipIpcCloseMemHandle(peer_V[r]);
@@ -685,6 +702,7 @@ struct sdp_problem {
         if (ev_enter) { (void)hipEventDestroy(ev_enter); ev_enter = nullptr; }
         if (ev_fence) { (void)hipEventDestroy(ev_fence); ev_fence = nullptr; }
         peer_exchange = false;
+        peer_me = -1;
     }
     ~sdp_problem()
     {
@@ -795,6 +813,44 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
             if (desc->tile[k] < 1) return fail(SDP_EINVAL, "staged kernel: tile[%d] = %d", k, (int)desc->tile[k]);
             p->stg_tiles *= (p->orders[k] + desc->tile[k] - 1) / desc->tile[k];
         }
+    }
+    // what the code object was generated for must be THIS problem: the kernels carry table
+    // sizes, dimensions and the real type as compile-time constants
+    {
+        hipDeviceptr_t mptr = nullptr;
+        size_t mbytes = 0;
+        if (hipModuleGetGlobal(&mptr, &mbytes, p->mod, "sdp_meta") != hipSuccess || mbytes != sizeof(p->meta)) {
+            (void)hipGetLastError();
+            return fail(SDP_EMODULE, "code object %s does not declare `sdp_meta` (%d words, sdp_kernel_args.h): "
+                        "cannot check that it was built for this problem", desc->module_path, SDP_META_WORDS);
+        }
+        HIP_TRY(hipMemcpyDtoH(p->meta, mptr, sizeof(p->meta)));
+        const int32_t *m = p->meta;
+        const int64_t controls = [&] {
+            if (p->box_per_node) return (int64_t)-1;
+            int64_t t = 1;
+            for (int c = 0; c < p->nu; ++c) t *= ((const int32_t *)desc->box_n)[c];
+            return t;
+        }();
+        const char *what = nullptr;
+        char detail[160] = "";
+#define META_CHECK(cond, ...) if (!what && !(cond)) { what = #cond; snprintf(detail, sizeof(detail), __VA_ARGS__); }
+        META_CHECK(m[SDP_META_MAGIC_AT] == SDP_META_MAGIC, "bad magic 0x%x", (unsigned)m[SDP_META_MAGIC_AT]);
+        META_CHECK(m[SDP_META_REAL_BYTES] == (int)rs, "built for %d-byte reals, the problem has %d-byte reals", m[SDP_META_REAL_BYTES], (int)rs);
+        META_CHECK(m[SDP_META_D] == p->d, "built for %d state variables, the problem has %d", m[SDP_META_D], p->d);
+        META_CHECK(m[SDP_META_NU] == p->nu, "built for %d controls, the problem has %d", m[SDP_META_NU], p->nu);
+        META_CHECK((m[SDP_META_HAS_W] != 0) == (p->W > 0), "built %s a perturbation, the problem has W = %d", m[SDP_META_HAS_W] ? "with" : "without", p->W);
+        META_CHECK(m[SDP_META_LAYOUT] == p->layout, "built for layout %d, the problem asks for layout %d", m[SDP_META_LAYOUT], p->layout);
+        META_CHECK(((m[SDP_META_FLAGS] & SDP_META_F_STAGED) != 0) == (p->variant == SDP_VARIANT_STAGED), "staged-tile kernel %s in the code object, variant %d asked", (m[SDP_META_FLAGS] & SDP_META_F_STAGED) ? "present" : "absent", p->variant);
+        if (p->layout == SDP_LAYOUT_COLUMNS) {
+            META_CHECK(m[SDP_META_COL_N0] == p->orders[0], "column table built for %d points along axis 0, the grid has %d", m[SDP_META_COL_N0], p->orders[0]);
+            META_CHECK(m[SDP_META_COL_W] == (p->W > 0 ? p->W : 1), "column table built for %d perturbation points, the problem has %d", m[SDP_META_COL_W], p->W);
+            META_CHECK(((m[SDP_META_FLAGS] & SDP_META_F_WINDOW) != 0) == (p->col_seg > 0) || (m[SDP_META_FLAGS] & SDP_META_F_TRAIL_HAS_U), "row-window kernel %s but col_seg_nodes = %d", (m[SDP_META_FLAGS] & SDP_META_F_WINDOW) ? "present" : "absent", p->col_seg);
+            META_CHECK(m[SDP_META_UTAB] == 0 || controls == m[SDP_META_UTAB_N], "control table built for one lattice of %d controls at every node, the problem has %s%lld", m[SDP_META_UTAB_N], controls < 0 ? "per-node boxes " : "", (long long)controls);
+        }
+#undef META_CHECK
+        if (what)
+            return fail(SDP_EMODULE, "code object %s was not built for this problem: %s", desc->module_path, detail);
     }
     const char *k_sweep = p->layout == SDP_LAYOUT_COLUMNS ? "sdp_sweep_col"
                           : (p->variant == SDP_VARIANT_STAGED ? "sdp_sweep_lds" : "sdp_sweep");
@@ -977,7 +1033,10 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
     // time and the RCCL kernels of the previous phase's all-gather (on their
     // own, higher-priority stream) get scheduled beside the sweep instead of
     // behind it.
-    int64_t blocks = (p->comm && p->comm->nranks > 1) ? units : (int64_t)p->cus * 8;
+    // (kernels whose workgroups CLAIM their units are persistent whatever the grid: a workgroup per
+    // unit would only add thousands of workgroups that start, find nothing left and leave)
+    const bool claims = (p->meta[SDP_META_FLAGS] & SDP_META_F_CLAIMS) != 0;
+    int64_t blocks = (p->comm && p->comm->nranks > 1 && !claims) ? units : (int64_t)p->cus * (claims ? 4 : 8);
     if (blocks > units) blocks = units;
     blocks = ((blocks + 7) / 8) * 8;
     if (blocks < 8) blocks = 8;
@@ -1130,10 +1189,16 @@ static int open_pushes(sdp_problem *p)
 
 // End of a peer-write backup: when the tiny all-reduce below completes on this rank, every
 // rank has passed its own copies (stream order), so all rows have landed everywhere.
-static int finish_pushes(sdp_problem *p)
+static int finish_pushes(sdp_problem *p, hipEvent_t last_kernel)
 {
     const int n = p->comm->nranks, me = p->comm->rank;
     hipStream_t cs = p->comm->stream;
+    // The rendezvous must also say "this rank has finished READING V": once it completes, a peer may
+    // start the next step and write rows into this rank's next J buffer -- the buffer this step's
+    // kernels read as V.  With the dense exchange every phase's pushes wait for that phase's kernel,
+    // so the copy streams carry the order; with the sparse one a rank whose last phases send nothing
+    // would join the rendezvous with kernels still running.
+    if (last_kernel) HIP_TRY(hipStreamWaitEvent(cs, last_kernel, 0));
     for (int q = 0; q < n; ++q) {
         if (q == me) continue;
         HIP_TRY(hipEventRecord(p->peer_done[q], p->peer_stream[q]));
@@ -1180,7 +1245,7 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
         }
     }
     if (n > 1) {
-        if (p->peer_exchange && (rc = finish_pushes(p))) return rc;
+        if (p->peer_exchange && (rc = finish_pushes(p, p->n_phases ? p->ev_phase[p->n_phases - 1] : nullptr))) return rc;
         HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
         p->comm_pending = true;
         p->J_partial = p->peer_exchange && p->sparse && !everything;
@@ -1210,7 +1275,7 @@ static int complete_J(sdp_problem *p)
     HIP_TRY(hipEventRecord(p->ev_enter, p->stream));
     for (int ph = 0; ph < p->n_phases; ++ph)
         if ((rc = push_phase(p, ph, p->ev_enter, true))) return rc;
-    if ((rc = finish_pushes(p))) return rc;
+    if ((rc = finish_pushes(p, p->ev_enter))) return rc;
     HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
     p->comm_pending = true;
     if ((rc = join_comm(p))) return rc;
@@ -1253,6 +1318,21 @@ static int check_ref(const sdp_problem *p, int rel_dp, int64_t &ref_index)
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         const int64_t n0 = p->orders[0], P = p->S / n0;
         ref_index = (ref_index % P) * n0 + ref_index / P;
+    }
+    if (p->sparse && p->comm && p->comm->nranks > 1) {
+        // sparse exchange: the shift reads J[ref] / V[ref] on every rank, so the node must be one this
+        // rank computes or receives (the host puts the reference column into every need list)
+        const int me = p->comm->rank;
+        bool have = false;
+        for (int ph = 0; ph < p->n_phases && !have; ++ph) {
+            const int64_t *b = p->parts.data() + (size_t)ph * (p->comm->nranks + 1);
+            have = ref_index >= b[me] && ref_index < b[me + 1];
+        }
+        for (size_t k = 0; k < p->need[(size_t)me].size() && !have; ++k)
+            have = ref_index >= p->need[(size_t)me][k].first && ref_index < p->need[(size_t)me][k].second;
+        if (!have)
+            return fail(SDP_EINVAL, "sparse exchange: reference node %lld is neither computed nor received by rank %d "
+                        "(it must be in every rank's need list)", (long long)ref_index, me);
     }
     return SDP_OK;
 }
@@ -1656,14 +1736,44 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
             (void)hipGetLastError();
         }
     }
-    DevBuf stage;
-    int rc = stage.alloc(sizeof(hipIpcMemHandle_t) * 2 * n);
-    if (rc) return rc;
+    // Between the two agreements below nothing returns early: a local failure raises `failed`, and
+    // a failure of the communicator's own calls (a broken communicator or device: the other ranks
+    // would wait in a collective for ever) ends the process with a message.
+#define COLLECTIVE_OR_DIE(expr)                                                                 \
+    do {                                                                                        \
+        const int r__ = (int)(expr);                                                            \
+        if (r__ != 0) {                                                                         \
+            fprintf(stderr, "sdp_problem_enable_peer_exchange: %s failed (%d) inside a collective "  \
+                    "section; aborting this rank\n", #expr, r__);                               \
+            abort();                                                                            \
+        }                                                                                       \
+    } while (0)
     hipStream_t cs = p->comm->stream;
-    HIP_TRY(hipMemcpyAsync((char *)stage.p + (size_t)me * 128, &all[2 * me], 128, hipMemcpyHostToDevice, cs));
-    NCCL_TRY(g_rccl.AllGather((char *)stage.p + (size_t)me * 128, stage.p, 128, NCCL_INT8, p->comm->comm, cs));
-    HIP_TRY(hipMemcpyAsync(all.data(), stage.p, (size_t)n * 128, hipMemcpyDeviceToHost, cs));
-    HIP_TRY(hipStreamSynchronize(cs));
+    int *const d_agree = (int *)p->comm->d_scalar;          // 8 bytes owned by the communicator
+    auto agree = [&](int mine) -> int {                     // max over the ranks of `mine`
+        int any = 0;
+        COLLECTIVE_OR_DIE(hipMemcpyAsync(d_agree, &mine, sizeof(int), hipMemcpyHostToDevice, cs));
+        COLLECTIVE_OR_DIE(g_rccl.AllReduce(d_agree, d_agree, 1, NCCL_INT32, NCCL_MAX, p->comm->comm, cs));
+        COLLECTIVE_OR_DIE(hipMemcpyAsync(&any, d_agree, sizeof(int), hipMemcpyDeviceToHost, cs));
+        COLLECTIVE_OR_DIE(hipStreamSynchronize(cs));
+        return any;
+    };
+    DevBuf stage;
+    if (stage.alloc(sizeof(hipIpcMemHandle_t) * 2 * n) != SDP_OK && !failed) {
+        failed = 1;
+        snprintf(why, sizeof(why), "staging buffer for the handle exchange: out of device memory");
+    }
+    // first agreement: every rank can export its buffers and holds a staging buffer
+    if (agree(failed)) {
+        p->release_peers();
+        return fail(SDP_ECOMM, "peer exchange not available (%s): the RCCL exchange stays in place",
+                    failed ? why : "another rank could not export its buffers");
+    }
+    COLLECTIVE_OR_DIE(hipMemcpyAsync((char *)stage.p + (size_t)me * 128, &all[2 * me], 128, hipMemcpyHostToDevice, cs));
+    COLLECTIVE_OR_DIE(g_rccl.AllGather((char *)stage.p + (size_t)me * 128, stage.p, 128, NCCL_INT8, p->comm->comm, cs));
+    COLLECTIVE_OR_DIE(hipMemcpyAsync(all.data(), stage.p, (size_t)n * 128, hipMemcpyDeviceToHost, cs));
+    COLLECTIVE_OR_DIE(hipStreamSynchronize(cs));
+    p->peer_me = me;
     p->peer_V.assign(n, nullptr); p->peer_J.assign(n, nullptr);
     p->peer_stream.assign(n, nullptr); p->peer_done.assign(n, nullptr);
     p->peer_V[me] = p->V.p; p->peer_J[me] = p->J.p;
@@ -1688,20 +1798,15 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
                     hipEventCreateWithFlags(&p->ev_fence, hipEventDisableTiming) != hipSuccess)) {
         failed = 1; snprintf(why, sizeof(why), "hipEventCreate");
     }
-    // all ranks or none: the ranks agree on the outcome before anybody writes into a peer
-    // (this also guarantees that every rank has mapped everything before the first write)
-    int *d_fail = (int *)stage.p;
-    HIP_TRY(hipMemcpyAsync(d_fail, &failed, sizeof(int), hipMemcpyHostToDevice, cs));
-    NCCL_TRY(g_rccl.AllReduce(d_fail, d_fail, 1, NCCL_INT32, NCCL_MAX, p->comm->comm, cs));
-    int any_failed = 0;
-    HIP_TRY(hipMemcpyAsync(&any_failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, cs));
-    HIP_TRY(hipStreamSynchronize(cs));
-    if (any_failed) {
+    if (!failed && hipMemset(p->d_flag, 0, 8) != hipSuccess) { failed = 1; snprintf(why, sizeof(why), "hipMemset"); }
+    // second agreement, all ranks or none: the ranks agree on the outcome before anybody writes
+    // into a peer (this also guarantees that every rank has mapped everything before the first write)
+    if (agree(failed)) {
         p->release_peers();
         return fail(SDP_ECOMM, "peer exchange not available (%s): the RCCL exchange stays in place",
                     failed ? why : "another rank could not map its peers");
     }
-    HIP_TRY(hipMemset(p->d_flag, 0, 8));
+#undef COLLECTIVE_OR_DIE
     p->peer_exchange = true;
     p->peer_fence = true;
     return SDP_OK;

@@ -5,6 +5,29 @@
 #include <stdint.h>
 
 #define SDP_MAXD 4   // multilinear_cython.pyx:33-47 dispatches d = 1..4 only
+
+// Every model code object carries `extern "C" __constant__ int32_t sdp_meta[SDP_META_WORDS]`: what it
+// was generated for.  sdp_problem_create reads it and refuses (SDP_EMODULE) a problem it does not
+// match -- compiled-in table sizes, dtype, dimensions -- instead of launching a kernel that would
+// return stale results (the kernels trap on such a launch: sdp_trap_unless).
+#define SDP_META_WORDS 16
+#define SDP_META_MAGIC 0x33504453      // "SDP3"
+enum {
+    SDP_META_MAGIC_AT = 0, SDP_META_REAL_BYTES, SDP_META_D, SDP_META_NU, SDP_META_HAS_W,
+    SDP_META_LAYOUT,        // 0 node order, 1 columns (axis 0 fastest)
+    SDP_META_COL_N0,        // points of axis 0 the column table was sized for (0: node-order unit)
+    SDP_META_COL_W,         // perturbation points of the column table (>= 1)
+    SDP_META_FLAGS,         // SDP_META_F_*
+    SDP_META_UTAB,          // tabulated values per control (0: none)
+    SDP_META_UTAB_N,        // controls of the lattice the control table was sized for
+    SDP_META_THREADS,       // workgroup size of the sweep kernel (column / staged units)
+    SDP_META_COL_ROWS       // rows of axis 0 the table holds (< COL_N0: row window)
+};
+enum {
+    SDP_META_F_FILTER = 1, SDP_META_F_WINDOW = 2, SDP_META_F_TRAIL_HAS_U = 4, SDP_META_F_STAGED = 8,
+    SDP_META_F_WPAIR = 16, SDP_META_F_LEAN = 32,
+    SDP_META_F_CLAIMS = 64  // the sweep kernel's workgroups claim their units (persistent: a bounded grid)
+};
 #define SDP_MAXU 4   // control variables per system
 
 // One Bellman backup over a contiguous range of state nodes

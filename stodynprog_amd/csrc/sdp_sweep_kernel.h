@@ -279,3 +279,18 @@ extern "C" __global__ void __launch_bounds__(64) sdp_simulate(SdpSimArgs a)
         }
     }
 }
+
+// what this code object was generated for (sdp_kernel_args.h, SDP_META_*); units that include
+// sdp_column_kernel.h define it at the end of that file, where the column macros are complete
+#if !defined(SDP_COL_N0)
+extern "C" {
+__constant__ int32_t sdp_meta[SDP_META_WORDS] = {
+    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1,
+#if defined(SDP_STG_THREADS)
+    SDP_META_F_STAGED, 0, 0, SDP_STG_THREADS, 0,
+#else
+    0, 0, 0, 256, 0,
+#endif
+    0, 0, 0};
+}
+#endif

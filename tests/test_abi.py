@@ -80,3 +80,34 @@ def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
     with pytest.raises(nat.NativeError) as e:
         nat.lib()
     assert 'no CPU fallback' in str(e.value)
+
+
+def test_the_product_library_has_no_collective_override(tmp_path):
+    """SDP_RCCL_LIBRARY (the stand-in for the collective library used by the multi-rank tests) is
+    compiled into the TEST build only (-DSDP_TEST_HOOKS): the product library neither reports test
+    hooks nor contains the variable's name; the test build, made from the same source, does."""
+    lib = nat.lib()
+    assert lib.sdp_test_hooks() == 0
+    assert b'SDP_RCCL_LIBRARY' not in open(nat.LIB_PATH, 'rb').read()
+    if not os.path.exists(nat.HIPCC):
+        pytest.skip('hipcc not available to build the test variant')
+    hooks = nat.build_library(test_hooks_to=str(tmp_path / 'libsdp_hip_testhooks.so'))
+    assert b'SDP_RCCL_LIBRARY' in open(hooks, 'rb').read()
+    h = C.CDLL(hooks)
+    h.sdp_test_hooks.restype = C.c_int
+    assert h.sdp_test_hooks() == 1
+
+
+def test_every_generated_unit_declares_what_it_was_built_for():
+    """`sdp_meta` (csrc/sdp_kernel_args.h): column units, staged units and node-order units all
+    define it, with the table sizes of the plan they were generated from"""
+    from stodynprog_amd import models
+    for make, kernel in ((lambda: models.synthetic3d(N=20), 'auto'), (lambda: models.synthetic3d(N=20), 'staged'),
+                         (lambda: models.inventory(), 'auto'), (lambda: models.storage_ar1(), 'generic')):
+        _, s = make()
+        s.kernel = kernel
+        src = s._kernel_plan()['source']
+        headers = ''.join(open(os.path.join(nat.CSRC, h)).read() for h in
+                          ('sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_staged_kernel.h'))
+        assert 'sdp_meta[SDP_META_WORDS]' in headers
+        assert '#include "sdp_' in src

@@ -167,6 +167,26 @@ def _build_mock(tmp_path, asynchronous=False):
     return out
 
 
+def _hooks_library(tmp_path):
+    """the TEST build of the library (-DSDP_TEST_HOOKS): the only one that honours SDP_RCCL_LIBRARY"""
+    from stodynprog_amd import _native as nat
+    return nat.build_library(test_hooks_to=str(tmp_path / 'libsdp_hip_testhooks.so'))
+
+
+def _with_hooks(tmp_path, script):
+    """a launcher script that makes `script` run on the test build of the library: the product
+    library has no way of being pointed at a stand-in for librccl"""
+    hooks = _hooks_library(tmp_path)
+    wrapper = tmp_path / ('hooks_' + os.path.basename(str(script)))
+    wrapper.write_text(
+        'import runpy, sys\nsys.path.insert(0, {root!r})\n'
+        'from stodynprog_amd import _native as nat\nnat.LIB_PATH = {hooks!r}\n'
+        'assert nat.lib().sdp_test_hooks() == 1\n'
+        'sys.argv[0] = {script!r}\nrunpy.run_path({script!r}, run_name="__main__")\n'.format(
+            root=ROOT, hooks=hooks, script=str(script)))
+    return str(wrapper)
+
+
 def _run_ranks(script, world, extra_env, timeout=560, argv=()):
     port = _free_port()
     procs = []
@@ -255,7 +275,7 @@ def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, worl
     mock = _build_mock(tmp_path, asynchronous)
     script = tmp_path / 'lib_worker.py'
     script.write_text(LIB_WORKER.format(root=ROOT))
-    outs = _run_ranks(script, world, dict(SDP_RCCL_LIBRARY=mock))
+    outs = _run_ranks(_with_hooks(tmp_path, script), world, dict(SDP_RCCL_LIBRARY=mock))
     for rank, out in enumerate(outs):
         assert 'rank {} all ok'.format(rank) in out, out
 
@@ -269,7 +289,7 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path, asynchronous):
     sharded result checked against a single-GPU chain of sweeps"""
     import json
     mock = _build_mock(tmp_path, asynchronous)
-    outs = _run_ranks(os.path.join(ROOT, 'bench.py'), 2, dict(SDP_RCCL_LIBRARY=mock),
+    outs = _run_ranks(_with_hooks(tmp_path, os.path.join(ROOT, 'bench.py')), 2, dict(SDP_RCCL_LIBRARY=mock),
                       argv=['--gpus', '2', '--grid', '48', '--steps', '3', '--warmup', '1',
                             '--no-cpu-baseline'])
     assert outs[1].strip() == ''
@@ -277,14 +297,56 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path, asynchronous):
     assert len(lines) == 1, outs[0]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['sharded_matches_single_gpu'] is True, d
-    plans = {'2', '4', '8', '16', '4t', '8t'}
+    # the RCCL plans are timed first (and reported whatever happens later), then the optional exchanges
     assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == (
-        plans | {p + '/peer' for p in plans} | {p + '/sparse' for p in plans if not p.endswith('t')}), d['config']
-    assert d['config']['comm_exchange'] in ('rccl', 'peer', 'peer-sparse') and d['config']['comm_exchange_note'] is None
+        {'1', '2', '4', '8', '16', '4t', '8t'} | {p + '/peer' for p in ('1', '2', '4', '8')}
+        | {p + '/sparse' for p in ('1', '2', '4')}), d['config']
+    assert d['config']['comm_exchange'] in ('rccl', 'peer', 'peer-sparse'), d['config']
+    note = d['config']['comm_exchange_note']
+    assert note is None or 'not faster in tuning' in note, note
     assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
     import glob
     for leftover in glob.glob('/dev/shm/sdp_mock_*'):      # bench.py leaves its communicator to the OS
         os.unlink(leftover)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world,kind', [(8, 'raise'), (2, 'reject'), (2, 'hang')])
+def test_bench_keeps_the_rccl_result_when_an_optional_exchange_fails(gpu, tmp_path, world, kind):
+    """bench.py times and keeps the RCCL exchange first; an optional exchange that fails on one
+    rank (SDP_BENCH_FAULT: an exception, a wrong J, a rank that never answers) must not cost the
+    run: every rank exits 0 and rank 0 prints ONE line, from an exchange that passed its checks,
+    with the reason in config.comm_exchange_note.  (8 ranks on the asynchronous stand-in for the
+    exception case; the watchdog case waits out its time limit, so it runs with 2 ranks.)"""
+    import json
+    mock = _build_mock(tmp_path, asynchronous=True)
+    env = dict(SDP_RCCL_LIBRARY=mock, SDP_BENCH_FAULT='peer:{}:1'.format(kind), SDP_BENCH_OPTIONAL_TIMEOUT='45')
+    if kind == 'hang':
+        env['SDP_COMM_EXCHANGES'] = 'rccl,peer'
+    outs = _run_ranks(_with_hooks(tmp_path, os.path.join(ROOT, 'bench.py')), world, env,
+                      argv=['--gpus', str(world), '--grid', '48', '--steps', '3', '--warmup', '1',
+                            '--no-cpu-baseline'])
+    lines = [l for l in outs[0].strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and all(o.strip() == '' for o in outs[1:]), outs
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == world and d['value'] > 0 and d['sharded_matches_single_gpu'] is True, d
+    note = d['config']['comm_exchange_note']
+    times = d['config']['comm_phase_tuning_ms_per_sweep']
+    assert {'1', '2', '4', '8', '16', '4t', '8t'} <= set(times)              # the RCCL plans were all timed
+    assert d['config']['comm_exchange'] != 'peer'
+    if kind == 'raise':
+        assert 'peer exchange not used' in note, note
+        assert not any(k.endswith('/peer') for k in times)
+    elif kind == 'reject':
+        assert 'peer exchange not used' in note, note
+    else:
+        assert 'peer exchange abandoned' in note and d['config']['comm_exchange'] == 'rccl', note
+    import glob
+    for leftover in glob.glob('/dev/shm/sdp_mock_*') + glob.glob('/dev/shm/sdp_rccl_uid_*'):
+        try:
+            os.unlink(leftover)
+        except OSError:
+            pass
 
 
 @pytest.mark.timeout(900)
@@ -304,8 +366,8 @@ def test_bench_under_the_real_launcher(gpu, tmp_path):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--grid', '48', '--steps', '3', '--warmup', '1',
-           '--no-cpu-baseline']
+           _with_hooks(tmp_path, os.path.join(ROOT, 'bench.py')), '--gpus', '2', '--grid', '48', '--steps', '3',
+           '--warmup', '1', '--no-cpu-baseline']
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=850,
                          cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr.decode()[-3000:]

@@ -88,6 +88,17 @@ if key:
     elif 'SQ_INSTS_VALU' in mean:
         out['valu_wave_instr'] = mean['SQ_INSTS_VALU']
         out['valu_wave_instr_counters'] = 'SQ_INSTS_VALU (all vector ALU instructions)'
+    # the version of the kernel the counts belong to (bench.py prints it; it marks the counts stale
+    # when the kernel sources change afterwards)
+    for bj in sorted(glob.glob(os.path.join(root, 'bench_*.json'))):
+        try:
+            with open(bj) as f:
+                key_ = json.loads(f.read().strip().splitlines()[-1])['roofline'].get('kernel_source_key')
+        except (OSError, ValueError, KeyError, IndexError):
+            key_ = None
+        if key_:
+            out['kernel_source_key'] = key_
+            break
     if 'FETCH_SIZE' in mean and 'WRITE_SIZE' in mean:
         out['hbm_bytes'] = (2 * mean['FETCH_SIZE'] + mean['WRITE_SIZE']) * 1024
         out['hbm_bytes_formula'] = ('(2 x FETCH_SIZE + WRITE_SIZE) KiB: separate --pmc passes; FETCH_SIZE '
