@@ -352,7 +352,7 @@ def run_sharded(args, env):
                 if f_exch == exch and f_kind == 'hang' and str(rank) == f_rank:
                     time.sleep(1e6)
                 trial = configure(exch, ph, taper)
-                got = solver.backend_info.get('exchange', 'rccl')
+                got = solver.backend_info.get('exchange') or 'rccl'        # (None with one rank)
                 if got != {'sparse': 'peer-sparse'}.get(exch, exch):
                     local_error = ('not available on this node: {}'.format(getattr(trial, 'peer_failure', 'buffers not mappable'))
                                    if got == 'rccl' else 'does not apply to this kernel family')
@@ -663,6 +663,41 @@ def finish_single(args, env, out):
             del lprob, J_f, idx_f, idx_l
         except Exception as e:
             out['every_control_the_long_way'] = {'error': repr(e)}
+    if world == 1 and args.config == 'synth256' and not args.grid and not args.no_other_configs:
+        # The other GPU configurations of BASELINE.json (configs[1], [2], [4]) in the same run, outside
+        # the timed region: steady-state kernel time per sweep (sweeps 6..25 of a chain, HIP events),
+        # so that their numbers are reproducible from the default command.  Parity cases, not bench
+        # lines: `value` above is configs[3] alone.
+        import copy
+        others = {}
+        for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
+            solver._cache.pop(k_).close()
+        for name in ('ar1', 'searev', 'synth512f32'):
+            try:
+                a2 = copy.copy(args)
+                a2.config, a2.grid, a2.dtype = name, 0, None
+                sysd2, ref2, s2, V2, dt2, cfg2, label2, _ = build_solver(a2, models, DPSolver, None)
+                p2 = s2._problem()
+                p2.set_value(V2)
+                p2.bench_sweeps(5)
+                p2.swap()
+                _, k2 = p2.bench_sweeps(20)
+                bp2 = s2._box_plan()
+                per2 = np.prod(bp2['n'].astype(np.int64), axis=0)
+                cells2 = float(per2.sum() if bp2['per_node'] else per2[0] * V2.size) * max(
+                    len(s2.perturb_grid[0]) if s2.perturb_grid else 1, 1)
+                others[name] = {'workload': '{} (BASELINE.json configs[{}])'.format(label2, cfg2),
+                                'dtype': 'f64' if dt2.itemsize == 8 else 'f32',
+                                'kernel_ms_per_sweep': k2 / 20, 'sweeps_per_s': 20e3 / k2,
+                                'lattice_cells_per_sec': cells2 * 20e3 / k2,
+                                'kernel_family': s2.backend_info.get('kernel'),
+                                'certified_filter': bool(s2.backend_info.get('certified_filter'))}
+                for k_ in [k_ for k_ in s2._cache if k_[0] == 'problem']:
+                    s2._cache.pop(k_).close()
+            except Exception as e:
+                others[name] = {'error': repr(e)}
+        out['other_configs'] = dict(others, note='steady state (sweeps 6..25 of a chain from a closed-form start), kernel '
+                                    'time by HIP events; outside the timed region of `value`')
     if not args.no_cpu_baseline and world == 1:
         try:
             if model_name == 'synthetic3d':
@@ -724,6 +759,8 @@ def main():
                     help='also time the opt-in fused-arithmetic variant (secondary figure; off by default so '
                          'that a profile of the default command holds ONE flavour of sdp_sweep_col)')
     ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the untimed steady-state runs of the other BASELINE configurations')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))
     # native libraries (RCCL's version banner, stdio-buffered until exit) must not

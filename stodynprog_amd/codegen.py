@@ -324,7 +324,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             ''] + (['#define SDP_COL_UTAB {}'.format(len(utab[0])),
@@ -533,7 +533,7 @@ def column_build_order(threads, w, rows):
 def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False):
     # reduced: + the (A[r], D[r]) table of the certified filter (full-column table only)
     raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16
-           + (2 * rows * rs if reduced else 0))
+           + ((4 if rs == 4 else 2) * rows * rs if reduced else 0))
     return (raw + 15) // 16 * 16
 
 

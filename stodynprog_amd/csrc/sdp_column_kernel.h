@@ -53,6 +53,7 @@
 //                                    on the prediction
 #pragma once
 #include "sdp_sweep_kernel.h"
+#include <type_traits>
 
 #if SDP_D >= 2
 
@@ -129,6 +130,16 @@
 // of one per control, F as two fused multiply-adds on a table of A[r] alone.  See SdpColFilter.
 #define SDP_COL_LEAN -1          // -1: for 8-byte reals; 0 / 1 force it (A/B runs)
 #endif
+#ifndef SDP_COL_WIDE
+// Wide first pass for 4-byte reals: F in 8-byte arithmetic on a table of A[r] accumulated in 8-byte
+// reals -- its own error is negligible, so the radius only has to cover the reference's W x 6
+// roundings -- and a bound per control that follows those roundings term by term (position-weighted:
+// a term added at step w passes through W - w + 4 roundings, not W + 4) with the actual |T[w][r]|
+// instead of their maximum.  In 4-byte reals the radius is what decides how many nodes keep a
+// second control (5 % at first, more and more as the cost-to-go grows over a chain of sweeps), i.e.
+// how often the long way runs twice: see SdpColWide.
+#define SDP_COL_WIDE -1          // -1: for 4-byte reals; 0 / 1 force it off / on (A/B runs; needs 4-byte reals)
+#endif
 #ifndef SDP_COL_UTAB
 // K > 0: the generated unit provides sdp_model_utab / sdp_model_lead_tab / sdp_model_cost_tab
 // (codegen.control_table_source): the K sub-expressions of x0' and of the cost that depend on the
@@ -188,7 +199,8 @@ struct __attribute__((aligned(16))) SdpColLds {
     sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N : 2] __attribute__((aligned(16)));
 #if SDP_COL_FILTER
     // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
-    sdp_real ad[2 * SDP_COL_ROWS] __attribute__((aligned(16)));
+    // (wide first pass of 4-byte reals: 16 bytes per row -- A[r] as a double, then the bound B[r])
+    sdp_real ad[(sizeof(sdp_real) == 4 ? 4 : 2) * SDP_COL_ROWS] __attribute__((aligned(16)));
 #endif
 };
 static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
@@ -1119,9 +1131,17 @@ struct SdpColFilter {
     sdp_real cu;        // 4 (W + 8) u  (x SDP_COL_FILTER_SCALE)
     sdp_real floor;     // 2 tiny / cu, added to every D[r]: cu S^ >= tiny whatever the values
     sdp_real ratio;     // pcap / |psum| (lean first pass: |g| pcap <= ratio (|F| + |h|))
+    double psum64;      // wide first pass: sum_w p_w in 8-byte arithmetic
+    sdp_real gc;        // wide first pass: sum_w n_w |p_w| (rounded up), n_w = roundings the term of w passes through
     bool ok;            // weights are finite and of ordinary size
 };
 constexpr bool SDP_COL_LEAN_ON = SDP_COL_LEAN < 0 ? sizeof(sdp_real) == 8 : SDP_COL_LEAN != 0;
+constexpr bool SDP_COL_WIDE_ON = sizeof(sdp_real) == 4 && !SDP_COL_LEAN_ON && SDP_COL_WIDE != 0;
+// type of the filter values F and of the radius
+typedef std::conditional<SDP_COL_WIDE_ON, double, sdp_real>::type sdp_fkey;
+// roundings the term of perturbation point w passes through on the reference's path: the two products
+// and the sum of the lerp, the cost, the weight, and the additions from step w on (the first one, 0 + t, is exact)
+SDP_DEV sdp_real sdp_col_wide_nw(int w) { return (sdp_real)(w == 0 ? SDP_COL_W + 3 : SDP_COL_W - w + 4); }
 template <typename R> struct SdpFilterConst;
 template <> struct SdpFilterConst<double> {
     static constexpr double tiny = 2.2250738585072014e-308, limit = 0x1p1000, eps = 0x1p-52;
@@ -1146,6 +1166,14 @@ SDP_DEV void sdp_col_filter_setup(const SdpSweepArgs &a, SdpColFilter &f)
     f.cu = (sdp_real)SDP_COL_FILTER_SCALE * (sdp_real)(2 * (SDP_COL_W + 8)) * SDP_COL_FILTER_EPS;   // u = eps / 2
     f.floor = (sdp_real)2 * SDP_COL_FILTER_TINY / f.cu;
     f.ratio = f.pcap / fabs(ps);                           // (psum = 0: infinite -> every node takes the long way)
+    double ps64 = 0.0;
+    sdp_real gc = (sdp_real)0;
+    for (int w = 0; w < SDP_COL_W; ++w) {
+        ps64 += (double)p[w];
+        gc = gc + sdp_col_wide_nw(w) * (p[w] < (sdp_real)0 ? -p[w] : p[w]);
+    }
+    f.psum64 = ps64;
+    f.gc = gc * (sdp_real)1.0001;                          // (the roundings of this sum itself)
     f.ok = pa <= (sdp_real)1024;                           // false for NaN
 }
 
@@ -1157,6 +1185,27 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
     constexpr int N0 = SDP_COL_ROWS;
     const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
     sdp_real dmax = (sdp_real)0;
+    if (SDP_COL_WIDE_ON) {
+        // wide layout, 16 bytes per row: A[r] = sum_w p_w T[w][r] accumulated in 8-byte reals (the
+        // products are exact there), then B[r] = sum_w n_w |p_w| |T[w][r]| (sdp_col_wide_nw)
+        for (int r = threadIdx.x; r < N0; r += blockDim.x) {
+            double acc = 0.0;
+            sdp_real bsum = (sdp_real)0;
+#pragma unroll SDP_COL_FILTER_RUNROLL
+            for (int w = 0; w < SDP_COL_W; ++w) {
+#if SDP_COL_WPAIR
+                const sdp_real v = m.T[((w >> 1) * N0 + r) * 2 + (w & 1)];
+#else
+                const sdp_real v = m.T[w * N0 + r];
+#endif
+                acc = fma((double)p[w], (double)v, acc);
+                bsum = fma(sdp_col_wide_nw(w) * fabs(p[w]), fabs(v), bsum);
+            }
+            *(double *)(m.ad + 4 * r) = acc;
+            m.ad[4 * r + 2] = bsum;
+        }
+        return;
+    }
     for (int r = threadIdx.x; r < N0; r += blockDim.x) {
         sdp_real acc = (sdp_real)0, big = (sdp_real)0;
 #pragma unroll SDP_COL_FILTER_RUNROLL
@@ -1302,6 +1351,56 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
 }
 #endif
 
+// ---------------------------------------------------------------------------
+// Wide first pass (SDP_COL_WIDE, 4-byte reals).  q0, lam0, oml0 = fl(1 - lam0) and g are the
+// reference's 4-byte values (inputs of E); everything after them runs in 8-byte arithmetic:
+//     F = g P + oml0 A[q0] + lam0 A[q0+1]        P, A accumulated in 8-byte reals
+// so |F - R| is of the order of the 8-byte roundoff (~1e-15 of the terms) and the radius has to
+// cover |E - R| alone, which it follows rounding by rounding:
+//     |E - R| <= sum_w gamma_{n_w} |p_w| (|g| + |oml0 T[w][q0]| + |lam0 T[w][q0+1]|)
+//             <= u' ( Gc |g| + |oml0| B[q0] + |lam0| B[q0+1] ),     B[r] = sum_w n_w |p_w| |T[w][r]|,  Gc = sum_w n_w |p_w|
+// n_w = the roundings the term of point w passes through (sdp_col_wide_nw); u' = u (1 + 1e-3) absorbs
+// gamma_n / (n u) <= 1 + 5e-6, the 4-byte roundings of B, Gc and of the bound itself (a few (W+8) u
+// relative), and |F - R|; the bound carries `floor` so that the radius never drops below the smallest
+// normal number (operations that underflow).  One radius per node: u' x the largest bound of its controls.
+template <int AXIS>
+SDP_DEV void sdp_col_wide_core(const sdp_real *ad, const SdpColFilter &f, const SdpLeadAxis &l,
+                               sdp_real xn0, sdp_real g, double &F, sdp_real &bound, sdp_real &pmax)
+{
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
+    const sdp_real p = sn * l.nm1;
+    pmax = sdp_vmax_abs(pmax, p);
+    int q0 = (int)p;                                        // (saturating conversion; NaN -> 0)
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));
+    const sdp_real lam0 = p - (sdp_real)q0;
+    const sdp_real oml0 = (sdp_real)1 - lam0;
+    const sdp_real *row = ad + 4 * q0;
+    const double a0 = *(const double *)row, a1 = *(const double *)(row + 4);
+    const sdp_real b0 = row[2], b1 = row[6];
+    F = fma((double)g, f.psum64, fma((double)oml0, a0, (double)lam0 * a1));
+    bound = fma(fabs(g), f.gc, fma(fabs(oml0), b0, fabs(lam0) * b1));
+}
+template <int AXIS>
+SDP_DEV void sdp_col_wide_eval(const sdp_real *ad, const SdpColFilter &f, const SdpLeadAxis &l,
+                               const sdp_real *x, const sdp_real *u, sdp_real t, double &F, sdp_real &bound, sdp_real &pmax)
+{
+    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+    const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+    sdp_col_wide_core<AXIS>(ad, f, l, xn0, g, F, bound, pmax);
+}
+#if SDP_COL_UTAB
+template <int AXIS>
+SDP_DEV void sdp_col_wide_eval_tab(const sdp_real *ad, const sdp_real *utab, const SdpColFilter &f,
+                                   const SdpLeadAxis &l, const sdp_real *x, int ci, sdp_real t,
+                                   double &F, sdp_real &bound, sdp_real &pmax)
+{
+    sdp_real tab[SDP_COL_UTAB];
+#pragma unroll
+    for (int k = 0; k < SDP_COL_UTAB; ++k) tab[k] = utab[ci * SDP_COL_UTAB + k];
+    sdp_col_wide_core<AXIS>(ad, f, l, sdp_model_lead_tab(x, tab, t), sdp_model_cost_tab(x, tab, t), F, bound, pmax);
+}
+#endif
+
 // What the first pass keeps of a node's controls: the two smallest F (and whose the smallest
 // is), the largest S^ -- one radius cu * s_max then covers every control of the node -- and the
 // sum of the S^, in which a NaN or an infinity of any control sticks (|F| <~ S^, and a NaN of
@@ -1316,14 +1415,15 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
 #endif
 constexpr bool SDP_COL_TOP2 = SDP_COL_FILTER_TOP2 < 0 ? sizeof(sdp_real) == 4 : SDP_COL_FILTER_TOP2 != 0;
 struct SdpColBounds {
-    sdp_real f1, f2, f3, s_max, s_sum, p_max;
+    sdp_fkey f1, f2, f3, s_sum;      // (wide: s_sum = the sum of the |F|, which catches NaN / infinite values)
+    sdp_real s_max, p_max;           // (wide: s_max = the largest bound of a control)
     int i1, i2;
 };
 // 8-byte reals: the SUM of the S^ serves as the node's bound (no running maximum; a radius
 // U times the necessary one, ~1e-12 relative, still leaves one survivor); 4-byte reals keep the maximum
 constexpr bool SDP_COL_RADIUS_FROM_SUM = sizeof(sdp_real) == 8;
 // one more value (of control ci) into the running two / three smallest
-SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_real F, int ci)
+SDP_DEV void sdp_col_bounds_insert(SdpColBounds &b, sdp_fkey F, int ci)
 {
     if (SDP_COL_TOP2) {
         b.f3 = sdp_vmin(b.f3, sdp_vmax(b.f2, F));
@@ -1344,11 +1444,21 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
                                   int c_lo, int c_hi, SdpColBounds &b)
 {
 #if SDP_COL_UTAB
-    if (SDP_COL_LEAN_ON) {
+    if (SDP_COL_LEAN_ON || SDP_COL_WIDE_ON) {
         (void)box;
         auto one = [&](int ci) {
-            sdp_real F;
-            sdp_col_lean_eval_tab<AXIS>(ad_tab, utab, f, l, x, ci, t, F, b.p_max);
+            sdp_fkey F;
+            if (SDP_COL_WIDE_ON) {
+                double Fw;
+                sdp_real bound;
+                sdp_col_wide_eval_tab<AXIS>(ad_tab, utab, f, l, x, ci, t, Fw, bound, b.p_max);
+                b.s_max = sdp_vmax(b.s_max, bound);
+                F = (sdp_fkey)Fw;
+            } else {
+                sdp_real Fl;
+                sdp_col_lean_eval_tab<AXIS>(ad_tab, utab, f, l, x, ci, t, Fl, b.p_max);
+                F = (sdp_fkey)Fl;
+            }
             b.s_sum = b.s_sum + fabs(F);
             sdp_col_bounds_insert(b, F, ci);
         };
@@ -1365,6 +1475,15 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
     (void)utab;
     auto eval = [&](int ci, const sdp_real *u) {
         sdp_real F, S;
+        if (SDP_COL_WIDE_ON) {
+            double Fw;
+            sdp_real bound;
+            sdp_col_wide_eval<AXIS>(ad_tab, f, l, x, u, t, Fw, bound, b.p_max);
+            b.s_max = sdp_vmax(b.s_max, bound);
+            b.s_sum = b.s_sum + (sdp_fkey)fabs(Fw);
+            sdp_col_bounds_insert(b, (sdp_fkey)Fw, ci);
+            return;
+        }
         if (SDP_COL_LEAN_ON) {
             // (p_max holds the largest |lam0|, s_sum the sum of the |F|: see sdp_col_lean_eval)
             sdp_col_lean_eval<AXIS>(ad_tab, f, l, x, u, t, F, b.p_max);
@@ -1396,19 +1515,20 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
 
 SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
 {
-    const sdp_real o_f1 = sdp_shfl_xor(b.f1, d), o_f2 = sdp_shfl_xor(b.f2, d);
-    const sdp_real o_max = sdp_shfl_xor(b.s_max, d), o_sum = sdp_shfl_xor(b.s_sum, d);
+    const sdp_fkey o_f1 = sdp_shfl_xor(b.f1, d), o_f2 = sdp_shfl_xor(b.f2, d);
+    const sdp_real o_max = sdp_shfl_xor(b.s_max, d);
+    const sdp_fkey o_sum = sdp_shfl_xor(b.s_sum, d);
     const int o_i1 = __shfl_xor(b.i1, d, 64);
     if (SDP_COL_TOP2) {
         // the other lane's three smallest, one after the other (its third cannot end up among
         // the two smallest of the union unless it ties with them -- and then f3 says so)
-        const sdp_real o_f3 = sdp_shfl_xor(b.f3, d);
+        const sdp_fkey o_f3 = sdp_shfl_xor(b.f3, d);
         const int o_i2 = __shfl_xor(b.i2, d, 64);
         sdp_col_bounds_insert(b, o_f1, o_i1);
         sdp_col_bounds_insert(b, o_f2, o_i2);
         sdp_col_bounds_insert(b, o_f3, INT_MAX);
     } else {
-        const sdp_real mx = o_f1 > b.f1 ? o_f1 : b.f1;
+        const sdp_fkey mx = o_f1 > b.f1 ? o_f1 : b.f1;
         b.f2 = o_f2 < b.f2 ? o_f2 : b.f2;
         b.f2 = mx < b.f2 ? mx : b.f2;
         if (o_f1 < b.f1) { b.f1 = o_f1; b.i1 = o_i1; }     // (equal: f2 = f1, the node keeps both)
@@ -1483,17 +1603,23 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         diag.tp1 += diag.m2 - diag.m1;
 #endif
         bool bad;
-        sdp_real radius;
-        if (SDP_COL_LEAN_ON) {
+        sdp_fkey radius;
+        if (SDP_COL_WIDE_ON) {
+            // (s_sum: a NaN or an infinity of any F sticks in it; s_max: the largest bound -- infinite when a
+            // value is, and < 2^100 means that nothing overflows on the reference's 4-byte path)
+            bad = !filt.ok || !(bd.s_sum == bd.s_sum) || !(bd.s_max < SDP_COL_FILTER_LIMIT) ||
+                  !(bd.p_max < (sdp_real)2147483648.0);
+            radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)bd.s_max + (sdp_fkey)filt.floor);
+        } else if (SDP_COL_LEAN_ON) {
             const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
             const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
             bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
             radius = filt.cu * s_node;
         } else {
             bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)2147483648.0);
-            radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? bd.s_sum : bd.s_max);
+            radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? (sdp_real)bd.s_sum : bd.s_max);
         }
-        const sdp_real m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
+        const sdp_fkey m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
         const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
         // exactly two survivors (TOP2): the lanes of the node take one each (a lane alone takes both)
         const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
@@ -1513,7 +1639,13 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             sdp_real u[1][SDP_NU], jc[1];
             sdp_controls_at(box, ci, u[0]);
             bool cand = single || pair || bad;
-            if (!cand) {
+            if (!cand && SDP_COL_WIDE_ON) {
+                double Fw;
+                sdp_real bnd, pm = (sdp_real)0;
+                if (lead.pow2) sdp_col_wide_eval<1>(ad_tab, filt, lead, x, u[0], t, Fw, bnd, pm);
+                else sdp_col_wide_eval<0>(ad_tab, filt, lead, x, u[0], t, Fw, bnd, pm);
+                cand = !((sdp_fkey)Fw - radius > m_hi);
+            } else if (!cand) {
                 sdp_real F, S;
                 sdp_real pm = (sdp_real)0;
                 if (SDP_COL_LEAN_ON) {

@@ -91,22 +91,23 @@ class MultilinearInterpolator(object):
     values : (n_v, S) array, each row a function sampled on the grid with the
              last index varying fastest
     """
-    __grid__ = None
-
     def __init__(self, smin, smax, orders, values=None, dtype=np.float64):
         self.smin = np.array(smin, dtype=dtype)
         self.smax = np.array(smax, dtype=dtype)
         self.orders = np.array(orders, dtype=np.int64)
         self.d = len(orders)
         self.dtype = dtype
+        self._nodes = None                 # the grid nodes, enumerated on first use of `.grid`
         if values is not None:
             self.set_values(values)
 
     @property
     def grid(self):
-        if self.__grid__ is None:
-            self.__grid__ = mlinspace(self.smin, self.smax, self.orders)
-        return self.__grid__
+        """(d, S) coordinates of the grid nodes (the attribute name is API: multilinear.py:79-84)"""
+        nodes = self._nodes
+        if nodes is None:
+            nodes = self._nodes = mlinspace(self.smin, self.smax, self.orders)
+        return nodes
 
     def set_values(self, values):
         self.values = np.ascontiguousarray(values, dtype=self.dtype)

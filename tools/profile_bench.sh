@@ -11,7 +11,7 @@ KEY=${1:-synth256_f64_column}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps ${PROF_STEPS:-10} --warmup 2 --no-cpu-baseline --no-fused --no-filter-check $*"
+ARGS="--steps ${PROF_STEPS:-10} --warmup 2 --no-cpu-baseline --no-fused --no-filter-check --no-other-configs $*"
 run_pmc() {   # name counters...
     local name=$1; shift
     rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.log"

@@ -10,7 +10,7 @@ for cfg in sys.argv[1:]:
         k, v = kv.split('=', 1)
         env[k] = v
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '10', '--warmup', '3',
-                        '--no-cpu-baseline', '--no-fused'] + os.environ.get('TUNE_BENCH_ARGS', '').split(),
+                        '--no-cpu-baseline', '--no-fused', '--no-other-configs'] + os.environ.get('TUNE_BENCH_ARGS', '').split(),
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     try:
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
