@@ -682,6 +682,7 @@ struct sdp_problem {
     int cus = 256;
     int refs_cap = 0;
     int col_threads = 512;
+    int col_occupancy = 8;                 // workgroups of sdp_sweep_col a CU holds at once
     int32_t meta[SDP_META_WORDS] = {0};    // `sdp_meta` of the code object
     int peer_me = -1;                      // this rank, as of sdp_problem_enable_peer_exchange
     void release_peers()
@@ -840,8 +841,10 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         META_CHECK(m[SDP_META_D] == p->d, "built for %d state variables, the problem has %d", m[SDP_META_D], p->d);
         META_CHECK(m[SDP_META_NU] == p->nu, "built for %d controls, the problem has %d", m[SDP_META_NU], p->nu);
         META_CHECK((m[SDP_META_HAS_W] != 0) == (p->W > 0), "built %s a perturbation, the problem has W = %d", m[SDP_META_HAS_W] ? "with" : "without", p->W);
-        META_CHECK(m[SDP_META_LAYOUT] == p->layout, "built for layout %d, the problem asks for layout %d", m[SDP_META_LAYOUT], p->layout);
-        META_CHECK(((m[SDP_META_FLAGS] & SDP_META_F_STAGED) != 0) == (p->variant == SDP_VARIANT_STAGED), "staged-tile kernel %s in the code object, variant %d asked", (m[SDP_META_FLAGS] & SDP_META_F_STAGED) ? "present" : "absent", p->variant);
+        // (every unit also carries the node-order kernels sdp_sweep / sdp_evalpol: a column or staged unit
+        // may serve a node-layout, direct-variant problem; the reverse is what must be refused)
+        META_CHECK(p->layout != SDP_LAYOUT_COLUMNS || m[SDP_META_LAYOUT] == SDP_LAYOUT_COLUMNS, "the column layout was asked of a code object without column kernels");
+        META_CHECK(p->variant != SDP_VARIANT_STAGED || (m[SDP_META_FLAGS] & SDP_META_F_STAGED), "the staged-tile variant was asked of a code object without sdp_sweep_lds");
         if (p->layout == SDP_LAYOUT_COLUMNS) {
             META_CHECK(m[SDP_META_COL_N0] == p->orders[0], "column table built for %d points along axis 0, the grid has %d", m[SDP_META_COL_N0], p->orders[0]);
             META_CHECK(m[SDP_META_COL_W] == (p->W > 0 ? p->W : 1), "column table built for %d perturbation points, the problem has %d", m[SDP_META_COL_W], p->W);
@@ -862,6 +865,13 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         int mt = 0;
         if (hipFuncGetAttribute(&mt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, p->f_sweep) == hipSuccess && mt >= 64)
             p->col_threads = mt > 1024 ? 1024 : mt;
+        {
+            int occ = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, p->f_sweep, p->col_threads, 0) == hipSuccess && occ >= 1)
+                p->col_occupancy = occ > 16 ? 16 : occ;
+            else
+                (void)hipGetLastError();
+        }
         // unit counters of the filtered column kernel (SdpSweepArgs.claim): zero once, the kernel
         // leaves them zero
         int rc = p->claim.alloc(4 * (8 * 32 + 32));
@@ -1035,8 +1045,10 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
     // behind it.
     // (kernels whose workgroups CLAIM their units are persistent whatever the grid: a workgroup per
     // unit would only add thousands of workgroups that start, find nothing left and leave)
+    // Their grid is what the chip holds at once (occupancy of the kernel: LDS, registers, wave slots).
     const bool claims = (p->meta[SDP_META_FLAGS] & SDP_META_F_CLAIMS) != 0;
-    int64_t blocks = (p->comm && p->comm->nranks > 1 && !claims) ? units : (int64_t)p->cus * (claims ? 4 : 8);
+    int64_t blocks = (p->comm && p->comm->nranks > 1 && !claims) ? units
+                     : (int64_t)p->cus * (claims ? p->col_occupancy : 8);
     if (blocks > units) blocks = units;
     blocks = ((blocks + 7) / 8) * 8;
     if (blocks < 8) blocks = 8;
