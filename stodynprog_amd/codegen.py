@@ -209,7 +209,7 @@ def control_table_plan(model, dtype, per_node, max_controls):
     is the same at every node (constant box) and small enough for LDS.  Returns the frontier
     nodes (TracedModel.control_uniform_frontier) or None.  SDP_COL_UTAB=0 in the environment
     switches it off (A/B runs)."""
-    if os.environ.get('SDP_COL_UTAB', '1') == '0' or per_node:
+    if os.environ.get('SDP_COL_UTAB', '1') == '0' or per_node or model.cost_depends_on_w:
         return None
     fr = model.control_uniform_frontier()
     if fr is None or len(fr) > UTAB_MAX_VALUES:
@@ -480,7 +480,9 @@ def column_filter_applies(model, fused=False, window=None, per_control=None):
     the environment switches it off (A/B runs)."""
     if os.environ.get('SDP_COL_FILTER', '1') == '0':
         return False
-    return bool(model.n_perturb > 0 and not model.lead_depends_on_w and not model.cost_depends_on_w
+    # (a cost that depends on the perturbation is fine since round 3: the first pass accumulates its
+    # expectation with the reference's own values, sdp_col_cost_expect; x0' must still not depend on it)
+    return bool(model.n_perturb > 0 and not model.lead_depends_on_w
                 and not model.trail_depends_on_u and not fused and window is None
                 and per_control is None)
 

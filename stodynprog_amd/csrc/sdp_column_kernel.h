@@ -154,9 +154,11 @@
 #ifndef SDP_COL_FILTER_SCALE
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
-#if SDP_COL_FILTER && (!SDP_HAS_W || SDP_LEAD_HAS_W || SDP_COST_HAS_W || SDP_TRAIL_HAS_U || SDP_COL_FUSED || \
-                       SDP_COL_ROWS < SDP_COL_N0)
-#error "SDP_COL_FILTER needs a perturbation that reaches neither x0' nor the cost, and the plain full-column table"
+#if SDP_COL_FILTER && (!SDP_HAS_W || SDP_LEAD_HAS_W || SDP_TRAIL_HAS_U || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
+#error "SDP_COL_FILTER needs a perturbation that does not reach x0', and the plain full-column table"
+#endif
+#if SDP_COL_FILTER && SDP_COST_HAS_W && SDP_COL_UTAB
+#error "the control table holds sub-expressions without the perturbation: not with a cost that depends on it"
 #endif
 #if SDP_TRAIL_HAS_U && (SDP_COL_WPAIR || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
 #error "control-dependent trailing dynamics: plain full table, exact arithmetic only"
@@ -1131,12 +1133,15 @@ struct SdpColFilter {
     sdp_real cu;        // 4 (W + 8) u  (x SDP_COL_FILTER_SCALE)
     sdp_real floor;     // 2 tiny / cu, added to every D[r]: cu S^ >= tiny whatever the values
     sdp_real ratio;     // pcap / |psum| (lean first pass: |g| pcap <= ratio (|F| + |h|))
+    const sdp_cst_real *p, *wg;   // weights and points (scalar loads): the cost's expectation when the cost depends on w
     double psum64;      // wide first pass: sum_w p_w in 8-byte arithmetic
     sdp_real gc;        // wide first pass: sum_w n_w |p_w| (rounded up), n_w = roundings the term of w passes through
     bool ok;            // weights are finite and of ordinary size
 };
 constexpr bool SDP_COL_LEAN_ON = SDP_COL_LEAN < 0 ? sizeof(sdp_real) == 8 : SDP_COL_LEAN != 0;
 constexpr bool SDP_COL_WIDE_ON = sizeof(sdp_real) == 4 && !SDP_COL_LEAN_ON && SDP_COL_WIDE != 0;
+static_assert(!SDP_COST_HAS_W || SDP_COL_LEAN_ON || SDP_COL_WIDE_ON,
+              "a cost that depends on the perturbation needs the lean / wide first pass (sdp_col_cost_expect)");
 // type of the filter values F and of the radius
 typedef std::conditional<SDP_COL_WIDE_ON, double, sdp_real>::type sdp_fkey;
 // roundings the term of perturbation point w passes through on the reference's path: the two products
@@ -1172,6 +1177,8 @@ SDP_DEV void sdp_col_filter_setup(const SdpSweepArgs &a, SdpColFilter &f)
         ps64 += (double)p[w];
         gc = gc + sdp_col_wide_nw(w) * (p[w] < (sdp_real)0 ? -p[w] : p[w]);
     }
+    f.p = p;
+    f.wg = (const sdp_cst_real *)a.wgrid;
     f.psum64 = ps64;
     f.gc = gc * (sdp_real)1.0001;                          // (the roundings of this sum itself)
     f.ok = pa <= (sdp_real)1024;                           // false for NaN
@@ -1300,6 +1307,31 @@ SDP_DEV int sdp_col_axis_mode(const SdpLeadAxis &l)
 // sticks in Fs; an infinity makes Fs or D infinite; |p| >= 2^31 (where the truncation of the
 // reference has x86 semantics, sdp_trunc_i32) makes |lam0| >= 2^30: all of them mark the node
 // `bad`, and a bad node evaluates every control the long way.
+#if SDP_COST_HAS_W
+// A cost that depends on the perturbation (x0' still does not): the expectation no longer reduces g to
+// one value, but it still commutes with the lerp along axis 0 -- R(u) = sum_w p_w g_w + oml0 A0* + lam0 A1*.
+// The first pass accumulates G = sum_w p_w g_w with the reference's own g_w (W cost evaluations per control:
+// the lerp, the add, the weight and the accumulation of the long way -- 6 of its c + 6 operations per
+// perturbation point -- are what is saved) and, for the bound, Gabs = sum_w c_w |g_w| with c_w = |p_w| (lean:
+// |fl(G) - sum p_w g_w| <= gamma_W sum |p_w g_w|, and the reference's own path adds gamma_{W+4} of the same
+// sum) or n_w |p_w| (wide: the roundings of term w, sdp_col_wide_nw).  Gabs replaces |g| Pcap / Gc |g| in
+// the bounds of sdp_col_lean_core / sdp_col_wide_core; everything else is unchanged.
+template <bool WIDE, typename ACC>
+SDP_DEV void sdp_col_cost_expect(const SdpColFilter &f, const sdp_real *x, const sdp_real *u, sdp_real t,
+                                 ACC &G, sdp_real &Gabs)
+{
+    G = (ACC)0;
+    Gabs = (sdp_real)0;
+#pragma unroll 4
+    for (int w = 0; w < SDP_COL_W; ++w) {
+        const sdp_real pw = f.p[w];
+        const sdp_real gw = sdp_model_cost(x, u, f.wg[w], t);
+        G = fma((ACC)pw, (ACC)gw, G);
+        Gabs = fma((WIDE ? sdp_col_wide_nw(w) : (sdp_real)1) * fabs(pw), fabs(gw), Gabs);
+    }
+}
+#endif
+
 template <int AXIS>
 SDP_DEV void sdp_col_lean_core(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
                                sdp_real xn0, sdp_real g, sdp_real &F, sdp_real &lmax)
@@ -1311,14 +1343,27 @@ SDP_DEV void sdp_col_lean_core(const sdp_real *A, const SdpColFilter &f, const S
     const sdp_real lam0 = p - (sdp_real)q0;
     lmax = sdp_vmax_abs(lmax, lam0);
     const sdp_real a0 = A[q0], a1 = A[q0 + 1];
+#if SDP_COST_HAS_W
+    F = g + fma(lam0, a1 - a0, a0);                          // (g: the expectation G of the cost)
+#else
     F = fma(g, f.psum, fma(lam0, a1 - a0, a0));
+#endif
 }
+// gmax: with a cost that depends on w, the largest Gabs of the node's controls (else untouched)
 template <int AXIS>
 SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
-                               const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &lmax)
+                               const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &lmax,
+                               sdp_real &gmax)
 {
     const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+#if SDP_COST_HAS_W
+    sdp_real g, gabs;
+    sdp_col_cost_expect<false>(f, x, u, t, g, gabs);
+    gmax = sdp_vmax(gmax, gabs);
+#else
+    (void)gmax;
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
+#endif
     sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax);
 }
 #if SDP_COL_UTAB
@@ -1363,9 +1408,10 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
 // gamma_n / (n u) <= 1 + 5e-6, the 4-byte roundings of B, Gc and of the bound itself (a few (W+8) u
 // relative), and |F - R|; the bound carries `floor` so that the radius never drops below the smallest
 // normal number (operations that underflow).  One radius per node: u' x the largest bound of its controls.
+// (with a cost that depends on w: g64 = the expectation G accumulated in 8-byte reals, gabs = Gabs)
 template <int AXIS>
 SDP_DEV void sdp_col_wide_core(const sdp_real *ad, const SdpColFilter &f, const SdpLeadAxis &l,
-                               sdp_real xn0, sdp_real g, double &F, sdp_real &bound, sdp_real &pmax)
+                               sdp_real xn0, double g64, sdp_real gabs, double &F, sdp_real &bound, sdp_real &pmax)
 {
     const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
     const sdp_real p = sn * l.nm1;
@@ -1377,16 +1423,28 @@ SDP_DEV void sdp_col_wide_core(const sdp_real *ad, const SdpColFilter &f, const 
     const sdp_real *row = ad + 4 * q0;
     const double a0 = *(const double *)row, a1 = *(const double *)(row + 4);
     const sdp_real b0 = row[2], b1 = row[6];
-    F = fma((double)g, f.psum64, fma((double)oml0, a0, (double)lam0 * a1));
-    bound = fma(fabs(g), f.gc, fma(fabs(oml0), b0, fabs(lam0) * b1));
+#if SDP_COST_HAS_W
+    F = g64 + fma((double)oml0, a0, (double)lam0 * a1);
+    bound = gabs + fma(fabs(oml0), b0, fabs(lam0) * b1);
+#else
+    F = fma(g64, f.psum64, fma((double)oml0, a0, (double)lam0 * a1));
+    bound = fma(gabs, f.gc, fma(fabs(oml0), b0, fabs(lam0) * b1));
+#endif
 }
 template <int AXIS>
 SDP_DEV void sdp_col_wide_eval(const sdp_real *ad, const SdpColFilter &f, const SdpLeadAxis &l,
                                const sdp_real *x, const sdp_real *u, sdp_real t, double &F, sdp_real &bound, sdp_real &pmax)
 {
     const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+#if SDP_COST_HAS_W
+    double g64;
+    sdp_real gabs;
+    sdp_col_cost_expect<true>(f, x, u, t, g64, gabs);
+    sdp_col_wide_core<AXIS>(ad, f, l, xn0, g64, gabs, F, bound, pmax);
+#else
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
-    sdp_col_wide_core<AXIS>(ad, f, l, xn0, g, F, bound, pmax);
+    sdp_col_wide_core<AXIS>(ad, f, l, xn0, (double)g, fabs(g), F, bound, pmax);
+#endif
 }
 #if SDP_COL_UTAB
 template <int AXIS>
@@ -1397,7 +1455,8 @@ SDP_DEV void sdp_col_wide_eval_tab(const sdp_real *ad, const sdp_real *utab, con
     sdp_real tab[SDP_COL_UTAB];
 #pragma unroll
     for (int k = 0; k < SDP_COL_UTAB; ++k) tab[k] = utab[ci * SDP_COL_UTAB + k];
-    sdp_col_wide_core<AXIS>(ad, f, l, sdp_model_lead_tab(x, tab, t), sdp_model_cost_tab(x, tab, t), F, bound, pmax);
+    const sdp_real g = sdp_model_cost_tab(x, tab, t);
+    sdp_col_wide_core<AXIS>(ad, f, l, sdp_model_lead_tab(x, tab, t), (double)g, fabs(g), F, bound, pmax);
 }
 #endif
 
@@ -1486,7 +1545,7 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
         }
         if (SDP_COL_LEAN_ON) {
             // (p_max holds the largest |lam0|, s_sum the sum of the |F|: see sdp_col_lean_eval)
-            sdp_col_lean_eval<AXIS>(ad_tab, f, l, x, u, t, F, b.p_max);
+            sdp_col_lean_eval<AXIS>(ad_tab, f, l, x, u, t, F, b.p_max, b.s_max);
             b.s_sum = b.s_sum + fabs(F);
         } else {
             sdp_col_filter_eval<AXIS>(ad_tab, f, l, x, u, t, F, S, b.p_max);
@@ -1612,7 +1671,12 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)bd.s_max + (sdp_fkey)filt.floor);
         } else if (SDP_COL_LEAN_ON) {
             const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
+#if SDP_COST_HAS_W
+            // (the largest Gabs of the node's controls stands where |g| Pcap stood; a NaN shows in the sum of the |F|)
+            const sdp_real s_node = bd.s_sum == bd.s_sum ? (sdp_real)bd.s_max + h_cap : (sdp_real)NAN;
+#else
             const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
+#endif
             bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
             radius = filt.cu * s_node;
         } else {
@@ -1649,8 +1713,9 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
                 sdp_real F, S;
                 sdp_real pm = (sdp_real)0;
                 if (SDP_COL_LEAN_ON) {
-                    if (lead.pow2) sdp_col_lean_eval<1>(ad_tab, filt, lead, x, u[0], t, F, pm);
-                    else sdp_col_lean_eval<0>(ad_tab, filt, lead, x, u[0], t, F, pm);
+                    sdp_real gm = (sdp_real)0;
+                    if (lead.pow2) sdp_col_lean_eval<1>(ad_tab, filt, lead, x, u[0], t, F, pm, gm);
+                    else sdp_col_lean_eval<0>(ad_tab, filt, lead, x, u[0], t, F, pm, gm);
                 } else if (lead.pow2) sdp_col_filter_eval<1>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
                 else sdp_col_filter_eval<0>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
                 cand = !(F - radius > m_hi);

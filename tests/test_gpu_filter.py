@@ -174,13 +174,56 @@ def test_chained_sweeps_and_relative_dp(gpu):
     assert np.array_equal(a.last_policy_index, b.last_policy_index)
 
 
-def test_where_the_filter_does_not_apply(gpu):
-    """a cost or an x0' that sees the perturbation: every control the long way"""
-    sysd, s = _stock()
-    sysd.cost = lambda x, y, u, w: (y + w) * u + 0.2 * u * u
+def _stock_cost_w(box_on_state=False, tilt=None):
+    """the stock of _stock with a cost that sees the perturbation (x0' still does not)"""
+    sysd, s = _stock(box_on_state=box_on_state)
+    if tilt is None:
+        sysd.cost = lambda x, y, u, w: (y + w) * u + 0.2 * u * u + 0.05 * x * (1.0 + w)
+    else:                                        # flat in the control up to tilt u^2 (cf. _flat)
+        sysd.cost = lambda x, y, u, w: (-1.37 * 0.7) * u * (1.0 + 0.0 * w) + w * (0.3 * y) + tilt * (u * u)
     s._cache.clear()
-    s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
-    assert s.backend_info['kernel'] == 'column' and not s.backend_info['certified_filter']
+    return sysd, s
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('box_on_state', [False, True])
+def test_a_cost_that_depends_on_the_perturbation_is_filtered_with_the_same_bits(gpu, dtype, box_on_state):
+    """the first pass accumulates the cost's expectation with the reference's own g_w (sdp_col_cost_expect)"""
+    make = lambda: _stock_cost_w(box_on_state)
+    V = np.random.default_rng(21).standard_normal(make()[1]._state_grid_shape)
+    on, off = _sweep(make, True, V, dtype), _sweep(make, False, V, dtype)
+    assert on[3].backend_info['certified_filter'] and not off[3].backend_info['certified_filter']
+    assert 'SDP_COST_HAS_W 1' in on[3]._kernel_plan()['source']
+    _same(on, off)
+    _same(on, _sweep(make, True, V, dtype, kernel='generic'))
+    # special values: a forbidden region, a NaN patch
+    V2 = V.copy()
+    V2[40:, :] = np.inf
+    V2[10:14, 2:5] = np.nan
+    _same(_sweep(make, True, V2, dtype), _sweep(make, False, V2, dtype))
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('scale', [None, '0.5'])
+def test_near_ties_with_the_perturbation_in_the_cost(gpu, monkeypatch, dtype, scale):
+    s_ = 1.37
+    for tilt in ([0.0, 1e-15, 1e-13] if dtype == np.float64 else [0.0, 1e-7, 1e-5]):
+        make = lambda: _stock_cost_w(tilt=tilt)
+        g = make()[1].state_grid
+        V = s_ * np.asarray(g[0])[:, None] + np.cos(3 * np.asarray(g[1]))[None, :]
+        off = _sweep(make, False, V, dtype)
+        if scale:
+            monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+        on = _sweep(make, True, V, dtype)
+        if scale:
+            monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+        _same(on, off)
+        if tilt == 0.0:
+            assert len(np.unique(off[2])) > 3
+
+
+def test_where_the_filter_does_not_apply(gpu):
+    """an x0' that sees the perturbation, or fused arithmetic: every control the long way"""
     sysd, s = _stock()
     sysd.dyn = lambda x, y, u, w: (x + 0.7 * u + 0.1 * w, 0.8 * y + w)
     s._cache.clear()
