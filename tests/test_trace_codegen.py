@@ -380,10 +380,47 @@ def test_certified_filter_planning_without_a_gpu():
     s.discretize_state(0, 1, 512, 0, 1, 16, 0, 1, 16)
     s.dtype = np.dtype('float32')
     assert '#define SDP_COL_THREADS 512' in s._kernel_plan()['source']
-    # a perturbation in x0' or in the cost: the expectation no longer commutes with the lerp
+    # a perturbation in x0': the expectation no longer commutes with the lerp along axis 0
     m = trace_model(lambda x, y, u, w: (x + u + 0.1 * w, 0.5 * y + w), lambda x, y, u, w: u * u, 2, 1, 1)
     assert m.storage_separable and not codegen.column_filter_applies(m)
+    # a perturbation in the COST still commutes (round 3: the first pass accumulates its expectation),
+    # but the control table, which holds sub-expressions without w, is not used then
     m = trace_model(lambda x, y, u, w: (x + u, 0.5 * y + w), lambda x, y, u, w: u * w, 2, 1, 1)
-    assert m.storage_separable and not codegen.column_filter_applies(m)
+    assert m.storage_separable and codegen.column_filter_applies(m)
+    assert codegen.control_table_plan(m, np.float64, False, 64) is None
     m = trace_model(lambda x, y, u, w: (x + u, 0.5 * y + w), lambda x, y, u, w: u * y, 2, 1, 1)
     assert codegen.column_filter_applies(m)
+
+
+def test_control_table_planning_without_a_gpu():
+    """the sub-expressions of x0' and of the cost that depend on the control but not on the leading
+    state variable (TracedModel.control_uniform_frontier) and the table codegen builds from them"""
+    from stodynprog_amd.trace import DEP_X, DEP_W, DEP_U
+    _, s = models.synthetic3d(N=32)
+    plan = s._kernel_plan()
+    fr = plan['model'].control_uniform_frontier()
+    assert fr is not None and len(fr) == 2                 # b u  and  (k1 x1 - k0 - u)^2 + eps u^2
+    for n in fr:
+        assert n.deps & DEP_U and not n.deps & (DEP_X | DEP_W)
+    src = plan['source']
+    assert '#define SDP_COL_UTAB 2' in src and '#define SDP_COL_UTAB_N 64' in src
+    assert 'sdp_model_utab' in src and 'sdp_model_lead_tab' in src and 'sdp_model_cost_tab' in src
+    lead_tab = src[src.index('sdp_model_lead_tab'):src.index('sdp_model_cost_tab')]
+    assert 'u[' not in lead_tab and 'x[0] + tab[0]' in lead_tab      # what is left per (node, control)
+    # a lattice that differs from node to node (Searev, storage-AR1: the box depends on the stock): no table
+    for make in (models.searev, models.storage_ar1):
+        _, s2 = make()
+        p2 = s2._kernel_plan()
+        assert p2['filtered'] and p2['per_node'] and 'SDP_COL_UTAB' not in p2['source']
+    # a lattice too long for the LDS budget: no table
+    _, s3 = models.synthetic3d(N=32)
+    s3.control_steps = (2.0 / 4000,)
+    assert 'SDP_COL_UTAB' not in s3._kernel_plan()['source']
+    # the whole cost independent of x0: it IS a table entry
+    m = trace_model(lambda x, y, u, w: (x + 0.5 * u, 0.5 * y + w), lambda x, y, u, w: (y - u) * (y - u), 2, 1, 1)
+    fr = m.control_uniform_frontier()
+    assert fr is not None and m.cost.id in [n.id for n in fr]
+    # nothing to tabulate when the control enters only together with x0
+    m = trace_model(lambda x, y, u, w: (x * u, 0.5 * y + w), lambda x, y, u, w: x * u, 2, 1, 1)
+    fr = m.control_uniform_frontier()
+    assert fr is not None and [n.op for n in fr] == ['var']            # only u itself
