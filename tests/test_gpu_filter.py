@@ -222,6 +222,29 @@ def test_near_ties_with_the_perturbation_in_the_cost(gpu, monkeypatch, dtype, sc
             assert len(np.unique(off[2])) > 3
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_two_controls_on_one_lattice_go_through_the_control_table(gpu, dtype):
+    """a 2-D control lattice shared by all nodes (flat index -> both control values in the table), the
+    second control only in the cost; three tabulated values per control"""
+    def make():
+        sysd = SysDescription((2, 2, 1), name='stock with two controls')
+        sysd.dyn = lambda x, y, u, v, w: (x + 0.7 * u, 0.8 * y + w)
+        sysd.cost = lambda x, y, u, v, w: (y - 0.3) * u + 0.2 * u * u + 0.05 * x * (1.0 + v) + (v - 0.25 * y) * (v - 0.25 * y)
+        sysd.control_box = lambda x, y: ((-1.0, 1.0), (0.0, 0.5))
+        sysd.perturb_laws = [NormalLaw(0, 0.2)]
+        s = DPSolver(sysd)
+        s.discretize_state(0, 3, 80, -1, 1, 9)
+        s.discretize_perturb(-0.5, 0.5, 7)
+        s.control_steps = (0.125, 0.1)
+        return sysd, s
+    V = np.random.default_rng(31).standard_normal(make()[1]._state_grid_shape)
+    on, off = _sweep(make, True, V, dtype), _sweep(make, False, V, dtype)
+    assert on[3].backend_info['certified_filter']
+    assert 'SDP_COL_UTAB' in on[3]._kernel_plan()['source']
+    _same(on, off)
+    _same(on, _sweep(make, True, V, dtype, kernel='generic'))
+
+
 def test_where_the_filter_does_not_apply(gpu):
     """an x0' that sees the perturbation, or fused arithmetic: every control the long way"""
     sysd, s = _stock()
