@@ -300,7 +300,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         elif window is not None:
             col_cfg = window
         else:
-            col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair, filtered)
+            col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair, filtered,
+                                    max_controls=column[2] if len(column) > 2 else None,
+                                    n_columns=column[3] if len(column) > 3 else None)
         assert col_cfg is not None
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
@@ -487,7 +489,7 @@ def column_filter_applies(model, fused=False, window=None, per_control=None):
                 and per_control is None)
 
 
-def column_config(n0, w, n_state, dtype, wpair=False, filtered=False):
+def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_controls=None, n_columns=None):
     """Compile-time shape of the column kernel for a grid with n0 points along
     axis 0 and w perturbation points: (threads, lds_bytes), or None if the
     table does not fit the LDS of a CU.  512-thread workgroups while two of
@@ -497,13 +499,26 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False):
     `filtered` (certified filter, SDP_COL_FILTER): one lane per node of the column where that
     fits a workgroup (n0 <= 512) -- the lanes of a node then share nothing, the second pass
     is not repeated on them and fewer waves meet at the barriers; measured on 256^3 x 64 x 32
-    fp64: 2.56 ms with 512 threads, 2.32 ms with 256 (and no register cap: 165 VGPRs)."""
+    fp64: 2.56 ms with 512 threads, 2.32 ms with 256 (and no register cap: 165 VGPRs).
+    Long control lattices (`max_controls`, with `n_columns` columns in the grid) get more lanes per
+    node: a lane walks its share of a node's controls one after the other, and at the reference's own
+    problem sizes that share is what takes the time -- storage-AR1 41 x 61 nodes x <= 8001 controls:
+    64 threads 4.13 ms, 512: 0.59, 1024: 0.37 (61 columns: one workgroup per CU at most anyway); Searev
+    31 x 61 x 61 x <= 2201: 64 threads 1.91 ms, 512: 0.65, 1024: 0.74.  About 128 controls per lane,
+    512 threads at most while the grid has columns for every CU, else 1024."""
     rs = np.dtype(dtype).itemsize
     w = max(int(w), 1)
     tw = w + (w & 1) if wpair else w
     sizes = (512, 1024)
     if filtered and n0 <= 512:
-        sizes = (max(64, (int(n0) + 63) // 64 * 64),) + sizes
+        first = max(64, (int(n0) + 63) // 64 * 64)
+        if max_controls:
+            lanes = 1
+            while lanes * 128 < int(max_controls) and lanes < 64:
+                lanes *= 2
+            cap = 1024 if (n_columns is not None and int(n_columns) < 256) else 512
+            first = max(first, min(first * lanes, cap))
+        sizes = (first,) + tuple(t for t in sizes if t > first)
     if os.environ.get('SDP_COL_THREADS'):               # A/B runs (a CU then holds as many workgroups as fit)
         sizes = (int(os.environ['SDP_COL_THREADS']),)
     for threads in sizes:

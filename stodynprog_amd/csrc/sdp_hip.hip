@@ -1024,7 +1024,7 @@ static int launch_module(hipFunction_t f, SdpSweepArgs &a, unsigned blocks, unsi
 // Column kernels: a unit of work is (column, split).  Splitting a column over
 // several workgroups repeats its table build, so split only as far as needed
 // to give every CU a few workgroups; `min_nodes` nodes per split at least.
-static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes)
+static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes, bool sweep_kernel)
 {
     const int64_t cols = a.col_end - a.col_begin;
     const int n0 = p->orders[0];
@@ -1046,7 +1046,8 @@ static unsigned column_grid(const sdp_problem *p, SdpSweepArgs &a, int min_nodes
     // (kernels whose workgroups CLAIM their units are persistent whatever the grid: a workgroup per
     // unit would only add thousands of workgroups that start, find nothing left and leave)
     // Their grid is what the chip holds at once (occupancy of the kernel: LDS, registers, wave slots).
-    const bool claims = (p->meta[SDP_META_FLAGS] & SDP_META_F_CLAIMS) != 0;
+    // (sdp_evalpol_col strides over the units: it takes the bounded grid of the other kernels)
+    const bool claims = sweep_kernel && (p->meta[SDP_META_FLAGS] & SDP_META_F_CLAIMS) != 0;
     int64_t blocks = (p->comm && p->comm->nranks > 1 && !claims) ? units
                      : (int64_t)p->cus * (claims ? p->col_occupancy : 8);
     if (blocks > units) blocks = units;
@@ -1078,7 +1079,7 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         // 512-thread workgroups: 8 waves share one LDS table, one lane per node
         const unsigned threads = (unsigned)p->col_threads;   // SDP_COL_THREADS of the code object
-        const unsigned blocks = column_grid(p, a, 64);
+        const unsigned blocks = column_grid(p, a, 64, true);
         return launch_module(p->f_sweep, a, blocks, threads, p->stream);
     }
     if (p->variant == SDP_VARIANT_STAGED) {
@@ -1101,7 +1102,7 @@ static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne,
     a.shift_index = shift_index;
     a.ref_out = ref_out;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
-        const unsigned blocks = column_grid(p, a, 64);       // one lane per node
+        const unsigned blocks = column_grid(p, a, 64, false);      // one lane per node
         const int per_split = (p->orders[0] + a.col_splits - 1) / a.col_splits;
         unsigned threads = (unsigned)((per_split + 63) / 64) * 64;
         if (threads > (unsigned)p->col_threads) threads = (unsigned)p->col_threads;

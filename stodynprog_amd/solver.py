@@ -650,7 +650,7 @@ class DPSolver(object):
             fr = codegen.control_table_plan(model, dt, bp['per_node'], bp['max_u'])
             utab = (fr, bp['max_u']) if fr is not None else None
         source = codegen.translation_unit(model, dt, lanes,
-                                          column=(shape[0], W) if column else None,
+                                          column=(shape[0], W, bp['max_u'], int(np.prod(shape[1:]))) if column else None,
                                           fused=(self.arithmetic == 'fused'), staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
                                           filtered=filtered, utab=utab)
