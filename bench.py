@@ -696,6 +696,26 @@ def finish_single(args, env, out):
                     s2._cache.pop(k_).close()
             except Exception as e:
                 others[name] = {'error': repr(e)}
+        try:
+            # the one case the reference publishes a time for: storage-AR1 at the
+            # notebook's size, 41 x 61 nodes x 4001..8001 controls x 9 perturbation points
+            _, s3 = models.storage_ar1()
+            p3 = s3._problem()
+            p3.set_value(np.zeros(s3._state_grid_shape))
+            p3.bench_sweeps(5)
+            p3.swap()
+            _, k3 = p3.bench_sweeps(20)
+            others['ar1_reference_size'] = {
+                'workload': 'storage-AR1 41x61 state x 4001..8001 controls x 9 perturbations (the reference notebook\'s own problem)',
+                'dtype': 'f64', 'kernel_ms_per_sweep': k3 / 20, 'sweeps_per_s': 20e3 / k3,
+                'reference_published_s_per_sweep': [4.89, 5.50],
+                'reference_source': 'examples/howto storage-AR1.ipynb:596-608 ("a good Intel Core i7 laptop", one thread)',
+                'kernel_family': s3.backend_info.get('kernel'),
+                'certified_filter': bool(s3.backend_info.get('certified_filter'))}
+            for k_ in [k_ for k_ in s3._cache if k_[0] == 'problem']:
+                s3._cache.pop(k_).close()
+        except Exception as e:
+            others['ar1_reference_size'] = {'error': repr(e)}
         out['other_configs'] = dict(others, note='steady state (sweeps 6..25 of a chain from a closed-form start), kernel '
                                     'time by HIP events; outside the timed region of `value`')
     if not args.no_cpu_baseline and world == 1:
