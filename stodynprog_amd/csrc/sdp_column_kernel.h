@@ -38,6 +38,13 @@
 //                                    their control values (box independent of x0)
 //   sdp_model_cost(x, u, w, t)       -> g
 //   SDP_COST_HAS_W                   0: g is hoisted out of the w loop
+//   SDP_COL_FILTER                   1: certified expectation-first filter in phase B (SdpColFilter below):
+//                                    a first pass over every control on a table reduced over w -- lean
+//                                    (SDP_COL_LEAN, 8-byte reals) or wide (SDP_COL_WIDE, 4-byte reals) --
+//                                    and the reference's operations on the survivors only; same bits
+//   SDP_COL_UTAB (+ _N)              K > 0: sdp_model_utab / sdp_model_lead_tab / sdp_model_cost_tab are
+//                                    provided too: the K sub-expressions of x0' and of the cost that depend
+//                                    on the control but not on x0, tabulated once per (column, control)
 //   SDP_COL_N0, SDP_COL_W            points of axis 0 / perturbation points (1 if
 //                                    deterministic): compile-time, they size the
 //                                    statically allocated LDS table
