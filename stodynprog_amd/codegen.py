@@ -318,15 +318,18 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             ['#define SDP_COL_FILTER 1'] + (
             ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
             if os.environ.get('SDP_COL_FILTER_SCALE') else []) if filtered else []) + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
-                  int(os.environ.get('SDP_COL_A_LW') or _order[1]))]
+                  int(os.environ.get('SDP_COL_A_LW') or _order[1]))] + (
+                      ['#define SDP_COL_A_WIDE_LOADS 1'] if _wide and not os.environ.get('SDP_COL_A_WIDE_LOADS') else [])
              if (not os.environ.get('SDP_COL_A_ORDER') and per_control is None and
+                 (_wide := column_wide_loads(column[0], dtype, fused, window)) is not None and
                  (_order := column_build_order(int(col_cfg[0]), column[1],
-                                               int(window[2]) if window is not None else column[0]))[0] == 2)
+                                               int(window[2]) if window is not None else column[0],
+                                               (16 // np.dtype(dtype).itemsize) if _wide else 1))[0] == 2)
              else []) + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + (
             ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE', 'SDP_COL_A_WIDE_LOADS')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             ''] + (['#define SDP_COL_UTAB {}'.format(len(utab[0])),
@@ -528,7 +531,21 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_contro
     return None
 
 
-def column_build_order(threads, w, rows):
+def column_wide_loads(n0, dtype, fused, window):
+    """16-byte vertex loads in the table build (SDP_COL_A_WIDE_LOADS of csrc/sdp_column_kernel.h): a lane
+    takes 16 / sizeof(real) adjacent rows.  Needs whole groups of rows, no row window, exact arithmetic.
+    SDP_COL_A_WIDE_LOADS=0 in the environment switches it off (A/B runs)."""
+    if os.environ.get('SDP_COL_A_WIDE_LOADS', '1') == '0':
+        return False
+    rpl = 16 // np.dtype(dtype).itemsize
+    if rpl != 2 and os.environ.get('SDP_COL_A_WIDE_LOADS') != '1':
+        # 4-byte reals: four rows per lane, but the pair layout of their table scatters the stores --
+        # measured on 512^3 fp32: 11.5 ms against 11.2 without (not used)
+        return False
+    return int(n0) % rpl == 0 and not fused and window is None
+
+
+def column_build_order(threads, w, rows, rows_per_lane=1):
     """How phase A of the column kernel deals the W x rows table entries to the threads
     (SDP_COL_A_ORDER / SDP_COL_A_LW of csrc/sdp_column_kernel.h): (2, lanes_per_w) when the
     perturbation points fill the workgroup's thread groups -- a thread then keeps its w, reads
@@ -537,8 +554,9 @@ def column_build_order(threads, w, rows):
     points on 16 groups of 32 lanes the first form leaves 44 % of the threads idle: +3 %)."""
     w = max(int(w), 1)
     best = (0, 0, 0.0)
-    for lw in (64, 32, 16, 8):
-        if lw > rows or threads % lw:
+    # (with 16-byte loads 32 lanes per point measured best: 256^3 x 64 x 32 fp64 1.65 ms, 64: 1.74, 16: 1.74)
+    for lw in ((32, 64, 16, 8) if rows_per_lane > 1 else (64, 32, 16, 8)):
+        if lw * rows_per_lane > rows or threads % lw:
             continue
         groups = threads // lw
         util = w / float(-(-w // groups) * groups)

@@ -82,6 +82,12 @@
 #ifndef SDP_COL_A_LW
 #define SDP_COL_A_LW 16
 #endif
+#ifndef SDP_COL_A_WIDE_LOADS
+#define SDP_COL_A_WIDE_LOADS 0   // table build, order 2: 16-byte vertex loads, two adjacent rows per lane (see there)
+#endif
+#if SDP_COL_A_WIDE_LOADS && SDP_COL_FUSED
+#error "SDP_COL_A_WIDE_LOADS: exact arithmetic only"
+#endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
 #endif
@@ -369,6 +375,58 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
         }
 #if SDP_COL_FUSED && SDP_HAS_W
         const sdp_real pw_ = ((const sdp_real *)a.proba)[w];
+#endif
+#if SDP_COL_A_WIDE_LOADS
+        // 16-byte vertex loads: a lane takes RPL = 16 / sizeof(real) ADJACENT rows (RPL rl .. RPL rl + RPL - 1),
+        // then the rows RPL LW further on, ..: 1 / RPL of the vector-memory instructions for the same bytes
+        // (the build is bound by the rate of its load instructions through the texture path, not only by
+        // bytes: 256^3 x 64 x 32 fp64, same box: 1.86 -> 1.74 ms, with 32 lanes per perturbation point
+        // 1.65 ms), and with the plain layout the RPL entries go out as one 16-byte LDS store.  Needs N0 to be
+        // a multiple of RPL and no row window (the strips then start on 16-byte boundaries).
+        {
+            constexpr int RPL = 16 / (int)sizeof(sdp_real);
+            static_assert(N0 % RPL == 0 && SDP_COL_ROWS == SDP_COL_N0, "wide loads: whole groups of rows, no row window");
+            typedef sdp_real sdp_rows __attribute__((ext_vector_type(RPL)));
+            constexpr int GP = G / RPL > 0 ? G / RPL : 1;        // row groups per round
+            int voff[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                int o = 0;
+#pragma unroll
+                for (int k = 0; k < SDP_DT; ++k) o += off[k] + (((q >> (SDP_DT - 1 - k)) & 1) ? tg.M[k] : 0);
+                voff[q] = o;
+            }
+            for (int j0 = 0; j0 * RPL * LW < N0; j0 += GP) {
+                sdp_rows vals2[GP][NV];
+#pragma unroll
+                for (int j = 0; j < GP; ++j) {
+                    const int r = min(((j0 + j) * LW + rl) * RPL, N0 - RPL);  // clamp: result unused
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) vals2[j][q] = *(const sdp_rows *)(V + r + voff[q]);
+                }
+#pragma unroll
+                for (int j = 0; j < GP; ++j) {
+                    const int r = ((j0 + j) * LW + rl) * RPL;
+                    if (r < N0) {
+                        sdp_rows e;
+#pragma unroll
+                        for (int c = 0; c < RPL; ++c) {
+                            sdp_real one[NV];
+#pragma unroll
+                            for (int q = 0; q < NV; ++q) one[q] = vals2[j][q][c];
+                            e[c] = SdpColNest<0, SHIFT>::run(one, lam, oml, tg.shift);
+                        }
+#if SDP_COL_WPAIR
+#pragma unroll
+                        for (int c = 0; c < RPL; ++c) s.T[((w >> 1) * N0 + r + c) * 2 + (w & 1)] = e[c];
+#else
+                        *(sdp_rows *)(s.T + w * N0 + r) = e;
+#endif
+                    }
+                }
+            }
+            continue;
+        }
 #endif
         for (int j0 = 0; j0 * LW < N0; j0 += G) {
             sdp_real vals[G][NV];
