@@ -326,10 +326,13 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
                                                int(window[2]) if window is not None else column[0],
                                                (16 // np.dtype(dtype).itemsize) if _wide else 1))[0] == 2)
              else []) + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + (
-            ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
+            ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] + (
+                ['#define SDP_COLU_WIDE_LOADS 1'] if (int(column[0]) % (16 // np.dtype(dtype).itemsize) == 0
+                                                      and not os.environ.get('SDP_COLU_WIDE_LOADS')) else [])
+            if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
              for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
                        'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE', 'SDP_COL_A_WIDE_LOADS')
+                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE', 'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP')
              if os.environ.get(k)] + [
             separable_functions_source(model),
             ''] + (['#define SDP_COL_UTAB {}'.format(len(utab[0])),

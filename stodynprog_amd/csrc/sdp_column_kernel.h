@@ -82,6 +82,15 @@
 #ifndef SDP_COL_A_LW
 #define SDP_COL_A_LW 16
 #endif
+#ifndef SDP_COLU_WIDE_LOADS
+#define SDP_COLU_WIDE_LOADS 0    // table-per-control kernel: 16-byte vertex loads in its table build (see sdp_colu_phase_a)
+#endif
+#ifndef SDP_COLU_A_GROUP
+// perturbation points per round of that build.  Same-box A/B on the control-coupled benchmark (256^3 x 64 x 32
+// fp64): 8-byte loads 59.3 ms (groups of 4; 2: 60.4); 16-byte loads, groups of 1 / 2 / 3 / 4 / 8: 38.4 / 37.4 /
+// 41.0 / 43.7 / 73.6 ms
+#define SDP_COLU_A_GROUP (SDP_COLU_WIDE_LOADS ? 2 : SDP_COL_A_GROUP)
+#endif
 #ifndef SDP_COL_A_WIDE_LOADS
 #define SDP_COL_A_WIDE_LOADS 0   // table build, order 2: 16-byte vertex loads, two adjacent rows per lane (see there)
 #endif
@@ -2134,9 +2143,66 @@ SDP_DEV void sdp_colu_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP
                               const SdpColShared &s, int w_lo, int cnt)
 {
     constexpr int N0 = SDP_COL_N0;
-    constexpr int G = SDP_COL_A_GROUP;
+    constexpr int G = SDP_COLU_A_GROUP;
     constexpr int NV = 1 << SDP_DT;
     const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+#if SDP_COLU_WIDE_LOADS
+    // 16-byte vertex loads (cf. SDP_COL_A_WIDE_LOADS): a thread takes RPL adjacent rows, and the threads beyond
+    // N0 / RPL take other perturbation points of the chunk: as many entries per thread, 1 / RPL of the
+    // vector-memory instructions -- this kernel is bound by its strip reads
+    {
+        constexpr int RPL = 16 / (int)sizeof(sdp_real);
+        static_assert(N0 % RPL == 0, "wide loads: whole groups of rows");
+        typedef sdp_real sdp_rows __attribute__((ext_vector_type(RPL)));
+        constexpr int ROWG = N0 / RPL;                           // row groups of a column
+        const int lanes_r = min((int)blockDim.x, ROWG);
+        const int wgroups = max((int)blockDim.x / lanes_r, 1);    // thread groups along w
+        const int wg = threadIdx.x / lanes_r;
+        for (int rg = threadIdx.x - wg * lanes_r; rg < ROWG && wg < wgroups; rg += lanes_r) {
+            const int r = rg * RPL;
+            for (int w0 = wg * G; w0 < cnt; w0 += wgroups * G) {
+                sdp_rows vals2[G][NV];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int w = w_lo + min(w0 + j, cnt - 1);           // clamp: result unused
+                    int base[NV];
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) {
+                        int o = 0;
+#pragma unroll
+                        for (int k = 0; k < SDP_DT; ++k)
+                            o += s.w_off[w * SDP_DT + k] + (((q >> (SDP_DT - 1 - k)) & 1) ? tg.M[k] : 0);
+                        base[q] = o;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) vals2[j][q] = *(const sdp_rows *)(V + r + base[q]);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (w0 + j < cnt) {
+                        const int w = w_lo + w0 + j;
+                        sdp_real lam[SDP_DT], oml[SDP_DT];
+#pragma unroll
+                        for (int k = 0; k < SDP_DT; ++k) {
+                            lam[k] = s.w_lam[w * SDP_DT + k];
+                            oml[k] = s.w_oml[w * SDP_DT + k];
+                        }
+                        sdp_rows e;
+#pragma unroll
+                        for (int c = 0; c < RPL; ++c) {
+                            sdp_real one[NV];
+#pragma unroll
+                            for (int q = 0; q < NV; ++q) one[q] = vals2[j][q][c];
+                            e[c] = SdpColNest<0, false>::run(one, lam, oml, tg.shift);
+                        }
+                        *(sdp_rows *)(s.T + (w0 + j) * N0 + r) = e;
+                    }
+                }
+            }
+        }
+        return;
+    }
+#endif
     // consecutive threads = consecutive rows (coalesced strips); a thread keeps its row and
     // takes G consecutive perturbation points per round: their strips overlap (L1 hits)
     for (int r = threadIdx.x; r < N0; r += blockDim.x) {
