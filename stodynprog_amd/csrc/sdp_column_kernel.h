@@ -1210,6 +1210,7 @@ struct SdpColFilter {
     const sdp_cst_real *p, *wg;   // weights and points (scalar loads): the cost's expectation when the cost depends on w
     double psum64;      // wide first pass: sum_w p_w in 8-byte arithmetic
     sdp_real gc;        // wide first pass: sum_w n_w |p_w| (rounded up), n_w = roundings the term of w passes through
+    sdp_real glimit;    // min(1, sum_w |p_w|): a bound below LIMIT x glimit keeps |g| itself below LIMIT
     bool ok;            // weights are finite and of ordinary size
 };
 constexpr bool SDP_COL_LEAN_ON = SDP_COL_LEAN < 0 ? sizeof(sdp_real) == 8 : SDP_COL_LEAN != 0;
@@ -1255,6 +1256,7 @@ SDP_DEV void sdp_col_filter_setup(const SdpSweepArgs &a, SdpColFilter &f)
     f.wg = (const sdp_cst_real *)a.wgrid;
     f.psum64 = ps64;
     f.gc = gc * (sdp_real)1.0001;                          // (the roundings of this sum itself)
+    f.glimit = pa < (sdp_real)1 ? pa : (sdp_real)1;        // (bound >= n_w |p_w| |g| summed >= |g| sum |p_w|)
     f.ok = pa <= (sdp_real)1024;                           // false for NaN
 }
 
@@ -1269,6 +1271,10 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
     if (SDP_COL_WIDE_ON) {
         // wide layout, 16 bytes per row: A[r] = sum_w p_w T[w][r] accumulated in 8-byte reals (the
         // products are exact there), then B[r] = sum_w n_w |p_w| |T[w][r]| (sdp_col_wide_nw)
+        // The bounds weigh |T| with the weights, which may be tiny: the RAW magnitude of the column's
+        // entries is published beside them (dcol), for the check that nothing can overflow on the
+        // reference's 4-byte path ((1 + 2 max |p|) max |T| < 2^100, sdp_col_filter_nodes).
+        sdp_real tmax = (sdp_real)0;
         for (int r = threadIdx.x; r < N0; r += blockDim.x) {
             double acc = 0.0;
             sdp_real bsum = (sdp_real)0;
@@ -1281,10 +1287,15 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
 #endif
                 acc = fma((double)p[w], (double)v, acc);
                 bsum = fma(sdp_col_wide_nw(w) * fabs(p[w]), fabs(v), bsum);
+                tmax = sdp_vmax_abs(tmax, v);
             }
             *(double *)(m.ad + 4 * r) = acc;
             m.ad[4 * r + 2] = bsum;
+            if (!(acc == acc)) tmax = (sdp_real)INFINITY;        // (a NaN entry, which the maximum skips)
         }
+        tmax = sdp_wave_max(tmax);
+        if ((threadIdx.x & 63) == 0)
+            atomicMax(&m.dcol[parity], (unsigned long long)__double_as_longlong((double)tmax));
         return;
     }
     for (int r = threadIdx.x; r < N0; r += blockDim.x) {
@@ -1319,7 +1330,7 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
 // after the barrier that follows the reduction: the column's bound; the slot of the next unit is cleared
 SDP_DEV sdp_real sdp_col_filter_dcol(SdpColLds &m, int parity)
 {
-    if (!SDP_COL_LEAN_ON) return (sdp_real)0;
+    if (!SDP_COL_LEAN_ON && !SDP_COL_WIDE_ON) return (sdp_real)0;
     const unsigned long long bits = m.dcol[parity];
     if (threadIdx.x == 0) m.dcol[parity ^ 1] = 0ull;
     return (sdp_real)__longlong_as_double((long long)bits);
@@ -1396,13 +1407,18 @@ SDP_DEV void sdp_col_cost_expect(const SdpColFilter &f, const sdp_real *x, const
 {
     G = (ACC)0;
     Gabs = (sdp_real)0;
+    sdp_real graw = (sdp_real)0;
 #pragma unroll 4
     for (int w = 0; w < SDP_COL_W; ++w) {
         const sdp_real pw = f.p[w];
         const sdp_real gw = sdp_model_cost(x, u, f.wg[w], t);
         G = fma((ACC)pw, (ACC)gw, G);
         Gabs = fma((WIDE ? sdp_col_wide_nw(w) : (sdp_real)1) * fabs(pw), fabs(gw), Gabs);
+        graw = sdp_vmax_abs(graw, gw);
     }
+    // (the RAW magnitude too: a tiny or zero weight must not hide a g_w that overflows g_w + val on the
+    // reference's path -- the bound is compared with the overflow limit)
+    Gabs = sdp_vmax(Gabs, graw);
 }
 #endif
 
@@ -1740,8 +1756,10 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         if (SDP_COL_WIDE_ON) {
             // (s_sum: a NaN or an infinity of any F sticks in it; s_max: the largest bound -- infinite when a
             // value is, and < 2^100 means that nothing overflows on the reference's 4-byte path)
-            bad = !filt.ok || !(bd.s_sum == bd.s_sum) || !(bd.s_max < SDP_COL_FILTER_LIMIT) ||
-                  !(bd.p_max < (sdp_real)2147483648.0);
+            // (dcol: the largest |T| of the column, raw -- the bounds weigh |T| and |g| with the weights)
+            bad = !filt.ok || !(bd.s_sum == bd.s_sum) || !(bd.s_max < SDP_COL_FILTER_LIMIT * filt.glimit) ||
+                  !(bd.p_max < (sdp_real)2147483648.0) ||
+                  !(((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol < SDP_COL_FILTER_LIMIT);
             radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)bd.s_max + (sdp_fkey)filt.floor);
         } else if (SDP_COL_LEAN_ON) {
             const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D

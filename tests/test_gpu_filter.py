@@ -117,6 +117,21 @@ def test_special_values_take_the_long_way(gpu, case):
     _same(on, off)
 
 
+@pytest.mark.parametrize('dtype,scale_v', [(np.float32, 2e38), (np.float64, 1e307)])
+def test_tiny_weights_do_not_hide_an_overflow(gpu, dtype, scale_v):
+    """weights of 1e-30: the weighted bounds of the first pass are small although the lerp of the
+    reference's path overflows on extrapolated cells -- the raw magnitude of the table decides"""
+    def make():
+        sysd, s = _stock()
+        s.perturb_proba = [np.asarray(s.perturb_proba[0]) * 1e-30]
+        return sysd, s
+    V = np.random.default_rng(8).standard_normal(make()[1]._state_grid_shape)
+    V = V / np.abs(V).max() * scale_v
+    on, off = _sweep(make, True, V, dtype), _sweep(make, False, V, dtype)
+    assert on[3].backend_info['certified_filter']
+    _same(on, off)
+
+
 def test_weights_that_do_not_sum_to_one(gpu):
     def make():
         sysd, s = _stock()
