@@ -196,6 +196,20 @@ def separable_functions_source(model):
     names = _emit_body(model, model.slice_nodes([model.cost]), lines)
     lines += ['    return {};'.format(names[model.cost.id]), '}']
     out.append('\n'.join(lines))
+    split = model.lead_split()
+    if split is not None:
+        # x0' = a(x, u) +- b(x_1.., w): the two halves, each with the reference's own operations
+        # (SDP_COL_SHIFT of csrc/sdp_column_kernel.h)
+        lines = ['SDP_DEV sdp_real sdp_model_lead_a(const sdp_real *x, const sdp_real *u, sdp_real t)',
+                 '{', '    (void)x; (void)u; (void)t;']
+        names = _emit_body(model, model.slice_nodes([split[0]]), lines)
+        lines += ['    return {};'.format(names[split[0].id]), '}']
+        out.append('\n'.join(lines))
+        lines = ['SDP_DEV sdp_real sdp_model_lead_b(const sdp_real *x, sdp_real w, sdp_real t)',
+                 '{', '    (void)x; (void)w; (void)t;']
+        names = _emit_body(model, model.slice_nodes([split[1]]), lines)
+        lines += ['    return {};'.format(names[split[1].id]), '}']
+        out.append('\n'.join(lines))
     return '\n\n'.join(out)
 
 
@@ -211,7 +225,13 @@ def control_table_plan(model, dtype, per_node, max_controls):
     switches it off (A/B runs)."""
     if os.environ.get('SDP_COL_UTAB', '1') == '0' or per_node or model.cost_depends_on_w:
         return None
-    fr = model.control_uniform_frontier()
+    lead = None
+    if model.lead_depends_on_w:
+        split = model.lead_split()
+        if split is None:
+            return None
+        lead = split[0]
+    fr = model.control_uniform_frontier(lead)
     if fr is None or len(fr) > UTAB_MAX_VALUES:
         return None
     if len(fr) * int(max_controls) * np.dtype(dtype).itemsize > UTAB_MAX_BYTES:
@@ -232,7 +252,9 @@ def control_table_source(model, frontier):
     lines.append('}')
     out.append('\n'.join(lines))
     pre = {n.id: 'tab[{}]'.format(slot[n.id]) for n in frontier}
-    for fname, node in (('sdp_model_lead_tab', model.x_next[0]), ('sdp_model_cost_tab', model.cost)):
+    split = model.lead_split() if model.lead_depends_on_w else None
+    for fname, node in (('sdp_model_lead_tab', split[0] if split else model.x_next[0]),     # (shifted table: the w-free half)
+                        ('sdp_model_cost_tab', model.cost)):
         lines = ['SDP_DEV sdp_real {}(const sdp_real *x, const sdp_real *tab, sdp_real t)'.format(fname),
                  '{', '    (void)x; (void)tab; (void)t;']
         names = _emit_body(model, model.slice_nodes_until([node], set(slot)), lines, pre)
@@ -302,7 +324,10 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         else:
             col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair, filtered,
                                     max_controls=column[2] if len(column) > 2 else None,
-                                    n_columns=column[3] if len(column) > 3 else None)
+                                    n_columns=column[3] if len(column) > 3 else None,
+                                    shift=filtered and column_shift_applies(model, dtype),
+                                    extra_bytes=(2 * len(utab[0]) * int(utab[1]) * np.dtype(dtype).itemsize
+                                                 if utab is not None and filtered else 0))
         assert col_cfg is not None
         head += [
             '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
@@ -315,7 +340,11 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
         ] + (['#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap']
              if filtered and int(col_cfg[0]) <= 256 and not os.environ.get('SDP_COL_MIN_WAVES') else []) + (
-            ['#define SDP_COL_FILTER 1'] + (
+            ['#define SDP_COL_FILTER 1'] + ([
+                '#define SDP_COL_SHIFT 1        // x0\' = a(x, u) +- b(x_1.., w): first pass on the shifted lattice',
+                '#define SDP_COL_SHIFT_SIGN {}'.format(int(model.lead_split()[2])),
+                '#define SDP_COL_SHIFT_ROWS {}'.format(int(col_cfg[2]))]
+                if column_shift_applies(model, dtype) else []) + (
             ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
             if os.environ.get('SDP_COL_FILTER_SCALE') else []) if filtered else []) + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
                   int(os.environ.get('SDP_COL_A_LW') or _order[1]))] + (
@@ -478,7 +507,23 @@ def use_wpair(model, dtype):
             and not model.lead_depends_on_w and not model.trail_depends_on_u)
 
 
-def column_filter_applies(model, fused=False, window=None, per_control=None):
+def column_shift_applies(model, dtype, table=None):
+    """The certified filter with a perturbation that reaches x0' additively (`x + u - w`): the first
+    pass then reads a table reduced over w on a lattice that the perturbation points have SHIFTED
+    (SDP_COL_SHIFT of csrc/sdp_column_kernel.h).  8-byte reals only: in 4-byte reals the rounding of
+    the positions alone would put most controls inside the radius.  SDP_COL_SHIFT=0 in the
+    environment switches it off (A/B runs)."""
+    if os.environ.get('SDP_COL_SHIFT', '1') == '0':
+        return False
+    ok = bool(model.n_perturb > 0 and model.lead_depends_on_w and model.lead_split() is not None
+              and dtype is not None and np.dtype(dtype).itemsize == 8)
+    if ok and table is not None:       # (n0, w, n_state): the shifted lattice must fit LDS beside the table
+        ok = column_config(table[0], table[1], table[2], dtype, False, True, shift=True,
+                           extra_bytes=2 * UTAB_MAX_BYTES) is not None      # (whatever the control table takes)
+    return ok
+
+
+def column_filter_applies(model, fused=False, window=None, per_control=None, dtype=None, table=None):
     """Can phase B of the column kernel run the certified expectation-first filter
     (SDP_COL_FILTER of csrc/sdp_column_kernel.h)?  It needs a perturbation that reaches
     neither x0' nor the cost -- then the expectation commutes with the lerp along axis 0 and
@@ -490,12 +535,14 @@ def column_filter_applies(model, fused=False, window=None, per_control=None):
         return False
     # (a cost that depends on the perturbation is fine since round 3: the first pass accumulates its
     # expectation with the reference's own values, sdp_col_cost_expect; x0' must still not depend on it)
-    return bool(model.n_perturb > 0 and not model.lead_depends_on_w
+    # (and so is a perturbation that reaches x0' through a final sum, in 8-byte reals: column_shift_applies)
+    return bool(model.n_perturb > 0 and (not model.lead_depends_on_w or column_shift_applies(model, dtype, table))
                 and not model.trail_depends_on_u and not fused and window is None
                 and per_control is None)
 
 
-def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_controls=None, n_columns=None):
+def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_controls=None, n_columns=None,
+                  shift=False, extra_bytes=0):
     """Compile-time shape of the column kernel for a grid with n0 points along
     axis 0 and w perturbation points: (threads, lds_bytes), or None if the
     table does not fit the LDS of a CU.  512-thread workgroups while two of
@@ -527,6 +574,19 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_contro
         sizes = (first,) + tuple(t for t in sizes if t > first)
     if os.environ.get('SDP_COL_THREADS'):               # A/B runs (a CU then holds as many workgroups as fit)
         sizes = (int(os.environ['SDP_COL_THREADS']),)
+    if shift:
+        # (threads, lds_bytes, rows of the shifted lattice): as many rows as LDS has room for beside the table
+        # (`extra_bytes`: the control table) while two workgroups share a CU -- at least n0 + n0 / 8, so that
+        # shifts spread over an eighth of the axis still fit --, else one workgroup per CU and 2 n0 rows
+        for per_cu in (2, 1):
+            for threads in sizes:
+                if per_cu == 2 and threads > 512:
+                    continue
+                base = _column_lds(tw, w, 0, n_state, rs, threads, shift=True) + tw * int(n0) * rs + int(extra_bytes)
+                rows = min(2 * int(n0), (COLUMN_LDS_MAX // per_cu - base - 1024) // (2 * rs))
+                if rows >= int(n0) + max(8, int(n0) // 8):
+                    return threads, base + 2 * rows * rs, int(rows)
+        return None
     for threads in sizes:
         lds = _column_lds(tw, w, n0, n_state, rs, threads, reduced=True)   # (whether or not it is compiled in)
         if lds * (2 if threads <= 512 else 1) <= COLUMN_LDS_MAX:
@@ -568,10 +628,13 @@ def column_build_order(threads, w, rows, rows_per_lane=1):
     return (best[0], best[1]) if best[2] >= 0.85 else (0, 0)
 
 
-def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False):
+def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False):
     # reduced: + the (A[r], D[r]) table of the certified filter (full-column table only)
+    # shift: the shifts of the perturbation points (two parities; the reduced table on the shifted lattice is
+    # sized by column_config)
     raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16
-           + ((4 if rs == 4 else 2) * rows * rs if reduced else 0))
+           + ((4 if rs == 4 else 2) * rows * rs if reduced else 0)
+           + (2 * w * (2 * rs + 4) + 64 if shift else 0))
     return (raw + 15) // 16 * 16
 
 

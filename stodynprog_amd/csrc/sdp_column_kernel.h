@@ -176,8 +176,20 @@
 #ifndef SDP_COL_FILTER_SCALE
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
-#if SDP_COL_FILTER && (!SDP_HAS_W || SDP_LEAD_HAS_W || SDP_TRAIL_HAS_U || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
-#error "SDP_COL_FILTER needs a perturbation that does not reach x0', and the plain full-column table"
+#ifndef SDP_COL_SHIFT
+// 1: the perturbation reaches x0' through a final sum, x0' = a(x, u) +- b(x_1.., w) (the generated unit
+// provides sdp_model_lead_a / sdp_model_lead_b and SDP_COL_SHIFT_SIGN): the first pass of the filter reads
+// the table reduced over w on a lattice SHIFTED by the perturbation points -- see sdp_col_shift_reduce.
+#define SDP_COL_SHIFT 0
+#endif
+#ifndef SDP_COL_SHIFT_ROWS
+#define SDP_COL_SHIFT_ROWS (2 * SDP_COL_N0)     // rows of the shifted lattice held in LDS
+#endif
+#if SDP_COL_FILTER && (!SDP_HAS_W || (SDP_LEAD_HAS_W && !SDP_COL_SHIFT) || SDP_TRAIL_HAS_U || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
+#error "SDP_COL_FILTER needs a perturbation that reaches x0' through a final sum at most, and the plain full-column table"
+#endif
+#if SDP_COL_SHIFT && (!SDP_COL_FILTER || !SDP_LEAD_HAS_W || SDP_COL_WPAIR)
+#error "SDP_COL_SHIFT is a form of the certified filter for a perturbation that reaches x0'"
 #endif
 #if SDP_COL_FILTER && SDP_COST_HAS_W && SDP_COL_UTAB
 #error "the control table holds sub-expressions without the perturbation: not with a cost that depends on it"
@@ -224,7 +236,15 @@ struct __attribute__((aligned(16))) SdpColLds {
 #if SDP_COL_FILTER
     // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
     // (wide first pass of 4-byte reals: 16 bytes per row -- A[r] as a double, then the bound B[r])
-    sdp_real ad[(sizeof(sdp_real) == 4 ? 4 : 2) * SDP_COL_ROWS] __attribute__((aligned(16)));
+    sdp_real ad[(sizeof(sdp_real) == 4 ? 4 : 2) * (SDP_COL_SHIFT ? SDP_COL_SHIFT_ROWS : SDP_COL_ROWS)] __attribute__((aligned(16)));
+#endif
+#if SDP_COL_SHIFT
+    // per parity of the unit: the shift of every perturbation point in rows of axis 0 -- whole part, fraction
+    // in [0, 1), |p_w| f (1 - f) -- and (largest whole part, minus the smallest, "not usable")
+    int sh_q[2][SDP_COL_W];
+    sdp_real sh_f[2][SDP_COL_W];
+    sdp_real sh_c[2][SDP_COL_W];
+    int sh_k[2][4];
 #endif
 };
 static_assert(sizeof(SdpColLds) <= 160 * 1024, "column table exceeds the 160 KiB LDS of a CU");
@@ -579,6 +599,7 @@ SDP_DEV sdp_real sdp_col_inner_global(const SdpSweepArgs &a, const SdpGrid<sdp_r
 
 struct SdpLeadAxis {
     sdp_real smin, span, nm1, rspan;
+    sdp_real koff;      // shifted lattice (SDP_COL_SHIFT, first pass only): position of its first row
     int ordm2;
     bool pow2;          // span is a power of two: (x - smin) / span == (x - smin) * rspan, bit for bit
 };
@@ -592,6 +613,7 @@ SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
     l.pow2 = __builtin_amdgcn_readfirstlane((int)sdp_is_pow2(l.span)) != 0;
     l.nm1 = (sdp_real)(a.orders[0] - 1);
     l.ordm2 = a.orders[0] - 2;
+    l.koff = (sdp_real)0;
 }
 
 // Where the inner loop takes the perturbation weights p_w (and points w, when
@@ -1215,6 +1237,7 @@ struct SdpColFilter {
 };
 constexpr bool SDP_COL_LEAN_ON = SDP_COL_LEAN < 0 ? sizeof(sdp_real) == 8 : SDP_COL_LEAN != 0;
 constexpr bool SDP_COL_WIDE_ON = sizeof(sdp_real) == 4 && !SDP_COL_LEAN_ON && SDP_COL_WIDE != 0;
+static_assert(!SDP_COL_SHIFT || SDP_COL_LEAN_ON, "the shifted lattice is a form of the lean first pass (8-byte reals)");
 static_assert(!SDP_COST_HAS_W || SDP_COL_LEAN_ON || SDP_COL_WIDE_ON,
               "a cost that depends on the perturbation needs the lean / wide first pass (sdp_col_cost_expect)");
 // type of the filter values F and of the radius
@@ -1336,6 +1359,135 @@ SDP_DEV sdp_real sdp_col_filter_dcol(SdpColLds &m, int parity)
     return (sdp_real)__longlong_as_double((long long)bits);
 }
 
+#if SDP_COL_SHIFT
+// ---------------------------------------------------------------------------
+// Shifted lattice (SDP_COL_SHIFT): the certified filter when the perturbation reaches x0' through a
+// final sum, x0' = fl(a(x, u) +- b(x_1.., w)) -- the stock of the inventory example, `x + u - w`
+// (reference doc/example_inventory.py:31-33; expectation at stodynprog.py:679-683).
+// With Tw(s) the reference's interpolation of row w of the table at axis-0 position s (continuous,
+// piecewise linear, linear beyond both ends: pyx:75-88 clamps the cell, not lam), c = (N0-1)/span,
+//     R(u) = sum_w p_w (g + Tw(s_w)),      s_w = the reference's position of fl(a +- b_w)
+// and in real arithmetic s_w = pa + pb_w, pa = (a - smin) c, pb_w = +- b_w c: every control of the column
+// sees the perturbation points as the SAME shifts pb_w of its own position pa.  So
+//     G(s) = sum_w p_w Tw(s + pb_w)
+// is ONE function per column, R(u) = g P + G(pa(u)).  G is piecewise linear with W kinks per row; it is
+// tabulated at the whole positions k = kmin .. kmax (A'[k] = G(k), 32 x 3 LDS reads per entry -- once per
+// column, not per control) and the first pass is the lean one on that table: F = fma(g, psum, lerp(A', pa)).
+// What the lerp between whole positions leaves out is bounded cell by cell: on [k, k+1] the function
+// Tw(. + pb_w) has one kink, at distance f_w = frac(pb_w) from the cell's upper end, where its slope changes
+// by the second difference d2 = T[w][j+2] - 2 T[w][j+1] + T[w][j] (j = k + floor(pb_w); no kink beyond the
+// ends of the axis); a function with one kink of size d2 leaves its chord by at most f (1 - f) |d2|.  Hence
+//     |G(s) - chord_k(s)| <= B'[k] = sum_w |p_w| f_w (1 - f_w) |d2_w,k|        for s in [k, k+1]
+// and G is LINEAR below 1 - max pb and above N0 - 2 - min pb: with kmin = -(max floor pb + 1), kmax =
+// N0 - 1 - min floor pb the first and the last cell of the lattice lie in those ranges, the clamped cell
+// with an unclamped lam extrapolates G exactly, and B' is zero there by construction.
+// Roundings (u the unit roundoff, D = Pcap max |T| of the column as in the lean pass, P = sum |p_w|):
+//  * positions: the reference rounds fl(a +- b), then (. - smin) / span * (N0-1); this pass rounds pa, pb_w,
+//    pa - kmin.  a and b_w are the reference's own values (same operations on the same inputs), so
+//    |s_w - (pa + pb_w)| <= u (8 |pa| + 7 |pb_w| + 1.1 |smin| c) and |Tw(s) - Tw(s')| <= 2 max|T| |s - s'|;
+//  * |E - R| <= (W+4) u [ |g| P + (1 + 2 Lam) D ],  Lam = max_w |lam_w| <= |s_w| + N0;
+//  * A'[k] carries (W+4) u (1 + 2 (spread + 2)) D (lam of an entry reaches spread + 2 at the ends of the
+//    lattice, spread = max - min floor pb), the lerp and the fma 4 u (1 + 2 |lam0|) max |A'|.
+// With L = max |lam0| of the node (|pa - kmin| <= rows + L), Lc = rows + |kmin| + max |pb| + |smin| c + N0 + 1
+// (column-uniform) and Es = 1 + 2 (spread + 2) all of it is below
+//     (2W+8) u |g| P  +  (W+8) u H D,      H = (1 + 2 L + 2 Lc) (2 + Es)
+// and with |g| Pcap <= ratio (|F| (1 + u) + |h|), |h| <= (1 + 2 L) Es D <= H D, as in the lean pass:
+//     radius = cu S_node + max_u B'[q0(u)],    S_node = ratio (sum |F| + H D) + H D,   cu = 4 (W+8) u
+// (a factor 2 on the |g| term, 4 on the D term to spare; the roundings of B' itself -- (W+8) u relative and
+// 3 u max |T| per d2 -- are far inside that slack since B' <= D).  |s_w| < 2^31 for every w (the x86
+// truncation of the reference, sdp_trunc_i32) follows from L + Lc < 2^30.  A column whose shifts are not
+// finite, exceed 2^29 rows or need more than SDP_COL_SHIFT_ROWS rows marks all its nodes: they evaluate
+// every control the long way, like a node with a NaN.
+// The second pass is unchanged (sdp_col_expected_cost with the position located per perturbation point).
+// In 8-byte reals the radius is now B' -- of the order of h^2 V'' / 16 for a smooth cost-to-go -- and no
+// longer 1e-13: two or three controls around the optimum survive, hence SDP_COL_FILTER_TOP2.
+
+// the shifts of the perturbation points for the column at x[1..] into the tables of parity `par`
+// (threads `first` ..; sh_k[par] was reset a barrier ago)
+SDP_DEV void sdp_col_phase_shift(const SdpSweepArgs &a, SdpColLds &m, const SdpLeadAxis &l, const sdp_real *x,
+                                 sdp_real t, int par, int first = 0)
+{
+    if ((int)threadIdx.x < first) return;
+    const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
+    const sdp_real *__restrict__ p = (const sdp_real *)a.proba;
+    for (int w = (int)threadIdx.x - first; w < SDP_COL_W; w += (int)blockDim.x - first) {
+        sdp_real b = sdp_model_lead_b(x, wgrid[w], t);
+        if (SDP_COL_SHIFT_SIGN < 0) b = -b;
+        const sdp_real pb = sdp_div_span<sdp_real>(b, l.span, l.rspan, l.pow2) * l.nm1;
+        const bool ok = fabs(pb) < (sdp_real)536870912.0;            // (false for a NaN)
+        const sdp_real fl = ok ? floor(pb) : (sdp_real)0;
+        const sdp_real f = ok ? pb - fl : (sdp_real)0;                // exact, in [0, 1)
+        const int q = (int)fl;
+        m.sh_q[par][w] = q;
+        m.sh_f[par][w] = f;
+        m.sh_c[par][w] = fabs(p[w]) * (f * ((sdp_real)1 - f));
+        atomicMax(&m.sh_k[par][0], q);
+        atomicMax(&m.sh_k[par][1], -q);
+        if (!ok) atomicMax(&m.sh_k[par][2], 1);
+    }
+}
+SDP_DEV void sdp_col_shift_reset(SdpColLds &m, int par)
+{
+    m.sh_k[par][0] = INT_MIN;
+    m.sh_k[par][1] = INT_MIN;
+    m.sh_k[par][2] = 0;
+}
+// what the first pass needs of the lattice of parity `par` (after the barrier that follows sdp_col_phase_shift)
+struct SdpColShiftCol {
+    int kmin, rows;     // first whole position, number of positions
+    bool ok;            // usable (else every node of the unit takes the long way)
+    sdp_real lc, es;    // Lc and Es of the bound
+};
+SDP_DEV void sdp_col_shift_col(const SdpColLds &m, const SdpLeadAxis &l, int par, SdpColShiftCol &c)
+{
+    const int flmax = __builtin_amdgcn_readfirstlane(m.sh_k[par][0]);
+    const int nflmin = __builtin_amdgcn_readfirstlane(m.sh_k[par][1]);
+    const int flag = __builtin_amdgcn_readfirstlane(m.sh_k[par][2]);
+    c.kmin = -(flmax + 1);
+    c.rows = SDP_COL_N0 + flmax + nflmin + 1;
+    c.ok = flag == 0 && c.rows <= SDP_COL_SHIFT_ROWS && c.rows >= 2 && SDP_COL_N0 >= 3;
+    const sdp_real pbmax = (sdp_real)(max(abs(flmax), abs(nflmin)) + 1);
+    const sdp_real p0 = fabs(l.smin) * (l.nm1 / fabs(l.span));
+    c.lc = (sdp_real)c.rows + (sdp_real)abs(c.kmin) + pbmax + p0 * (sdp_real)1.001 + (sdp_real)(SDP_COL_N0 + 1);
+    c.es = (sdp_real)(1 + 2 * (flmax + nflmin + 2));
+    if (!(c.lc < (sdp_real)1073741824.0)) c.ok = false;              // (a NaN or an infinity of p0)
+}
+
+// after phase A (and a barrier): the table reduced over w on the shifted lattice, one thread per
+// position: ad[2 i] = A'[kmin + i], ad[2 i + 1] = B'[kmin + i] (the cell above it); dcol as in the lean pass
+SDP_DEV void sdp_col_shift_reduce(const SdpSweepArgs &a, SdpColLds &m, const SdpColFilter &f,
+                                  const SdpColShiftCol &c, int parity, int par)
+{
+    constexpr int N0 = SDP_COL_N0;
+    if (!c.ok) return;
+    const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
+    sdp_real dmax = (sdp_real)0;
+    for (int ki = threadIdx.x; ki < c.rows; ki += blockDim.x) {
+        const int k = c.kmin + ki;
+        sdp_real acc = (sdp_real)0, bnd = (sdp_real)0, big = (sdp_real)0;
+#pragma unroll 4
+        for (int w = 0; w < SDP_COL_W; ++w) {
+            const int j = k + m.sh_q[par][w];
+            const int q = max(min(j, N0 - 2), 0);
+            const sdp_real lam = (sdp_real)(j - q) + m.sh_f[par][w];
+            const sdp_real *row = m.T + w * N0 + q;
+            const sdp_real t0 = row[0], t1 = row[1], t2 = row[q + 2 < N0 ? 2 : 1];
+            acc = fma((sdp_real)p[w], fma(lam, t1 - t0, t0), acc);
+            const sdp_real d2 = (t2 - t1) - (t1 - t0);
+            const bool kink = (unsigned)j <= (unsigned)(N0 - 3);     // a kink inside the cell: row j+1 is an inner row
+            bnd = fma(m.sh_c[par][w], kink ? fabs(d2) : (sdp_real)0, bnd);
+            big = sdp_vmax_abs(sdp_vmax_abs(big, t0), t1);
+        }
+        m.ad[2 * ki] = acc;
+        m.ad[2 * ki + 1] = bnd;
+        dmax = sdp_vmax(dmax, acc == acc ? f.pcap * big + f.floor : (sdp_real)INFINITY);
+    }
+    dmax = sdp_wave_max(dmax);
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(&m.dcol[parity], (unsigned long long)__double_as_longlong((double)dmax));
+}
+#endif  // SDP_COL_SHIFT
+
 // F(u) and S^(u) of one control (x0' cell and cost exactly as sdp_col_expected_cost computes them).
 // AXIS, a template argument so that the loop of the first pass carries no branch: 0 the true
 // division of pyx:75; 1 a power-of-two span (product with the reciprocal: sdp_div_span); 2 the
@@ -1424,15 +1576,29 @@ SDP_DEV void sdp_col_cost_expect(const SdpColFilter &f, const sdp_real *x, const
 
 template <int AXIS>
 SDP_DEV void sdp_col_lean_core(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
-                               sdp_real xn0, sdp_real g, sdp_real &F, sdp_real &lmax)
+                               sdp_real xn0, sdp_real g, sdp_real &F, sdp_real &lmax, sdp_real &bmax)
 {
     const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
     const sdp_real p = sn * l.nm1;
+#if SDP_COL_SHIFT
+    // shifted lattice: xn0 = a(x, u), `l` = the lattice (koff = its first position, ordm2 = its rows - 2),
+    // A = (A', B') pairs; pk >= 0 inside the lattice, so the truncation is the floor there, and below it
+    // the clamp takes the first cell, which extrapolates G exactly (see sdp_col_shift_reduce)
+    const sdp_real pk = p - l.koff;
+    int q0 = (int)pk;
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));
+    const sdp_real lam0 = pk - (sdp_real)q0;
+    lmax = sdp_vmax_abs(lmax, lam0);
+    const sdp_real a0 = A[2 * q0], a1 = A[2 * q0 + 2];
+    bmax = sdp_vmax(bmax, A[2 * q0 + 1]);
+#else
+    (void)bmax;
     int q0 = (int)p;                                        // (saturating conversion; NaN -> 0)
     asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // max(min(q0, ordm2), 0): ordm2 >= 0
     const sdp_real lam0 = p - (sdp_real)q0;
     lmax = sdp_vmax_abs(lmax, lam0);
     const sdp_real a0 = A[q0], a1 = A[q0 + 1];
+#endif
 #if SDP_COST_HAS_W
     F = g + fma(lam0, a1 - a0, a0);                          // (g: the expectation G of the cost)
 #else
@@ -1443,9 +1609,13 @@ SDP_DEV void sdp_col_lean_core(const sdp_real *A, const SdpColFilter &f, const S
 template <int AXIS>
 SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const SdpLeadAxis &l,
                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &F, sdp_real &lmax,
-                               sdp_real &gmax)
+                               sdp_real &gmax, sdp_real &bmax)
 {
+#if SDP_COL_SHIFT
+    const sdp_real xn0 = sdp_model_lead_a(x, u, t);
+#else
     const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+#endif
 #if SDP_COST_HAS_W
     sdp_real g, gabs;
     sdp_col_cost_expect<false>(f, x, u, t, g, gabs);
@@ -1454,21 +1624,21 @@ SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const S
     (void)gmax;
     const sdp_real g = sdp_model_cost(x, u, (sdp_real)0, t);
 #endif
-    sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax);
+    sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax, bmax);
 }
 #if SDP_COL_UTAB
 // the same with the column-uniform parts of x0' and of the cost read from the control table
 template <int AXIS>
 SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f,
                                    const SdpLeadAxis &l, const sdp_real *x, int ci, sdp_real t,
-                                   sdp_real &F, sdp_real &lmax)
+                                   sdp_real &F, sdp_real &lmax, sdp_real &bmax)
 {
     sdp_real tab[SDP_COL_UTAB];
 #pragma unroll
     for (int k = 0; k < SDP_COL_UTAB; ++k) tab[k] = utab[ci * SDP_COL_UTAB + k];
     const sdp_real xn0 = sdp_model_lead_tab(x, tab, t);
     const sdp_real g = sdp_model_cost_tab(x, tab, t);
-    sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax);
+    sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax, bmax);
 }
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
 SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0)
@@ -1562,10 +1732,11 @@ SDP_DEV void sdp_col_wide_eval_tab(const sdp_real *ad, const sdp_real *utab, con
 #ifndef SDP_COL_FILTER_TOP2
 #define SDP_COL_FILTER_TOP2 -1   // -1: for 4-byte reals only
 #endif
-constexpr bool SDP_COL_TOP2 = SDP_COL_FILTER_TOP2 < 0 ? sizeof(sdp_real) == 4 : SDP_COL_FILTER_TOP2 != 0;
+constexpr bool SDP_COL_TOP2 = SDP_COL_FILTER_TOP2 < 0 ? (sizeof(sdp_real) == 4 || SDP_COL_SHIFT) : SDP_COL_FILTER_TOP2 != 0;
 struct SdpColBounds {
     sdp_fkey f1, f2, f3, s_sum;      // (wide: s_sum = the sum of the |F|, which catches NaN / infinite values)
     sdp_real s_max, p_max;           // (wide: s_max = the largest bound of a control)
+    sdp_real b_max;                  // shifted lattice: the largest B' of the cells the controls fall in
     int i1, i2;
 };
 // 8-byte reals: the SUM of the S^ serves as the node's bound (no running maximum; a radius
@@ -1605,7 +1776,7 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
                 F = (sdp_fkey)Fw;
             } else {
                 sdp_real Fl;
-                sdp_col_lean_eval_tab<AXIS>(ad_tab, utab, f, l, x, ci, t, Fl, b.p_max);
+                sdp_col_lean_eval_tab<AXIS>(ad_tab, utab, f, l, x, ci, t, Fl, b.p_max, b.b_max);
                 F = (sdp_fkey)Fl;
             }
             b.s_sum = b.s_sum + fabs(F);
@@ -1635,7 +1806,7 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
         }
         if (SDP_COL_LEAN_ON) {
             // (p_max holds the largest |lam0|, s_sum the sum of the |F|: see sdp_col_lean_eval)
-            sdp_col_lean_eval<AXIS>(ad_tab, f, l, x, u, t, F, b.p_max, b.s_max);
+            sdp_col_lean_eval<AXIS>(ad_tab, f, l, x, u, t, F, b.p_max, b.s_max, b.b_max);
             b.s_sum = b.s_sum + fabs(F);
         } else {
             sdp_col_filter_eval<AXIS>(ad_tab, f, l, x, u, t, F, S, b.p_max);
@@ -1686,6 +1857,10 @@ SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
     b.s_sum = b.s_sum + o_sum;
     const sdp_real o_p = sdp_shfl_xor(b.p_max, d);
     b.p_max = o_p > b.p_max ? o_p : b.p_max;
+    if (SDP_COL_SHIFT) {
+        const sdp_real o_b = sdp_shfl_xor(b.b_max, d);
+        b.b_max = o_b > b.b_max ? o_b : b.b_max;
+    }
 }
 
 
@@ -1700,10 +1875,20 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
                                   const SdpColFilter &filt, int axis_mode, const sdp_real *ad_tab,
                                   const sdp_real *utab, sdp_real dcol,
                                   int64_t col, int i_lo, int i_hi, int wave, int waves,
-                                  sdp_real *x, sdp_real t, SdpColDiag &diag)
+                                  sdp_real *x, sdp_real t, SdpColDiag &diag
+#if SDP_COL_SHIFT
+                                  , const SdpColShiftCol &shc
+#endif
+                                  )
 {
     constexpr int N0 = SDP_COL_N0;
     const int lane = threadIdx.x & 63;
+    // the axis the FIRST pass locates its positions on: axis 0, or the shifted lattice of this column
+    SdpLeadAxis lead1 = lead;
+#if SDP_COL_SHIFT
+    lead1.koff = (sdp_real)shc.kmin;
+    lead1.ordm2 = shc.ok ? shc.rows - 2 : 0;
+#endif
     const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
     (void)diag;
     const int n_nodes = i_hi - i_lo;
@@ -1730,20 +1915,20 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         SDP_COL_MARK(diag.m1);
         SdpColBounds bd;
         bd.f1 = bd.f2 = bd.f3 = INFINITY;
-        bd.s_max = bd.s_sum = bd.p_max = (sdp_real)0;
+        bd.s_max = bd.s_sum = bd.p_max = bd.b_max = (sdp_real)0;
         bd.i1 = bd.i2 = INT_MAX;
         const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
 #ifdef SDP_DIAG_NO_PASS1
         if (t == (sdp_real)123.456)
 #endif
         if (__all(plain)) {
-            if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else sdp_col_filter_pass1<true, 0>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(ad_tab, utab, filt, lead1, box, x, t, c_lo, c_hi, bd);
+            else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(ad_tab, utab, filt, lead1, box, x, t, c_lo, c_hi, bd);
+            else sdp_col_filter_pass1<true, 0>(ad_tab, utab, filt, lead1, box, x, t, c_lo, c_hi, bd);
         } else {
-            if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
-            else sdp_col_filter_pass1<false, 0>(ad_tab, utab, filt, lead, box, x, t, c_lo, c_hi, bd);
+            if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(ad_tab, utab, filt, lead1, box, x, t, c_lo, c_hi, bd);
+            else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(ad_tab, utab, filt, lead1, box, x, t, c_lo, c_hi, bd);
+            else sdp_col_filter_pass1<false, 0>(ad_tab, utab, filt, lead1, box, x, t, c_lo, c_hi, bd);
         }
         for (int d = npw; d < 64; d <<= 1) sdp_col_bounds_merge(bd, d);
         // pass 2: the reference's operations on the survivors
@@ -1762,15 +1947,25 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
                   !(((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol < SDP_COL_FILTER_LIMIT);
             radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)bd.s_max + (sdp_fkey)filt.floor);
         } else if (SDP_COL_LEAN_ON) {
+#if SDP_COL_SHIFT
+            // H D, H = (1 + 2 L + 2 Lc) (2 + Es): see sdp_col_shift_reduce
+            const sdp_real h_cap = (((sdp_real)1 + (sdp_real)2 * (bd.p_max + shc.lc)) * ((sdp_real)2 + shc.es)) * dcol;
+#else
             const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
+#endif
 #if SDP_COST_HAS_W
             // (the largest Gabs of the node's controls stands where |g| Pcap stood; a NaN shows in the sum of the |F|)
             const sdp_real s_node = bd.s_sum == bd.s_sum ? (sdp_real)bd.s_max + h_cap : (sdp_real)NAN;
 #else
             const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
 #endif
+#if SDP_COL_SHIFT
+            bad = !filt.ok || !shc.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max + shc.lc < (sdp_real)1073741824.0);
+            radius = fma(filt.cu, s_node, (sdp_real)(SDP_COL_FILTER_SCALE) * bd.b_max);
+#else
             bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
             radius = filt.cu * s_node;
+#endif
         } else {
             bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)2147483648.0);
             radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? (sdp_real)bd.s_sum : bd.s_max);
@@ -1805,9 +2000,9 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
                 sdp_real F, S;
                 sdp_real pm = (sdp_real)0;
                 if (SDP_COL_LEAN_ON) {
-                    sdp_real gm = (sdp_real)0;
-                    if (lead.pow2) sdp_col_lean_eval<1>(ad_tab, filt, lead, x, u[0], t, F, pm, gm);
-                    else sdp_col_lean_eval<0>(ad_tab, filt, lead, x, u[0], t, F, pm, gm);
+                    sdp_real gm = (sdp_real)0, bm = (sdp_real)0;
+                    if (lead.pow2) sdp_col_lean_eval<1>(ad_tab, filt, lead1, x, u[0], t, F, pm, gm, bm);
+                    else sdp_col_lean_eval<0>(ad_tab, filt, lead1, x, u[0], t, F, pm, gm, bm);
                 } else if (lead.pow2) sdp_col_filter_eval<1>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
                 else sdp_col_filter_eval<0>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
                 cand = !(F - radius > m_hi);
@@ -1870,6 +2065,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
+#if SDP_COL_SHIFT
+    if (threadIdx.x < 2) sdp_col_shift_reset(sdp_lds, threadIdx.x);
+#endif
     int parity = 0;
 #if SDP_STAMP == 2     // diagnostic: shader clocks thread 0 spends in phases W, A, B (+ idle at barriers)
     unsigned long long tw = 0, ta = 0, tb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, tstart = __builtin_amdgcn_s_memtime();
@@ -1898,6 +2096,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_UTAB
         sdp_col_phase_u(a, sdp_lds.utab[0], xn, t);
 #endif
+#if SDP_COL_SHIFT
+        sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
+#endif
     }
     while (unit < u_end) {
         int64_t next_unit;
@@ -1920,6 +2121,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         SDP_COL_MARK(t1);
         int nx = 0;                                        // the next unit: claimed here, the atomic's
         if (wave == waves - 1 && lane == 0) nx = (int)atomicAdd(claim, 1u);   // round trip hides under phase A
+#if SDP_COL_SHIFT
+        if (threadIdx.x == 0) sdp_col_shift_reset(sdp_lds, upar ^ 1);    // (its readers left at the barrier above)
+#endif
         sdp_col_phase_a<false>(a, tg, s);
         __syncthreads();
         SDP_COL_MARK(t2);
@@ -1932,6 +2136,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
 #if SDP_COL_UTAB
                 sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, (int)blockDim.x - 64);
+#endif
+#if SDP_COL_SHIFT
+                sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, (int)blockDim.x - 64);
 #endif
             }
         }
@@ -1954,7 +2161,16 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 
 #if SDP_COL_FILTER
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);        // (see phase B)
+#if SDP_COL_SHIFT
+        SdpColShiftCol shc;
+        sdp_col_shift_col(sdp_lds, lead, upar, shc);
+        sdp_col_shift_reduce(a, sdp_lds, filt, shc, parity, upar);
+#else
         sdp_col_filter_reduce(a, sdp_lds, filt, parity);
+#endif
+#if SDP_STAMP == 2
+        { unsigned long long r1 = __builtin_amdgcn_s_memtime(); diag.n_slow += r1 - t2; }
+#endif
         __syncthreads();
         const sdp_real dcol = sdp_col_filter_dcol(sdp_lds, parity);
         parity ^= 1;
@@ -1964,7 +2180,11 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         tr += m0 - t2;
 #endif
         // ---- phase B, filtered: sdp_col_filter_nodes
-        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, sdp_lds.utab[upar], dcol, col, i_lo, i_hi, wave, waves, x, t, diag);
+        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, sdp_lds.utab[upar], dcol, col, i_lo, i_hi, wave, waves, x, t, diag
+#if SDP_COL_SHIFT
+                             , shc
+#endif
+                             );
         upar ^= 1;
 #else
         // ---- phase B.  One LANE per node (64 consecutive nodes of the column
@@ -2072,6 +2292,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         a.stamps[(gridDim.x + blockIdx.x) * 4 + 0] = tr;
         a.stamps[(gridDim.x + blockIdx.x) * 4 + 1] = diag.tp1;
         a.stamps[(gridDim.x + blockIdx.x) * 4 + 2] = diag.tp2;
+        a.stamps[(2 * gridDim.x + blockIdx.x) * 4 + 0] = diag.n_slow;
 #endif
     }
 #else
@@ -2406,7 +2627,7 @@ __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
     (SDP_COL_FILTER ? SDP_META_F_FILTER : 0) | (SDP_COL_ROWS < SDP_COL_N0 ? SDP_META_F_WINDOW : 0) |
         (SDP_TRAIL_HAS_U ? SDP_META_F_TRAIL_HAS_U : 0) | (SDP_COL_WPAIR ? SDP_META_F_WPAIR : 0) |
 #if SDP_COL_FILTER
-        (SDP_COL_LEAN_ON ? SDP_META_F_LEAN : 0) |
+        (SDP_COL_LEAN_ON ? SDP_META_F_LEAN : 0) | (SDP_COL_SHIFT ? SDP_META_F_SHIFT : 0) |
 #endif
         ((SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? SDP_META_F_CLAIMS : 0),
     SDP_COL_FILTER ? SDP_COL_UTAB : 0, SDP_COL_FILTER ? SDP_COL_UTAB_N : 0, SDP_COL_THREADS, SDP_COL_ROWS,

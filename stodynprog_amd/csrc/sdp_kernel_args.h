@@ -26,7 +26,8 @@ enum {
 enum {
     SDP_META_F_FILTER = 1, SDP_META_F_WINDOW = 2, SDP_META_F_TRAIL_HAS_U = 4, SDP_META_F_STAGED = 8,
     SDP_META_F_WPAIR = 16, SDP_META_F_LEAN = 32,
-    SDP_META_F_CLAIMS = 64  // the sweep kernel's workgroups claim their units (persistent: a bounded grid)
+    SDP_META_F_CLAIMS = 64, // the sweep kernel's workgroups claim their units (persistent: a bounded grid)
+    SDP_META_F_SHIFT = 128  // certified filter on the shifted lattice (a perturbation that reaches x0')
 };
 #define SDP_MAXU 4   // control variables per system
 

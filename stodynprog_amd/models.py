@@ -91,6 +91,36 @@ def inventory(api=None, h=0.5, p=3, c=1):
     return shop, solver
 
 
+def inventory_markov(api=None, n_x=128, n_d=32, n_w=9, h=0.5, p=3., c=1., x_max=24., order_max=10.,
+                     order_step=0.25):
+    """The shop inventory next to an exogenous demand level (two state variables): the stock follows
+    `x + u - demand` as in the reference's example (doc/example_inventory.py:31-33, cost :59-65), the
+    demand of a period is a mean-reverting level plus noise.  The perturbation reaches the stock, not
+    the cost: the column kernel filters it on the shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)."""
+    SysDescription, DPSolver = _classes(api)
+    shop = SysDescription((2, 1, 1), name='Shop inventory, Markov demand')
+    mean, corr, sigma = 2.0, 0.7, 0.6
+
+    def shop_dyn(x, d, u, w):
+        return (x + u - (d + w), mean + corr * (d - mean) + 0.5 * w)
+    shop.dyn = shop_dyn
+    shop.perturb_laws = [NormalLaw(0, sigma)]
+
+    def order_box(x, d):
+        return ((0., order_max),)
+    shop.control_box = order_box
+
+    def shop_cost(x, d, u, w):
+        return np.where(x > 0, x * h, -x * p) + u * c
+    shop.cost = shop_cost
+
+    solver = DPSolver(shop)
+    solver.discretize_state(-8., x_max, n_x, 0., 4., n_d)
+    solver.discretize_perturb(-3 * sigma, 3 * sigma, n_w)
+    solver.control_steps = (order_step,)
+    return shop, solver
+
+
 # ----------------------------------------------------------------------------
 # 2. Energy storage facing an AR(1) mismatch (config 2)
 # ----------------------------------------------------------------------------
@@ -252,7 +282,9 @@ SYNTH_PAR = [SYNTH[k] for k in ('b', 'm1', 'a11', 'a12', 'm2', 'a21', 'a22', 'c'
                                 'k1', 'k0', 'eps', 'kx')]
 
 
-def synthetic3d(api=None, N=256, n_w=32):
+def synthetic3d(api=None, N=256, n_w=32, stock_noise=0.0):
+    """(`stock_noise` != 0: the perturbation also reaches the stock, x0' = (x0 + b u) - stock_noise w --
+    the shape of the reference's inventory example, doc/example_inventory.py:31-33, at benchmark size)"""
     SysDescription, DPSolver = _classes(api)
     p = SYNTH
     b, a11, a12, a21, a22, c = p['b'], p['a11'], p['a12'], p['a21'], p['a22'], p['c']
@@ -261,6 +293,8 @@ def synthetic3d(api=None, N=256, n_w=32):
 
     def synth_dyn(x0, x1, x2, u, w):
         x0n = x0 + b * u
+        if stock_noise:
+            x0n = x0n - stock_noise * w
         x1n = m1 + a11 * x1 + a12 * x2 + w
         x2n = m2 + a21 * x1 + a22 * x2 + c * w
         return (x0n, x1n, x2n)

@@ -600,10 +600,12 @@ class DPSolver(object):
         if self.kernel not in ('auto', 'generic', 'column', 'staged'):
             raise ValueError("kernel must be 'auto', 'column', 'staged' or 'generic'")
         may_filter = (getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'
-                      and codegen.column_filter_applies(model))
+                      and codegen.column_filter_applies(model, dtype=dt, table=(shape[0], W, len(shape))))
         column = (self.kernel in ('auto', 'column') and model.storage_separable and
                   codegen.column_config(shape[0], W, len(shape), dt,
-                                        codegen.use_wpair(model, dt), may_filter) is not None)
+                                        codegen.use_wpair(model, dt), may_filter,
+                                        shift=may_filter and codegen.column_shift_applies(model, dt),
+                                        extra_bytes=2 * codegen.UTAB_MAX_BYTES) is not None)
         # trailing next states that depend on the control but not on x0: the nodes of a
         # column still share a table, control by control, provided they share their control
         # values (box independent of x0) -- csrc/sdp_column_kernel.h, SDP_TRAIL_HAS_U
@@ -644,7 +646,8 @@ class DPSolver(object):
                                                0.0 if box_t is None else float(box_t))
                 self._cache[key] = staged
         filtered = bool(column and getattr(self, 'certified_filter', True) and codegen.column_filter_applies(
-            model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None))
+            model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None, dtype=dt,
+            table=(shape[0], W, len(shape))))
         utab = None
         if filtered:
             fr = codegen.control_table_plan(model, dt, bp['per_node'], bp['max_u'])
@@ -819,6 +822,9 @@ class DPSolver(object):
                                      if plan['window'] else None),
                          table_per_control=bool(plan['per_control']),
                          certified_filter=bool(plan.get('filtered')),
+                         # 'shifted lattice': the perturbation reaches x0' through a final sum (SDP_COL_SHIFT)
+                         filter_form=(None if not plan.get('filtered') else
+                                      ('shifted lattice' if '#define SDP_COL_SHIFT 1' in plan['source'] else 'reduced table')),
                          arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),

@@ -552,8 +552,9 @@ class TracedModel(object):
             stack.extend(a for a in n.args if a.id not in stop_ids)
         return [n for n in self.graph.nodes if n.id in seen]
 
-    def control_uniform_frontier(self):
-        """Sub-expressions of x0' and of the cost that depend on the control (and possibly on
+    def control_uniform_frontier(self, lead=None):
+        """(`lead`: the node standing for x0' -- its w-free part a of `lead_split` when the
+        perturbation reaches x0'.)  Sub-expressions of x0' and of the cost that depend on the control (and possibly on
         x_1.., t) but neither on the leading state variable x0 nor on w -- so they take the same
         value at every node of a column along axis 0 -- and feed an expression that does depend on
         x0 (or are x0' / the cost themselves).  With a control lattice shared by the nodes of a
@@ -561,7 +562,7 @@ class TracedModel(object):
         control): the same operations on the same operands, hence the same bits
         (csrc/sdp_column_kernel.h, SDP_COL_UTAB).  Returns the nodes in recording order, or None
         when there is none or a boolean is among them."""
-        outs = [self.x_next[0], self.cost]
+        outs = [lead if lead is not None else self.x_next[0], self.cost]
         nodes = self.slice_nodes(outs)
 
         def uniform(n):
@@ -659,6 +660,29 @@ class TracedModel(object):
     @property
     def cost_depends_on_w(self):
         return bool(self.cost.deps & DEP_W)
+
+    def lead_split(self):
+        """x0' = a(x, u[, t]) + b(x_1.., w[, t])  or  a - b, with the sum as the LAST operation of the
+        recorded expression (`x + u - w` of the inventory example, reference
+        doc/example_inventory.py:31-33): returns (a, b, sign) with sign = +1 / -1, or None.
+        The perturbation then moves the axis-0 position of every control of a column by the same
+        amounts, so the expectation over w can still be taken on the table before the controls
+        are looked at (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)."""
+        top = self.x_next[0]
+        if top.op not in ('add', 'sub') or not (top.deps & DEP_W):
+            return None
+
+        def is_a(n):
+            return (n.deps & DEP_W) == 0
+
+        def is_b(n):
+            return (n.deps & (DEP_X | DEP_U)) == 0 and (n.deps & DEP_W) != 0
+        l, r = top.args
+        if is_a(l) and is_b(r):
+            return l, r, (1 if top.op == 'add' else -1)
+        if top.op == 'add' and is_b(l) and is_a(r):
+            return r, l, 1
+        return None
 
 
 def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True,

@@ -1,0 +1,192 @@
+"""Certified filter on the SHIFTED lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT): a perturbation
+that reaches the stock through a final sum, x0' = a(x, u) +- b(x_1.., w) -- the reference's inventory
+example `x + u - w` (doc/example_inventory.py:31-33) next to an exogenous axis.  The first pass reads
+G(s) = sum_w p_w T_w(s + shift_w), tabulated at the whole positions of a lattice moved by the
+perturbation points, with a certified bound on what the interpolation between them leaves out; the
+survivors take the reference's operations.  The claim under test is the one of test_gpu_filter.py:
+J, policy and policy index are BIT-IDENTICAL to the kernel that evaluates every control the long way
+and to the numpy oracle -- smooth and rough cost-to-go arrays, stocks that leave the grid, shifts wider
+than the lattice held in LDS (the column then takes the long way), special values, any larger radius."""
+import numpy as np
+import pytest
+
+from stodynprog_amd import models, SysDescription, DPSolver
+from stodynprog_amd.models import NormalLaw
+
+pytestmark = pytest.mark.gpu
+
+
+def _sweep(make, filt, V, kernel='auto', sweeps=1):
+    _, s = make()
+    s.kernel = kernel
+    s.certified_filter = filt
+    J = np.asarray(V, dtype=float)
+    with np.errstate(all='ignore'):
+        for _ in range(sweeps):
+            J, pol = s.value_iteration(J, report_time=False)
+    return J, pol, s.last_policy_index, s
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0], equal_nan=True), 'J differs'
+    assert np.array_equal(a[2], b[2]), 'policy index differs'
+    assert np.array_equal(a[1], b[1], equal_nan=True), 'policy differs'
+
+
+def _shop(n_x=96, n_d=12, n_w=7, w_gain=1.0, x_range=(-8., 24.), box_on_state=False, sign=-1, cost_w=False,
+          order_step=0.25):
+    """inventory next to a demand level: x' = (x + u) -+ (d + w_gain w)"""
+    sysd = SysDescription((2, 1, 1), name='shop')
+    if sign < 0:
+        sysd.dyn = lambda x, d, u, w: (x + u - (d + w_gain * w), 2.0 + 0.7 * (d - 2.0) + 0.5 * w)
+    else:
+        sysd.dyn = lambda x, d, u, w: ((0.25 * d + w_gain * w) + (x + u), 2.0 + 0.7 * (d - 2.0) + 0.5 * w)
+    if cost_w:
+        sysd.cost = lambda x, d, u, w: np.where(x > 0, x * 0.5, -x * 3.0) + u * (1.0 + 0.1 * w)
+    else:
+        sysd.cost = lambda x, d, u, w: np.where(x > 0, x * 0.5, -x * 3.0) + u * 1.0
+    if box_on_state:
+        sysd.control_box = lambda x, d: ((0., 6. + 0.1 * x + d),)
+    else:
+        sysd.control_box = lambda x, d: ((0., 10.),)
+    sysd.perturb_laws = [NormalLaw(0, 0.6)]
+    s = DPSolver(sysd)
+    s.discretize_state(x_range[0], x_range[1], n_x, 0., 4., n_d)
+    s.discretize_perturb(-1.8, 1.8, n_w)
+    s.control_steps = (order_step,)
+    return sysd, s
+
+
+def _smooth(s):
+    x = np.asarray(s.state_grid[0])[:, None]
+    d = np.asarray(s.state_grid[1])[None, :]
+    return 0.05 * (x - 3.0) ** 2 + np.where(x > 0, 0.5 * x, -3.0 * x) + 0.3 * np.cos(d) * (1 + 0.01 * x)
+
+
+def test_the_plan_and_the_generated_halves(gpu):
+    _, s = _shop()
+    plan = s._kernel_plan()
+    assert plan['column'] and plan['filtered']
+    src = plan['source']
+    assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_SHIFT_SIGN -1' in src
+    assert 'sdp_model_lead_a' in src and 'sdp_model_lead_b' in src
+    s.dtype = np.dtype('float32')                 # 4-byte reals: every control the long way
+    assert not s._kernel_plan()['filtered']
+
+
+@pytest.mark.parametrize('sign', [-1, 1])
+@pytest.mark.parametrize('box_on_state', [False, True])
+def test_inventory_with_markov_demand_same_bits(gpu, sign, box_on_state):
+    make = lambda: _shop(sign=sign, box_on_state=box_on_state)
+    V = _smooth(make()[1])
+    on, off = _sweep(make, True, V), _sweep(make, False, V)
+    assert on[3].backend_info['filter_form'] == 'shifted lattice' and not off[3].backend_info['certified_filter']
+    assert on[3].backend_info['kernel'] == off[3].backend_info['kernel'] == 'column'
+    _same(on, off)
+    _same(on, _sweep(make, True, V, kernel='generic'))
+    # a rough cost-to-go: large second differences, many survivors
+    V = np.random.default_rng(5).standard_normal(V.shape)
+    _same(_sweep(make, True, V), _sweep(make, False, V))
+
+
+def test_against_the_numpy_oracle_over_a_chain_of_sweeps(gpu):
+    from oracle import vi_numpy
+    make = lambda: models.inventory_markov(n_x=64, n_d=10, n_w=7)
+    _, s = make()
+    V = np.zeros(s._state_grid_shape)
+    on = _sweep(make, True, V, sweeps=4)
+    assert on[3].backend_info['filter_form'] == 'shifted lattice'
+    J = V
+    spec = vi_numpy.Spec.from_solver(s)
+    for _ in range(4):
+        J, pol, idx, _ = vi_numpy.value_iteration(spec, J)
+    assert np.array_equal(on[0], J) and np.array_equal(on[2], idx)
+
+
+@pytest.mark.parametrize('case', ['leaves_the_grid', 'wide_shifts', 'shifts_beyond_the_lattice', 'coarse_axis'])
+def test_edges_of_the_lattice(gpu, case):
+    if case == 'leaves_the_grid':                # orders push the stock far above the axis, demand below it
+        make = lambda: _shop(x_range=(-2., 6.))
+    elif case == 'wide_shifts':                  # shifts spread over ~60 % of the axis
+        make = lambda: _shop(w_gain=5.0)
+    elif case == 'shifts_beyond_the_lattice':    # spread > the axis: more rows than LDS holds -> the long way
+        make = lambda: _shop(w_gain=12.0)
+    else:                                        # three rows: one inner row
+        make = lambda: _shop(n_x=3)
+    V = _smooth(make()[1])
+    on, off = _sweep(make, True, V), _sweep(make, False, V)
+    assert on[3].backend_info['filter_form'] == 'shifted lattice'
+    _same(on, off)
+    V = np.random.default_rng(9).standard_normal(V.shape)
+    _same(_sweep(make, True, V), _sweep(make, False, V))
+
+
+@pytest.mark.parametrize('case', ['nan', 'inf', '-inf', 'huge', 'subnormal', 'mixed_scales', 'constant'])
+def test_special_values(gpu, case):
+    make = lambda: _shop()
+    shape = make()[1]._state_grid_shape
+    V = np.random.default_rng(5).standard_normal(shape)
+    if case == 'nan':
+        V[10:14, 2:5] = np.nan
+    elif case == 'inf':
+        V[:8, :] = np.inf                        # a forbidden region (deep backlog)
+    elif case == '-inf':
+        V[::7, 3] = -np.inf
+    elif case == 'huge':
+        V *= 1e302
+    elif case == 'subnormal':
+        V *= 1e-310
+    elif case == 'mixed_scales':
+        V[30:50] *= 1e12
+    else:
+        V[:] = 2.5                               # exact ties wherever the cost does not decide
+    _same(_sweep(make, True, V), _sweep(make, False, V))
+
+
+def test_a_cost_that_sees_the_perturbation_too(gpu):
+    make = lambda: _shop(cost_w=True)
+    V = _smooth(make()[1])
+    on, off = _sweep(make, True, V), _sweep(make, False, V)
+    assert on[3].backend_info['filter_form'] == 'shifted lattice'
+    assert 'SDP_COST_HAS_W 1' in on[3]._kernel_plan()['source']
+    _same(on, off)
+
+
+def test_weights_that_do_not_sum_to_one_and_tiny_weights(gpu):
+    for factor in (3.7, 1e-30):
+        def make():
+            sysd, s = _shop()
+            s.perturb_proba = [np.asarray(s.perturb_proba[0]) * factor]
+            return sysd, s
+        V = _smooth(make()[1]) * (1e300 if factor < 1 else 1.0)
+        _same(_sweep(make, True, V), _sweep(make, False, V))
+
+
+@pytest.mark.parametrize('scale', ['1e3', '1e9', '1e18'])
+def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
+    make = lambda: _shop()
+    V = _smooth(make()[1])
+    ref = _sweep(make, False, V)
+    monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+    on = _sweep(make, True, V)
+    assert 'SDP_COL_FILTER_SCALE' in on[3]._kernel_plan()['source']
+    _same(on, ref)
+
+
+def test_a_radius_far_too_small_is_noticed(gpu, monkeypatch):
+    """the interpolation bound B' is what decides here: without it (radius x 1e-6) the first pass
+    trusts the chord where the kinks of the cost-to-go matter, and picks other controls"""
+    make = lambda: _shop(order_step=0.05)
+    V = np.random.default_rng(13).standard_normal(make()[1]._state_grid_shape)
+    ref = _sweep(make, False, V)
+    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '1e-6')
+    on = _sweep(make, True, V)
+    assert (on[2] != ref[2]).sum() > 0
+
+
+def test_the_benchmark_model_with_noise_in_the_stock(gpu):
+    make = lambda: models.synthetic3d(N=24, n_w=8, stock_noise=0.07)
+    V = models.synthetic3d_V0(make()[1].state_grid)
+    on, off = _sweep(make, True, V, sweeps=3), _sweep(make, False, V, sweeps=3)
+    assert on[3].backend_info['filter_form'] == 'shifted lattice'
+    _same(on, off)

@@ -1,6 +1,7 @@
 """A/B of the certified expectation-first filter of the column kernel (SdpColFilter in
 csrc/sdp_column_kernel.h): same problem with DPSolver.certified_filter on / off -- J, policy
-index bit for bit, and kernel time per sweep.  Usage: python tools/filter_ab.py [N] [dtype]"""
+index bit for bit, and kernel time per sweep.  Usage: python tools/filter_ab.py [N] [dtype]
+(SDP_STOCK_NOISE=c in the environment: the perturbation also reaches the stock, x0' = (x0 + b u) - c w)"""
 import os
 import sys
 import time
@@ -14,7 +15,7 @@ def main():
     dtype = np.dtype(sys.argv[2]) if len(sys.argv) > 2 else np.dtype('float64')
     out = {}
     for flt in (False, True):
-        sysd, s = models.synthetic3d(N=N)
+        sysd, s = models.synthetic3d(N=N, stock_noise=float(os.environ.get('SDP_STOCK_NOISE', 0)))
         s.dtype = dtype
         s.certified_filter = flt
         V0 = models.synthetic3d_V0(s.state_grid, dtype)
@@ -27,7 +28,7 @@ def main():
         pol, idx = prob.get_policy()
         out[flt] = (J, idx, kern / 10)
         print('certified_filter={}: kernel {:.3f} ms per sweep   ({})'.format(
-            flt, kern / 10, {k: s.backend_info[k] for k in ('kernel', 'certified_filter')}), flush=True)
+            flt, kern / 10, {k: s.backend_info[k] for k in ('kernel', 'certified_filter', 'filter_form')}), flush=True)
     (Ja, ia, ta), (Jb, ib, tb) = out[False], out[True]
     print('J identical: {}   index identical: {}   speed-up {:.2f}x'.format(
         np.array_equal(Ja, Jb), np.array_equal(ia, ib), ta / tb))

@@ -14,7 +14,7 @@ from stodynprog_amd import models, _native as nat
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dtype = np.dtype(sys.argv[3]) if len(sys.argv) > 3 else np.dtype('float64')
-_, s = models.synthetic3d(N=N)
+_, s = models.synthetic3d(N=N, stock_noise=float(os.environ.get('SDP_STOCK_NOISE', 0)))
 s.dtype = dtype
 prob = s._problem()
 assert s.backend_info['certified_filter']

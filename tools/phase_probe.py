@@ -23,10 +23,11 @@ st = np.zeros(65536 * 4, dtype=np.uint64)
 nat.check(nat.lib().sdp_problem_debug_stamps(prob.h, 1, st.ctypes.data_as(C.c_void_p), st.size))
 st = st.reshape(-1, 4).astype(float)
 n_wg = int((st[:, 3] > 0).sum())
+inside = st[2 * n_wg:3 * n_wg, 0]
 extra = st[n_wg:2 * n_wg]                 # filter builds: reduce, first pass, second pass of phase B
 st = st[:n_wg]
 busy = st[:, 2] > 0                       # (units are claimed in order: late workgroups find nothing left)
-st, extra = st[busy], extra[busy[:len(extra)]] if len(extra) else extra
+st, extra, inside = st[busy], extra[busy[:len(extra)]] if len(extra) else extra, inside[busy]
 tot = st[:, 3]
 print('kernel {:.3f} ms; {} workgroups; lifetime of a workgroup: median {:.3e} clk'.format(k / 5, len(st), np.median(tot)))
 for name, col in (('W (trailing cells + barrier)', 0), ('A (table build + barrier)', 1), ('B (cells, argmin, stores + barrier)', 2)):
@@ -38,3 +39,5 @@ if s.backend_info.get('certified_filter'):
     for name, col in (('B: reduction of the table over w + barrier', 0), ('B: first pass (bounds of every control)', 1),
                       ('B: second pass (survivors, merge, stores)', 2)):
         print('{:40s} {:6.2f} %'.format(name, 100 * np.median(extra[:, col] / tot)))
+    if inside.any():
+        print('{:40s} {:6.2f} %'.format('   of it: thread 0 inside the reduction', 100 * np.median(inside / tot)))
