@@ -68,6 +68,11 @@ WORKLOADS = {
                'Searev + storage 128^3 state x <=32 controls x 9 perturbations'),
     # not a BASELINE config: the benchmark problem with the control also driving x1
     # (x1' += 0.1 u) -- not storage-separable, runs the LDS-staged tile kernel
+    # not a BASELINE config: the benchmark problem with the perturbation also reaching the stock,
+    # x0' = (x0 + b u) - 0.07 w (the shape of the reference's inventory example): the certified filter
+    # runs on the shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)
+    'noisy256': ('synthetic3d', dict(N=256, stock_noise=0.07), 'float64', None,
+                 'synthetic3d {n}^3 x 64 controls x 32 perturbations, perturbation also in the stock'),
     'coupled256': ('synthetic3d_coupled', dict(N=256), 'float64', None,
                    'synthetic3d {n}^3 x 64 controls x 32 perturbations, control-coupled x1 (non-separable)'),
 }
@@ -672,7 +677,7 @@ def finish_single(args, env, out):
         others = {}
         for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
             solver._cache.pop(k_).close()
-        for name in ('ar1', 'searev', 'synth512f32'):
+        for name in ('ar1', 'searev', 'synth512f32', 'noisy256'):
             try:
                 a2 = copy.copy(args)
                 a2.config, a2.grid, a2.dtype = name, 0, None
@@ -686,12 +691,14 @@ def finish_single(args, env, out):
                 per2 = np.prod(bp2['n'].astype(np.int64), axis=0)
                 cells2 = float(per2.sum() if bp2['per_node'] else per2[0] * V2.size) * max(
                     len(s2.perturb_grid[0]) if s2.perturb_grid else 1, 1)
-                others[name] = {'workload': '{} (BASELINE.json configs[{}])'.format(label2, cfg2),
+                others[name] = {'workload': ('{} (BASELINE.json configs[{}])'.format(label2, cfg2) if cfg2 is not None
+                                             else '{} (not a BASELINE config)'.format(label2)),
                                 'dtype': 'f64' if dt2.itemsize == 8 else 'f32',
                                 'kernel_ms_per_sweep': k2 / 20, 'sweeps_per_s': 20e3 / k2,
                                 'lattice_cells_per_sec': cells2 * 20e3 / k2,
                                 'kernel_family': s2.backend_info.get('kernel'),
-                                'certified_filter': bool(s2.backend_info.get('certified_filter'))}
+                                'certified_filter': bool(s2.backend_info.get('certified_filter')),
+                                'filter_form': s2.backend_info.get('filter_form')}
                 for k_ in [k_ for k_ in s2._cache if k_[0] == 'problem']:
                     s2._cache.pop(k_).close()
             except Exception as e:
@@ -720,7 +727,7 @@ def finish_single(args, env, out):
                                     'time by HIP events; outside the timed region of `value`')
     if not args.no_cpu_baseline and world == 1:
         try:
-            if model_name == 'synthetic3d':
+            if model_name == 'synthetic3d' and args.config != 'noisy256':     # (the C oracle's model has no noise in the stock)
                 out['cpu_baseline'] = cpu_baseline_synth(ref_solver, np.asarray(V0, dtype=np.float64),
                                                          models, U_max)
             else:

@@ -198,17 +198,25 @@ def separable_functions_source(model):
     out.append('\n'.join(lines))
     split = model.lead_split()
     if split is not None:
-        # x0' = a(x, u) +- b(x_1.., w): the two halves, each with the reference's own operations
+        # x0' = a(x, u) +- b_1(x_1.., w) +- b_2 ..: a, the sum B of the signed b_i in the reference's order, and
+        # the sum of the |b_i| (for the error bound), each b_i with the reference's own operations
         # (SDP_COL_SHIFT of csrc/sdp_column_kernel.h)
+        a_node, terms = split
         lines = ['SDP_DEV sdp_real sdp_model_lead_a(const sdp_real *x, const sdp_real *u, sdp_real t)',
                  '{', '    (void)x; (void)u; (void)t;']
-        names = _emit_body(model, model.slice_nodes([split[0]]), lines)
-        lines += ['    return {};'.format(names[split[0].id]), '}']
+        names = _emit_body(model, model.slice_nodes([a_node]), lines)
+        lines += ['    return {};'.format(names[a_node.id]), '}']
         out.append('\n'.join(lines))
-        lines = ['SDP_DEV sdp_real sdp_model_lead_b(const sdp_real *x, sdp_real w, sdp_real t)',
+        lines = ['SDP_DEV void sdp_model_lead_b(const sdp_real *x, sdp_real w, sdp_real t, sdp_real &b, sdp_real &babs)',
                  '{', '    (void)x; (void)w; (void)t;']
-        names = _emit_body(model, model.slice_nodes([split[1]]), lines)
-        lines += ['    return {};'.format(names[split[1].id]), '}']
+        names = _emit_body(model, model.slice_nodes([b for b, _ in terms]), lines)
+        b0, s0 = terms[0]
+        lines.append('    b = {}{};'.format('-' if s0 < 0 else '', names[b0.id]))
+        lines.append('    babs = fabs({});'.format(names[b0.id]))
+        for bn, sg in terms[1:]:
+            lines.append('    b = b {} {};'.format('+' if sg > 0 else '-', names[bn.id]))
+            lines.append('    babs = babs + fabs({});'.format(names[bn.id]))
+        lines.append('}')
         out.append('\n'.join(lines))
     return '\n\n'.join(out)
 
@@ -341,8 +349,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         ] + (['#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap']
              if filtered and int(col_cfg[0]) <= 256 and not os.environ.get('SDP_COL_MIN_WAVES') else []) + (
             ['#define SDP_COL_FILTER 1'] + ([
-                '#define SDP_COL_SHIFT 1        // x0\' = a(x, u) +- b(x_1.., w): first pass on the shifted lattice',
-                '#define SDP_COL_SHIFT_SIGN {}'.format(int(model.lead_split()[2])),
+                '#define SDP_COL_SHIFT 1        // x0\' = a(x, u) +- b_1(x_1.., w) +- ..: first pass on the shifted lattice',
+                '#define SDP_COL_SHIFT_TERMS {}'.format(len(model.lead_split()[1])),
                 '#define SDP_COL_SHIFT_ROWS {}'.format(int(col_cfg[2]))]
                 if column_shift_applies(model, dtype) else []) + (
             ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
@@ -583,7 +591,7 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_contro
                 if per_cu == 2 and threads > 512:
                     continue
                 base = _column_lds(tw, w, 0, n_state, rs, threads, shift=True) + tw * int(n0) * rs + int(extra_bytes)
-                rows = min(2 * int(n0), (COLUMN_LDS_MAX // per_cu - base - 1024) // (2 * rs))
+                rows = min(2 * int(n0) + 16, (COLUMN_LDS_MAX // per_cu - base - 1024) // (2 * rs))
                 if rows >= int(n0) + max(8, int(n0) // 8):
                     return threads, base + 2 * rows * rs, int(rows)
         return None

@@ -177,8 +177,8 @@
 #define SDP_COL_FILTER_SCALE 1   // test knob: multiplies the error radius (any value >= 1 gives the same bits)
 #endif
 #ifndef SDP_COL_SHIFT
-// 1: the perturbation reaches x0' through a final sum, x0' = a(x, u) +- b(x_1.., w) (the generated unit
-// provides sdp_model_lead_a / sdp_model_lead_b and SDP_COL_SHIFT_SIGN): the first pass of the filter reads
+// 1: the perturbation reaches x0' through final sums, x0' = a(x, u) +- b_1(x_1.., w) +- b_2 .. (the generated
+// unit provides sdp_model_lead_a / sdp_model_lead_b, at most four terms): the first pass of the filter reads
 // the table reduced over w on a lattice SHIFTED by the perturbation points -- see sdp_col_shift_reduce.
 #define SDP_COL_SHIFT 0
 #endif
@@ -338,14 +338,16 @@ struct SdpColNest<SDP_DT - 1, SHIFT> {
 // (`first`: the threads from `first` on do it, the others pass)
 SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
                              const SdpColShared &s, const sdp_real *x, const sdp_real *u, sdp_real t,
-                             int first = 0)
+                             int first = 0, int count = 0)
 {
+    // (threads first .. first + count - 1 do the work; count = 0: all threads from `first` on)
     constexpr int Wn = SDP_COL_W;
 #if SDP_HAS_W
     const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
 #endif
-    if ((int)threadIdx.x < first) return;
-    for (int w = (int)threadIdx.x - first; w < Wn; w += (int)blockDim.x - first) {
+    if (count == 0) count = (int)blockDim.x - first;
+    if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
+    for (int w = (int)threadIdx.x - first; w < Wn; w += count) {
         sdp_real xn[SDP_D];
 #if SDP_HAS_W
         sdp_model_trail(x, u, wgrid[w], t, xn);
@@ -1361,14 +1363,15 @@ SDP_DEV sdp_real sdp_col_filter_dcol(SdpColLds &m, int parity)
 
 #if SDP_COL_SHIFT
 // ---------------------------------------------------------------------------
-// Shifted lattice (SDP_COL_SHIFT): the certified filter when the perturbation reaches x0' through a
-// final sum, x0' = fl(a(x, u) +- b(x_1.., w)) -- the stock of the inventory example, `x + u - w`
-// (reference doc/example_inventory.py:31-33; expectation at stodynprog.py:679-683).
+// Shifted lattice (SDP_COL_SHIFT): the certified filter when the perturbation reaches x0' through final
+// sums, x0' = fl(.. fl(fl(a(x, u) +- b_1) +- b_2) ..), b_i = b_i(x_1.., w), k <= 4 terms -- the stock of the
+// inventory example, `x + u - w` (reference doc/example_inventory.py:31-33; expectation at
+// stodynprog.py:679-683), a reservoir `x + u - 0.5 w - 0.1 y`.
 // With Tw(s) the reference's interpolation of row w of the table at axis-0 position s (continuous,
 // piecewise linear, linear beyond both ends: pyx:75-88 clamps the cell, not lam), c = (N0-1)/span,
-//     R(u) = sum_w p_w (g + Tw(s_w)),      s_w = the reference's position of fl(a +- b_w)
-// and in real arithmetic s_w = pa + pb_w, pa = (a - smin) c, pb_w = +- b_w c: every control of the column
-// sees the perturbation points as the SAME shifts pb_w of its own position pa.  So
+//     R(u) = sum_w p_w (g + Tw(s_w)),      s_w = the reference's position of its x0'
+// and in real arithmetic s_w = pa + pb_w, pa = (a - smin) c, pb_w = B_w c, B_w = sum_i +- b_i: every control
+// of the column sees the perturbation points as the SAME shifts pb_w of its own position pa.  So
 //     G(s) = sum_w p_w Tw(s + pb_w)
 // is ONE function per column, R(u) = g P + G(pa(u)).  G is piecewise linear with W kinks per row; it is
 // tabulated at the whole positions k = kmin .. kmax (A'[k] = G(k), 32 x 3 LDS reads per entry -- once per
@@ -1382,15 +1385,17 @@ SDP_DEV sdp_real sdp_col_filter_dcol(SdpColLds &m, int parity)
 // N0 - 1 - min floor pb the first and the last cell of the lattice lie in those ranges, the clamped cell
 // with an unclamped lam extrapolates G exactly, and B' is zero there by construction.
 // Roundings (u the unit roundoff, D = Pcap max |T| of the column as in the lean pass, P = sum |p_w|):
-//  * positions: the reference rounds fl(a +- b), then (. - smin) / span * (N0-1); this pass rounds pa, pb_w,
-//    pa - kmin.  a and b_w are the reference's own values (same operations on the same inputs), so
-//    |s_w - (pa + pb_w)| <= u (8 |pa| + 7 |pb_w| + 1.1 |smin| c) and |Tw(s) - Tw(s')| <= 2 max|T| |s - s'|;
+//  * positions: the reference rounds its k sums (each partial sum is at most |a| + sum |b_i|), then
+//    (. - smin) / span * (N0-1); this pass rounds B (k-1 sums), pa, pb_w, pa - kmin.  a and the b_i are the
+//    reference's own values (same operations on the same inputs), so with PB >= c sum_i |b_i|
+//    |s_w - (pa + pb_w)| <= u ((k + 6.2) |pa| + (2k + 5.2) PB + k |smin| c) <= 14 u (|pa| + PB + |smin| c),
+//    and |Tw(s) - Tw(s')| <= 2 max|T| |s - s'|;
 //  * |E - R| <= (W+4) u [ |g| P + (1 + 2 Lam) D ],  Lam = max_w |lam_w| <= |s_w| + N0;
 //  * A'[k] carries (W+4) u (1 + 2 (spread + 2)) D (lam of an entry reaches spread + 2 at the ends of the
 //    lattice, spread = max - min floor pb), the lerp and the fma 4 u (1 + 2 |lam0|) max |A'|.
-// With L = max |lam0| of the node (|pa - kmin| <= rows + L), Lc = rows + |kmin| + max |pb| + |smin| c + N0 + 1
+// With L = max |lam0| of the node (|pa - kmin| <= rows + L), Lc = rows + |kmin| + max PB + |smin| c + N0 + 1
 // (column-uniform) and Es = 1 + 2 (spread + 2) all of it is below
-//     (2W+8) u |g| P  +  (W+8) u H D,      H = (1 + 2 L + 2 Lc) (2 + Es)
+//     (2W+8) u |g| P  +  (W+8) u H D,      H = (1 + 2 L + 2 Lc) (3 + Es)
 // and with |g| Pcap <= ratio (|F| (1 + u) + |h|), |h| <= (1 + 2 L) Es D <= H D, as in the lean pass:
 //     radius = cu S_node + max_u B'[q0(u)],    S_node = ratio (sum |F| + H D) + H D,   cu = 4 (W+8) u
 // (a factor 2 on the |g| term, 4 on the D term to spare; the roundings of B' itself -- (W+8) u relative and
@@ -1400,21 +1405,23 @@ SDP_DEV sdp_real sdp_col_filter_dcol(SdpColLds &m, int parity)
 // every control the long way, like a node with a NaN.
 // The second pass is unchanged (sdp_col_expected_cost with the position located per perturbation point).
 // In 8-byte reals the radius is now B' -- of the order of h^2 V'' / 16 for a smooth cost-to-go -- and no
-// longer 1e-13: two or three controls around the optimum survive, hence SDP_COL_FILTER_TOP2.
+// longer 1e-13: ~1 % of the nodes of the benchmark problem keep two controls, hence SDP_COL_FILTER_TOP2.
 
 // the shifts of the perturbation points for the column at x[1..] into the tables of parity `par`
 // (threads `first` ..; sh_k[par] was reset a barrier ago)
 SDP_DEV void sdp_col_phase_shift(const SdpSweepArgs &a, SdpColLds &m, const SdpLeadAxis &l, const sdp_real *x,
-                                 sdp_real t, int par, int first = 0)
+                                 sdp_real t, int par, int first = 0, int count = 0)
 {
-    if ((int)threadIdx.x < first) return;
+    if (count == 0) count = (int)blockDim.x - first;
+    if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
     const sdp_real *__restrict__ p = (const sdp_real *)a.proba;
-    for (int w = (int)threadIdx.x - first; w < SDP_COL_W; w += (int)blockDim.x - first) {
-        sdp_real b = sdp_model_lead_b(x, wgrid[w], t);
-        if (SDP_COL_SHIFT_SIGN < 0) b = -b;
+    for (int w = (int)threadIdx.x - first; w < SDP_COL_W; w += count) {
+        sdp_real b, babs;                                            // the signed sum of the b_i, and the sum of the |b_i|
+        sdp_model_lead_b(x, wgrid[w], t, b, babs);
         const sdp_real pb = sdp_div_span<sdp_real>(b, l.span, l.rspan, l.pow2) * l.nm1;
-        const bool ok = fabs(pb) < (sdp_real)536870912.0;            // (false for a NaN)
+        const sdp_real pbabs = fabs(sdp_div_span<sdp_real>(babs, l.span, l.rspan, l.pow2) * l.nm1);
+        const bool ok = fabs(pb) < (sdp_real)536870912.0 && pbabs < (sdp_real)536870912.0;     // (false for a NaN)
         const sdp_real fl = ok ? floor(pb) : (sdp_real)0;
         const sdp_real f = ok ? pb - fl : (sdp_real)0;                // exact, in [0, 1)
         const int q = (int)fl;
@@ -1424,6 +1431,7 @@ SDP_DEV void sdp_col_phase_shift(const SdpSweepArgs &a, SdpColLds &m, const SdpL
         atomicMax(&m.sh_k[par][0], q);
         atomicMax(&m.sh_k[par][1], -q);
         if (!ok) atomicMax(&m.sh_k[par][2], 1);
+        atomicMax(&m.sh_k[par][3], ok ? (int)pbabs + 1 : 0);         // >= sum_i |b_i| c, in rows
     }
 }
 SDP_DEV void sdp_col_shift_reset(SdpColLds &m, int par)
@@ -1431,10 +1439,12 @@ SDP_DEV void sdp_col_shift_reset(SdpColLds &m, int par)
     m.sh_k[par][0] = INT_MIN;
     m.sh_k[par][1] = INT_MIN;
     m.sh_k[par][2] = 0;
+    m.sh_k[par][3] = 0;
 }
 // what the first pass needs of the lattice of parity `par` (after the barrier that follows sdp_col_phase_shift)
 struct SdpColShiftCol {
     int kmin, rows;     // first whole position, number of positions
+    int flmin, flmax;   // smallest / largest whole part of a shift
     bool ok;            // usable (else every node of the unit takes the long way)
     sdp_real lc, es;    // Lc and Es of the bound
 };
@@ -1445,45 +1455,105 @@ SDP_DEV void sdp_col_shift_col(const SdpColLds &m, const SdpLeadAxis &l, int par
     const int flag = __builtin_amdgcn_readfirstlane(m.sh_k[par][2]);
     c.kmin = -(flmax + 1);
     c.rows = SDP_COL_N0 + flmax + nflmin + 1;
+    c.flmax = flmax;
+    c.flmin = -nflmin;
     c.ok = flag == 0 && c.rows <= SDP_COL_SHIFT_ROWS && c.rows >= 2 && SDP_COL_N0 >= 3;
-    const sdp_real pbmax = (sdp_real)(max(abs(flmax), abs(nflmin)) + 1);
+    const sdp_real pbmax = (sdp_real)(max(max(abs(flmax), abs(nflmin)), __builtin_amdgcn_readfirstlane(m.sh_k[par][3])) + 1);
     const sdp_real p0 = fabs(l.smin) * (l.nm1 / fabs(l.span));
     c.lc = (sdp_real)c.rows + (sdp_real)abs(c.kmin) + pbmax + p0 * (sdp_real)1.001 + (sdp_real)(SDP_COL_N0 + 1);
     c.es = (sdp_real)(1 + 2 * (flmax + nflmin + 2));
     if (!(c.lc < (sdp_real)1073741824.0)) c.ok = false;              // (a NaN or an infinity of p0)
 }
 
-// after phase A (and a barrier): the table reduced over w on the shifted lattice, one thread per
-// position: ad[2 i] = A'[kmin + i], ad[2 i + 1] = B'[kmin + i] (the cell above it); dcol as in the lean pass
+// before phase A (the readers of the previous unit's table left at the barrier): clear the lattice
+SDP_DEV void sdp_col_shift_zero(SdpColLds &m, const SdpColShiftCol &c)
+{
+    if (!c.ok) return;
+    for (int i = threadIdx.x; i < 2 * c.rows; i += blockDim.x) m.ad[i] = (sdp_real)0;
+}
+// after phase A (and a barrier): the table reduced over w on the shifted lattice: ad[2 i] = A'[kmin + i],
+// ad[2 i + 1] = B'[kmin + i] (the cell above it); dcol as in the lean pass.  A wave takes every waves-th
+// perturbation point and walks the lattice in blocks of 64 positions (a lane per position: consecutive rows
+// of one table row, no bank conflict), adding its partial sums into the cleared lattice (LDS atomics, two per
+// lane and block): the positions rarely fill a whole number of thread-per-position rounds, the (block, w)
+// items do.  Blocks whose positions stay inside the axis for every perturbation point -- all but the first
+// and the last ones -- skip the clamps.
 SDP_DEV void sdp_col_shift_reduce(const SdpSweepArgs &a, SdpColLds &m, const SdpColFilter &f,
                                   const SdpColShiftCol &c, int parity, int par)
 {
     constexpr int N0 = SDP_COL_N0;
     if (!c.ok) return;
     const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
+    const int lane = threadIdx.x & 63;
+    // (compile-time trip counts; the shifts of a wave's perturbation points are fetched once, so that the table
+    // reads of a block do not wait for them one after the other: the loop is bound by LDS latency, not by issue)
+    constexpr int waves = SDP_COL_THREADS / 64, rounds = (SDP_COL_W + waves - 1) / waves, CH = rounds < 8 ? rounds : 8;
+    sdp_trap_unless(blockDim.x == SDP_COL_THREADS);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave >= SDP_COL_W) return;
+    const int blocks = (c.rows + 63) >> 6;
     sdp_real dmax = (sdp_real)0;
-    for (int ki = threadIdx.x; ki < c.rows; ki += blockDim.x) {
-        const int k = c.kmin + ki;
-        sdp_real acc = (sdp_real)0, bnd = (sdp_real)0, big = (sdp_real)0;
-#pragma unroll 4
-        for (int w = 0; w < SDP_COL_W; ++w) {
-            const int j = k + m.sh_q[par][w];
-            const int q = max(min(j, N0 - 2), 0);
-            const sdp_real lam = (sdp_real)(j - q) + m.sh_f[par][w];
-            const sdp_real *row = m.T + w * N0 + q;
-            const sdp_real t0 = row[0], t1 = row[1], t2 = row[q + 2 < N0 ? 2 : 1];
-            acc = fma((sdp_real)p[w], fma(lam, t1 - t0, t0), acc);
-            const sdp_real d2 = (t2 - t1) - (t1 - t0);
-            const bool kink = (unsigned)j <= (unsigned)(N0 - 3);     // a kink inside the cell: row j+1 is an inner row
-            bnd = fma(m.sh_c[par][w], kink ? fabs(d2) : (sdp_real)0, bnd);
-            big = sdp_vmax_abs(sdp_vmax_abs(big, t0), t1);
+    for (int i0 = 0; i0 < rounds; i0 += CH) {
+        int tq[CH];
+        sdp_real tf[CH], tc[CH], tp[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int w = wave + (i0 + i) * waves;
+            const bool valid = w < SDP_COL_W;                          // (past the end: this wave's first point
+            const int wv = valid ? w : wave;                           //  again, with weights zero)
+            tq[i] = wv * N0 + __builtin_amdgcn_readfirstlane(m.sh_q[par][wv]);
+            tf[i] = m.sh_f[par][wv];
+            tc[i] = valid ? m.sh_c[par][wv] : (sdp_real)0;
+            tp[i] = valid ? (sdp_real)p[wv] : (sdp_real)0;
         }
-        m.ad[2 * ki] = acc;
-        m.ad[2 * ki + 1] = bnd;
-        dmax = sdp_vmax(dmax, acc == acc ? f.pcap * big + f.floor : (sdp_real)INFINITY);
+        for (int b = 0; b < blocks; ++b) {
+            const int ki = b * 64 + lane;
+            const int kb = c.kmin + b * 64;
+            const int k = min(kb + lane, c.kmin + c.rows - 1);
+            sdp_real acc = (sdp_real)0, bnd = (sdp_real)0, big = (sdp_real)0;
+            if (kb + c.flmin >= 0 && kb + 63 + c.flmax <= N0 - 3) {    // (wave-uniform)
+                sdp_real tv[CH][3];                                    // (all reads of the block first)
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const sdp_real *row = m.T + (tq[i] + k);
+                    tv[i][0] = row[0];
+                    tv[i][1] = row[1];
+                    tv[i][2] = row[2];
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const sdp_real t0 = tv[i][0], t1 = tv[i][1], t2 = tv[i][2];
+                    acc = fma(tp[i], fma(tf[i], t1 - t0, t0), acc);
+                    bnd = fma(tc[i], fabs((t2 - t1) - (t1 - t0)), bnd);
+                    big = sdp_vmax_abs(big, t1);                       // (every entry is the t1 of some position,
+                }                                                      //  row 0 the t0 of a clamped one)
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int w = min(wave + (i0 + i) * waves, SDP_COL_W - 1);
+                    const int wrow = w < wave + (i0 + i) * waves ? wave : w;
+                    const int j = k + (tq[i] - wrow * N0);
+                    const int q = max(min(j, N0 - 2), 0);
+                    const sdp_real lam = (sdp_real)(j - q) + tf[i];
+                    const sdp_real *row = m.T + wrow * N0 + q;
+                    const sdp_real t0 = row[0], t1 = row[1], t2 = row[q + 2 < N0 ? 2 : 1];
+                    acc = fma(tp[i], fma(lam, t1 - t0, t0), acc);
+                    const sdp_real d2 = (t2 - t1) - (t1 - t0);
+                    const bool kink = (unsigned)j <= (unsigned)(N0 - 3);   // a kink inside the cell: row j+1 is an inner row
+                    bnd = fma(tc[i], kink ? fabs(d2) : (sdp_real)0, bnd);
+                    big = sdp_vmax_abs(sdp_vmax_abs(big, t0), t1);
+                }
+            }
+            if (ki < c.rows) {
+                __hip_atomic_fetch_add(&m.ad[2 * ki], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&m.ad[2 * ki + 1], bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // (a NaN entry, which the max skips, shows in the partial sum and makes the bound infinite)
+            dmax = sdp_vmax(dmax, acc == acc ? f.pcap * big + f.floor : (sdp_real)INFINITY);
+        }
     }
     dmax = sdp_wave_max(dmax);
-    if ((threadIdx.x & 63) == 0)
+    if (lane == 0)
         atomicMax(&m.dcol[parity], (unsigned long long)__double_as_longlong((double)dmax));
 }
 #endif  // SDP_COL_SHIFT
@@ -1641,12 +1711,14 @@ SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, cons
     sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax, bmax);
 }
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
-SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0)
+SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0,
+                             int count = 0)
 {
-    if ((int)threadIdx.x < first) return;
+    if (count == 0) count = (int)blockDim.x - first;
+    if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     SdpBox box;
     sdp_load_box(a, 0, box);                                // (one box for every node: checked at launch)
-    for (int ci = (int)threadIdx.x - first; ci < SDP_COL_UTAB_N; ci += (int)blockDim.x - first) {
+    for (int ci = (int)threadIdx.x - first; ci < SDP_COL_UTAB_N; ci += count) {
         sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
         sdp_controls_at(box, ci, u);
         sdp_model_utab(x, u, t, tab);
@@ -1948,8 +2020,8 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)bd.s_max + (sdp_fkey)filt.floor);
         } else if (SDP_COL_LEAN_ON) {
 #if SDP_COL_SHIFT
-            // H D, H = (1 + 2 L + 2 Lc) (2 + Es): see sdp_col_shift_reduce
-            const sdp_real h_cap = (((sdp_real)1 + (sdp_real)2 * (bd.p_max + shc.lc)) * ((sdp_real)2 + shc.es)) * dcol;
+            // H D, H = (1 + 2 L + 2 Lc) (3 + Es): see sdp_col_shift_reduce
+            const sdp_real h_cap = (((sdp_real)1 + (sdp_real)2 * (bd.p_max + shc.lc)) * ((sdp_real)3 + shc.es)) * dcol;
 #else
             const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
 #endif
@@ -2123,22 +2195,28 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         if (wave == waves - 1 && lane == 0) nx = (int)atomicAdd(claim, 1u);   // round trip hides under phase A
 #if SDP_COL_SHIFT
         if (threadIdx.x == 0) sdp_col_shift_reset(sdp_lds, upar ^ 1);    // (its readers left at the barrier above)
+        SdpColShiftCol shc;
+        sdp_col_shift_col(sdp_lds, lead, upar, shc);
+        sdp_col_shift_zero(sdp_lds, shc);
 #endif
         sdp_col_phase_a<false>(a, tg, s);
+        if (wave == waves - 1 && lane == 0) sdp_lds.next_unit = nx;      // (read after the barrier below, and after the next one)
         __syncthreads();
         SDP_COL_MARK(t2);
-        if (wave == waves - 1) {                           // nothing reads the cells after phase A
-            nx = __builtin_amdgcn_readfirstlane(nx);
-            if (lane == 0) sdp_lds.next_unit = nx;
-            if (u_base + nx < u_end) {
+        {
+            // the next unit's column-level tables (nothing reads the cells after phase A), a wave each where
+            // the workgroup has that many: they are short but made of dependent latencies (divisions, loads
+            // of the box and of the axes), and the barrier after the reduction waits for the last of them
+            const int nxu = __builtin_amdgcn_readfirstlane(sdp_lds.next_unit);
+            if (u_base + nxu < u_end) {
                 sdp_real xn[SDP_D];
-                sdp_col_coords(a, sdp_col_of_unit(a, u_base + nx), xn);
-                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (int)blockDim.x - 64);
+                sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
+                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64);
 #if SDP_COL_UTAB
-                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, (int)blockDim.x - 64);
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64);
 #endif
 #if SDP_COL_SHIFT
-                sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, (int)blockDim.x - 64);
+                sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);
 #endif
             }
         }
@@ -2162,8 +2240,6 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_FILTER
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);        // (see phase B)
 #if SDP_COL_SHIFT
-        SdpColShiftCol shc;
-        sdp_col_shift_col(sdp_lds, lead, upar, shc);
         sdp_col_shift_reduce(a, sdp_lds, filt, shc, parity, upar);
 #else
         sdp_col_filter_reduce(a, sdp_lds, filt, parity);

@@ -661,28 +661,42 @@ class TracedModel(object):
     def cost_depends_on_w(self):
         return bool(self.cost.deps & DEP_W)
 
+    LEAD_SPLIT_MAX_TERMS = 4
+
     def lead_split(self):
-        """x0' = a(x, u[, t]) + b(x_1.., w[, t])  or  a - b, with the sum as the LAST operation of the
-        recorded expression (`x + u - w` of the inventory example, reference
-        doc/example_inventory.py:31-33): returns (a, b, sign) with sign = +1 / -1, or None.
-        The perturbation then moves the axis-0 position of every control of a column by the same
-        amounts, so the expectation over w can still be taken on the table before the controls
-        are looked at (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)."""
+        """x0' = a(x, u[, t]) +- b_1(x_1.., w[, t]) +- b_2 ..  with the sums as the LAST operations of
+        the recorded expression, a innermost: `x + u - w` of the inventory example (reference
+        doc/example_inventory.py:31-33), `x + u - 0.5 * w - 0.1 * y`.  Returns (a, [(b_1, sign_1), ..])
+        in the order the reference adds them, sign = +1 / -1, or None.  The perturbation then moves
+        the axis-0 position of every control of a column by the same amounts, so the expectation over
+        w can still be taken on the table before the controls are looked at
+        (csrc/sdp_column_kernel.h, SDP_COL_SHIFT).  `a` is one sub-expression, evaluated as the
+        reference evaluates it: the first pass then starts from the reference's own value of it."""
         top = self.x_next[0]
-        if top.op not in ('add', 'sub') or not (top.deps & DEP_W):
+        if not (top.deps & DEP_W):
             return None
 
-        def is_a(n):
-            return (n.deps & DEP_W) == 0
-
         def is_b(n):
-            return (n.deps & (DEP_X | DEP_U)) == 0 and (n.deps & DEP_W) != 0
-        l, r = top.args
-        if is_a(l) and is_b(r):
-            return l, r, (1 if top.op == 'add' else -1)
-        if top.op == 'add' and is_b(l) and is_a(r):
-            return r, l, 1
-        return None
+            return (n.deps & (DEP_X | DEP_U)) == 0
+
+        terms = []
+        node = top
+        while node.deps & DEP_W:
+            if node.op not in ('add', 'sub') or len(terms) == self.LEAD_SPLIT_MAX_TERMS:
+                return None
+            l, r = node.args
+            if is_b(r):
+                terms.append((r, 1 if node.op == 'add' else -1))
+                node = l
+            elif node.op == 'add' and is_b(l):
+                terms.append((l, 1))
+                node = r
+            else:
+                return None
+        terms.reverse()
+        if not any(b.deps & DEP_W for b, _ in terms):
+            return None
+        return node, terms
 
 
 def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True,

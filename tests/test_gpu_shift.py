@@ -68,7 +68,7 @@ def test_the_plan_and_the_generated_halves(gpu):
     plan = s._kernel_plan()
     assert plan['column'] and plan['filtered']
     src = plan['source']
-    assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_SHIFT_SIGN -1' in src
+    assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_SHIFT_TERMS 1' in src
     assert 'sdp_model_lead_a' in src and 'sdp_model_lead_b' in src
     s.dtype = np.dtype('float32')                 # 4-byte reals: every control the long way
     assert not s._kernel_plan()['filtered']
@@ -141,6 +141,30 @@ def test_special_values(gpu, case):
     else:
         V[:] = 2.5                               # exact ties wherever the cost does not decide
     _same(_sweep(make, True, V), _sweep(make, False, V))
+
+
+def test_a_chain_of_sums(gpu):
+    """x' = x + u - 0.5 w - 0.1 y: two terms without the stock or the control after a = x + u, one of them
+    without the perturbation; and a cost that sees the perturbation"""
+    def make():
+        sysd = SysDescription((2, 1, 1), name='reservoir')
+        sysd.dyn = lambda x, y, u, w: (x + u - 0.5 * w - 0.1 * y, 0.8 * y + w)
+        sysd.cost = lambda x, y, u, w: (x - 0.3) * (x - 0.3) + 0.1 * u * u + 0.05 * w * u
+        sysd.control_box = lambda x, y: ((-1., 1.),)
+        sysd.perturb_laws = [NormalLaw(0, 0.2)]
+        s = DPSolver(sysd)
+        s.discretize_state(-1, 1, 65, -1, 1, 17)
+        s.discretize_perturb(-0.5, 0.5, 7)
+        s.control_steps = (0.05,)
+        return sysd, s
+    src = make()[1]._kernel_plan()['source']
+    assert '#define SDP_COL_SHIFT_TERMS 2' in src and '#define SDP_COST_HAS_W 1' in src
+    for V in (np.random.default_rng(21).standard_normal((65, 17)),
+              np.add.outer(np.linspace(-1, 1, 65) ** 2, np.cos(np.linspace(-1, 1, 17)))):
+        on, off = _sweep(make, True, V, sweeps=2), _sweep(make, False, V, sweeps=2)
+        assert on[3].backend_info['filter_form'] == 'shifted lattice'
+        _same(on, off)
+        _same(on, _sweep(make, True, V, kernel='generic', sweeps=2))
 
 
 def test_a_cost_that_sees_the_perturbation_too(gpu):

@@ -976,6 +976,8 @@ def test_column_kernel_with_noise_driven_stock(gpu):
     Jc, uc = col.value_iteration(V, report_time=False)
     Jg, ug = gen.value_iteration(V, report_time=False)
     assert col.backend_info['kernel'] == 'column'
+    # (since round 3 filtered on the shifted lattice: x0' = (x + u) - 0.5 w - 0.1 y is a chain of final sums)
+    assert col.backend_info['filter_form'] == 'shifted lattice'
     Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(ref), V)
     assert np.array_equal(Jc, Jo) and np.array_equal(Jg, Jo)
     assert np.array_equal(col.last_policy_index, io) and np.array_equal(gen.last_policy_index, io)

@@ -380,9 +380,10 @@ def test_certified_filter_planning_without_a_gpu():
     s.discretize_state(0, 1, 512, 0, 1, 16, 0, 1, 16)
     s.dtype = np.dtype('float32')
     assert '#define SDP_COL_THREADS 512' in s._kernel_plan()['source']
-    # a perturbation in x0': the expectation no longer commutes with the lerp along axis 0
-    m = trace_model(lambda x, y, u, w: (x + u + 0.1 * w, 0.5 * y + w), lambda x, y, u, w: u * u, 2, 1, 1)
-    assert m.storage_separable and not codegen.column_filter_applies(m)
+    # a perturbation in x0' other than through a final sum (that form: test_shifted_lattice_planning_without_a_gpu):
+    # the expectation no longer commutes with the lerp along axis 0
+    m = trace_model(lambda x, y, u, w: ((x + u) * (1.0 + 0.1 * w), 0.5 * y + w), lambda x, y, u, w: u * u, 2, 1, 1)
+    assert m.storage_separable and not codegen.column_filter_applies(m, dtype=np.float64)
     # a perturbation in the COST still commutes (round 3: the first pass accumulates its expectation),
     # but the control table, which holds sub-expressions without w, is not used then
     m = trace_model(lambda x, y, u, w: (x + u, 0.5 * y + w), lambda x, y, u, w: u * w, 2, 1, 1)
@@ -390,6 +391,45 @@ def test_certified_filter_planning_without_a_gpu():
     assert codegen.control_table_plan(m, np.float64, False, 64) is None
     m = trace_model(lambda x, y, u, w: (x + u, 0.5 * y + w), lambda x, y, u, w: u * y, 2, 1, 1)
     assert codegen.column_filter_applies(m)
+
+
+def test_shifted_lattice_planning_without_a_gpu():
+    """a perturbation that reaches x0' through final sums (TracedModel.lead_split): what is recognised, what
+    codegen emits for it and where the plan falls back to every control the long way"""
+    from stodynprog_amd import codegen
+    from stodynprog_amd.trace import DEP_W, DEP_X, DEP_U
+    tr = lambda dyn: trace_model(dyn, lambda x, y, u, w: u * u, 2, 1, 1)
+    m = tr(lambda x, y, u, w: (x + u - w, 0.5 * y + w))                       # the inventory example next to an AR(1)
+    a, terms = m.lead_split()
+    assert not a.deps & DEP_W and len(terms) == 1 and terms[0][1] == -1
+    assert not terms[0][0].deps & (DEP_X | DEP_U)
+    m2 = tr(lambda x, y, u, w: (x + u - 0.5 * w - 0.1 * y, 0.5 * y + w))      # a chain, one term without w
+    assert [sg for _, sg in m2.lead_split()[1]] == [-1, -1]
+    m3 = tr(lambda x, y, u, w: ((y + w) + (x + 0.7 * u), 0.5 * y + w))        # the w-part first
+    assert m3.lead_split()[1][0][1] == 1 and m3.lead_split()[0].deps & DEP_U
+    for bad in (lambda x, y, u, w: ((x + u) * (1.0 + 0.1 * w), 0.5 * y + w),  # not a sum
+                lambda x, y, u, w: (x + (w - u), 0.5 * y + w),                # the control inside the w-part
+                lambda x, y, u, w: (x + u - 0.1 * y, 0.5 * y + w),            # no perturbation in x0' at all
+                lambda x, y, u, w: (x + u - w - w - w - w - w, 0.5 * y + w)): # more terms than the bound covers
+        assert tr(bad).lead_split() is None
+    assert codegen.column_shift_applies(m, np.float64) and not codegen.column_shift_applies(m, np.float32)
+    assert codegen.column_filter_applies(m, dtype=np.float64, table=(256, 32, 2))
+    assert not codegen.column_filter_applies(m, dtype=np.float32, table=(256, 32, 2))
+    # LDS: the lattice gets the room two workgroups per CU leave beside the table, at least n0 + n0/8 rows
+    cfg = codegen.column_config(256, 32, 3, np.float64, False, True, shift=True, extra_bytes=2048)
+    assert cfg[0] == 256 and 2 * cfg[1] <= codegen.COLUMN_LDS_MAX and 288 <= cfg[2] <= 528
+    assert codegen.column_config(3, 7, 2, np.float64, False, True, shift=True)[2] >= 11
+    _, s = models.inventory_markov()
+    plan = s._kernel_plan()
+    src = plan['source']
+    assert plan['column'] and plan['filtered'] and '#define SDP_COL_SHIFT 1' in src
+    assert 'sdp_model_lead_a' in src and 'sdp_model_lead_b' in src and '#define SDP_COL_SHIFT_TERMS 1' in src
+    assert 'sdp_model_lead_tab' in src                   # the control table holds the parts of a(x, u)
+    s.dtype = np.dtype('float32')
+    plan = s._kernel_plan()
+    assert plan['column'] and not plan['filtered'] and 'SDP_COL_SHIFT' not in plan['source']
+    _, s = models.synthetic3d(N=256, stock_noise=0.07)
+    assert '#define SDP_COL_SHIFT 1' in s._kernel_plan()['source']
 
 
 def test_control_table_planning_without_a_gpu():

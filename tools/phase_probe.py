@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from stodynprog_amd import models, _native as nat
 
-_, s = models.synthetic3d(N=256)
+_, s = models.synthetic3d(N=256, stock_noise=float(os.environ.get('SDP_STOCK_NOISE', 0)))
 prob = s._problem()
 prob.set_value(models.synthetic3d_V0(s.state_grid))
 prob.bench_sweeps(30)
