@@ -221,6 +221,49 @@ def separable_functions_source(model):
     return '\n\n'.join(out)
 
 
+def lead_functions_source(model, m):
+    """C++ text of the slices csrc/sdp_lead_kernel.h uses for a model whose first `m` state variables
+    are controlled stocks and whose other state variables are exogenous (TracedModel.controlled_axes)."""
+    d = model.n_state
+    out = []
+    lines = ['SDP_DEV void sdp_model_leads(const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real *xl)',
+             '{', '    (void)x; (void)u; (void)t;']
+    names = _emit_body(model, model.slice_nodes(model.x_next[:m]), lines)
+    for k, n in enumerate(model.x_next[:m]):
+        lines.append('    xl[{}] = {};'.format(k, names[n.id]))
+    lines.append('}')
+    out.append('\n'.join(lines))
+    if m < d:
+        lines = ['SDP_DEV void sdp_model_trails(const sdp_real *x, sdp_real w, sdp_real t, sdp_real *xt)',
+                 '{', '    (void)x; (void)w; (void)t;']
+        names = _emit_body(model, model.slice_nodes(model.x_next[m:]), lines)
+        for k, n in enumerate(model.x_next[m:]):
+            lines.append('    xt[{}] = {};'.format(k, names[n.id]))
+        lines.append('}')
+        out.append('\n'.join(lines))
+    lines = ['SDP_DEV sdp_real sdp_model_cost(const sdp_real *x, const sdp_real *u, sdp_real w,',
+             '                                sdp_real t)',
+             '{', '    (void)x; (void)u; (void)w; (void)t;']
+    names = _emit_body(model, model.slice_nodes([model.cost]), lines)
+    lines += ['    return {};'.format(names[model.cost.id]), '}']
+    out.append('\n'.join(lines))
+    return '\n\n'.join(out)
+
+
+def lead_filter_applies(model, dtype):
+    """Several controlled state variables next to an exogenous process (TracedModel.controlled_axes
+    >= 2; one stock is the column kernel's case), a perturbation that reaches neither them nor the
+    cost, 8-byte reals: the node-order sweep with the certified filter on an array reduced over w
+    (csrc/sdp_lead_kernel.h).  Returns the number of controlled axes, or 0.  SDP_LEAD_FILTER=0 in the
+    environment switches it off (A/B runs)."""
+    if os.environ.get('SDP_LEAD_FILTER', '1') == '0':
+        return 0
+    if model.n_perturb != 1 or model.cost_depends_on_w or np.dtype(dtype).itemsize != 8:
+        return 0
+    m = model.controlled_axes()
+    return int(m) if m is not None and m >= 2 else 0
+
+
 UTAB_MAX_VALUES = 4          # tabulated sub-expressions per control
 UTAB_MAX_BYTES = 4096        # per parity buffer of the table in LDS
 
@@ -281,7 +324,7 @@ def lanes_for(max_controls):
 
 
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
-                     per_control=None, filtered=False, utab=None):
+                     per_control=None, filtered=False, utab=None, lead_axes=0):
     """column: None for the generic node-order kernels, or (N0, W) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
@@ -388,6 +431,13 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '#define SDP_STG_CAP {}'.format(int(staged['cap'])),
             '#include "sdp_staged_kernel.h"    // also brings in sdp_sweep_kernel.h',
             '']
+    elif lead_axes:
+        # several controlled state variables: node-order sweep with the filter on an array reduced over w
+        head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes))] + (
+            ['#define SDP_LEAD_FILTER_SCALE {}'.format(float(os.environ['SDP_LEAD_FILTER_SCALE']))]
+            if os.environ.get('SDP_LEAD_FILTER_SCALE') else []) + [
+            lead_functions_source(model, int(lead_axes)), '',
+            '#include "sdp_sweep_kernel.h"    // brings in sdp_lead_kernel.h', '']
     else:
         head += ['#include "sdp_sweep_kernel.h"', '']
     return '\n'.join(head)
@@ -696,7 +746,7 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
                '-fno-fast-math', '-std=c++17', '-I', CSRC]
 
 
-_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h',
+_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_lead_kernel.h',
             'sdp_staged_kernel.h')
 _digest_cache = {}
 

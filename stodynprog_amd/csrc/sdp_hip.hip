@@ -664,6 +664,10 @@ struct sdp_problem {
     size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
     hipFunction_t f_sweep = nullptr, f_evalpol = nullptr, f_simulate = nullptr;
+    // several controlled state variables (csrc/sdp_lead_kernel.h): the kernel that reduces V over w, launched
+    // before every sweep, and its outputs (A[S], E[nodes per trailing block], bits of max |V|)
+    hipFunction_t f_lead_reduce = nullptr;
+    DevBuf lead_a, lead_e, lead_vmax;
     hipDeviceptr_t prm_dev = nullptr;     // `sdp_model_prm` of the code object (lifted model constants)
     size_t prm_bytes = 0;
     hipStream_t stream = nullptr;
@@ -878,6 +882,15 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         if (rc) return rc;
         HIP_TRY(hipMemset(p->claim.p, 0, 4 * (8 * 32 + 32)));
     }
+    if (p->layout != SDP_LAYOUT_COLUMNS && p->variant != SDP_VARIANT_STAGED && (p->meta[SDP_META_FLAGS] & SDP_META_F_LEAD)) {
+        e = hipModuleGetFunction(&p->f_lead_reduce, p->mod, "sdp_lead_reduce");
+        if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_lead_reduce kernel: %s", desc->module_path, hipGetErrorString(e));
+        if (p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
+        int rc = p->lead_a.alloc((size_t)p->S * rs);
+        if (!rc) rc = p->lead_e.alloc((size_t)p->S * rs / (size_t)p->orders[0]);      // (>= nodes per trailing block)
+        if (!rc) rc = p->lead_vmax.alloc(8);
+        if (rc) return rc;
+    }
     if (p->variant == SDP_VARIANT_STAGED) {
         int mt = 0;
         if (hipFuncGetAttribute(&mt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, p->f_sweep) != hipSuccess || mt < 64)
@@ -1003,6 +1016,7 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     a.shift_index = -1; a.ref_out = nullptr;
     a.stamps = (unsigned long long *)p->stamps.p;
     a.claim = (unsigned int *)p->claim.p;
+    a.aux_a = p->lead_a.p; a.aux_e = p->lead_e.p; a.aux_vmax = (unsigned long long *)p->lead_vmax.p;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
         a.col_begin = nb / p->orders[0];
@@ -1089,6 +1103,15 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
         if (blocks > p->stg_tiles) blocks = p->stg_tiles;
         blocks = ((blocks + 7) / 8) * 8;
         return launch_module(p->f_sweep, a, (unsigned)blocks, (unsigned)p->stg_threads, p->stream);
+    }
+    if (p->f_lead_reduce) {
+        // the array reduced over w, from the whole of V (every node's first pass reads it at other nodes)
+        if (p->V_partial) return fail(SDP_EINVAL, "the reduced-array sweep needs the whole cost-to-go array on this device");
+        HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 8, p->stream));
+        SdpSweepArgs r = a;
+        r.node_begin = 0; r.node_end = p->S;
+        int rc = launch_module(p->f_lead_reduce, r, sweep_blocks(p, p->S), 256, p->stream);
+        if (rc) return rc;
     }
     return launch_module(p->f_sweep, a, sweep_blocks(p, ne - nb), 256, p->stream);
 }

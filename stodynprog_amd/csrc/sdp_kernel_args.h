@@ -27,7 +27,9 @@ enum {
     SDP_META_F_FILTER = 1, SDP_META_F_WINDOW = 2, SDP_META_F_TRAIL_HAS_U = 4, SDP_META_F_STAGED = 8,
     SDP_META_F_WPAIR = 16, SDP_META_F_LEAN = 32,
     SDP_META_F_CLAIMS = 64, // the sweep kernel's workgroups claim their units (persistent: a bounded grid)
-    SDP_META_F_SHIFT = 128  // certified filter on the shifted lattice (a perturbation that reaches x0')
+    SDP_META_F_SHIFT = 128, // certified filter on the shifted lattice (a perturbation that reaches x0')
+    SDP_META_F_LEAD = 256   // node-order sweep with the filter on an array reduced over w (sdp_lead_kernel.h):
+                            // the code object also exports sdp_lead_reduce, launched before every sweep
 };
 #define SDP_MAXU 4   // control variables per system
 
@@ -72,6 +74,10 @@ struct SdpSweepArgs {
     // claim[32 * k], k = 0..7: next unit of XCD k's share (relative); claim[256]: workgroups that
     // have finished (the last one zeroes everything for the next launch).  Zero before the first launch.
     unsigned int *claim;
+    // ---- several controlled state variables (sdp_lead_kernel.h): the array reduced over w, in node order ----
+    void *aux_a;           // [S] A[n] = sum_w p_w inner_w(n), written by sdp_lead_reduce, read by sdp_sweep
+    void *aux_e;           // [nodes per block of trailing coordinates] bound factor of the trailing cells
+    unsigned long long *aux_vmax;   // bits of max |V| as a double (zero before sdp_lead_reduce)
 };
 
 // Batched closed-loop simulation (the user loop of the reference's examples, e.g.

@@ -1,0 +1,282 @@
+// sdp_lead_kernel.h -- Bellman backup for models with SEVERAL controlled state variables next to an
+// exogenous process (gfx950, wave64; node order, no transposed layout):
+//     x_k' = f_k(x, u[, t])      k <  m = SDP_LEAD_AXES     ("stocks": no perturbation)
+//     x_k' = f_k(x_m.., w[, t])  k >= m                      (exogenous: no control, no stock)
+// and a cost without the perturbation (TracedModel.controlled_axes; the reference's API admits any
+// `dims`, stodynprog.py:57-81, multi-control lattice :655-660).  The column kernel covers m = 1; with two
+// stocks its table would be W x N0 x N1 values.  Here the certified expectation-first filter of
+// sdp_column_kernel.h runs on a REDUCED ARRAY IN GLOBAL MEMORY instead of an LDS table:
+//
+//   sdp_lead_reduce   A[n] = sum_w p_w inner_w(n),  inner_w(n) = the reference's interpolation over the
+//                     trailing axes m.. of V[lead indices of n, .] at the trailing next state of (n, w)
+//                     -- one pass over the grid per sweep, W x 2^(d-m) vertex loads per node (what ONE
+//                     control costs the direct kernel); E[plane] = max_w prod_k (|1-lam_k| + |lam_k|) of the
+//                     trailing cells of a plane (nodes with the same x_m..), vmax = max |V|
+//   sdp_sweep         one lane per node (consecutive lanes = consecutive nodes along the last axis: the
+//                     A reads of a wave are contiguous where the nodes' controls agree).
+//     pass 1, every control:  F = fma(g, psum, multilerp_m(A; q_k, lam_k)), 2^m loads and ~25 + 12 m
+//                     instructions instead of W x (2^d loads + ~6 d + 10 instructions);
+//                     per node the two smallest F, sum |F|, Lp = max_u prod_k (1 + 2 |lam_k|)
+//     pass 2, survivors:  the reference's W x 2^d cell evaluation (sdp_expected_cost), so J, policy and
+//                     index have the reference's bits
+// In real arithmetic the nested lerp of pyx:88-300 is sum over the 2^d vertices of (lead weights, free of w)
+// x (trailing weights, free of u) x V, so  R(u) = g P + sum_lead-corners wl A*[corner]  exactly.
+// Roundings, u the unit roundoff, first order:
+//     |E - R| <= (W + 3d + 2) u S      E: per term d lerp levels of 3 roundings, g + val, . p_w, W additions
+//     |F - R| <= (W + 3d + 4) u S      A: W fma + 3 (d-m) per inner; m lerp levels; the fma with g
+//     S(u) = |g| Pcap + prod_k<m (1 + 2 |lam_k|) Dabs,   Dabs = Pcap max_w E_w vmax >= sum_w |p_w| sum |wt| |V|
+// and with |g| Pcap <= ratio (|F| (1 + u) + |h|), |h| <= Lp Dabs:
+//     S_node = ratio (sum |F| + Lp Dabs) + Lp Dabs,   radius = cu S_node,   cu = 4 (W + 3d + 4) u
+// (a factor 2 over the first-order bound, as in sdp_col_lean_core).  A NaN anywhere makes F a NaN, which
+// sticks in sum |F|; an infinity makes Dabs or sum |F| infinite; |p_k| >= 2^31 (x86 truncation of the
+// reference, sdp_trunc_i32) makes Lp >= 2^30: all of them mark the node, which then evaluates every
+// control the long way.  Dabs carries 2 tiny / cu so that the radius never drops below the smallest
+// normal number.  8-byte reals only (in 4-byte reals the radius, ~1e-5 relative, leaves too many survivors
+// for a pass 2 that costs 2^d loads per perturbation point).
+#pragma once
+
+#if SDP_LEAD_AXES < 1 || SDP_LEAD_AXES > SDP_D || !SDP_HAS_W || SDP_LANES != 1
+#error "sdp_lead_kernel.h: 1 <= SDP_LEAD_AXES <= SDP_D, a perturbation, one lane per node"
+#endif
+static_assert(sizeof(sdp_real) == 8, "the global-memory filter is built for 8-byte reals");
+#ifndef SDP_LEAD_FILTER_SCALE
+#define SDP_LEAD_FILTER_SCALE 1      // test knob: multiplies the radius (any value >= 1: same bits)
+#endif
+constexpr int SDP_LM = SDP_LEAD_AXES, SDP_LT = SDP_D - SDP_LEAD_AXES;
+
+SDP_DEV double sdp_lead_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SDP_DEV double sdp_lead_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+SDP_DEV double sdp_lead_vmax_abs(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+extern "C" __device__ double __ockl_wfred_max_f64(double);
+
+// trailing axes m.. as a grid of their own (C-order strides inside one block of trailing nodes)
+struct SdpLeadGeom {
+    int64_t ts;                 // nodes per block of trailing coordinates = prod orders[m..]
+    int64_t lm[SDP_LM];         // strides of the lead axes (in nodes)
+    sdp_real smin[SDP_LM], span[SDP_LM], rspan[SDP_LM], nm1[SDP_LM];
+    int ordm2[SDP_LM];
+    int pow2;
+};
+SDP_DEV void sdp_lead_geom(const SdpSweepArgs &a, SdpLeadGeom &g)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    int64_t m = 1;
+#pragma unroll
+    for (int k = SDP_D - 1; k >= SDP_LM; --k) m *= a.orders[k];
+    g.ts = m;
+    g.pow2 = 0;
+#pragma unroll
+    for (int k = SDP_LM - 1; k >= 0; --k) {
+        g.lm[k] = m;
+        m *= a.orders[k];
+        g.smin[k] = axes[a.axis_off[k]];
+        g.span[k] = axes[a.axis_off[k] + a.orders[k] - 1] - g.smin[k];
+        g.rspan[k] = (sdp_real)1 / g.span[k];
+        g.nm1[k] = (sdp_real)(a.orders[k] - 1);
+        g.ordm2[k] = a.orders[k] - 2;
+        if (sdp_is_pow2(g.span[k])) g.pow2 |= 1 << k;
+    }
+    g.pow2 = __builtin_amdgcn_readfirstlane(g.pow2);
+}
+#if SDP_LEAD_AXES < SDP_D
+SDP_DEV void sdp_lead_trail_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_LT> &tg)
+{
+    const sdp_real *axes = (const sdp_real *)a.axes;
+    sdp_real smin[SDP_LT], smax[SDP_LT];
+    int32_t ord[SDP_LT];
+#pragma unroll
+    for (int k = 0; k < SDP_LT; ++k) {
+        ord[k] = a.orders[SDP_LM + k];
+        smin[k] = axes[a.axis_off[SDP_LM + k]];
+        smax[k] = axes[a.axis_off[SDP_LM + k] + ord[k] - 1];
+    }
+    sdp_make_grid<sdp_real, SDP_LT>(tg, ord, smin, smax);
+}
+#endif
+
+// ---- the reduced array ------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a)
+{
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+    sdp_real *__restrict__ A = (sdp_real *)a.aux_a;
+    sdp_real *__restrict__ E = (sdp_real *)a.aux_e;
+    const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
+    const sdp_real *__restrict__ proba = (const sdp_real *)a.proba;
+    const sdp_real t = (sdp_real)a.t_k;
+    SdpLeadGeom geo;
+    sdp_lead_geom(a, geo);
+#if SDP_LEAD_AXES < SDP_D
+    SdpGrid<sdp_real, SDP_LT> tg;
+    sdp_lead_trail_grid(a, tg);
+#endif
+    sdp_real vmax = (sdp_real)0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; node < a.S; node += stride) {
+        sdp_real x[SDP_D];
+        sdp_node_coords(a, node, x);
+        const int64_t lead = node / geo.ts, trail = node - lead * geo.ts;
+        sdp_real acc = (sdp_real)0, emax = (sdp_real)0;
+        for (int wi = 0; wi < a.W; ++wi) {
+#if SDP_LEAD_AXES < SDP_D
+            sdp_real xt[SDP_LT];
+            sdp_model_trails(x, wgrid[wi], t, xt);
+            SdpCell<sdp_real, SDP_LT, sdp_real> c;
+            sdp_real ew = (sdp_real)1;
+#pragma unroll
+            for (int k = 0; k < SDP_LT; ++k) {
+                sdp_locate_axis<sdp_real, SDP_LT, sdp_real>(tg, k, xt[k], c);      // (the reference's cell: pyx:75-81)
+                ew = ew * (fabs(c.oml[k]) + fabs(c.lam[k]));
+            }
+            const sdp_real inner = SdpLerp<sdp_real, SDP_LT, sdp_real, 0>::eval(V + lead * geo.ts, tg, c, 0);
+            emax = ew > emax || ew != ew ? ew : emax;                              // (a NaN sticks)
+#else
+            const sdp_real inner = V[node];
+            emax = (sdp_real)1;
+#endif
+            acc = fma(proba[wi], inner, acc);
+        }
+        A[node] = acc;
+        if (lead == 0) E[trail] = emax;
+        vmax = sdp_lead_vmax_abs(vmax, V[node]);
+    }
+    vmax = __ockl_wfred_max_f64(vmax);
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(a.aux_vmax, (unsigned long long)__double_as_longlong(vmax));   // (>= 0: ordered as integers)
+}
+
+// ---- the sweep ---------------------------------------------------------------------------------
+// multilinear interpolation of A over the lead axes, last lead axis innermost, fused (a filter value)
+template <int K>
+struct SdpLeadLerp {
+    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int64_t *off, const int64_t *lm,
+                                 const sdp_real *lam, int64_t base)
+    {
+        const sdp_real lo = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K]);
+        const sdp_real hi = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K] + lm[K]);
+        return fma(lam[K], hi - lo, lo);
+    }
+};
+template <>
+struct SdpLeadLerp<SDP_LM> {
+    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int64_t *, const int64_t *,
+                                 const sdp_real *, int64_t base) { return A[base]; }
+};
+
+struct SdpLeadConst {
+    sdp_real psum, pcap, ratio, cu, floor;
+    bool ok;
+};
+SDP_DEV void sdp_lead_const(const SdpSweepArgs &a, SdpLeadConst &f)
+{
+    const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
+    sdp_real ps = (sdp_real)0, pa = (sdp_real)0;
+    for (int w = 0; w < a.W; ++w) {
+        ps = ps + p[w];
+        pa = pa + fabs(p[w]);
+    }
+    f.psum = ps;
+    f.pcap = pa > (sdp_real)1 ? pa : (sdp_real)1;
+    f.ratio = f.pcap / fabs(ps);                   // (psum = 0: infinite -> every node takes the long way)
+    f.cu = (sdp_real)SDP_LEAD_FILTER_SCALE * (sdp_real)(4 * (a.W + 3 * SDP_D + 4)) * (sdp_real)0x1p-53;
+    f.floor = (sdp_real)2 * (sdp_real)2.2250738585072014e-308 / f.cu;
+    f.ok = pa <= (sdp_real)1024;                   // (false for a NaN)
+}
+
+// F of one control and the product of the (1 + 2 |lam_k|); q_k, lam_k, g as the reference computes them
+SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeom &geo, const SdpLeadConst &f,
+                                const sdp_real *x, const sdp_real *u, sdp_real t, int64_t trail, sdp_real &lp)
+{
+    sdp_real xl[SDP_LM], lam[SDP_LM];
+    int64_t off[SDP_LM];
+    sdp_model_leads(x, u, t, xl);
+    sdp_real prod = (sdp_real)1;
+#pragma unroll
+    for (int k = 0; k < SDP_LM; ++k) {
+        const sdp_real sn = sdp_div_span<sdp_real>(xl[k] - geo.smin[k], geo.span[k], geo.rspan[k], (geo.pow2 >> k) & 1);
+        const sdp_real p = sn * geo.nm1[k];
+        const int q = max(min((int)p, geo.ordm2[k]), 0);       // (saturating conversion; NaN -> 0)
+        lam[k] = p - (sdp_real)q;
+        off[k] = (int64_t)q * geo.lm[k];
+        prod = prod * fma((sdp_real)2, fabs(lam[k]), (sdp_real)1);
+    }
+    lp = sdp_lead_vmax(lp, prod);
+    const sdp_real h = SdpLeadLerp<0>::eval(A, off, geo.lm, lam, trail);
+    return fma(sdp_model_cost(x, u, (sdp_real)0, t), f.psum, h);
+}
+
+extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
+{
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
+    const sdp_real *__restrict__ A = (const sdp_real *)a.aux_a;
+    const sdp_real *__restrict__ E = (const sdp_real *)a.aux_e;
+    SdpGrid<sdp_real, SDP_D> grid;
+    sdp_grid_from_args(a, grid);
+    SdpLeadGeom geo;
+    sdp_lead_geom(a, geo);
+    SdpLeadConst fc;
+    sdp_lead_const(a, fc);
+    const sdp_real t = (sdp_real)a.t_k;
+    const sdp_real vmax = (sdp_real)__longlong_as_double((long long)*a.aux_vmax);
+    sdp_trap_unless(a.aux_a != nullptr && a.aux_e != nullptr);
+
+    // XCD-aware walk over tiles of 256 consecutive nodes (see the direct kernel)
+    const int64_t n_nodes = a.node_end - a.node_begin;
+    const int64_t n_tiles = (n_nodes + blockDim.x - 1) / blockDim.x;
+    const int xcd = blockIdx.x & 7;
+    const int64_t per_xcd = (n_tiles + 7) / 8;
+    const int64_t t_end = min((int64_t)(xcd + 1) * per_xcd, n_tiles);
+    const int64_t stride = gridDim.x >> 3;
+    for (int64_t tile = (int64_t)xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += stride) {
+        const int64_t node = a.node_begin + tile * blockDim.x + threadIdx.x;
+        if (node >= a.node_end) continue;
+        sdp_real x[SDP_D];
+        SdpBox box;
+        sdp_node_coords(a, node, x);
+        sdp_load_box(a, node, box);
+        const int64_t trail = node % geo.ts;
+        const sdp_real dabs = fc.pcap * (E[trail] * vmax) + fc.floor;
+        // pass 1
+        sdp_real f1 = INFINITY, f2 = INFINITY, fsum = (sdp_real)0, lp = (sdp_real)0;
+        int i1 = INT_MAX;
+        for (int ci = 0; ci < box.total; ++ci) {
+            sdp_real u[SDP_NU];
+            sdp_controls_at(box, ci, u);
+            const sdp_real F = sdp_lead_first(A, geo, fc, x, u, t, trail, lp);
+            fsum = fsum + fabs(F);
+            f2 = sdp_lead_vmin(f2, sdp_lead_vmax(f1, F));
+            i1 = F < f1 ? ci : i1;
+            f1 = sdp_lead_vmin(f1, F);
+        }
+        const sdp_real h_cap = lp * dabs;
+        const sdp_real s_node = fma(fc.ratio, fsum + h_cap, h_cap);
+        const bool bad = !fc.ok || !(s_node < (sdp_real)0x1p1000) || !(lp < (sdp_real)1073741824.0);
+        const sdp_real radius = fc.cu * s_node;
+        const sdp_real m_hi = f1 + radius;                 // >= the minimum of E over the node
+        const bool single = !bad && i1 != INT_MAX && f2 - radius > m_hi;
+        // pass 2: the reference's operations on the survivors, in lattice order
+        sdp_real best = INFINITY;
+        int ibest = INT_MAX;
+        const int first = single ? i1 : 0, last = single ? i1 + 1 : box.total;
+        for (int ci = first; ci < last; ++ci) {
+            sdp_real u[SDP_NU];
+            sdp_controls_at(box, ci, u);
+            bool cand = single || bad;
+            if (!cand) {
+                sdp_real lq = (sdp_real)0;
+                cand = !(sdp_lead_first(A, geo, fc, x, u, t, trail, lq) - radius > m_hi);
+            }
+            if (cand) {
+                const sdp_real jc = sdp_expected_cost(a, grid, V, x, u, t);
+                if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
+            }
+        }
+        ((sdp_real *)a.J)[node] = best;
+        if (a.idx) a.idx[node] = ibest;
+        if (a.pol) {
+            sdp_real u[SDP_NU];
+            sdp_controls_at(box, ibest, u);
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c) ((sdp_real *)a.pol)[node * SDP_NU + c] = u[c];
+        }
+    }
+}

@@ -151,6 +151,9 @@ SDP_DEV sdp_real sdp_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real
 #endif
 }
 
+#if defined(SDP_LEAD_AXES)
+#include "sdp_lead_kernel.h"    // sdp_sweep (+ sdp_lead_reduce) for several controlled state variables
+#else
 extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
 {
     constexpr int L = SDP_LANES;
@@ -206,6 +209,8 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         }
     }
 }
+
+#endif  // SDP_LEAD_AXES
 
 extern "C" __global__ void __launch_bounds__(256) sdp_evalpol(SdpSweepArgs a)
 {
@@ -288,6 +293,8 @@ __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
     SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1,
 #if defined(SDP_STG_THREADS)
     SDP_META_F_STAGED, 0, 0, SDP_STG_THREADS, 0,
+#elif defined(SDP_LEAD_AXES)
+    SDP_META_F_LEAD | SDP_META_F_FILTER, 0, 0, 256, 0,
 #else
     0, 0, 0, 256, 0,
 #endif

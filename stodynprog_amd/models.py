@@ -452,3 +452,35 @@ def pv_storage(api=None, T=48, N_E=50, u_step=0.001, dt=0.5, loss=0.05):
     solver.control_steps = (u_step,)
     solver.P_prod_data = P_prod_data
     return sto, solver
+
+
+# ----------------------------------------------------------------------------
+# Two controlled stocks next to an exogenous inflow (reduced-array sweep, csrc/sdp_lead_kernel.h)
+# ----------------------------------------------------------------------------
+def two_reservoirs(api=None, n_a=48, n_b=48, n_y=24, n_w=9, steps=(0.125, 0.125)):
+    """A cascade of two reservoirs fed by an AR(1) inflow: the upper one releases into the lower one,
+    the lower one into the turbine whose output should follow a demand.  Two state variables are
+    driven by the controls, the third is exogenous and carries the perturbation: the reference's API
+    admits it like any other `dims` (stodynprog.py:57-81; 2-D control lattice :655-660)."""
+    SysDescription, DPSolver = _classes(api)
+    sysd = SysDescription((3, 2, 1), name='Two reservoirs')
+
+    def dyn(a, b, y, u, v, w):
+        return (a + (0.6 + 0.4 * y) - u, b + u - v, 0.3 + 0.7 * (y - 0.3) + w)
+    sysd.dyn = dyn
+
+    def box(a, b, y):
+        return ((0., 1.), (0., 1.))
+    sysd.control_box = box
+
+    def cost(a, b, y, u, v, w):
+        spill = np.where(a > 2.0, a - 2.0, 0.0 * a) + np.where(b > 2.0, b - 2.0, 0.0 * b)
+        dry = np.where(a < 0.0, -a, 0.0 * a) + np.where(b < 0.0, -b, 0.0 * b)
+        return (v - 0.8) * (v - 0.8) + 0.05 * (u - v) * (u - v) + 4.0 * spill + 8.0 * dry
+    sysd.cost = cost
+    sysd.perturb_laws = [NormalLaw(0, 0.1)]
+    solver = DPSolver(sysd)
+    solver.discretize_state(0., 2., n_a, 0., 2., n_b, -0.2, 0.8, n_y)
+    solver.discretize_perturb(-0.3, 0.3, n_w)
+    solver.control_steps = steps
+    return sysd, solver

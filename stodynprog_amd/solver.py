@@ -597,8 +597,8 @@ class DPSolver(object):
         W = len(self.perturb_grid[0]) if self.perturb_grid else 0
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
-        if self.kernel not in ('auto', 'generic', 'column', 'staged'):
-            raise ValueError("kernel must be 'auto', 'column', 'staged' or 'generic'")
+        if self.kernel not in ('auto', 'generic', 'column', 'staged', 'lead'):
+            raise ValueError("kernel must be 'auto', 'column', 'lead', 'staged' or 'generic'")
         may_filter = (getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'
                       and codegen.column_filter_applies(model, dtype=dt, table=(shape[0], W, len(shape))))
         column = (self.kernel in ('auto', 'column') and model.storage_separable and
@@ -606,10 +606,21 @@ class DPSolver(object):
                                         codegen.use_wpair(model, dt), may_filter,
                                         shift=may_filter and codegen.column_shift_applies(model, dt),
                                         extra_bytes=2 * codegen.UTAB_MAX_BYTES) is not None)
+        # several controlled state variables next to an exogenous process: the node-order sweep with the
+        # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h); one GPU for now
+        lead_axes = 0
+        if (not column and self.kernel in ('auto', 'lead') and self.comm is None and W > 0
+                and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
+            lead_axes = codegen.lead_filter_applies(model, dt)
+        if self.kernel == 'lead' and not lead_axes:
+            raise ValueError("kernel = 'lead' needs several controlled state variables listed first, an exogenous "
+                             'process after them, a perturbation that reaches only that process, 8-byte reals')
+        if lead_axes:
+            lanes = 1                                     # one lane per node, the control loop in-lane
         # trailing next states that depend on the control but not on x0: the nodes of a
         # column still share a table, control by control, provided they share their control
         # values (box independent of x0) -- csrc/sdp_column_kernel.h, SDP_TRAIL_HAS_U
-        per_control = (not column and self.kernel in ('auto', 'column') and model.column_shareable
+        per_control = (not column and not lead_axes and self.kernel in ('auto', 'column') and model.column_shareable
                        and model.trail_depends_on_u and self.arithmetic == 'exact'
                        and self._box_constant_along_axis0(bp, shape))
         per_control_cfg = None
@@ -617,7 +628,7 @@ class DPSolver(object):
             per_control_cfg = codegen.column_percontrol_config(shape[0], W, len(shape), dt)
             column = per_control = per_control_cfg is not None
         window = None
-        if (not column and not per_control and self.kernel in ('auto', 'column')
+        if (not column and not per_control and not lead_axes and self.kernel in ('auto', 'column')
                 and model.storage_separable and self.arithmetic == 'exact'):
             # the W x N0 table exceeds the LDS of a CU: tabulate a window of rows per
             # segment of the column (csrc/sdp_column_kernel.h, SDP_COL_ROWS)
@@ -638,7 +649,7 @@ class DPSolver(object):
         if self.arithmetic not in ('exact', 'fused'):
             raise ValueError("arithmetic must be 'exact' or 'fused'")
         staged = None
-        if not column and self.kernel in ('auto', 'staged'):
+        if not column and not lead_axes and self.kernel in ('auto', 'staged'):
             key = ('staged', model.structure_key(), bp['digest'], str(dt), shape, W)
             staged = self._cache.get(key)
             if staged is None:
@@ -656,8 +667,10 @@ class DPSolver(object):
                                           column=(shape[0], W, bp['max_u'], int(np.prod(shape[1:]))) if column else None,
                                           fused=(self.arithmetic == 'fused'), staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
-                                          filtered=filtered, utab=utab)
+                                          filtered=filtered, utab=utab, lead_axes=lead_axes)
+        filtered = filtered or bool(lead_axes)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
+                    lead_axes=lead_axes,
                     window=window, per_control=per_control,
                     col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
@@ -816,7 +829,9 @@ class DPSolver(object):
             elif self.comm_exchange != 'rccl':
                 raise ValueError("comm_exchange must be 'rccl' or 'peer'")
         prob.info = dict(mode='traced', exchange=exchange,
-                         kernel='column' if column else ('staged' if plan['staged'] else 'generic'),
+                         kernel='column' if column else ('staged' if plan['staged'] else
+                                                         ('lead' if plan.get('lead_axes') else 'generic')),
+                         controlled_axes=int(plan.get('lead_axes') or (1 if column else 0)),
                          staged=plan['staged'],
                          row_window=(dict(rows=plan['window'][2], segment_nodes=plan['window'][3])
                                      if plan['window'] else None),
@@ -824,7 +839,8 @@ class DPSolver(object):
                          certified_filter=bool(plan.get('filtered')),
                          # 'shifted lattice': the perturbation reaches x0' through a final sum (SDP_COL_SHIFT)
                          filter_form=(None if not plan.get('filtered') else
-                                      ('shifted lattice' if '#define SDP_COL_SHIFT 1' in plan['source'] else 'reduced table')),
+                                      ('shifted lattice' if '#define SDP_COL_SHIFT 1' in plan['source'] else
+                                       ('reduced array' if plan.get('lead_axes') else 'reduced table'))),
                          arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),

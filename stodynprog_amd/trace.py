@@ -661,6 +661,49 @@ class TracedModel(object):
     def cost_depends_on_w(self):
         return bool(self.cost.deps & DEP_W)
 
+    def var_reach(self, node, _memo=None):
+        """names of the variables (`x0`, `u1`, `w0`, `t`) `node` depends on"""
+        memo = self.__dict__.setdefault('_reach', {})
+        stack = [node]
+        while stack:
+            n = stack[-1]
+            if n.id in memo:
+                stack.pop()
+                continue
+            if n.op == 'var':
+                memo[n.id] = frozenset([n.value])
+                stack.pop()
+                continue
+            todo = [a for a in n.args if a.id not in memo]
+            if todo:
+                stack.extend(todo)
+                continue
+            acc = frozenset()
+            for a in n.args:
+                acc = acc | memo[a.id]
+            memo[n.id] = acc
+            stack.pop()
+        return memo[node.id]
+
+    def controlled_axes(self):
+        """m such that the first m state variables are 'stocks' -- their next values may depend on the
+        whole state and on the control but NOT on the perturbation -- and the others an exogenous
+        process: next values that depend on x_m.., the perturbation and the time only:
+            x_k' = f_k(x, u[, t])  for k < m        x_k' = f_k(x_m.., w[, t])  for k >= m
+        (storage_separable is m = 1 with a stock that may also see w).  The expectation over w then
+        commutes with the interpolation along the first m axes -- csrc/sdp_lead_kernel.h.  Returns the
+        smallest such m >= 1, or None."""
+        d = self.n_state
+        reach = [self.var_reach(n) for n in self.x_next]
+        for m in range(1, d + 1):
+            lead_vars = set('x%d' % j for j in range(m))
+            ok = all(not any(v.startswith('w') for v in reach[k]) for k in range(m))
+            ok = ok and all(not (reach[k] & lead_vars) and not any(v.startswith('u') for v in reach[k])
+                            for k in range(m, d))
+            if ok:
+                return m
+        return None
+
     LEAD_SPLIT_MAX_TERMS = 4
 
     def lead_split(self):
