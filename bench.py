@@ -73,6 +73,11 @@ WORKLOADS = {
     # runs on the shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)
     'noisy256': ('synthetic3d', dict(N=256, stock_noise=0.07), 'float64', None,
                  'synthetic3d {n}^3 x 64 controls x 32 perturbations, perturbation also in the stock'),
+    # not a BASELINE config: two controlled stocks (a cascade of reservoirs) next to an exogenous inflow,
+    # 128 x 128 x 64 nodes x 16 x 16 controls x 16 perturbation points -- the node-order sweep with the
+    # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h)
+    'reservoirs': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float64', None,
+                   'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations (two controlled state variables)'),
     'coupled256': ('synthetic3d_coupled', dict(N=256), 'float64', None,
                    'synthetic3d {n}^3 x 64 controls x 32 perturbations, control-coupled x1 (non-separable)'),
 }
@@ -677,7 +682,7 @@ def finish_single(args, env, out):
         others = {}
         for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
             solver._cache.pop(k_).close()
-        for name in ('ar1', 'searev', 'synth512f32', 'noisy256'):
+        for name in ('ar1', 'searev', 'synth512f32', 'noisy256', 'reservoirs'):
             try:
                 a2 = copy.copy(args)
                 a2.config, a2.grid, a2.dtype = name, 0, None

@@ -50,7 +50,12 @@ extern "C" {
  *   SDP_VARIANT_DIRECT  `sdp_sweep`: one global load per interpolation vertex;
  *   SDP_VARIANT_STAGED  `sdp_sweep_lds`: a workgroup owns a tile of nodes and
  *                       stages the value sub-block its next states reach in LDS
- *                       (csrc/sdp_staged_kernel.h).  Same results, bit for bit. */
+ *                       (csrc/sdp_staged_kernel.h).  Same results, bit for bit.
+ * A SDP_VARIANT_DIRECT code object whose `sdp_meta` carries SDP_META_F_LEAD (several controlled
+ * state variables next to an exogenous process, csrc/sdp_lead_kernel.h; lanes_per_node must be 1)
+ * also exports `sdp_lead_reduce`: the library launches it over the whole grid before every `sdp_sweep`
+ * (it needs the whole cost-to-go array on the device: not with attached parts) and owns the arrays it
+ * fills.  Same results, bit for bit (reference stodynprog.py:639-691 with any `dims`, :57-81). */
 #define SDP_VARIANT_DIRECT 0
 #define SDP_VARIANT_STAGED 1
 

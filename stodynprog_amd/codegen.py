@@ -435,7 +435,9 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         # several controlled state variables: node-order sweep with the filter on an array reduced over w
         head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes))] + (
             ['#define SDP_LEAD_FILTER_SCALE {}'.format(float(os.environ['SDP_LEAD_FILTER_SCALE']))]
-            if os.environ.get('SDP_LEAD_FILTER_SCALE') else []) + [
+            if os.environ.get('SDP_LEAD_FILTER_SCALE') else []) + (
+            ['#define SDP_LEAD_UNROLL {}'.format(int(os.environ['SDP_LEAD_UNROLL']))]
+            if os.environ.get('SDP_LEAD_UNROLL') else []) + [
             lead_functions_source(model, int(lead_axes)), '',
             '#include "sdp_sweep_kernel.h"    // brings in sdp_lead_kernel.h', '']
     else:

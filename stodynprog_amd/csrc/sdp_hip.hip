@@ -665,9 +665,10 @@ struct sdp_problem {
     hipModule_t mod = nullptr;
     hipFunction_t f_sweep = nullptr, f_evalpol = nullptr, f_simulate = nullptr;
     // several controlled state variables (csrc/sdp_lead_kernel.h): the kernel that reduces V over w, launched
-    // before every sweep, and its outputs (A[S], E[nodes per trailing block], bits of max |V|)
+    // before every sweep, and its outputs (A[S] and a copy of V, both plane-major; E[nodes per trailing block];
+    // bits of max |V|)
     hipFunction_t f_lead_reduce = nullptr;
-    DevBuf lead_a, lead_e, lead_vmax;
+    DevBuf lead_a, lead_v, lead_e, lead_vmax;
     hipDeviceptr_t prm_dev = nullptr;     // `sdp_model_prm` of the code object (lifted model constants)
     size_t prm_bytes = 0;
     hipStream_t stream = nullptr;
@@ -887,6 +888,7 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_lead_reduce kernel: %s", desc->module_path, hipGetErrorString(e));
         if (p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
         int rc = p->lead_a.alloc((size_t)p->S * rs);
+        if (!rc) rc = p->lead_v.alloc((size_t)p->S * rs);
         if (!rc) rc = p->lead_e.alloc((size_t)p->S * rs / (size_t)p->orders[0]);      // (>= nodes per trailing block)
         if (!rc) rc = p->lead_vmax.alloc(8);
         if (rc) return rc;
@@ -1016,7 +1018,7 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     a.shift_index = -1; a.ref_out = nullptr;
     a.stamps = (unsigned long long *)p->stamps.p;
     a.claim = (unsigned int *)p->claim.p;
-    a.aux_a = p->lead_a.p; a.aux_e = p->lead_e.p; a.aux_vmax = (unsigned long long *)p->lead_vmax.p;
+    a.aux_a = p->lead_a.p; a.aux_v = p->lead_v.p; a.aux_e = p->lead_e.p; a.aux_vmax = (unsigned long long *)p->lead_vmax.p;
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
         a.col_begin = nb / p->orders[0];

@@ -75,7 +75,8 @@ struct SdpSweepArgs {
     // have finished (the last one zeroes everything for the next launch).  Zero before the first launch.
     unsigned int *claim;
     // ---- several controlled state variables (sdp_lead_kernel.h): the array reduced over w, in node order ----
-    void *aux_a;           // [S] A[n] = sum_w p_w inner_w(n), written by sdp_lead_reduce, read by sdp_sweep
+    void *aux_a;           // [S] A = sum_w p_w inner_w, plane-major, written by sdp_lead_reduce, read by sdp_sweep
+    void *aux_v;           // [S] copy of V, plane-major (the second pass reads it)
     void *aux_e;           // [nodes per block of trailing coordinates] bound factor of the trailing cells
     unsigned long long *aux_vmax;   // bits of max |V| as a double (zero before sdp_lead_reduce)
 };

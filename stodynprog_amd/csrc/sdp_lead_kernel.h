@@ -11,9 +11,14 @@
 //                     trailing axes m.. of V[lead indices of n, .] at the trailing next state of (n, w)
 //                     -- one pass over the grid per sweep, W x 2^(d-m) vertex loads per node (what ONE
 //                     control costs the direct kernel); E[plane] = max_w prod_k (|1-lam_k| + |lam_k|) of the
-//                     trailing cells of a plane (nodes with the same x_m..), vmax = max |V|
-//   sdp_sweep         one lane per node (consecutive lanes = consecutive nodes along the last axis: the
-//                     A reads of a wave are contiguous where the nodes' controls agree).
+//                     trailing cells of a plane (nodes with the same x_m..), vmax = max |V|.
+//                     A and a copy of V are written PLANE-MAJOR ([trailing index][lead index], the last stock
+//                     fastest): what the controls of a node reach is then a patch of ONE plane (N0 x N1
+//                     values, 128 KiB at 128 x 128) instead of a slab of the whole array
+//   sdp_sweep         one lane per node, in plane-major order: consecutive lanes = consecutive values of the
+//                     last stock, so the reads of a wave are contiguous, neighbouring controls re-read the
+//                     same lines (L1), and the planes an XCD works on stay in its L2.  (In node order the
+//                     same kernel read the reduced array at the Infinity Cache's rate: 1.5 ms, now below.)
 //     pass 1, every control:  F = fma(g, psum, multilerp_m(A; q_k, lam_k)), 2^m loads and ~25 + 12 m
 //                     instructions instead of W x (2^d loads + ~6 d + 10 instructions);
 //                     per node the two smallest F, sum |F|, Lp = max_u prod_k (1 + 2 |lam_k|)
@@ -39,6 +44,9 @@
 #error "sdp_lead_kernel.h: 1 <= SDP_LEAD_AXES <= SDP_D, a perturbation, one lane per node"
 #endif
 static_assert(sizeof(sdp_real) == 8, "the global-memory filter is built for 8-byte reals");
+#ifndef SDP_LEAD_UNROLL
+#define SDP_LEAD_UNROLL 1            // controls of the first pass per round (2 and 4 measured the same: 0.98 ms)
+#endif
 #ifndef SDP_LEAD_FILTER_SCALE
 #define SDP_LEAD_FILTER_SCALE 1      // test knob: multiplies the radius (any value >= 1: same bits)
 #endif
@@ -52,7 +60,9 @@ extern "C" __device__ double __ockl_wfred_max_f64(double);
 // trailing axes m.. as a grid of their own (C-order strides inside one block of trailing nodes)
 struct SdpLeadGeom {
     int64_t ts;                 // nodes per block of trailing coordinates = prod orders[m..]
-    int64_t lm[SDP_LM];         // strides of the lead axes (in nodes)
+    int64_t ls;                 // nodes per plane = prod orders[..m-1]
+    int64_t lm[SDP_LM];         // strides of the lead axes in node order
+    int pm[SDP_LM];             // strides of the lead axes inside a plane (plane-major arrays)
     sdp_real smin[SDP_LM], span[SDP_LM], rspan[SDP_LM], nm1[SDP_LM];
     int ordm2[SDP_LM];
     int pow2;
@@ -65,10 +75,13 @@ SDP_DEV void sdp_lead_geom(const SdpSweepArgs &a, SdpLeadGeom &g)
     for (int k = SDP_D - 1; k >= SDP_LM; --k) m *= a.orders[k];
     g.ts = m;
     g.pow2 = 0;
+    int pm = 1;
 #pragma unroll
     for (int k = SDP_LM - 1; k >= 0; --k) {
         g.lm[k] = m;
         m *= a.orders[k];
+        g.pm[k] = pm;
+        pm *= a.orders[k];
         g.smin[k] = axes[a.axis_off[k]];
         g.span[k] = axes[a.axis_off[k] + a.orders[k] - 1] - g.smin[k];
         g.rspan[k] = (sdp_real)1 / g.span[k];
@@ -76,6 +89,7 @@ SDP_DEV void sdp_lead_geom(const SdpSweepArgs &a, SdpLeadGeom &g)
         g.ordm2[k] = a.orders[k] - 2;
         if (sdp_is_pow2(g.span[k])) g.pow2 |= 1 << k;
     }
+    g.ls = pm;
     g.pow2 = __builtin_amdgcn_readfirstlane(g.pow2);
 }
 #if SDP_LEAD_AXES < SDP_D
@@ -99,6 +113,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
 {
     const sdp_real *__restrict__ V = (const sdp_real *)a.V;
     sdp_real *__restrict__ A = (sdp_real *)a.aux_a;
+    sdp_real *__restrict__ Vt = (sdp_real *)a.aux_v;
     sdp_real *__restrict__ E = (sdp_real *)a.aux_e;
     const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
     const sdp_real *__restrict__ proba = (const sdp_real *)a.proba;
@@ -135,9 +150,11 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
 #endif
             acc = fma(proba[wi], inner, acc);
         }
-        A[node] = acc;
+        const sdp_real vn = V[node];
+        A[trail * geo.ls + lead] = acc;                   // plane-major: [trailing index][lead index]
+        Vt[trail * geo.ls + lead] = vn;
         if (lead == 0) E[trail] = emax;
-        vmax = sdp_lead_vmax_abs(vmax, V[node]);
+        vmax = sdp_lead_vmax_abs(vmax, vn);
     }
     vmax = __ockl_wfred_max_f64(vmax);
     if ((threadIdx.x & 63) == 0)
@@ -148,8 +165,8 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
 // multilinear interpolation of A over the lead axes, last lead axis innermost, fused (a filter value)
 template <int K>
 struct SdpLeadLerp {
-    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int64_t *off, const int64_t *lm,
-                                 const sdp_real *lam, int64_t base)
+    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int *off, const int *lm,
+                                 const sdp_real *lam, int base)
     {
         const sdp_real lo = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K]);
         const sdp_real hi = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K] + lm[K]);
@@ -158,8 +175,8 @@ struct SdpLeadLerp {
 };
 template <>
 struct SdpLeadLerp<SDP_LM> {
-    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int64_t *, const int64_t *,
-                                 const sdp_real *, int64_t base) { return A[base]; }
+    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int *, const int *,
+                                 const sdp_real *, int base) { return A[base]; }
 };
 
 struct SdpLeadConst {
@@ -182,12 +199,41 @@ SDP_DEV void sdp_lead_const(const SdpSweepArgs &a, SdpLeadConst &f)
     f.ok = pa <= (sdp_real)1024;                   // (false for a NaN)
 }
 
+// the control lattice in C order (control 0 slowest) without a division per point: the flat index i of the
+// walk stands for the same point as sdp_controls_at(box, i, .), and the values are sdp_control_value's
+struct SdpLeadWalk {
+    int k[SDP_NU];
+    sdp_real u[SDP_NU];
+};
+SDP_DEV void sdp_lead_walk_begin(const SdpBox &b, SdpLeadWalk &w)
+{
+#pragma unroll
+    for (int c = 0; c < SDP_NU; ++c) {
+        w.k[c] = 0;
+        w.u[c] = sdp_control_value(b, c, 0);
+    }
+}
+SDP_DEV void sdp_lead_walk_next(const SdpBox &b, SdpLeadWalk &w)
+{
+    bool carry = true;
+#pragma unroll
+    for (int c = SDP_NU - 1; c >= 0; --c) {
+        if (carry) {
+            const int k = w.k[c] + 1;
+            carry = k >= b.n[c];
+            w.k[c] = carry ? 0 : k;
+            w.u[c] = sdp_control_value(b, c, w.k[c]);
+        }
+    }
+}
+
 // F of one control and the product of the (1 + 2 |lam_k|); q_k, lam_k, g as the reference computes them
+// (`A`: the node's plane of the reduced array)
 SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeom &geo, const SdpLeadConst &f,
-                                const sdp_real *x, const sdp_real *u, sdp_real t, int64_t trail, sdp_real &lp)
+                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &lp)
 {
     sdp_real xl[SDP_LM], lam[SDP_LM];
-    int64_t off[SDP_LM];
+    int off[SDP_LM];
     sdp_model_leads(x, u, t, xl);
     sdp_real prod = (sdp_real)1;
 #pragma unroll
@@ -196,56 +242,69 @@ SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeo
         const sdp_real p = sn * geo.nm1[k];
         const int q = max(min((int)p, geo.ordm2[k]), 0);       // (saturating conversion; NaN -> 0)
         lam[k] = p - (sdp_real)q;
-        off[k] = (int64_t)q * geo.lm[k];
+        off[k] = q * geo.pm[k];
         prod = prod * fma((sdp_real)2, fabs(lam[k]), (sdp_real)1);
     }
     lp = sdp_lead_vmax(lp, prod);
-    const sdp_real h = SdpLeadLerp<0>::eval(A, off, geo.lm, lam, trail);
+    const sdp_real h = SdpLeadLerp<0>::eval(A, off, geo.pm, lam, 0);
     return fma(sdp_model_cost(x, u, (sdp_real)0, t), f.psum, h);
 }
 
 extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
 {
-    const sdp_real *__restrict__ V = (const sdp_real *)a.V;
-    const sdp_real *__restrict__ A = (const sdp_real *)a.aux_a;
+    const sdp_real *__restrict__ Aall = (const sdp_real *)a.aux_a;
+    const sdp_real *__restrict__ Vt = (const sdp_real *)a.aux_v;
     const sdp_real *__restrict__ E = (const sdp_real *)a.aux_e;
-    SdpGrid<sdp_real, SDP_D> grid;
-    sdp_grid_from_args(a, grid);
     SdpLeadGeom geo;
     sdp_lead_geom(a, geo);
+    // the grid of the second pass: the reference's cells and weights, the strides of the plane-major copy of V
+    SdpGrid<sdp_real, SDP_D> grid;
+    sdp_grid_from_args(a, grid);
+    {
+        int m = (int)geo.ls;
+#pragma unroll
+        for (int k = SDP_D - 1; k >= SDP_LM; --k) { grid.M[k] = m; m *= a.orders[k]; }
+#pragma unroll
+        for (int k = 0; k < SDP_LM; ++k) grid.M[k] = geo.pm[k];
+    }
     SdpLeadConst fc;
     sdp_lead_const(a, fc);
     const sdp_real t = (sdp_real)a.t_k;
+    sdp_trap_unless(a.aux_a != nullptr && a.aux_e != nullptr && a.aux_v != nullptr);
     const sdp_real vmax = (sdp_real)__longlong_as_double((long long)*a.aux_vmax);
-    sdp_trap_unless(a.aux_a != nullptr && a.aux_e != nullptr);
 
-    // XCD-aware walk over tiles of 256 consecutive nodes (see the direct kernel)
-    const int64_t n_nodes = a.node_end - a.node_begin;
-    const int64_t n_tiles = (n_nodes + blockDim.x - 1) / blockDim.x;
+    // XCD-aware walk over tiles of 256 consecutive PLANE-MAJOR positions: an XCD takes a contiguous eighth,
+    // i.e. whole planes, whose reduced values then stay in its L2
+    const int64_t n_tiles = (a.S + blockDim.x - 1) / blockDim.x;
     const int xcd = blockIdx.x & 7;
     const int64_t per_xcd = (n_tiles + 7) / 8;
     const int64_t t_end = min((int64_t)(xcd + 1) * per_xcd, n_tiles);
     const int64_t stride = gridDim.x >> 3;
     for (int64_t tile = (int64_t)xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += stride) {
-        const int64_t node = a.node_begin + tile * blockDim.x + threadIdx.x;
-        if (node >= a.node_end) continue;
+        const int64_t pos = tile * blockDim.x + threadIdx.x;
+        if (pos >= a.S) continue;
+        const int64_t trail = pos / geo.ls, lead = pos - trail * geo.ls;
+        const int64_t node = lead * geo.ts + trail;
+        if (node < a.node_begin || node >= a.node_end) continue;
         sdp_real x[SDP_D];
         SdpBox box;
         sdp_node_coords(a, node, x);
         sdp_load_box(a, node, box);
-        const int64_t trail = node % geo.ts;
+        const sdp_real *__restrict__ A = Aall + trail * geo.ls;
         const sdp_real dabs = fc.pcap * (E[trail] * vmax) + fc.floor;
         // pass 1
         sdp_real f1 = INFINITY, f2 = INFINITY, fsum = (sdp_real)0, lp = (sdp_real)0;
         int i1 = INT_MAX;
+        SdpLeadWalk walk;
+        sdp_lead_walk_begin(box, walk);
+#pragma unroll SDP_LEAD_UNROLL
         for (int ci = 0; ci < box.total; ++ci) {
-            sdp_real u[SDP_NU];
-            sdp_controls_at(box, ci, u);
-            const sdp_real F = sdp_lead_first(A, geo, fc, x, u, t, trail, lp);
+            const sdp_real F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp);
             fsum = fsum + fabs(F);
             f2 = sdp_lead_vmin(f2, sdp_lead_vmax(f1, F));
             i1 = F < f1 ? ci : i1;
             f1 = sdp_lead_vmin(f1, F);
+            sdp_lead_walk_next(box, walk);
         }
         const sdp_real h_cap = lp * dabs;
         const sdp_real s_node = fma(fc.ratio, fsum + h_cap, h_cap);
@@ -257,18 +316,19 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         sdp_real best = INFINITY;
         int ibest = INT_MAX;
         const int first = single ? i1 : 0, last = single ? i1 + 1 : box.total;
+        if (single) sdp_controls_at(box, i1, walk.u);
+        else sdp_lead_walk_begin(box, walk);
         for (int ci = first; ci < last; ++ci) {
-            sdp_real u[SDP_NU];
-            sdp_controls_at(box, ci, u);
             bool cand = single || bad;
             if (!cand) {
                 sdp_real lq = (sdp_real)0;
-                cand = !(sdp_lead_first(A, geo, fc, x, u, t, trail, lq) - radius > m_hi);
+                cand = !(sdp_lead_first(A, geo, fc, x, walk.u, t, lq) - radius > m_hi);
             }
             if (cand) {
-                const sdp_real jc = sdp_expected_cost(a, grid, V, x, u, t);
+                const sdp_real jc = sdp_expected_cost(a, grid, Vt, x, walk.u, t);
                 if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
             }
+            if (!single) sdp_lead_walk_next(box, walk);
         }
         ((sdp_real *)a.J)[node] = best;
         if (a.idx) a.idx[node] = ibest;

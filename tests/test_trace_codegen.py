@@ -432,6 +432,38 @@ def test_shifted_lattice_planning_without_a_gpu():
     assert '#define SDP_COL_SHIFT 1' in s._kernel_plan()['source']
 
 
+def test_controlled_axes_and_the_reduced_array_plan_without_a_gpu():
+    """several controlled state variables next to an exogenous process (TracedModel.controlled_axes) and
+    the kernel family planned for them (csrc/sdp_lead_kernel.h)"""
+    from stodynprog_amd import codegen
+    tr3 = lambda dyn, cost=None: trace_model(dyn, cost or (lambda a, b, y, u, v, w: u * u + v * v + y * u), 3, 2, 1)
+    assert tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w)).controlled_axes() == 2
+    assert tr3(lambda a, b, y, u, v, w: (a + u, 0.9 * b + y, 0.8 * y + w)).controlled_axes() == 1     # one stock
+    assert tr3(lambda a, b, y, u, v, w: (a + u + w, b + v, 0.8 * y + w)).controlled_axes() is None    # w in a stock
+    assert tr3(lambda a, b, y, u, v, w: (a + u, b + v, 0.8 * y + w + 0.1 * a)).controlled_axes() is None   # a stock drives y
+    assert tr3(lambda a, b, y, u, v, w: (a + u, b + v + y, 0.8 * y + w + 0.1 * u)).controlled_axes() is None   # the control drives y, which sees w
+    assert models.synthetic3d(N=8)[1]._traced().controlled_axes() == 1
+    m = tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w))
+    assert codegen.lead_filter_applies(m, np.float64) == 2 and codegen.lead_filter_applies(m, np.float32) == 0
+    mw = tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w), lambda a, b, y, u, v, w: u * w)
+    assert codegen.lead_filter_applies(mw, np.float64) == 0          # a cost that sees the perturbation: not yet
+    _, s = models.two_reservoirs(n_a=12, n_b=10, n_y=6, n_w=5)
+    plan = s._kernel_plan()
+    assert plan['lead_axes'] == 2 and plan['lanes'] == 1 and plan['filtered'] and not plan['column'] and plan['staged'] is None
+    src = plan['source']
+    assert '#define SDP_LEAD_AXES 2' in src and '#define SDP_LANES 1' in src
+    for fn in ('sdp_model_leads', 'sdp_model_trails', 'sdp_model_cost', 'sdp_model_cell'):
+        assert fn in src
+    s.kernel = 'generic'
+    assert not s._kernel_plan()['lead_axes']
+    s.kernel = 'column'                          # the table-per-control column kernel still takes the model when asked
+    assert s._kernel_plan()['column'] and s._kernel_plan()['per_control']
+    s.kernel = 'lead'
+    s.dtype = np.dtype('float32')
+    with pytest.raises(ValueError):
+        s._kernel_plan()
+
+
 def test_control_table_planning_without_a_gpu():
     """the sub-expressions of x0' and of the cost that depend on the control but not on the leading
     state variable (TracedModel.control_uniform_frontier) and the table codegen builds from them"""

@@ -13,6 +13,8 @@ out = {}
 for kernel, env in (('lead', {}), ('staged', {}), ('column', {}), ('generic', {})):
     if kernel == 'generic' and os.environ.get('LEAD_AB_SKIP_GENERIC'):
         continue
+    if os.environ.get('LEAD_AB_ONLY') and kernel not in os.environ['LEAD_AB_ONLY'].split(','):
+        continue
     _, s = models.two_reservoirs(n_a=n_a, n_b=n_b, n_y=n_y, n_w=n_w, steps=(1.0 / (n_u - 1), 1.0 / (n_u - 1)))
     s.kernel = kernel
     a, b, y = [np.asarray(g) for g in s.state_grid]
