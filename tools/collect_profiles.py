@@ -11,7 +11,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 runs = ((tag + '_final', 'synth256_f64_column_filter'), (tag + '_nofilter', 'synth256_f64_column'),
         (tag + '_synth512f32', 'synth512f32_f32_column_filter'), (tag + '_searev', 'searev_f64_column_filter'),
-        (tag + '_ar1', 'ar1_f64_column_filter'), (tag + '_coupled', 'coupled256_f64_column'))
+        (tag + '_ar1', 'ar1_f64_column_filter'), (tag + '_coupled', 'coupled256_f64_column'),
+        (tag + '_noisy', 'noisy256_f64_column_filter'), (tag + '_reservoirs', 'reservoirs_f64_lead_filter'))
 for t, key in runs:
     d = os.path.join(root, 'gpurun_out', 'prof_' + t)
     if not os.path.isdir(d):
@@ -29,7 +30,8 @@ if os.path.exists(clk):
     old['f64'], old['f32'], old['sweep_kernel_ghz'], old['round'] = new['f64'], new['f32'], new['sweep_kernel_ghz'], tag
     json.dump(old, open(os.path.join(root, 'profiles', 'clock.json'), 'w'), indent=1)
 for f in (tag + '_filter_radius_probe.txt', tag + '_filter_probe.txt', tag + '_parity_report.txt',
-          tag + '_ubench_valu_rate.txt', tag + '_fixed_cost_sharded.txt'):
+          tag + '_ubench_valu_rate.txt', tag + '_fixed_cost_sharded.txt', tag + '_filter_probe_noisy.txt',
+          tag + '_filter_ab_noisy.txt', tag + '_lead_ab.txt'):
     src = os.path.join(root, 'gpurun_out', f)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(root, 'profiles', f))
