@@ -252,13 +252,13 @@ def lead_functions_source(model, m):
 
 def lead_filter_applies(model, dtype):
     """Several controlled state variables next to an exogenous process (TracedModel.controlled_axes
-    >= 2; one stock is the column kernel's case), a perturbation that reaches neither them nor the
-    cost, 8-byte reals: the node-order sweep with the certified filter on an array reduced over w
+    >= 2; one stock is the column kernel's case), a perturbation that does not reach them (the cost may see
+    it), 8-byte reals: the node-order sweep with the certified filter on an array reduced over w
     (csrc/sdp_lead_kernel.h).  Returns the number of controlled axes, or 0.  SDP_LEAD_FILTER=0 in the
     environment switches it off (A/B runs)."""
     if os.environ.get('SDP_LEAD_FILTER', '1') == '0':
         return 0
-    if model.n_perturb != 1 or model.cost_depends_on_w or np.dtype(dtype).itemsize != 8:
+    if model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
         return 0
     m = model.controlled_axes()
     return int(m) if m is not None and m >= 2 else 0
@@ -433,7 +433,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '']
     elif lead_axes:
         # several controlled state variables: node-order sweep with the filter on an array reduced over w
-        head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes))] + (
+        head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes)),
+                 '#define SDP_LEAD_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0)] + (
             ['#define SDP_LEAD_FILTER_SCALE {}'.format(float(os.environ['SDP_LEAD_FILTER_SCALE']))]
             if os.environ.get('SDP_LEAD_FILTER_SCALE') else []) + (
             ['#define SDP_LEAD_UNROLL {}'.format(int(os.environ['SDP_LEAD_UNROLL']))]

@@ -2,7 +2,7 @@
 // exogenous process (gfx950, wave64; node order, no transposed layout):
 //     x_k' = f_k(x, u[, t])      k <  m = SDP_LEAD_AXES     ("stocks": no perturbation)
 //     x_k' = f_k(x_m.., w[, t])  k >= m                      (exogenous: no control, no stock)
-// and a cost without the perturbation (TracedModel.controlled_axes; the reference's API admits any
+// (TracedModel.controlled_axes; the cost may depend on everything; the reference's API admits any
 // `dims`, stodynprog.py:57-81, multi-control lattice :655-660).  The column kernel covers m = 1; with two
 // stocks its table would be W x N0 x N1 values.  Here the certified expectation-first filter of
 // sdp_column_kernel.h runs on a REDUCED ARRAY IN GLOBAL MEMORY instead of an LDS table:
@@ -44,6 +44,9 @@
 #error "sdp_lead_kernel.h: 1 <= SDP_LEAD_AXES <= SDP_D, a perturbation, one lane per node"
 #endif
 static_assert(sizeof(sdp_real) == 8, "the global-memory filter is built for 8-byte reals");
+#ifndef SDP_LEAD_COST_HAS_W
+#define SDP_LEAD_COST_HAS_W 0        // 1: the cost depends on the perturbation (see sdp_lead_first)
+#endif
 #ifndef SDP_LEAD_UNROLL
 #define SDP_LEAD_UNROLL 1            // controls of the first pass per round (2 and 4 measured the same: 0.98 ms)
 #endif
@@ -181,6 +184,8 @@ struct SdpLeadLerp<SDP_LM> {
 
 struct SdpLeadConst {
     sdp_real psum, pcap, ratio, cu, floor;
+    const sdp_cst_real *p, *wg;    // weights and points (scalar loads)
+    int W;
     bool ok;
 };
 SDP_DEV void sdp_lead_const(const SdpSweepArgs &a, SdpLeadConst &f)
@@ -192,6 +197,9 @@ SDP_DEV void sdp_lead_const(const SdpSweepArgs &a, SdpLeadConst &f)
         pa = pa + fabs(p[w]);
     }
     f.psum = ps;
+    f.p = p;
+    f.wg = (const sdp_cst_real *)a.wgrid;
+    f.W = a.W;
     f.pcap = pa > (sdp_real)1 ? pa : (sdp_real)1;
     f.ratio = f.pcap / fabs(ps);                   // (psum = 0: infinite -> every node takes the long way)
     f.cu = (sdp_real)SDP_LEAD_FILTER_SCALE * (sdp_real)(4 * (a.W + 3 * SDP_D + 4)) * (sdp_real)0x1p-53;
@@ -229,8 +237,13 @@ SDP_DEV void sdp_lead_walk_next(const SdpBox &b, SdpLeadWalk &w)
 
 // F of one control and the product of the (1 + 2 |lam_k|); q_k, lam_k, g as the reference computes them
 // (`A`: the node's plane of the reduced array)
+// With a cost that depends on the perturbation (SDP_LEAD_COST_HAS_W; the stocks still must not): the
+// expectation G = sum_w p_w g_w of the cost with the reference's own g_w takes the place of g psum
+// (W cost evaluations per control: the 2^d loads and the lerps of the long way are what is saved), and
+// gmax collects Gabs = max(sum_w |p_w g_w|, max_w |g_w|), which stands where |g| Pcap stood in the bound
+// (the raw magnitude too: a tiny weight must not hide a g_w that overflows g_w + val on the reference's path).
 SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeom &geo, const SdpLeadConst &f,
-                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &lp)
+                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &lp, sdp_real &gmax)
 {
     sdp_real xl[SDP_LM], lam[SDP_LM];
     int off[SDP_LM];
@@ -247,7 +260,21 @@ SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeo
     }
     lp = sdp_lead_vmax(lp, prod);
     const sdp_real h = SdpLeadLerp<0>::eval(A, off, geo.pm, lam, 0);
+#if SDP_LEAD_COST_HAS_W
+    sdp_real G = (sdp_real)0, gabs = (sdp_real)0, graw = (sdp_real)0;
+    for (int w = 0; w < f.W; ++w) {
+        const sdp_real pw = f.p[w];
+        const sdp_real gw = sdp_model_cost(x, u, f.wg[w], t);
+        G = fma(pw, gw, G);
+        gabs = fma(fabs(pw), fabs(gw), gabs);
+        graw = sdp_lead_vmax_abs(graw, gw);
+    }
+    gmax = sdp_lead_vmax(gmax, sdp_lead_vmax(gabs, graw));
+    return G + h;
+#else
+    (void)gmax;
     return fma(sdp_model_cost(x, u, (sdp_real)0, t), f.psum, h);
+#endif
 }
 
 extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
@@ -293,13 +320,13 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         const sdp_real *__restrict__ A = Aall + trail * geo.ls;
         const sdp_real dabs = fc.pcap * (E[trail] * vmax) + fc.floor;
         // pass 1
-        sdp_real f1 = INFINITY, f2 = INFINITY, fsum = (sdp_real)0, lp = (sdp_real)0;
+        sdp_real f1 = INFINITY, f2 = INFINITY, fsum = (sdp_real)0, lp = (sdp_real)0, gmax = (sdp_real)0;
         int i1 = INT_MAX;
         SdpLeadWalk walk;
         sdp_lead_walk_begin(box, walk);
 #pragma unroll SDP_LEAD_UNROLL
         for (int ci = 0; ci < box.total; ++ci) {
-            const sdp_real F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp);
+            const sdp_real F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp, gmax);
             fsum = fsum + fabs(F);
             f2 = sdp_lead_vmin(f2, sdp_lead_vmax(f1, F));
             i1 = F < f1 ? ci : i1;
@@ -307,7 +334,11 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
             sdp_lead_walk_next(box, walk);
         }
         const sdp_real h_cap = lp * dabs;
+#if SDP_LEAD_COST_HAS_W
+        const sdp_real s_node = fsum == fsum ? gmax + h_cap : (sdp_real)NAN;     // (a NaN of any F sticks in the sum)
+#else
         const sdp_real s_node = fma(fc.ratio, fsum + h_cap, h_cap);
+#endif
         const bool bad = !fc.ok || !(s_node < (sdp_real)0x1p1000) || !(lp < (sdp_real)1073741824.0);
         const sdp_real radius = fc.cu * s_node;
         const sdp_real m_hi = f1 + radius;                 // >= the minimum of E over the node
@@ -321,8 +352,8 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         for (int ci = first; ci < last; ++ci) {
             bool cand = single || bad;
             if (!cand) {
-                sdp_real lq = (sdp_real)0;
-                cand = !(sdp_lead_first(A, geo, fc, x, walk.u, t, lq) - radius > m_hi);
+                sdp_real lq = (sdp_real)0, gq = (sdp_real)0;
+                cand = !(sdp_lead_first(A, geo, fc, x, walk.u, t, lq, gq) - radius > m_hi);
             }
             if (cand) {
                 const sdp_real jc = sdp_expected_cost(a, grid, Vt, x, walk.u, t);

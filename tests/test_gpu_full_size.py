@@ -65,3 +65,65 @@ def test_every_node_through_the_multi_survivor_pass_at_full_size(gpu, monkeypatc
     Jb, _ = b.value_iteration(V0, report_time=False)
     assert 'SDP_COL_FILTER_SCALE' in b._kernel_plan()['source']
     assert np.array_equal(Ja, Jb) and np.array_equal(ia, b.last_policy_index)
+
+
+@pytest.mark.timeout(900)
+def test_noise_in_the_stock_at_full_size(gpu):
+    """The benchmark problem with the perturbation also in the stock (x0' = (x0 + b u) - 0.07 w: the shape of the
+    reference's inventory example) at 256^3: sweep 4 of a chain with the certified filter on the shifted
+    lattice against the kernel that evaluates every control the long way on all 16.7 M nodes, and against
+    the numpy oracle on 3000 sampled nodes -- J bit for bit, indices exact."""
+    import io
+    import contextlib
+    import numpy as np
+    from stodynprog_amd import models
+    from oracle import vi_numpy
+    out = {}
+    for flt in (True, False):
+        _, s = models.synthetic3d(N=256, stock_noise=0.07)
+        s.certified_filter = flt
+        V0 = models.synthetic3d_V0(s.state_grid)
+        with contextlib.redirect_stdout(io.StringIO()):
+            J3, _ = s.value_iterations(V0, 3)
+            J4, _ = s.value_iteration(J3)
+        out[flt] = (J3, J4, s.last_policy_index, s)
+        assert s.backend_info['filter_form'] == ('shifted lattice' if flt else None)
+        for k_ in [k_ for k_ in s._cache if k_[0] == 'problem']:
+            s._cache.pop(k_).close()
+    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
+    assert np.array_equal(out[True][2], out[False][2])
+    nodes = np.random.default_rng(8).choice(out[True][0].size, size=3000, replace=False)
+    Jo, _, io_, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(out[True][3]), out[True][0], nodes=np.sort(nodes))
+    assert np.array_equal(out[True][1].ravel()[np.sort(nodes)], Jo)
+    assert np.array_equal(out[True][2].ravel()[np.sort(nodes)], io_)
+
+
+@pytest.mark.timeout(900)
+def test_two_reservoirs_at_bench_size(gpu):
+    """Two controlled stocks, 128 x 128 x 64 nodes x 16 x 16 controls x 16 perturbation points (bench.py --config
+    reservoirs): sweep 3 of a chain on the reduced-array sweep against the direct kernel on all 1 M nodes and
+    against the numpy oracle on 2000 sampled nodes."""
+    import io
+    import contextlib
+    import numpy as np
+    from stodynprog_amd import models
+    from oracle import vi_numpy
+    out = {}
+    for kernel in ('auto', 'generic'):
+        _, s = models.two_reservoirs(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15))
+        s.kernel = kernel
+        a, b, y = [np.asarray(g) for g in s.state_grid]
+        V0 = ((a[:, None, None] - 1.0) ** 2 + 0.5 * (b[None, :, None] - 0.7) ** 2
+              + 0.3 * np.cos(3 * y)[None, None, :] * (1 + 0.1 * a[:, None, None]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            J2, _ = s.value_iterations(V0, 2)
+            J3, _ = s.value_iteration(J2)
+        out[kernel] = (J2, J3, s.last_policy_index, s)
+        assert s.backend_info['kernel'] == ('lead' if kernel == 'auto' else 'generic')
+        for k_ in [k_ for k_ in s._cache if k_[0] == 'problem']:
+            s._cache.pop(k_).close()
+    assert np.array_equal(out['auto'][1], out['generic'][1]) and np.array_equal(out['auto'][2], out['generic'][2])
+    nodes = np.sort(np.random.default_rng(9).choice(out['auto'][0].size, size=2000, replace=False))
+    Jo, _, io_, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(out['auto'][3]), out['auto'][0], nodes=nodes)
+    assert np.array_equal(out['auto'][1].ravel()[nodes], Jo)
+    assert np.array_equal(out['auto'][2].ravel()[nodes], io_)

@@ -123,6 +123,35 @@ def test_one_exogenous_axis_less_and_one_more(gpu):
     _same(lead, gen)
 
 
+def test_a_cost_that_sees_the_perturbation(gpu):
+    """the first pass accumulates the cost's expectation with the reference's own g_w"""
+    def make():
+        sysd, s = _small()()
+        sysd.cost = lambda a, b, y, u, v, w: ((v - 0.8 - w) * (v - 0.8 - w) + 0.05 * (u - v) * (u - v)
+                                              + 0.3 * (a - 1.0) * (a - 1.0) * (1.0 + w) + 0.2 * b * u)
+        s._cache.clear()
+        return sysd, s
+    src = make()[1]._kernel_plan()['source']
+    assert '#define SDP_LEAD_COST_HAS_W 1' in src
+    for V in (_smooth(make()[1]), np.random.default_rng(17).standard_normal(make()[1]._state_grid_shape)):
+        lead, gen = _sweep(make, 'auto', V, sweeps=2), _sweep(make, 'generic', V, sweeps=2)
+        assert lead[3].backend_info['kernel'] == 'lead'
+        _same(lead, gen)
+    V = np.random.default_rng(18).standard_normal(make()[1]._state_grid_shape)
+    V[:2] = np.inf
+    V[5, 3, 2] = np.nan
+    _same(_sweep(make, 'auto', V), _sweep(make, 'generic', V))
+
+    def tiny():                                   # weights of 1e-30 and a cost of 1e307: the raw magnitude decides
+        sysd, s = make()
+        sysd.cost = lambda a, b, y, u, v, w: 1e307 * ((v - 0.8 - w) * (v - 0.8 - w) + (a - 1.0) * (a - 1.0))
+        s.perturb_proba = [np.asarray(s.perturb_proba[0]) * 1e-30]
+        s._cache.clear()
+        return sysd, s
+    V = _smooth(tiny()[1]) * 1e306
+    _same(_sweep(tiny, 'auto', V), _sweep(tiny, 'generic', V))
+
+
 @pytest.mark.parametrize('scale', ['1e4', '1e12', '1e18'])
 def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
     make = _small()

@@ -446,7 +446,7 @@ def test_controlled_axes_and_the_reduced_array_plan_without_a_gpu():
     m = tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w))
     assert codegen.lead_filter_applies(m, np.float64) == 2 and codegen.lead_filter_applies(m, np.float32) == 0
     mw = tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w), lambda a, b, y, u, v, w: u * w)
-    assert codegen.lead_filter_applies(mw, np.float64) == 0          # a cost that sees the perturbation: not yet
+    assert codegen.lead_filter_applies(mw, np.float64) == 2          # a cost that sees the perturbation: its expectation per control
     _, s = models.two_reservoirs(n_a=12, n_b=10, n_y=6, n_w=5)
     plan = s._kernel_plan()
     assert plan['lead_axes'] == 2 and plan['lanes'] == 1 and plan['filtered'] and not plan['column'] and plan['staged'] is None
