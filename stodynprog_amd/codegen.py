@@ -250,7 +250,7 @@ def lead_functions_source(model, m):
     return '\n\n'.join(out)
 
 
-def lead_filter_applies(model, dtype):
+def lead_filter_applies(model, dtype, min_axes=2):
     """Several controlled state variables next to an exogenous process (TracedModel.controlled_axes
     >= 2; one stock is the column kernel's case), a perturbation that does not reach them (the cost may see
     it), 8-byte reals: the node-order sweep with the certified filter on an array reduced over w
@@ -261,7 +261,7 @@ def lead_filter_applies(model, dtype):
     if model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
         return 0
     m = model.controlled_axes()
-    return int(m) if m is not None and m >= 2 else 0
+    return int(m) if m is not None and m >= min_axes else 0
 
 
 UTAB_MAX_VALUES = 4          # tabulated sub-expressions per control

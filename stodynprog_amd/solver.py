@@ -611,7 +611,10 @@ class DPSolver(object):
         lead_axes = 0
         if (not column and self.kernel in ('auto', 'lead') and self.comm is None and W > 0
                 and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
-            lead_axes = codegen.lead_filter_applies(model, dt)
+            # (one stock whose table does not fit LDS too: measured 5.9 ms against 12.7 ms of the row-window
+            # column kernel at 1024 x 128 x 128 x 64 x 32, tools/window_vs_lead.py)
+            lead_axes = codegen.lead_filter_applies(
+                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2)
         if self.kernel == 'lead' and not lead_axes:
             raise ValueError("kernel = 'lead' needs several controlled state variables listed first, an exogenous "
                              'process after them, a perturbation that reaches only that process, 8-byte reals')

@@ -769,13 +769,19 @@ def test_column_kernel_is_the_default_for_storage_problems(gpu):
     _, big = models.synthetic3d(N=20)
     big.state_grid[0] = np.linspace(0, 1, 1000)
     big._state_grid_shape = (1000, 20, 20)
+    big.kernel = 'column'
     plan = big._kernel_plan()
     assert plan['column'] and plan['window'] and plan['window'][2] < 1000
+    big.kernel = 'auto'                              # (8-byte reals: the reduced-array sweep, one controlled axis)
+    assert big._kernel_plan()['lead_axes'] == 1
     # unless the controls of one node span more rows than a window can hold: then the
     # LDS-staged tile kernel runs, and forcing 'column' says why it cannot
     _, wide = models.synthetic3d(N=20)
     wide.state_grid[0] = np.linspace(0, 0.01, 1000)    # the controls cross this axis end to end
     wide._state_grid_shape = (1000, 20, 20)
+    plan = wide._kernel_plan()
+    assert not plan['column'] and plan['lead_axes'] == 1
+    wide.certified_filter = False                      # (without the filter there is no reduced-array sweep)
     plan = wide._kernel_plan()
     assert not plan['column'] and plan['staged']
     wide.kernel = 'column'
@@ -1244,8 +1250,13 @@ def test_random_models_match_numpy_bit_for_bit(gpu, seed):
         Jo, uo, io, mo = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
     # storage-separable -> column kernel; trailing axes that depend on the control but not on
     # the leading state -> column kernel with a table per control; anything else -> staged tiles
-    assert solver.backend_info['kernel'] == ('column' if model.column_shareable else 'staged')
-    assert bool(solver.backend_info.get('table_per_control')) == (model.column_shareable
+    # (round 3: state variables the perturbation does not reach, all of them controlled or followed by an
+    # exogenous rest -> the reduced-array sweep, csrc/sdp_lead_kernel.h)
+    from stodynprog_amd import codegen
+    lead_family = bool(codegen.lead_filter_applies(model, np.float64)) and not model.storage_separable
+    assert solver.backend_info['kernel'] == ('lead' if lead_family else
+                                             ('column' if model.column_shareable else 'staged'))
+    assert bool(solver.backend_info.get('table_per_control')) == (model.column_shareable and not lead_family
                                                                  and not model.storage_separable)
     if model.bit_exact:
         assert np.array_equal(J, Jo, equal_nan=True), (lead, trail, cst)

@@ -38,7 +38,7 @@ def _storage(n_E=2048, n_P=9, n_w=11, p_max=0.35):
 
 def _pair(make, **attrs):
     out = []
-    for kernel in ('generic', 'auto'):
+    for kernel in ('generic', 'column'):       # ('auto' prefers the reduced-array sweep where it applies: see below)
         _, s = make()
         s.kernel = kernel
         for k, v in attrs.items():
@@ -59,6 +59,17 @@ def test_table_larger_than_lds_runs_the_windowed_column_kernel(gpu):
     _check(a, b)
     win = b[3].backend_info['row_window']
     assert win['rows'] < 1024 and win['segment_nodes'] >= 64
+
+
+def test_auto_takes_the_reduced_array_sweep_for_one_long_stock(gpu):
+    """8-byte reals, a stock the perturbation does not reach: 'auto' runs csrc/sdp_lead_kernel.h with one
+    controlled axis (5.9 ms against 12.7 ms at 1024 x 128 x 128, tools/window_vs_lead.py) -- same bits"""
+    a, b = _pair(_long_lead)
+    _, s = _long_lead()
+    J, pol = s.value_iteration(a[4], report_time=False)
+    assert s.backend_info['kernel'] == 'lead' and s.backend_info['controlled_axes'] == 1
+    assert np.array_equal(J, a[0]) and np.array_equal(pol, a[1]) and np.array_equal(s.last_policy_index, a[2])
+    assert np.array_equal(J, b[0])
 
 
 def test_window_with_per_node_boxes_and_a_perturbed_stock(gpu):

@@ -307,8 +307,13 @@ def test_kernel_family_planning_without_a_gpu():
     assert plan['column'] and not plan['window'] and not plan['per_control'] and plan['staged'] is None
     assert '#define SDP_TRAIL_HAS_U 0' in plan['source'] and 'SDP_COL_ROWS' not in plan['source']
     # same model, 1024-point leading axis: 32 x 1024 x 8 B = 256 KiB > LDS -> row window
+    # (kernel = 'column'; in 8-byte reals 'auto' now prefers the reduced-array sweep with one controlled axis)
     s.discretize_state(0, 1, 1024, 0, 1, 12, 0, 1, 12)
+    auto = s._kernel_plan()
+    assert auto['lead_axes'] == 1 and not auto['column'] and auto['filtered']
+    s.kernel = 'column'
     plan = s._kernel_plan()
+    s.kernel = 'auto'
     threads, lds, rows, seg = plan['window']
     assert plan['column'] and rows < 1024 and rows % 32 == 0 and seg >= 64 and seg % 64 == 0
     assert lds * (2 if threads == 512 else 1) <= codegen.COLUMN_LDS_MAX
