@@ -184,6 +184,8 @@ def test_near_ties_and_a_radius_far_too_small(gpu, monkeypatch):
     ref = _sweep(make, 'generic', V)
     assert len(np.unique(ref[2])) > 5
     _same(_sweep(make, 'auto', V), ref)
+    monkeypatch.setenv('SDP_LEAD_FILTER_SCALE', '0.5')            # half the proven radius: still the same bits
+    _same(_sweep(make, 'auto', V), ref)
     monkeypatch.setenv('SDP_LEAD_FILTER_SCALE', '1e-6')
     assert (_sweep(make, 'auto', V)[2] != ref[2]).sum() > 0
 

@@ -214,3 +214,45 @@ def test_the_benchmark_model_with_noise_in_the_stock(gpu):
     on, off = _sweep(make, True, V, sweeps=3), _sweep(make, False, V, sweeps=3)
     assert on[3].backend_info['filter_form'] == 'shifted lattice'
     _same(on, off)
+
+
+# ---------------------------------------------------------------------------
+# Two-sided evidence for the ROUNDING part of the radius: with a cost-to-go that is linear in the stock the
+# function G of a column is linear, the interpolation bound B' vanishes (up to the rounding of the second
+# differences) and the objective is flat in the control -- the reference's argmin hangs on the last bits of
+# its W x 6 roundings and of the positions, which the factor H of the bound has to cover on its own.
+# ---------------------------------------------------------------------------
+def _flat_shop(tilt, box_on_state=False):
+    s_, b_ = 1.37, 0.0731
+    sysd = SysDescription((2, 1, 1), name='flat objective, noise in the stock')
+    sysd.dyn = lambda x, y, u, w: (x + b_ * u - 0.11 * w, 0.8 * y + w)
+    sysd.cost = lambda x, y, u, w: (-s_ * b_) * u + tilt * (u * u)
+    if box_on_state:
+        sysd.control_box = lambda x, y: ((-1.0, 1.0 + 0.01 * x),)
+    else:
+        sysd.control_box = lambda x, y: ((-1.0, 1.0),)
+    sysd.perturb_laws = [NormalLaw(0, 0.2)]
+    s = DPSolver(sysd)
+    s.discretize_state(0, 3, 192, -1, 1, 6)
+    s.discretize_perturb(-0.5, 0.5, 7)
+    s.control_steps = (2.0 / 47,)
+    V = s_ * np.asarray(s.state_grid[0])[:, None] + np.cos(3 * np.asarray(s.state_grid[1]))[None, :]
+    return sysd, s, V
+
+
+@pytest.mark.parametrize('box_on_state', [False, True])
+@pytest.mark.parametrize('scale', [None, '0.5'])
+def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, monkeypatch, box_on_state, scale):
+    for tilt in (0.0, 1e-16, 1e-15, 4e-15, 3e-14, 1e-12):
+        make = lambda: _flat_shop(tilt, box_on_state)[:2]
+        V = _flat_shop(tilt)[2]
+        off = _sweep(make, False, V)
+        if scale:
+            monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+        on = _sweep(make, True, V)
+        if scale:
+            monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+        assert on[3].backend_info['filter_form'] == 'shifted lattice'
+        _same(on, off)
+        if tilt == 0.0:                          # (the case is what it claims to be: no clear winner)
+            assert len(np.unique(off[2])) > 3

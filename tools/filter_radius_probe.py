@@ -25,3 +25,20 @@ for dtype in (np.float64, np.float32):
         print('{} {:24s} nodes {:5d}   index mismatches by radius scale   {}'.format(
             np.dtype(dtype).name, 'box depends on x0' if box_on_state else 'constant box (table)',
             V.size, '   '.join(row)), flush=True)
+
+# the shifted lattice (a perturbation that reaches the stock): the same objective with noise in the stock --
+# the cost-to-go is linear in the stock, so the interpolation bound vanishes and the rounding part decides
+from tests import test_gpu_shift as ts
+for box_on_state in (False, True):
+    make = lambda: ts._flat_shop(0.0, box_on_state)[:2]
+    V = ts._flat_shop(0.0)[2]
+    os.environ.pop('SDP_COL_FILTER_SCALE', None)
+    off = ts._sweep(make, False, V)
+    row = []
+    for scale in ('1', '0.5', '0.1', '1e-2', '1e-3', '1e-4', '1e-5', '1e-6', '1e-8'):
+        os.environ['SDP_COL_FILTER_SCALE'] = scale
+        on = ts._sweep(make, True, V)
+        row.append('{}: {}'.format(scale, int((on[2] != off[2]).sum())))
+    os.environ.pop('SDP_COL_FILTER_SCALE', None)
+    print('float64 shifted lattice, {:24s} nodes {:5d}   index mismatches by radius scale   {}'.format(
+        'box depends on x0' if box_on_state else 'constant box (table)', V.size, '   '.join(row)), flush=True)
