@@ -466,7 +466,7 @@ def two_reservoirs(api=None, n_a=48, n_b=48, n_y=24, n_w=9, steps=(0.125, 0.125)
     sysd = SysDescription((3, 2, 1), name='Two reservoirs')
 
     def dyn(a, b, y, u, v, w):
-        return (a + (0.6 + 0.4 * y) - u, b + u - v, 0.3 + 0.7 * (y - 0.3) + w)
+        return (a + (0.7 + 0.5 * y) - u, b + u - v, 0.3 + 0.7 * (y - 0.3) + w)
     sysd.dyn = dyn
 
     def box(a, b, y):
@@ -474,8 +474,8 @@ def two_reservoirs(api=None, n_a=48, n_b=48, n_y=24, n_w=9, steps=(0.125, 0.125)
     sysd.control_box = box
 
     def cost(a, b, y, u, v, w):
-        spill = np.where(a > 2.0, a - 2.0, 0.0 * a) + np.where(b > 2.0, b - 2.0, 0.0 * b)
-        dry = np.where(a < 0.0, -a, 0.0 * a) + np.where(b < 0.0, -b, 0.0 * b)
+        spill = np.where(a > 1.7, a - 1.7, 0.0 * a) + np.where(b > 1.7, b - 1.7, 0.0 * b)
+        dry = np.where(a < 0.3, 0.3 - a, 0.0 * a) + np.where(b < 0.3, 0.3 - b, 0.0 * b)
         return (v - 0.8) * (v - 0.8) + 0.05 * (u - v) * (u - v) + 4.0 * spill + 8.0 * dry
     sysd.cost = cost
     sysd.perturb_laws = [NormalLaw(0, 0.1)]

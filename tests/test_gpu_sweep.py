@@ -1023,6 +1023,14 @@ def test_example_searev_policy_lookup_and_simulation(gpu):
     assert out['pol'].shape == (16, 21, 21, 1) and 0 < out['J_ref'] < 1
 
 
+def test_example_two_reservoirs(gpu):
+    out = quiet(_load_example('two_reservoirs.py').main, 20, 18, 10, 40, 300, True)
+    assert out['solver'].backend_info['kernel'] == 'lead' and out['solver'].backend_info['controlled_axes'] == 2
+    assert out['pol'].shape == (20, 18, 10, 2) and np.isfinite(out['J']).all() and 0 <= out['J_ref'] < 1
+    assert out['levels'][:, :2].min() > -0.3 and out['levels'][:, :2].max() < 2.5      # the policy keeps the levels in range
+    assert abs(out['output'][50:].mean() - 0.8) < 0.25                             # and the turbine near its set point
+
+
 def test_example_pv_storage_finite_horizon(gpu):
     J, pol, E, P_sto = quiet(_load_example('pv_storage.py').main, 48, 50)
     g = golden('g9_pv_storage')
