@@ -143,6 +143,22 @@ def test_special_values(gpu, case):
     _same(_sweep(make, True, V), _sweep(make, False, V))
 
 
+def test_split_columns_and_several_lanes_per_node(gpu):
+    """few long columns: a column is shared by two workgroups (each builds the lattice, takes half of the nodes);
+    a long control lattice: the lanes of a node share it and merge their bounds (b_max among them)"""
+    make = lambda: models.inventory_markov()                      # 128 x 32 nodes: two units per column
+    V = np.random.default_rng(23).standard_normal(make()[1]._state_grid_shape)
+    on, off = _sweep(make, True, V, sweeps=2), _sweep(make, False, V, sweeps=2)
+    assert on[3].backend_info['filter_form'] == 'shifted lattice'
+    _same(on, off)
+    make = lambda: _shop(order_step=0.02)                         # 501 controls per node
+    for V in (_smooth(make()[1]), np.random.default_rng(24).standard_normal(make()[1]._state_grid_shape)):
+        on, off = _sweep(make, True, V), _sweep(make, False, V)
+        assert '#define SDP_COL_THREADS 384' in on[3]._kernel_plan()['source'] or \
+            '#define SDP_COL_THREADS 512' in on[3]._kernel_plan()['source']
+        _same(on, off)
+
+
 def test_a_chain_of_sums(gpu):
     """x' = x + u - 0.5 w - 0.1 y: two terms without the stock or the control after a = x + u, one of them
     without the perturbation; and a cost that sees the perturbation"""
