@@ -616,8 +616,9 @@ class DPSolver(object):
             lead_axes = codegen.lead_filter_applies(
                 model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2)
         if self.kernel == 'lead' and not lead_axes:
-            raise ValueError("kernel = 'lead' needs several controlled state variables listed first, an exogenous "
-                             'process after them, a perturbation that reaches only that process, 8-byte reals')
+            raise ValueError("kernel = 'lead' needs controlled state variables listed first, an exogenous process "
+                             'after them, a perturbation that reaches only that process, 8-byte reals, the certified '
+                             'filter, exact arithmetic and a solver without a communicator (one GPU)')
         if lead_axes:
             lanes = 1                                     # one lane per node, the control loop in-lane
         # trailing next states that depend on the control but not on x0: the nodes of a
