@@ -253,6 +253,9 @@ def run(args):
     if args.gpus != world and rank == 0:
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
 
+    if args.debug_define:
+        # every solver of this run (the clones of the secondary figures too): an explicit dict, never the environment
+        DPSolver.debug_defines = dict(kv.split('=', 1) for kv in args.debug_define)
     sysd, ref_solver, solver, V0, dtype, cfg, label, model_name = build_solver(args, models, DPSolver, dev_comm)
     if args.kernel:
         solver.kernel = args.kernel
@@ -612,7 +615,8 @@ def report(args, env):
                    'comm_exchange': None if dev_comm is None else solver.backend_info.get('exchange'),
                    'comm_exchange_note': peer_note,
                    'comm_phase_tuning_ms_per_sweep': phase_times,
-                   'torch_imported': 'torch' in sys.modules},
+                   'torch_imported': 'torch' in sys.modules,
+                   'debug_defines': solver.backend_info.get('debug_defines')},
         'state_cells_per_sec': S * sweeps_per_s,
         'lattice_cells_per_sec': cells * sweeps_per_s,
         'roofline': roof,
@@ -793,6 +797,9 @@ def main():
     ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the untimed steady-state runs of the other BASELINE configurations')
+    ap.add_argument('--debug-define', action='append', default=[], metavar='NAME=VALUE',
+                    help='diagnostic switch of the generated kernels (stodynprog_amd.codegen.DEBUG_NAMES; A/B runs of '
+                         'tools/tune.py).  Recorded in config.debug_defines: such a line is not a product figure')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))
     # native libraries (RCCL's version banner, stdio-buffered until exit) must not

@@ -18,6 +18,45 @@ from .trace import TracedModel
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 
+
+# ---------------------------------------------------------------------------
+# Diagnostic / A-B switches.  The product has none: nothing in this module reads
+# the environment.  Tests and the tools under tools/ hand an explicit dict
+# (`DPSolver.debug_defines`, `bench.py --debug-define K=V`) to the planning
+# functions below as `debug`; the names are those of the macros of csrc/*.h they
+# set (plus a few planning switches: SDP_COL_FILTER / SDP_COL_SHIFT / SDP_COL_UTAB /
+# SDP_LEAD_FILTER = 0 switch a form off, SDP_COL_THREADS / SDP_COL_WCHUNK /
+# SDP_STG_CU / SDP_COL_WPAIR force a shape).  A solver that carries such a dict says
+# so in backend_info['debug_defines'], and bench.py in config.debug_defines.
+# ---------------------------------------------------------------------------
+# macros copied into the generated unit as they are (integers)
+DEBUG_INT_MACROS = ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
+                    'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO',
+                    'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE',
+                    'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP')
+# every name a `debug` dict may carry (a typo must not pass silently)
+DEBUG_NAMES = frozenset(DEBUG_INT_MACROS + (
+    'SDP_STAMP', 'SDP_NO_POW2', 'SDP_EXTRA_DEFINES', 'SDP_COL_FILTER_SCALE', 'SDP_LEAD_FILTER_SCALE',
+    'SDP_LEAD_UNROLL', 'SDP_COL_A_LW', 'SDP_COL_FILTER', 'SDP_COL_SHIFT', 'SDP_COL_UTAB', 'SDP_LEAD_FILTER',
+    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR'))
+
+
+def check_debug(debug):
+    """normalised copy of a debug dict (values as strings), or None; unknown names raise"""
+    if not debug:
+        return None
+    unknown = sorted(set(debug) - DEBUG_NAMES)
+    if unknown:
+        raise ValueError('unknown debug define(s): {}'.format(', '.join(unknown)))
+    return {k: str(v) for k, v in debug.items() if v is not None and str(v) != ''} or None
+
+
+def _dbg(debug, name, default=None):
+    if not debug:
+        return default
+    v = debug.get(name)
+    return default if v is None or str(v) == '' else str(v)
+
 _BIN_INFIX = {'add': '+', 'sub': '-', 'mul': '*', 'div': '/',
               'lt': '<', 'le': '<=', 'gt': '>', 'ge': '>=', 'eq': '==', 'ne': '!=',
               'and': '&&', 'or': '||', 'xor': '!='}
@@ -250,13 +289,13 @@ def lead_functions_source(model, m):
     return '\n\n'.join(out)
 
 
-def lead_filter_applies(model, dtype, min_axes=2):
+def lead_filter_applies(model, dtype, min_axes=2, debug=None):
     """Several controlled state variables next to an exogenous process (TracedModel.controlled_axes
     >= 2; one stock is the column kernel's case), a perturbation that does not reach them (the cost may see
     it), 8-byte reals: the node-order sweep with the certified filter on an array reduced over w
-    (csrc/sdp_lead_kernel.h).  Returns the number of controlled axes, or 0.  SDP_LEAD_FILTER=0 in the
-    environment switches it off (A/B runs)."""
-    if os.environ.get('SDP_LEAD_FILTER', '1') == '0':
+    (csrc/sdp_lead_kernel.h).  Returns the number of controlled axes, or 0.  (`debug`: SDP_LEAD_FILTER = 0
+    switches it off, A/B runs.)"""
+    if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0':
         return 0
     if model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
         return 0
@@ -268,13 +307,13 @@ UTAB_MAX_VALUES = 4          # tabulated sub-expressions per control
 UTAB_MAX_BYTES = 4096        # per parity buffer of the table in LDS
 
 
-def control_table_plan(model, dtype, per_node, max_controls):
+def control_table_plan(model, dtype, per_node, max_controls, debug=None):
     """Can the column-uniform sub-expressions of x0' and of the cost be tabulated once per
     (column, control) (SDP_COL_UTAB of csrc/sdp_column_kernel.h)?  Needs a control lattice that
     is the same at every node (constant box) and small enough for LDS.  Returns the frontier
-    nodes (TracedModel.control_uniform_frontier) or None.  SDP_COL_UTAB=0 in the environment
-    switches it off (A/B runs)."""
-    if os.environ.get('SDP_COL_UTAB', '1') == '0' or per_node or model.cost_depends_on_w:
+    nodes (TracedModel.control_uniform_frontier) or None.  (`debug`: SDP_COL_UTAB = 0 switches it
+    off, A/B runs.)"""
+    if _dbg(debug, 'SDP_COL_UTAB', '1') == '0' or per_node or model.cost_depends_on_w:
         return None
     lead = None
     if model.lead_depends_on_w:
@@ -323,11 +362,95 @@ def lanes_for(max_controls):
     return lanes
 
 
+def _prologue_lines(model, real, lanes, debug):
+    """what every generated unit starts with: the type and shape macros, the diagnostic
+    switches of an explicit `debug` dict (none in the product), the device helpers, the
+    lifted constants, the interpolation tables and sdp_model_cell"""
+    lines = ['// generated by stodynprog_amd.codegen -- do not edit',
+             '#define SDP_REAL {}'.format(real),
+             '#define SDP_D {}'.format(model.n_state),
+             '#define SDP_NU {}'.format(model.n_control),
+             '#define SDP_HAS_W {}'.format(1 if model.n_perturb else 0),
+             '#define SDP_LANES {}'.format(int(lanes))]
+    if _dbg(debug, 'SDP_STAMP') in ('1', '2', '3'):
+        lines.append('#define SDP_STAMP {}     // diagnostic build: in-kernel clock stamps (tools/clock_probe.py, '
+                     'tools/phase_probe.py)'.format(int(_dbg(debug, 'SDP_STAMP'))))
+    if _dbg(debug, 'SDP_NO_POW2') == '1':
+        lines.append('#define SDP_NO_POW2 1  // A/B: true division also for power-of-two spans')
+    for kv in (_dbg(debug, 'SDP_EXTRA_DEFINES') or '').split(','):
+        if '=' in kv:
+            lines.append('#define {} {}   // SDP_EXTRA_DEFINES (diagnostic builds)'.format(*kv.split('=', 1)))
+    lines += ['#include "sdp_device.h"', 'typedef SDP_REAL sdp_real;', '']
+    if getattr(model, 'param_index', None):
+        # lifted constants (TracedModel.lift_constants): set per launch through
+        # sdp_problem_set_params; uniform loads from constant memory
+        lines += ['#define SDP_NPARAMS {}'.format(len(model.param_index)),
+                  'extern "C" { __constant__ sdp_real sdp_model_prm[SDP_NPARAMS]; }     // a definition', '']
+    tables = interp_tables_source(model)
+    if tables:
+        lines.append(tables)
+    lines += [model_function_source(model), '']
+    return lines
+
+
+def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug):
+    """the macros and model slices of a unit that includes csrc/sdp_column_kernel.h"""
+    rs = np.dtype(dtype).itemsize
+    wpair = use_wpair(model, dtype, debug) and window is None
+    shifted = bool(filtered and column_shift_applies(model, dtype, debug=debug))
+    lines = ['#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
+             '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
+             '#define SDP_TRAIL_HAS_U {}'.format(1 if model.trail_depends_on_u else 0),
+             '#define SDP_COL_N0 {}'.format(int(column[0])),
+             '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
+             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
+             '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
+             '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0)]
+    if filtered and int(col_cfg[0]) <= 256 and not _dbg(debug, 'SDP_COL_MIN_WAVES'):
+        lines.append('#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap')
+    if filtered:
+        lines.append('#define SDP_COL_FILTER 1')
+        if shifted:
+            lines += ['#define SDP_COL_SHIFT 1        // x0\' = a(x, u) +- b_1(x_1.., w) +- ..: first pass on the shifted lattice',
+                      '#define SDP_COL_SHIFT_TERMS {}'.format(len(model.lead_split()[1])),
+                      '#define SDP_COL_SHIFT_ROWS {}'.format(int(col_cfg[2]))]
+        if _dbg(debug, 'SDP_COL_FILTER_SCALE'):
+            lines.append('#define SDP_COL_FILTER_SCALE {}'.format(float(_dbg(debug, 'SDP_COL_FILTER_SCALE'))))
+    # how the table build deals its entries to the threads
+    if per_control is None and not _dbg(debug, 'SDP_COL_A_ORDER'):
+        wide = column_wide_loads(column[0], dtype, fused, window, debug)
+        order = column_build_order(int(col_cfg[0]), column[1], int(window[2]) if window is not None else column[0],
+                                   (16 // rs) if wide else 1)
+        if order[0] == 2:
+            lines += ['#define SDP_COL_A_ORDER 2',
+                      '#define SDP_COL_A_LW {}'.format(int(_dbg(debug, 'SDP_COL_A_LW') or order[1]))]
+            if wide and not _dbg(debug, 'SDP_COL_A_WIDE_LOADS'):
+                lines.append('#define SDP_COL_A_WIDE_LOADS 1')
+    if window is not None:
+        lines.append('#define SDP_COL_ROWS {}'.format(int(window[2])))
+    if per_control is not None:
+        lines.append('#define SDP_COL_WCHUNK {}'.format(int(per_control[2])))
+        if int(column[0]) % (16 // rs) == 0 and not _dbg(debug, 'SDP_COLU_WIDE_LOADS'):
+            lines.append('#define SDP_COLU_WIDE_LOADS 1')
+    for k in DEBUG_INT_MACROS:                                   # tuning knobs of A/B runs (explicit dict only)
+        if _dbg(debug, k):
+            lines.append('#define {} {}'.format(k, int(_dbg(debug, k))))
+    lines += [separable_functions_source(model), '']
+    if utab is not None and filtered:
+        lines += ['#define SDP_COL_UTAB {}'.format(len(utab[0])),
+                  '#define SDP_COL_UTAB_N {}'.format(int(utab[1])),
+                  control_table_source(model, utab[0]), '']
+    lines += ['#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h', '']
+    return lines
+
+
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
-                     per_control=None, filtered=False, utab=None, lead_axes=0):
-    """column: None for the generic node-order kernels, or (N0, W) to also
+                     per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None):
+    """column: None for the generic node-order kernels, or (N0, W[, controls, columns]) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
+    col_cfg: the tuple `column_config` returned for exactly this unit (the caller plans once and
+    hands the plan over; None: planned here, same arguments).
     staged: None, or the dict of `staged_config` to also build the LDS-staged
     generic kernel of csrc/sdp_staged_kernel.h (node order, any traceable model).
     window: None, or the tuple of `column_window_config` (column kernel whose
@@ -336,92 +459,29 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
     that rebuilds its table for every control).
     filtered: column kernel with the certified expectation-first filter (SDP_COL_FILTER of
     csrc/sdp_column_kernel.h; see `column_filter_applies`).
-    utab: None, or (frontier nodes, controls of the lattice) of `control_table_plan` (filtered
-    kernel only): the first pass reads the column-uniform sub-expressions from a table."""
+    utab: None, or (frontier nodes, capacity of the control table in controls) of `control_table_plan`
+    (filtered kernel only): the first pass reads the column-uniform sub-expressions from a table.
+    debug: None (the product), or a dict of diagnostic switches (see DEBUG_NAMES)."""
+    debug = check_debug(debug)
     real = {'float64': 'double', 'float32': 'float'}[np.dtype(dtype).name]
-    head = [
-        '// generated by stodynprog_amd.codegen -- do not edit',
-        '#define SDP_REAL {}'.format(real),
-        '#define SDP_D {}'.format(model.n_state),
-        '#define SDP_NU {}'.format(model.n_control),
-        '#define SDP_HAS_W {}'.format(1 if model.n_perturb else 0),
-        '#define SDP_LANES {}'.format(int(lanes)),
-        ] + (['#define SDP_STAMP {}     // diagnostic build: in-kernel clock stamps (tools/clock_probe.py, '
-              'tools/phase_probe.py)'.format(int(os.environ['SDP_STAMP']))]
-             if os.environ.get('SDP_STAMP') in ('1', '2', '3') else []) + (
-            ['#define SDP_NO_POW2 1  // A/B: true division also for power-of-two spans']
-            if os.environ.get('SDP_NO_POW2') == '1' else []) + [
-            '#define {} {}   // SDP_EXTRA_DEFINES (diagnostic builds)'.format(*kv.split('='))
-            for kv in os.environ.get('SDP_EXTRA_DEFINES', '').split(',') if '=' in kv] + [
-        '#include "sdp_device.h"',
-        'typedef SDP_REAL sdp_real;',
-        ''] + ([
-        # lifted constants (TracedModel.lift_constants): set per launch through
-        # sdp_problem_set_params; uniform loads from constant memory
-        '#define SDP_NPARAMS {}'.format(len(model.param_index)),
-        'extern "C" { __constant__ sdp_real sdp_model_prm[SDP_NPARAMS]; }     // a definition',
-        ''] if getattr(model, 'param_index', None) else []) + (
-        [interp_tables_source(model)] if interp_tables_source(model) else []) + [
-        model_function_source(model),
-        '',
-    ]
+    head = _prologue_lines(model, real, lanes, debug)
     if column is not None:
         assert model.column_shareable
-        wpair = use_wpair(model, dtype) and window is None
         if per_control is not None:
             col_cfg = per_control
         elif window is not None:
             col_cfg = window
-        else:
-            col_cfg = column_config(column[0], column[1], model.n_state, dtype, wpair, filtered,
+        elif col_cfg is None:
+            col_cfg = column_config(column[0], column[1], model.n_state, dtype,
+                                    use_wpair(model, dtype, debug), filtered,
                                     max_controls=column[2] if len(column) > 2 else None,
                                     n_columns=column[3] if len(column) > 3 else None,
-                                    shift=filtered and column_shift_applies(model, dtype),
-                                    extra_bytes=(2 * len(utab[0]) * int(utab[1]) * np.dtype(dtype).itemsize
-                                                 if utab is not None and filtered else 0))
-        assert col_cfg is not None
-        head += [
-            '#define SDP_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0),
-            '#define SDP_LEAD_HAS_W {}'.format(1 if model.lead_depends_on_w else 0),
-            '#define SDP_TRAIL_HAS_U {}'.format(1 if model.trail_depends_on_u else 0),
-            '#define SDP_COL_N0 {}'.format(int(column[0])),
-            '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
-            '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
-            '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
-            '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0),
-        ] + (['#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap']
-             if filtered and int(col_cfg[0]) <= 256 and not os.environ.get('SDP_COL_MIN_WAVES') else []) + (
-            ['#define SDP_COL_FILTER 1'] + ([
-                '#define SDP_COL_SHIFT 1        // x0\' = a(x, u) +- b_1(x_1.., w) +- ..: first pass on the shifted lattice',
-                '#define SDP_COL_SHIFT_TERMS {}'.format(len(model.lead_split()[1])),
-                '#define SDP_COL_SHIFT_ROWS {}'.format(int(col_cfg[2]))]
-                if column_shift_applies(model, dtype) else []) + (
-            ['#define SDP_COL_FILTER_SCALE {}'.format(float(os.environ['SDP_COL_FILTER_SCALE']))]
-            if os.environ.get('SDP_COL_FILTER_SCALE') else []) if filtered else []) + (['#define SDP_COL_A_ORDER 2', '#define SDP_COL_A_LW {}'.format(
-                  int(os.environ.get('SDP_COL_A_LW') or _order[1]))] + (
-                      ['#define SDP_COL_A_WIDE_LOADS 1'] if _wide and not os.environ.get('SDP_COL_A_WIDE_LOADS') else [])
-             if (not os.environ.get('SDP_COL_A_ORDER') and per_control is None and
-                 (_wide := column_wide_loads(column[0], dtype, fused, window)) is not None and
-                 (_order := column_build_order(int(col_cfg[0]), column[1],
-                                               int(window[2]) if window is not None else column[0],
-                                               (16 // np.dtype(dtype).itemsize) if _wide else 1))[0] == 2)
-             else []) + (['#define SDP_COL_ROWS {}'.format(int(window[2]))] if window is not None else []) + (
-            ['#define SDP_COL_WCHUNK {}'.format(int(per_control[2]))] + (
-                ['#define SDP_COLU_WIDE_LOADS 1'] if (int(column[0]) % (16 // np.dtype(dtype).itemsize) == 0
-                                                      and not os.environ.get('SDP_COLU_WIDE_LOADS')) else [])
-            if per_control is not None else []) + ['#define {} {}'.format(k, int(os.environ[k]))      # tuning knobs for A/B runs
-             for k in ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH',
-                       'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
-                       'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO', 'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE', 'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP')
-             if os.environ.get(k)] + [
-            separable_functions_source(model),
-            ''] + (['#define SDP_COL_UTAB {}'.format(len(utab[0])),
-                    '#define SDP_COL_UTAB_N {}'.format(int(utab[1])),
-                    control_table_source(model, utab[0]), '']
-                   if utab is not None and filtered else []) + [
-            '#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h',
-            '',
-        ]
+                                    shift=filtered and column_shift_applies(model, dtype, debug=debug),
+                                    utab_values=(len(utab[0]) * int(utab[1]) if utab is not None and filtered else 0),
+                                    debug=debug)
+        if col_cfg is None:
+            raise ValueError('the column kernel does not fit this grid (its table exceeds the LDS of a CU)')
+        head += _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug)
     elif staged is not None:
         tile = tuple(staged['tile']) + (1,) * (4 - len(staged['tile']))
         head += ['#define SDP_STG_THREADS {}'.format(int(staged['threads']))] + [
@@ -434,13 +494,13 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
     elif lead_axes:
         # several controlled state variables: node-order sweep with the filter on an array reduced over w
         head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes)),
-                 '#define SDP_LEAD_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0)] + (
-            ['#define SDP_LEAD_FILTER_SCALE {}'.format(float(os.environ['SDP_LEAD_FILTER_SCALE']))]
-            if os.environ.get('SDP_LEAD_FILTER_SCALE') else []) + (
-            ['#define SDP_LEAD_UNROLL {}'.format(int(os.environ['SDP_LEAD_UNROLL']))]
-            if os.environ.get('SDP_LEAD_UNROLL') else []) + [
-            lead_functions_source(model, int(lead_axes)), '',
-            '#include "sdp_sweep_kernel.h"    // brings in sdp_lead_kernel.h', '']
+                 '#define SDP_LEAD_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0)]
+        if _dbg(debug, 'SDP_LEAD_FILTER_SCALE'):
+            head.append('#define SDP_LEAD_FILTER_SCALE {}'.format(float(_dbg(debug, 'SDP_LEAD_FILTER_SCALE'))))
+        if _dbg(debug, 'SDP_LEAD_UNROLL'):
+            head.append('#define SDP_LEAD_UNROLL {}'.format(int(_dbg(debug, 'SDP_LEAD_UNROLL'))))
+        head += [lead_functions_source(model, int(lead_axes)), '',
+                 '#include "sdp_sweep_kernel.h"    // brings in sdp_lead_kernel.h', '']
     else:
         head += ['#include "sdp_sweep_kernel.h"', '']
     return '\n'.join(head)
@@ -460,7 +520,7 @@ def staged_row_stride(length, tile_last, d, rs):
     return (length + tile_last - 1) // (2 * tile_last) * (2 * tile_last) + tile_last
 
 
-def staged_config(model, state_grid, perturb_grid, box, dtype, t_value=0.0, n_samples=24):
+def staged_config(model, state_grid, perturb_grid, box, dtype, t_value=0.0, n_samples=24, debug=None):
     """Tile shape, chunk sizes and LDS budget of the staged kernel for `model`
     on this discretisation.  The chunk (controls x perturbation points whose
     next states share one staged box) is the largest whose box -- measured by
@@ -538,8 +598,8 @@ def staged_config(model, state_grid, perturb_grid, box, dtype, t_value=0.0, n_sa
     # the control-coupled 256^3 x 64 x 32 problem: 4 -> 93.7 ms, 2 -> 120.3 ms (4 spills five
     # registers at the 128-VGPR bound two workgroups per CU impose; still faster)
     cus = (4, 2, 1)
-    if os.environ.get('SDP_STG_CU'):                    # A/B runs
-        cus = (int(os.environ['SDP_STG_CU']),)
+    if _dbg(debug, 'SDP_STG_CU'):                       # A/B runs
+        cus = (int(_dbg(debug, 'SDP_STG_CU')),)
     for cu in cus:
         for cw in cws:
             if best is not None and cu * cw <= best[0] * best[1]:
@@ -555,61 +615,66 @@ def staged_config(model, state_grid, perturb_grid, box, dtype, t_value=0.0, n_sa
 COLUMN_LDS_MAX = 160 * 1024          # LDS of one gfx950 CU
 
 
-def use_wpair(model, dtype):
+def use_wpair(model, dtype, debug=None):
     """float32 tables interleave perturbation points 2k and 2k+1 (SDP_COL_WPAIR of
     csrc/sdp_column_kernel.h): one 8-byte LDS read serves two lattice cells.
     Needs a perturbation and an x0' that does not depend on it (one axis-0 cell
     per control).  Same bits as the plain layout; measured on 256^3 x 64 x 32:
     exact 6.05 -> 5.77 ms, fused 4.43 -> 3.66 ms.  (A table of (T[r], T[r+1])
     pairs was also measured for 4-byte reals and did not pay: not kept.)"""
-    if os.environ.get('SDP_COL_WPAIR'):                 # A/B runs
-        return bool(int(os.environ['SDP_COL_WPAIR']))
+    if _dbg(debug, 'SDP_COL_WPAIR'):                    # A/B runs
+        return bool(int(_dbg(debug, 'SDP_COL_WPAIR')))
     return (np.dtype(dtype).itemsize == 4 and model.n_perturb > 0
             and not model.lead_depends_on_w and not model.trail_depends_on_u)
 
 
-def column_shift_applies(model, dtype, table=None):
+def column_shift_applies(model, dtype, table=None, debug=None):
     """The certified filter with a perturbation that reaches x0' additively (`x + u - w`): the first
     pass then reads a table reduced over w on a lattice that the perturbation points have SHIFTED
     (SDP_COL_SHIFT of csrc/sdp_column_kernel.h).  8-byte reals only: in 4-byte reals the rounding of
-    the positions alone would put most controls inside the radius.  SDP_COL_SHIFT=0 in the
-    environment switches it off (A/B runs)."""
-    if os.environ.get('SDP_COL_SHIFT', '1') == '0':
+    the positions alone would put most controls inside the radius.  (`debug`: SDP_COL_SHIFT = 0 switches
+    it off, A/B runs.)"""
+    if _dbg(debug, 'SDP_COL_SHIFT', '1') == '0':
         return False
     ok = bool(model.n_perturb > 0 and model.lead_depends_on_w and model.lead_split() is not None
               and dtype is not None and np.dtype(dtype).itemsize == 8)
     if ok and table is not None:       # (n0, w, n_state): the shifted lattice must fit LDS beside the table
         ok = column_config(table[0], table[1], table[2], dtype, False, True, shift=True,
-                           extra_bytes=2 * UTAB_MAX_BYTES) is not None      # (whatever the control table takes)
+                           utab_values=UTAB_MAX_BYTES // np.dtype(dtype).itemsize,    # (whatever the control table takes)
+                           debug=debug) is not None
     return ok
 
 
-def column_filter_applies(model, fused=False, window=None, per_control=None, dtype=None, table=None):
+def column_filter_applies(model, fused=False, window=None, per_control=None, dtype=None, table=None, debug=None):
     """Can phase B of the column kernel run the certified expectation-first filter
     (SDP_COL_FILTER of csrc/sdp_column_kernel.h)?  It needs a perturbation that reaches
     neither x0' nor the cost -- then the expectation commutes with the lerp along axis 0 and
     all but the surviving controls of a node are decided on a table reduced over w -- and the
     plain full-column table with the reference's arithmetic.  Same bits as without it
-    (the survivors are re-evaluated with the reference's operations).  SDP_COL_FILTER=0 in
-    the environment switches it off (A/B runs)."""
-    if os.environ.get('SDP_COL_FILTER', '1') == '0':
+    (the survivors are re-evaluated with the reference's operations).  (`debug`: SDP_COL_FILTER = 0
+    switches it off, A/B runs.)"""
+    if _dbg(debug, 'SDP_COL_FILTER', '1') == '0':
         return False
     # (a cost that depends on the perturbation is fine since round 3: the first pass accumulates its
     # expectation with the reference's own values, sdp_col_cost_expect; x0' must still not depend on it)
     # (and so is a perturbation that reaches x0' through a final sum, in 8-byte reals: column_shift_applies)
-    return bool(model.n_perturb > 0 and (not model.lead_depends_on_w or column_shift_applies(model, dtype, table))
+    return bool(model.n_perturb > 0 and (not model.lead_depends_on_w or column_shift_applies(model, dtype, table, debug))
                 and not model.trail_depends_on_u and not fused and window is None
                 and per_control is None)
 
 
 def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_controls=None, n_columns=None,
-                  shift=False, extra_bytes=0):
+                  shift=False, utab_values=0, debug=None):
     """Compile-time shape of the column kernel for a grid with n0 points along
     axis 0 and w perturbation points: (threads, lds_bytes), or None if the
     table does not fit the LDS of a CU.  512-thread workgroups while two of
     them fit a CU, else 1024 threads (one workgroup then has to fill the CU's
     wave slots alone).  `wpair`: the table holds whole pairs of perturbation
-    points (an odd count is rounded up).
+    points (an odd count is rounded up).  `utab_values`: reals per parity buffer of the
+    control table (SDP_COL_UTAB x SDP_COL_UTAB_N; 0: none).  `lds_bytes` is sizeof(SdpColLds)
+    of the unit these arguments generate (`_column_lds` lays the struct out member by member;
+    tests/test_trace_codegen.py compiles the largest accepted sizes against the struct's
+    static_assert).
     `filtered` (certified filter, SDP_COL_FILTER): one lane per node of the column where that
     fits a workgroup (n0 <= 512) -- the lanes of a node then share nothing, the second pass
     is not repeated on them and fewer waves meet at the barriers; measured on 256^3 x 64 x 32
@@ -633,36 +698,38 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_contro
             cap = 1024 if (n_columns is not None and int(n_columns) < 256) else 512
             first = max(first, min(first * lanes, cap))
         sizes = (first,) + tuple(t for t in sizes if t > first)
-    if os.environ.get('SDP_COL_THREADS'):               # A/B runs (a CU then holds as many workgroups as fit)
-        sizes = (int(os.environ['SDP_COL_THREADS']),)
+    if _dbg(debug, 'SDP_COL_THREADS'):                  # A/B runs (a CU then holds as many workgroups as fit)
+        sizes = (int(_dbg(debug, 'SDP_COL_THREADS')),)
     if shift:
         # (threads, lds_bytes, rows of the shifted lattice): as many rows as LDS has room for beside the table
-        # (`extra_bytes`: the control table) while two workgroups share a CU -- at least n0 + n0 / 8, so that
+        # and the control table while two workgroups share a CU -- at least n0 + n0 / 8, so that
         # shifts spread over an eighth of the axis still fit --, else one workgroup per CU and 2 n0 rows
         for per_cu in (2, 1):
             for threads in sizes:
                 if per_cu == 2 and threads > 512:
                     continue
-                base = _column_lds(tw, w, 0, n_state, rs, threads, shift=True) + tw * int(n0) * rs + int(extra_bytes)
+                base = _column_lds(tw, w, n0, n_state, rs, threads, shift=True, shift_rows=0, utab_values=utab_values)
                 rows = min(2 * int(n0) + 16, (COLUMN_LDS_MAX // per_cu - base - 1024) // (2 * rs))
                 if rows >= int(n0) + max(8, int(n0) // 8):
-                    return threads, base + 2 * rows * rs, int(rows)
+                    return (threads, _column_lds(tw, w, n0, n_state, rs, threads, shift=True, shift_rows=rows,
+                                                 utab_values=utab_values), int(rows))
         return None
     for threads in sizes:
-        lds = _column_lds(tw, w, n0, n_state, rs, threads, reduced=True)   # (whether or not it is compiled in)
+        # (with the reduced table, whether or not it is compiled in)
+        lds = _column_lds(tw, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
         if lds * (2 if threads <= 512 else 1) <= COLUMN_LDS_MAX:
             return threads, lds
     return None
 
 
-def column_wide_loads(n0, dtype, fused, window):
+def column_wide_loads(n0, dtype, fused, window, debug=None):
     """16-byte vertex loads in the table build (SDP_COL_A_WIDE_LOADS of csrc/sdp_column_kernel.h): a lane
     takes 16 / sizeof(real) adjacent rows.  Needs whole groups of rows, no row window, exact arithmetic.
-    SDP_COL_A_WIDE_LOADS=0 in the environment switches it off (A/B runs)."""
-    if os.environ.get('SDP_COL_A_WIDE_LOADS', '1') == '0':
+    (`debug`: SDP_COL_A_WIDE_LOADS = 0 switches it off, 1 forces it for 4-byte reals: A/B runs.)"""
+    if _dbg(debug, 'SDP_COL_A_WIDE_LOADS', '1') == '0':
         return False
     rpl = 16 // np.dtype(dtype).itemsize
-    if rpl != 2 and os.environ.get('SDP_COL_A_WIDE_LOADS') != '1':
+    if rpl != 2 and _dbg(debug, 'SDP_COL_A_WIDE_LOADS') != '1':
         # 4-byte reals: four rows per lane, but the pair layout of their table scatters the stores --
         # measured on 512^3 fp32: 11.5 ms against 11.2 without (not used)
         return False
@@ -689,17 +756,32 @@ def column_build_order(threads, w, rows, rows_per_lane=1):
     return (best[0], best[1]) if best[2] >= 0.85 else (0, 0)
 
 
-def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False):
-    # reduced: + the (A[r], D[r]) table of the certified filter (full-column table only)
-    # shift: the shifts of the perturbation points (two parities; the reduced table on the shifted lattice is
-    # sized by column_config)
-    raw = (tw * rows * rs + w * (n_state - 1) * (2 * rs + 4) + threads * (rs + 4) + 2 * w * rs + 16
-           + ((4 if rs == 4 else 2) * rows * rs if reduced else 0)
-           + (2 * w * (2 * rs + 4) + 64 if shift else 0))
-    return (raw + 15) // 16 * 16
+def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False, shift_rows=0, utab_values=0):
+    """sizeof(SdpColLds) of csrc/sdp_column_kernel.h, member by member with the alignment rules of
+    the C++ struct.  tw: table rows per ... perturbation points the table holds (SDP_COL_TW, or
+    SDP_COL_WCHUNK for the table per control); rows: rows of axis 0 the table holds;
+    reduced: with the reduced table `ad` of the certified filter (full-column table);
+    shift: the shifted lattice -- `ad` then has `shift_rows` rows -- and the shifts of the perturbation
+    points; utab_values: reals per parity buffer of the control table (0: the struct's two)."""
+    dt = n_state - 1
+    members = [(rs, tw * rows, 16),                          # T
+               (rs, w * dt, rs), (rs, w * dt, rs),           # w_lam, w_oml
+               (rs, w, rs), (rs, w, rs),                     # pw, gw
+               (rs, threads, rs), (4, threads, 4),           # part_J, part_i
+               (4, w * dt, 4),                               # w_off
+               (4, 4, 4), (4, 1, 4), (8, 2, 8),              # win, next_unit, dcol
+               (rs, 2 * (int(utab_values) or 2), 16)]        # utab[2][..]
+    if reduced or shift:
+        members.append((rs, (4 if rs == 4 else 2) * int(shift_rows if shift else rows), 16))    # ad
+    if shift:
+        members += [(4, 2 * w, 4), (rs, 2 * w, rs), (rs, 2 * w, rs), (4, 8, 4)]                   # sh_q, sh_f, sh_c, sh_k
+    off = 0
+    for size, count, align in members:
+        off = (off + align - 1) // align * align + size * int(count)
+    return (off + 15) // 16 * 16
 
 
-def column_percontrol_config(n0, w, n_state, dtype):
+def column_percontrol_config(n0, w, n_state, dtype, debug=None):
     """Shape of the column kernel with a table per control (SDP_TRAIL_HAS_U of
     csrc/sdp_column_kernel.h): (threads, lds_bytes, w_chunk).  One thread per node of
     a column (at most 512; longer columns are split over workgroups), and a table of
@@ -709,8 +791,8 @@ def column_percontrol_config(n0, w, n_state, dtype):
     w = max(int(w), 1)
     threads = min(512, max(64, (int(n0) + 63) // 64 * 64))
     wchunk = max(1, min(w, (32 * 1024) // (int(n0) * rs)))
-    if os.environ.get('SDP_COL_WCHUNK'):                # A/B runs
-        wchunk = max(1, min(w, int(os.environ['SDP_COL_WCHUNK'])))
+    if _dbg(debug, 'SDP_COL_WCHUNK'):                   # A/B runs
+        wchunk = max(1, min(w, int(_dbg(debug, 'SDP_COL_WCHUNK'))))
     lds = _column_lds(wchunk, w, n0, n_state, rs, threads)
     if lds > COLUMN_LDS_MAX:
         return None

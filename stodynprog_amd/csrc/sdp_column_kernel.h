@@ -165,7 +165,7 @@
 #ifndef SDP_COL_UTAB
 // K > 0: the generated unit provides sdp_model_utab / sdp_model_lead_tab / sdp_model_cost_tab
 // (codegen.control_table_source): the K sub-expressions of x0' and of the cost that depend on the
-// control but not on x0 are tabulated once per (column, control) -- SDP_COL_UTAB_N controls, the
+// control but not on x0 are tabulated once per (column, control) -- at most SDP_COL_UTAB_N controls, the
 // same lattice at every node -- and the first pass of the filter reads them from LDS instead of
 // recomputing them at every node: the same operations on the same operands, the same bits.
 #define SDP_COL_UTAB 0
@@ -1718,7 +1718,8 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
     if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     SdpBox box;
     sdp_load_box(a, 0, box);                                // (one box for every node: checked at launch)
-    for (int ci = (int)threadIdx.x - first; ci < SDP_COL_UTAB_N; ci += count) {
+    const int n_tab = min(box.total, SDP_COL_UTAB_N);        // (SDP_COL_UTAB_N is a capacity: the host checks total <= it)
+    for (int ci = (int)threadIdx.x - first; ci < n_tab; ci += count) {
         sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
         sdp_controls_at(box, ci, u);
         sdp_model_utab(x, u, t, tab);

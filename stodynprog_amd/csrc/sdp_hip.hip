@@ -854,7 +854,7 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
             META_CHECK(m[SDP_META_COL_N0] == p->orders[0], "column table built for %d points along axis 0, the grid has %d", m[SDP_META_COL_N0], p->orders[0]);
             META_CHECK(m[SDP_META_COL_W] == (p->W > 0 ? p->W : 1), "column table built for %d perturbation points, the problem has %d", m[SDP_META_COL_W], p->W);
             META_CHECK(((m[SDP_META_FLAGS] & SDP_META_F_WINDOW) != 0) == (p->col_seg > 0) || (m[SDP_META_FLAGS] & SDP_META_F_TRAIL_HAS_U), "row-window kernel %s but col_seg_nodes = %d", (m[SDP_META_FLAGS] & SDP_META_F_WINDOW) ? "present" : "absent", p->col_seg);
-            META_CHECK(m[SDP_META_UTAB] == 0 || controls == m[SDP_META_UTAB_N], "control table built for one lattice of %d controls at every node, the problem has %s%lld", m[SDP_META_UTAB_N], controls < 0 ? "per-node boxes " : "", (long long)controls);
+            META_CHECK(m[SDP_META_UTAB] == 0 || (controls >= 1 && controls <= m[SDP_META_UTAB_N]), "control table built for one lattice of at most %d controls at every node, the problem has %s%lld", m[SDP_META_UTAB_N], controls < 0 ? "per-node boxes " : "", (long long)controls);
         }
 #undef META_CHECK
         if (what)

@@ -19,7 +19,7 @@ enum {
     SDP_META_COL_W,         // perturbation points of the column table (>= 1)
     SDP_META_FLAGS,         // SDP_META_F_*
     SDP_META_UTAB,          // tabulated values per control (0: none)
-    SDP_META_UTAB_N,        // controls of the lattice the control table was sized for
+    SDP_META_UTAB_N,        // controls the control table has room for (the lattice may be shorter)
     SDP_META_THREADS,       // workgroup size of the sweep kernel (column / staged units)
     SDP_META_COL_ROWS       // rows of axis 0 the table holds (< COL_N0: row window)
 };

@@ -190,6 +190,12 @@ class _DeviceProblem(object):
 
 
 class DPSolver(object):
+    # Diagnostic / A-B switches of the generated kernels (codegen.DEBUG_NAMES): None in the product.
+    # Tests and tools/ set a dict here (on an instance, or on the class for a block of solvers);
+    # nothing is ever read from the environment.  A radius scale below 1, say, voids the
+    # bit-identity guarantee -- which is why it takes an explicit assignment to get one.
+    debug_defines = None
+
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
         (a `SysDescription`).  Implements value iteration, policy evaluation,
@@ -451,7 +457,8 @@ class DPSolver(object):
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
                  id(self.comm), self.comm_phases, self.comm_taper, self.comm_exchange,
                  getattr(self, 'comm_sparse', False), self.kernel,
-                 self.arithmetic, getattr(self, 'certified_filter', True)]
+                 self.arithmetic, getattr(self, 'certified_filter', True),
+                 tuple(sorted((codegen.check_debug(self.debug_defines) or {}).items()))]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
         # the tuple itself is the cache key (not its hash): the callables stay alive as
@@ -594,18 +601,33 @@ class DPSolver(object):
         dt = self.dtype
         bp = self._box_plan(box_t)
         lanes = bp['lanes']
+        debug = codegen.check_debug(self.debug_defines)
         W = len(self.perturb_grid[0]) if self.perturb_grid else 0
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         if self.kernel not in ('auto', 'generic', 'column', 'staged', 'lead'):
             raise ValueError("kernel must be 'auto', 'column', 'lead', 'staged' or 'generic'")
         may_filter = (getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'
-                      and codegen.column_filter_applies(model, dtype=dt, table=(shape[0], W, len(shape))))
-        column = (self.kernel in ('auto', 'column') and model.storage_separable and
-                  codegen.column_config(shape[0], W, len(shape), dt,
-                                        codegen.use_wpair(model, dt), may_filter,
-                                        shift=may_filter and codegen.column_shift_applies(model, dt),
-                                        extra_bytes=2 * codegen.UTAB_MAX_BYTES) is not None)
+                      and codegen.column_filter_applies(model, dtype=dt, table=(shape[0], W, len(shape)), debug=debug))
+        # The shape of the full-table column kernel is planned ONCE, with everything that sizes its LDS image
+        # (the control table included), and handed to the code generator as it is.  A lattice that changes
+        # with the time index gets a control table with room to spare (a capacity, checked by the library as
+        # controls <= capacity), so that the steps of a horizon keep sharing one code object.
+        n_controls = bp['max_u'] if box_t is None else 1 << max(int(bp['max_u']) - 1, 0).bit_length()
+        col_cfg, utab = None, None
+        if self.kernel in ('auto', 'column') and model.storage_separable:
+            wpair = codegen.use_wpair(model, dt, debug)
+            shift = bool(may_filter and codegen.column_shift_applies(model, dt, debug=debug))
+            fr = codegen.control_table_plan(model, dt, bp['per_node'], n_controls, debug) if may_filter else None
+            for frontier in ((fr, None) if fr is not None else (None,)):
+                col_cfg = codegen.column_config(shape[0], W, len(shape), dt, wpair, may_filter,
+                                                max_controls=n_controls, n_columns=int(np.prod(shape[1:])),
+                                                shift=shift, utab_values=len(frontier) * n_controls if frontier else 0,
+                                                debug=debug)
+                if col_cfg is not None:                   # (else once more without the control table)
+                    utab = (frontier, n_controls) if frontier is not None else None
+                    break
+        column = col_cfg is not None
         # several controlled state variables next to an exogenous process: the node-order sweep with the
         # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h); one GPU for now
         lead_axes = 0
@@ -614,7 +636,7 @@ class DPSolver(object):
             # (one stock whose table does not fit LDS too: measured 5.9 ms against 12.7 ms of the row-window
             # column kernel at 1024 x 128 x 128 x 64 x 32, tools/window_vs_lead.py)
             lead_axes = codegen.lead_filter_applies(
-                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2)
+                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2, debug)
         if self.kernel == 'lead' and not lead_axes:
             raise ValueError("kernel = 'lead' needs controlled state variables listed first, an exogenous process "
                              'after them, a perturbation that reaches only that process, 8-byte reals, the certified '
@@ -629,7 +651,7 @@ class DPSolver(object):
                        and self._box_constant_along_axis0(bp, shape))
         per_control_cfg = None
         if per_control:
-            per_control_cfg = codegen.column_percontrol_config(shape[0], W, len(shape), dt)
+            per_control_cfg = codegen.column_percontrol_config(shape[0], W, len(shape), dt, debug)
             column = per_control = per_control_cfg is not None
         window = None
         if (not column and not per_control and not lead_axes and self.kernel in ('auto', 'column')
@@ -654,24 +676,23 @@ class DPSolver(object):
             raise ValueError("arithmetic must be 'exact' or 'fused'")
         staged = None
         if not column and not lead_axes and self.kernel in ('auto', 'staged'):
-            key = ('staged', model.structure_key(), bp['digest'], str(dt), shape, W)
+            key = ('staged', model.structure_key(), bp['digest'], str(dt), shape, W, _dbg_key(debug))
             staged = self._cache.get(key)
             if staged is None:
                 staged = codegen.staged_config(model, self.state_grid, self.perturb_grid, bp, dt,
-                                               0.0 if box_t is None else float(box_t))
+                                               0.0 if box_t is None else float(box_t), debug=debug)
                 self._cache[key] = staged
         filtered = bool(column and getattr(self, 'certified_filter', True) and codegen.column_filter_applies(
             model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None, dtype=dt,
-            table=(shape[0], W, len(shape))))
-        utab = None
-        if filtered:
-            fr = codegen.control_table_plan(model, dt, bp['per_node'], bp['max_u'])
-            utab = (fr, bp['max_u']) if fr is not None else None
+            table=(shape[0], W, len(shape)), debug=debug))
+        if not filtered or window is not None or per_control:
+            utab = None
         source = codegen.translation_unit(model, dt, lanes,
-                                          column=(shape[0], W, bp['max_u'], int(np.prod(shape[1:]))) if column else None,
+                                          column=(shape[0], W, n_controls, int(np.prod(shape[1:]))) if column else None,
                                           fused=(self.arithmetic == 'fused'), staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
-                                          filtered=filtered, utab=utab, lead_axes=lead_axes)
+                                          filtered=filtered, utab=utab, lead_axes=lead_axes,
+                                          col_cfg=col_cfg, debug=debug)
         filtered = filtered or bool(lead_axes)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
                     lead_axes=lead_axes,
@@ -849,7 +870,9 @@ class DPSolver(object):
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),
                          bit_exact_model=model.bit_exact,
-                         inexact_ops=model.inexact_ops())
+                         inexact_ops=model.inexact_ops(),
+                         # diagnostic switches this code object was built with (None in the product)
+                         debug_defines=codegen.check_debug(self.debug_defines))
         return prob
 
     def _peer_needs(self, model, parts, shape):
@@ -1498,6 +1521,10 @@ def _params_key(params):
             except TypeError:
                 out.append((k, repr(v)))
     return tuple(out)
+
+
+def _dbg_key(debug):
+    return tuple(sorted(debug.items())) if debug else ()
 
 
 def _same(a, b):

@@ -113,3 +113,24 @@ def gpu():
     nat.require_gpu()          # loud failure: GPU tests never fall back to anything
     nat.check(nat.lib().sdp_set_device(0))
     return nat
+
+
+@pytest.fixture
+def debug_defines(monkeypatch):
+    """Diagnostic switches of the generated kernels (stodynprog_amd.codegen.DEBUG_NAMES) for the
+    solvers a test creates: an explicit dict on the DPSolver class for the duration of the test
+    (undone by monkeypatch).  The product never reads such switches from the environment --
+    tests/test_trace_codegen.py::test_the_environment_does_not_reach_the_generated_source."""
+    from stodynprog_amd import DPSolver
+
+    class Switches(object):
+        def set(self, **kw):
+            cur = dict(DPSolver.debug_defines or {})
+            cur.update({k: str(v) for k, v in kw.items()})
+            monkeypatch.setattr(DPSolver, 'debug_defines', cur)
+
+        def unset(self, *names):
+            cur = {k: v for k, v in (DPSolver.debug_defines or {}).items() if k not in names}
+            monkeypatch.setattr(DPSolver, 'debug_defines', cur or None)
+
+    return Switches()

@@ -142,20 +142,20 @@ def test_weights_that_do_not_sum_to_one(gpu):
 
 
 @pytest.mark.parametrize('scale', ['1e6', '1e11', '1e18'])
-def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
+def test_any_larger_radius_gives_the_same_bits(gpu, debug_defines, scale):
     """SDP_COL_FILTER_SCALE multiplies the error radius: more and more controls survive the
     first pass (all of them at 1e18) and go through the second; the result cannot change"""
     make = lambda: models.synthetic3d(N=24)
     V = models.synthetic3d_V0(make()[1].state_grid)
     ref = _sweep(make, False, V)
-    monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+    debug_defines.set(SDP_COL_FILTER_SCALE=scale)
     on = _sweep(make, True, V)
     assert 'SDP_COL_FILTER_SCALE' in on[3]._kernel_plan()['source']
     _same(on, ref)
 
 
 @pytest.mark.parametrize('n_x', [96, 600])
-def test_two_survivors_take_the_short_cut(gpu, monkeypatch, n_x):
+def test_two_survivors_take_the_short_cut(gpu, debug_defines, n_x):
     """SDP_COL_FILTER_TOP2 (default for 4-byte reals): the first pass also keeps the second
     best control, and a node with exactly two survivors evaluates those two -- one per lane
     of the node, or both on a lane that has the node to itself (600 nodes per column)"""
@@ -165,11 +165,11 @@ def test_two_survivors_take_the_short_cut(gpu, monkeypatch, n_x):
     assert on[3].backend_info['certified_filter']
     _same(on, off)
     # the same path in 8-byte reals, with a radius wide enough to leave pairs
-    monkeypatch.setenv('SDP_COL_FILTER_TOP2', '1')
-    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '3e10')
+    debug_defines.set(SDP_COL_FILTER_TOP2='1')
+    debug_defines.set(SDP_COL_FILTER_SCALE='3e10')
     on = _sweep(make, True, V)
-    monkeypatch.delenv('SDP_COL_FILTER_TOP2')
-    monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+    debug_defines.unset('SDP_COL_FILTER_TOP2')
+    debug_defines.unset('SDP_COL_FILTER_SCALE')
     _same(on, _sweep(make, False, V))
 
 
@@ -220,7 +220,7 @@ def test_a_cost_that_depends_on_the_perturbation_is_filtered_with_the_same_bits(
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 @pytest.mark.parametrize('scale', [None, '0.5'])
-def test_near_ties_with_the_perturbation_in_the_cost(gpu, monkeypatch, dtype, scale):
+def test_near_ties_with_the_perturbation_in_the_cost(gpu, debug_defines, dtype, scale):
     s_ = 1.37
     for tilt in ([0.0, 1e-15, 1e-13] if dtype == np.float64 else [0.0, 1e-7, 1e-5]):
         make = lambda: _stock_cost_w(tilt=tilt)
@@ -228,10 +228,10 @@ def test_near_ties_with_the_perturbation_in_the_cost(gpu, monkeypatch, dtype, sc
         V = s_ * np.asarray(g[0])[:, None] + np.cos(3 * np.asarray(g[1]))[None, :]
         off = _sweep(make, False, V, dtype)
         if scale:
-            monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+            debug_defines.set(SDP_COL_FILTER_SCALE=scale)
         on = _sweep(make, True, V, dtype)
         if scale:
-            monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+            debug_defines.unset('SDP_COL_FILTER_SCALE')
         _same(on, off)
         if tilt == 0.0:
             assert len(np.unique(off[2])) > 3
@@ -308,17 +308,17 @@ NEAR_TIE_TILTS = {np.float64: [0.0, 1e-16, 1e-15, 4e-15, 3e-14, 1e-12],
 @pytest.mark.parametrize('box_on_state', [False, True])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 @pytest.mark.parametrize('scale', [None, '0.5'])
-def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, monkeypatch, dtype, box_on_state, scale):
+def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, debug_defines, dtype, box_on_state, scale):
     for tilt in NEAR_TIE_TILTS[dtype]:
         make = lambda: _flat(tilt, box_on_state=box_on_state)[:2]
         V = _flat(tilt)[2]
         off = _sweep(make, False, V, dtype)
         if scale:
-            monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+            debug_defines.set(SDP_COL_FILTER_SCALE=scale)
         on = _sweep(make, True, V, dtype)
         if scale:
             assert 'SDP_COL_FILTER_SCALE' in on[3]._kernel_plan()['source']
-            monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+            debug_defines.unset('SDP_COL_FILTER_SCALE')
         assert on[3].backend_info['certified_filter'] and not off[3].backend_info['certified_filter']
         _same(on, off)
         if tilt == 0.0:                          # (the case is what it claims to be: no clear winner)
@@ -326,14 +326,14 @@ def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, mon
 
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
-def test_a_radius_far_too_small_is_noticed(gpu, monkeypatch, dtype):
+def test_a_radius_far_too_small_is_noticed(gpu, debug_defines, dtype):
     """With the radius cut by 1e6 the first pass picks its own minimum of F where the reference's
     minimum of E differs in the last bits: policy indices (and J, by an ulp) change.  If this test
     ever fails, the near-tie tests above have stopped probing the radius."""
     make = lambda: _flat(0.0)[:2]
     V = _flat(0.0)[2]
     off = _sweep(make, False, V, dtype)
-    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '1e-6')
+    debug_defines.set(SDP_COL_FILTER_SCALE='1e-6')
     on = _sweep(make, True, V, dtype)
     assert 'SDP_COL_FILTER_SCALE' in on[3]._kernel_plan()['source']
     assert (on[2] != off[2]).sum() > 0

@@ -50,7 +50,7 @@ def test_chained_sweeps_at_full_size_match_the_oracle_on_sampled_nodes(gpu):
 
 
 @pytest.mark.timeout(900)
-def test_every_node_through_the_multi_survivor_pass_at_full_size(gpu, monkeypatch):
+def test_every_node_through_the_multi_survivor_pass_at_full_size(gpu, debug_defines):
     """At the benchmark size no node keeps a second control in 8-byte reals, so the second pass's
     walk over several survivors never runs there: force it (radius x 1e12: every node keeps
     several) once at 256^3 and compare all 16.7 M nodes with the ordinary run."""
@@ -60,7 +60,7 @@ def test_every_node_through_the_multi_survivor_pass_at_full_size(gpu, monkeypatc
     V0 = models.synthetic3d_V0(a.state_grid)
     Ja, _ = a.value_iteration(V0, report_time=False)
     ia = a.last_policy_index
-    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '1e12')
+    debug_defines.set(SDP_COL_FILTER_SCALE='1e12')
     _, b = models.synthetic3d(N=256)
     Jb, _ = b.value_iteration(V0, report_time=False)
     assert 'SDP_COL_FILTER_SCALE' in b._kernel_plan()['source']

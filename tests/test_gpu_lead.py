@@ -153,17 +153,17 @@ def test_a_cost_that_sees_the_perturbation(gpu):
 
 
 @pytest.mark.parametrize('scale', ['1e4', '1e12', '1e18'])
-def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
+def test_any_larger_radius_gives_the_same_bits(gpu, debug_defines, scale):
     make = _small()
     V = _smooth(make()[1])
     ref = _sweep(make, 'generic', V)
-    monkeypatch.setenv('SDP_LEAD_FILTER_SCALE', scale)
+    debug_defines.set(SDP_LEAD_FILTER_SCALE=scale)
     on = _sweep(make, 'auto', V)
     assert 'SDP_LEAD_FILTER_SCALE' in on[3]._kernel_plan()['source']
     _same(on, ref)
 
 
-def test_near_ties_and_a_radius_far_too_small(gpu, monkeypatch):
+def test_near_ties_and_a_radius_far_too_small(gpu, debug_defines):
     """an objective that is flat in the controls: V linear in both stocks, the cost cancels the slope --
     the reference's argmin hangs on the last bits of its W x (3d + 3) roundings.  Same bits at the proven
     radius; with the radius cut by 1e6 the first pass picks its own minimum and differs somewhere."""
@@ -184,9 +184,9 @@ def test_near_ties_and_a_radius_far_too_small(gpu, monkeypatch):
     ref = _sweep(make, 'generic', V)
     assert len(np.unique(ref[2])) > 5
     _same(_sweep(make, 'auto', V), ref)
-    monkeypatch.setenv('SDP_LEAD_FILTER_SCALE', '0.5')            # half the proven radius: still the same bits
+    debug_defines.set(SDP_LEAD_FILTER_SCALE='0.5')            # half the proven radius: still the same bits
     _same(_sweep(make, 'auto', V), ref)
-    monkeypatch.setenv('SDP_LEAD_FILTER_SCALE', '1e-6')
+    debug_defines.set(SDP_LEAD_FILTER_SCALE='1e-6')
     assert (_sweep(make, 'auto', V)[2] != ref[2]).sum() > 0
 
 

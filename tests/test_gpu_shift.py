@@ -203,23 +203,23 @@ def test_weights_that_do_not_sum_to_one_and_tiny_weights(gpu):
 
 
 @pytest.mark.parametrize('scale', ['1e3', '1e9', '1e18'])
-def test_any_larger_radius_gives_the_same_bits(gpu, monkeypatch, scale):
+def test_any_larger_radius_gives_the_same_bits(gpu, debug_defines, scale):
     make = lambda: _shop()
     V = _smooth(make()[1])
     ref = _sweep(make, False, V)
-    monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+    debug_defines.set(SDP_COL_FILTER_SCALE=scale)
     on = _sweep(make, True, V)
     assert 'SDP_COL_FILTER_SCALE' in on[3]._kernel_plan()['source']
     _same(on, ref)
 
 
-def test_a_radius_far_too_small_is_noticed(gpu, monkeypatch):
+def test_a_radius_far_too_small_is_noticed(gpu, debug_defines):
     """the interpolation bound B' is what decides here: without it (radius x 1e-6) the first pass
     trusts the chord where the kinks of the cost-to-go matter, and picks other controls"""
     make = lambda: _shop(order_step=0.05)
     V = np.random.default_rng(13).standard_normal(make()[1]._state_grid_shape)
     ref = _sweep(make, False, V)
-    monkeypatch.setenv('SDP_COL_FILTER_SCALE', '1e-6')
+    debug_defines.set(SDP_COL_FILTER_SCALE='1e-6')
     on = _sweep(make, True, V)
     assert (on[2] != ref[2]).sum() > 0
 
@@ -258,16 +258,16 @@ def _flat_shop(tilt, box_on_state=False):
 
 @pytest.mark.parametrize('box_on_state', [False, True])
 @pytest.mark.parametrize('scale', [None, '0.5'])
-def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, monkeypatch, box_on_state, scale):
+def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, debug_defines, box_on_state, scale):
     for tilt in (0.0, 1e-16, 1e-15, 4e-15, 3e-14, 1e-12):
         make = lambda: _flat_shop(tilt, box_on_state)[:2]
         V = _flat_shop(tilt)[2]
         off = _sweep(make, False, V)
         if scale:
-            monkeypatch.setenv('SDP_COL_FILTER_SCALE', scale)
+            debug_defines.set(SDP_COL_FILTER_SCALE=scale)
         on = _sweep(make, True, V)
         if scale:
-            monkeypatch.delenv('SDP_COL_FILTER_SCALE')
+            debug_defines.unset('SDP_COL_FILTER_SCALE')
         assert on[3].backend_info['filter_form'] == 'shifted lattice'
         _same(on, off)
         if tilt == 0.0:                          # (the case is what it claims to be: no clear winner)

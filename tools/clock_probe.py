@@ -15,10 +15,12 @@ import os
 import sys
 import time
 
-os.environ['SDP_STAMP'] = '1'                       # codegen: -> '#define SDP_STAMP 1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from stodynprog_amd import models, _native as nat
+from stodynprog_amd import models, DPSolver, _native as nat
+# diagnostic build (clock stamps), and whatever other switches the command line names as K=V
+DPSolver.debug_defines = dict([('SDP_STAMP', '1')] + [a.split('=', 1) for a in sys.argv[1:] if a.startswith('SDP_') and '=' in a])
+sys.argv = [a for a in sys.argv if not (a.startswith('SDP_') and '=' in a)]
 
 
 def probe(dtype, N=256, warm_s=2.5):
