@@ -317,13 +317,16 @@ def run_sharded(args, env):
     import threading
     solver, dev_comm, V0, rank, nat = (env[k] for k in ('solver', 'dev_comm', 'V0', 'rank', 'nat'))
     sync_all, timed_region = env['sync_all'], env['timed_region']
-    exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,peer,sparse').split(',') if e]
+    exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,direct,sparse,peer').split(',') if e]
     if 'rccl' not in exchanges:
         exchanges.insert(0, 'rccl')
     # phases per backup: each phase's exchange runs under the next phase's kernel.  Few phases leave
     # a long last exchange exposed, many add launches (measured on one GPU: ~0.03 ms per extra phase,
     # profiles/r03_fixed_cost_sharded.txt); sparse / peer writes need few.  `t`: tapered phases.
+    # 'direct': the kernel stores J into the ranks that read it (sparse need lists where the model has them):
+    # nothing to hide behind a second phase, so one launch per sweep comes first.
     PLANS = {'rccl': ((4, False), (2, False), (1, False), (8, False), (16, False), (4, True), (8, True)),
+             'direct': ((1, False), (2, False)),
              'peer': ((2, False), (1, False), (4, False), (8, False)),
              'sparse': ((1, False), (2, False), (4, False))}
     if os.environ.get('SDP_COMM_PHASES'):
@@ -333,6 +336,11 @@ def run_sharded(args, env):
     f_exch, f_kind, f_rank = (fault.split(':') + ['', '', ''])[:3]
     phase_times, notes = {}, []
     state = {'J_check': None}
+    lock = threading.Lock()              # the watchdog thread reads notes / phase_times while this one fills them
+
+    def note(text):
+        with lock:
+            notes.append(text)
 
     def key_of(exch, ph, taper):
         return '{}{}{}'.format(ph, 't' if taper else '', '' if exch == 'rccl' else '/' + exch)
@@ -340,7 +348,7 @@ def run_sharded(args, env):
     def configure(exch, ph, taper):
         solver.comm_phases, solver.comm_taper = ph, taper
         solver.comm_exchange = 'peer' if exch == 'sparse' else exch
-        solver.comm_sparse = exch == 'sparse'
+        solver.comm_sparse = exch in ('sparse', 'direct')
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             return solver._problem()
@@ -366,7 +374,7 @@ def run_sharded(args, env):
                     time.sleep(1e6)
                 trial = configure(exch, ph, taper)
                 got = solver.backend_info.get('exchange') or 'rccl'        # (None with one rank)
-                if got != {'sparse': 'peer-sparse'}.get(exch, exch):
+                if got not in {'sparse': ('peer-sparse',), 'direct': ('direct-sparse', 'direct')}.get(exch, (exch,)):
                     local_error = ('not available on this node: {}'.format(getattr(trial, 'peer_failure', 'buffers not mappable'))
                                    if got == 'rccl' else 'does not apply to this kernel family')
                 else:
@@ -393,7 +401,8 @@ def run_sharded(args, env):
             if failed:
                 return None, local_error or 'another rank failed'
             t = dev_comm.allreduce_max(t) / 3 * 1e3
-            phase_times[key_of(exch, ph, taper)] = t
+            with lock:
+                phase_times[key_of(exch, ph, taper)] = t
             _trace('candidate', key_of(exch, ph, taper), round(t, 3))
             if best[0] is None or t < best[1]:
                 best = ((ph, taper), t)
@@ -415,6 +424,7 @@ def run_sharded(args, env):
     if plan is None:
         raise RuntimeError('RCCL exchange failed: {}'.format(t_rccl))
     best_out, best_elapsed = measure('rccl', plan)
+    best_cfg = ('rccl', plan)
     _trace('rccl timed', best_elapsed)
 
     # ---- 2. optional exchanges, each under a watchdog that prints the best result so far
@@ -423,29 +433,77 @@ def run_sharded(args, env):
         box = {'out': best_out}
 
         def bail(exch=exch, box=box):
-            if rank == 0 and box['out'] is not None:
-                o = box['out']
-                o['config']['comm_exchange_note'] = '; '.join(notes + [
-                    '{} exchange abandoned: no answer within {:.0f} s (a rank hung)'.format(exch, budget)])
-                o['config']['comm_phase_tuning_ms_per_sweep'] = dict(phase_times)
-                # (file descriptor 1 is fenced off while run() executes: write to the real one)
-                os.write(_REAL_STDOUT[0] if _REAL_STDOUT else 1, (json.dumps(o) + '\n').encode())
-            os._exit(0)
+            # Every rank leaves with status 0 (the launcher turns any other status of any worker into a failed
+            # run, and the RCCL result is valid): the hang is reported IN the line, as its own field.
+            try:
+                if rank == 0 and box['out'] is not None:
+                    o = box['out']
+                    with lock:
+                        o['config']['comm_exchange_note'] = '; '.join(notes + [
+                            '{} exchange abandoned: no answer within {:.0f} s (a rank hung)'.format(exch, budget)])
+                        o['config']['comm_phase_tuning_ms_per_sweep'] = dict(phase_times)
+                    o['config']['optional_exchange_hang'] = exch
+                    # (file descriptor 1 is fenced off while run() executes: write to the real one)
+                    os.write(_REAL_STDOUT[0] if _REAL_STDOUT else 1, (json.dumps(o) + '\n').encode())
+            finally:
+                os._exit(0)
         dog = threading.Timer(budget, bail)
         dog.daemon = True
         dog.start()
         try:
             plan, t_opt = tune(exch)
             if plan is None:
-                notes.append('{} exchange not used: {}'.format(exch, t_opt))
+                note('{} exchange not used: {}'.format(exch, t_opt))
             elif t_opt >= t_rccl:
-                notes.append('{} exchange not faster in tuning ({:.3f} vs {:.3f} ms per sweep)'.format(exch, t_opt, t_rccl))
+                note('{} exchange not faster in tuning ({:.3f} vs {:.3f} ms per sweep)'.format(exch, t_opt, t_rccl))
             else:
                 out, elapsed = measure(exch, plan)
                 if dev_comm.allreduce_max(1.0 if (rank == 0 and out.get('sharded_matches_single_gpu') is not True) else 0.0) > 0:
-                    notes.append('{} exchange rejected: the sharded chain differs from the single-GPU one'.format(exch))
+                    note('{} exchange rejected: the sharded chain differs from the single-GPU one'.format(exch))
                 elif elapsed < best_elapsed:
                     best_out, best_elapsed = out, elapsed
+                    best_cfg = (exch, plan)
+        finally:
+            dog.cancel()
+    # ---- 3. the work-equivalent figure: the same chain with every control the long way (the certified filter
+    # off), sharded like the headline -- a curve that scales with the kernel, next to the absolute one.
+    # Optional like the exchanges: under the same watchdog, and its failure costs a note, not the run.
+    if not args.no_filter and not args.no_filter_check and dev_comm.nranks >= 1 and solver.backend_info.get('certified_filter'):
+        box = {'out': best_out}
+
+        def bail2(box=box):
+            try:
+                if rank == 0 and box['out'] is not None:
+                    o = box['out']
+                    with lock:
+                        o['config']['comm_exchange_note'] = '; '.join(notes + ['long-way chain abandoned: no answer within {:.0f} s'.format(budget)])
+                        o['config']['comm_phase_tuning_ms_per_sweep'] = dict(phase_times)
+                    o['config']['optional_exchange_hang'] = 'long-way chain'
+                    os.write(_REAL_STDOUT[0] if _REAL_STDOUT else 1, (json.dumps(o) + '\n').encode())
+            finally:
+                os._exit(0)
+        dog = threading.Timer(budget, bail2)
+        dog.daemon = True
+        dog.start()
+        try:
+            err = None
+            try:
+                solver.certified_filter = False
+                prob = configure(*((best_cfg[0],) + tuple(best_cfg[1])))
+                elapsed, kernel_ms = timed_region(prob)
+            except Exception as e:
+                err = '{}: {}'.format(type(e).__name__, e)
+            finally:
+                solver.certified_filter = True
+            if dev_comm.allreduce_max(1.0 if err else 0.0) > 0:
+                note('long-way chain not timed: {}'.format(err or 'another rank failed'))
+            elif rank == 0:
+                best_out['every_control_the_long_way'] = {
+                    'ms_per_step': elapsed * 1e3 / args.steps, 'sweeps_per_s': args.steps / elapsed,
+                    'kernel_ms_per_sweep': kernel_ms / args.steps, 'n_gpus': dev_comm.nranks,
+                    'exchange': solver.backend_info.get('exchange'),
+                    'note': 'DPSolver.certified_filter = False, same sharding and exchange as the headline: the '
+                            'reference\'s W x 6 operations for every control (work-equivalent curve)'}
         finally:
             dog.cancel()
     if rank == 0:

@@ -307,6 +307,24 @@ int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_off /* [nrank
 /* Sparse peer exchange: make the last backup's J complete on every rank (collective; a no-op
  * otherwise) -- what sdp_problem_get_value does before it downloads. */
 int sdp_problem_complete_value(sdp_problem *p);
+/*
+ * Direct exchange (after sdp_problem_enable_peer_exchange; at most 8 ranks, the GPUs of one node):
+ * the backup kernel that computes J[node] also STORES it into the mapped J buffer of every other rank
+ * (with need lists set: of the ranks that read the node's column) -- stores over xGMI issued by the
+ * kernel itself, spread over the whole sweep, instead of copies after each phase.  Nothing is left to
+ * move when the kernel ends: a backup costs ONE launch and ONE 1-word all-reduce (the ranks meet
+ * before anybody reads J or overwrites V).  Same results.  The reference has no counterpart (its only
+ * parallel attempt is the commented-out Pool.imap over the nodes, stodynprog.py:503-509).
+ */
+int sdp_problem_set_direct_exchange(sdp_problem *p, int on);
+/*
+ * Reduced-array sweep (several controlled state variables, csrc/sdp_lead_kernel.h) on a sharded
+ * problem: rows of the FIRST state axis the controls of a node reach on either side.  A rank then
+ * reduces its own rows plus that many instead of the whole grid.  A guess is enough: a node whose
+ * controls reach further is noticed by the kernel and evaluated from the value array itself (time,
+ * not correctness).  rows < 0 (default): every rank reduces everything.
+ */
+int sdp_problem_set_lead_halo(sdp_problem *p, int64_t rows);
 int sdp_comm_allreduce_max(sdp_comm *c, double *inout);    /* host scalar, for timing */
 int sdp_comm_barrier(sdp_comm *c);
 

@@ -33,12 +33,13 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 DEBUG_INT_MACROS = ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
                     'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO',
                     'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE',
-                    'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP')
+                    'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP', 'SDP_COL_LDS_PAD', 'SDP_COL_HOIST')
+# (SDP_COL_WRES is a planning switch: it sizes the LDS image -- column_config)
 # every name a `debug` dict may carry (a typo must not pass silently)
 DEBUG_NAMES = frozenset(DEBUG_INT_MACROS + (
     'SDP_STAMP', 'SDP_NO_POW2', 'SDP_EXTRA_DEFINES', 'SDP_COL_FILTER_SCALE', 'SDP_LEAD_FILTER_SCALE',
     'SDP_LEAD_UNROLL', 'SDP_COL_A_LW', 'SDP_COL_FILTER', 'SDP_COL_SHIFT', 'SDP_COL_UTAB', 'SDP_LEAD_FILTER',
-    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR'))
+    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES'))
 
 
 def check_debug(debug):
@@ -393,7 +394,7 @@ def _prologue_lines(model, real, lanes, debug):
     return lines
 
 
-def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug):
+def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug, wres=0):
     """the macros and model slices of a unit that includes csrc/sdp_column_kernel.h"""
     rs = np.dtype(dtype).itemsize
     wpair = use_wpair(model, dtype, debug) and window is None
@@ -406,8 +407,14 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
              '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
              '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
              '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0)]
+    if wres:
+        lines.append('#define SDP_COL_WRES {}         // resident-chunk form: perturbation points the table holds at a time'.format(int(wres)))
     if filtered and int(col_cfg[0]) <= 256 and not _dbg(debug, 'SDP_COL_MIN_WAVES'):
-        lines.append('#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap')
+        if wres:
+            lines.append('#define SDP_COL_MIN_WAVES {}    // as many waves per SIMD as the LDS image admits workgroups per CU'.format(
+                max(1, min(8, (COLUMN_LDS_MAX // int(col_cfg[1])) * int(col_cfg[0]) // 256))))
+        else:
+            lines.append('#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap')
     if filtered:
         lines.append('#define SDP_COL_FILTER 1')
         if shifted:
@@ -445,7 +452,7 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
 
 
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
-                     per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None):
+                     per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None, wres=0):
     """column: None for the generic node-order kernels, or (N0, W[, controls, columns]) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
@@ -481,7 +488,8 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
                                     debug=debug)
         if col_cfg is None:
             raise ValueError('the column kernel does not fit this grid (its table exceeds the LDS of a CU)')
-        head += _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug)
+        head += _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug,
+                              wres if (window is None and per_control is None) else 0)
     elif staged is not None:
         tile = tuple(staged['tile']) + (1,) * (4 - len(staged['tile']))
         head += ['#define SDP_STG_THREADS {}'.format(int(staged['threads']))] + [
@@ -664,7 +672,7 @@ def column_filter_applies(model, fused=False, window=None, per_control=None, dty
 
 
 def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_controls=None, n_columns=None,
-                  shift=False, utab_values=0, debug=None):
+                  shift=False, utab_values=0, debug=None, wres=0):
     """Compile-time shape of the column kernel for a grid with n0 points along
     axis 0 and w perturbation points: (threads, lds_bytes), or None if the
     table does not fit the LDS of a CU.  512-thread workgroups while two of
@@ -715,11 +723,45 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_contro
                                                  utab_values=utab_values), int(rows))
         return None
     for threads in sizes:
-        # (with the reduced table, whether or not it is compiled in)
-        lds = _column_lds(tw, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
+        # (`wres`: the resident-chunk form, whose table holds that many perturbation points; its workgroup has
+        # one lane per node, as many of them per CU as the image allows)
+        lds = _column_lds(int(wres) or tw, w, n0, n_state, rs, threads, reduced=filtered, utab_values=utab_values,
+                          partial_minima=not filtered)
         if lds * (2 if threads <= 512 else 1) <= COLUMN_LDS_MAX:
             return threads, lds
     return None
+
+
+def column_resident_points(model, n0, w, n_state, dtype, filtered, shift, wpair, threads, utab_values=0, debug=None):
+    """Perturbation points the LDS table of the filtered column kernel holds at a time (SDP_COL_WRES of
+    csrc/sdp_colres_kernel.h), or 0 for the plain kernel with the whole W x n0 table.
+    The whole table lets a CU hold two workgroups when it takes 64 KiB, and the kernel is bound by what there
+    is to overlap (one workgroup per CU: 3.39 ms, two: 1.67 on the benchmark problem).  Half of the points
+    resident -- the rest built twice -- halves the table: chosen when it takes the CU from < 3 to >= 3
+    workgroups.  Needs the lean first pass of 8-byte reals without the shifted lattice, a cost that does not
+    see the perturbation, one lane per node.  (`debug`: SDP_COL_WRES = 0 switches it off, k > 0 forces k.)"""
+    rs = np.dtype(dtype).itemsize
+    w = int(w)
+    ok = (filtered and rs == 8 and not shift and not wpair and not model.cost_depends_on_w and w >= 4
+          and int(threads) >= int(n0) and _dbg(debug, 'SDP_COL_LEAN', '-1') != '0')
+    forced = _dbg(debug, 'SDP_COL_WRES')
+    if forced is not None:
+        k = int(forced)
+        return k if (ok and 0 < k < w and 2 * k >= w) else 0
+    if not ok:
+        return 0
+    whole = _column_lds(w, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
+    half = (w + 1) // 2
+    part = _column_lds(half, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
+    if COLUMN_LDS_MAX // whole < 3 <= COLUMN_LDS_MAX // part:
+        return half if RESIDENT_CHUNKS_DEFAULT else 0
+    return 0
+
+
+# measured on the benchmark problem (256^3 x 64 x 32, 8-byte reals), same box: whole table, two workgroups per CU
+# 1.65 - 1.67 ms; 16 of 32 points resident, four per CU 1.555 ms (three: 1.62, two: 1.92 -- the chunked form costs
+# 15 % at equal occupancy and wins by what it lets overlap); profiles/r04_column_ab.txt
+RESIDENT_CHUNKS_DEFAULT = True
 
 
 def column_wide_loads(n0, dtype, fused, window, debug=None):
@@ -756,23 +798,28 @@ def column_build_order(threads, w, rows, rows_per_lane=1):
     return (best[0], best[1]) if best[2] >= 0.85 else (0, 0)
 
 
-def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False, shift_rows=0, utab_values=0):
+def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False, shift_rows=0, utab_values=0,
+                partial_minima=False):
     """sizeof(SdpColLds) of csrc/sdp_column_kernel.h, member by member with the alignment rules of
-    the C++ struct.  tw: table rows per ... perturbation points the table holds (SDP_COL_TW, or
-    SDP_COL_WCHUNK for the table per control); rows: rows of axis 0 the table holds;
-    reduced: with the reduced table `ad` of the certified filter (full-column table);
-    shift: the shifted lattice -- `ad` then has `shift_rows` rows -- and the shifts of the perturbation
-    points; utab_values: reals per parity buffer of the control table (0: the struct's two)."""
+    the C++ struct.  tw: perturbation points the table holds (SDP_COL_TW; SDP_COL_WRES of the resident-chunk
+    form; SDP_COL_WCHUNK of the table per control); rows: rows of axis 0 the table holds;
+    reduced: with the reduced table `ad` of the certified filter (full-column table) -- one real per row in the
+    lean form of 8-byte reals, 16 bytes per row otherwise;
+    shift: the shifted lattice -- `ad` then has `shift_rows` rows of two reals -- and the shifts of the
+    perturbation points; utab_values: reals per parity buffer of the control table (0: the struct's two);
+    partial_minima: the unfiltered sweep's per-thread partial minima (SDP_COL_LDS_PART)."""
     dt = n_state - 1
+    part = threads if partial_minima else 1
     members = [(rs, tw * rows, 16),                          # T
                (rs, w * dt, rs), (rs, w * dt, rs),           # w_lam, w_oml
-               (rs, w, rs), (rs, w, rs),                     # pw, gw
-               (rs, threads, rs), (4, threads, 4),           # part_J, part_i
+               (rs, 1, rs), (rs, 1, rs),                     # pw, gw (SDP_COL_WMODE 2 only: not generated)
+               (rs, part, rs), (4, part, 4),                 # part_J, part_i
                (4, w * dt, 4),                               # w_off
                (4, 4, 4), (4, 1, 4), (8, 2, 8),              # win, next_unit, dcol
                (rs, 2 * (int(utab_values) or 2), 16)]        # utab[2][..]
     if reduced or shift:
-        members.append((rs, (4 if rs == 4 else 2) * int(shift_rows if shift else rows), 16))    # ad
+        per_row = 4 if rs == 4 else (2 if shift else 1)      # SDP_COL_LDS_AD (8-byte reals: the lean form is the default)
+        members.append((rs, per_row * int(shift_rows if shift else rows), 16))    # ad
     if shift:
         members += [(4, 2 * w, 4), (rs, 2 * w, rs), (rs, 2 * w, rs), (4, 8, 4)]                   # sh_q, sh_f, sh_c, sh_k
     off = 0
@@ -831,8 +878,8 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
                '-fno-fast-math', '-std=c++17', '-I', CSRC]
 
 
-_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_lead_kernel.h',
-            'sdp_staged_kernel.h')
+_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_colres_kernel.h',
+            'sdp_lead_kernel.h', 'sdp_staged_kernel.h')
 _digest_cache = {}
 
 

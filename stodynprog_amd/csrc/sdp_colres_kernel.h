@@ -1,0 +1,337 @@
+// sdp_colres_kernel.h -- RESIDENT-CHUNK form of the filtered column kernel (SDP_COL_WRES = C < W = SDP_COL_W).
+// Included by sdp_column_kernel.h in place of its own sdp_sweep_col / sdp_evalpol_col; every building block
+// (table build, first pass, bounds, stores, unit claiming) is the one defined there.
+//
+// Why.  The W x N0 table of the column kernel (64 KiB at 32 x 256 x 8 B) lets a CU hold two workgroups: two waves
+// per SIMD, one of which is usually waiting (table loads, barriers, LDS round trips).  Measured on the benchmark
+// problem: ONE workgroup per CU takes 3.39 ms, two take 1.67 -- the kernel is bound by how much there is to
+// overlap, not by any unit (profiles/r04_column_ab.txt).  Holding only C of the W perturbation points at a time
+// shrinks the table to C x N0 (32 KiB at C = 16: four workgroups per CU, four waves per SIMD).
+//
+// How.  The first pass needs A[r] = sum_w p_w T[w][r] over ALL points, the second pass needs T[w][q0], T[w][q0+1]
+// of the surviving control for all points IN w ORDER (the reference accumulates its expectation in that order,
+// stodynprog.py:681).  So per column:
+//     build the tail  T[w], w = C .. W-1        partial sums of A (a register per row)
+//     build the head  T[w], w = 0 .. C-1        A complete  ->  LDS;  first pass on A (all controls)
+//     second pass, head:  the survivor's cells for w = 0 .. C-1 out of the resident table
+//     build the tail again                      second pass, tail: w = C .. W-1, added to the same accumulator
+// i.e. (W + (W - C)) / W times the table loads of the plain kernel (1.5 at C = W / 2) and seven barriers instead
+// of three, for twice the workgroups per CU.  The survivor's cell, weights and cost are computed once (second pass,
+// head) and kept in registers across the rebuild.  Every floating-point operation of the result is the reference's,
+// on the same operands, in the same order: J, policy and index have the same bits as the plain kernel.
+// A node with several survivors (near-ties, NaN / infinite values: none on ordinary 8-byte inputs) evaluates its
+// candidates from global memory (sdp_col_cost_global: the same operations), which needs no table at all.
+//
+// One lane per node (SDP_COL_THREADS >= SDP_COL_N0); 8-byte lean first pass (with or without the control table);
+// the perturbation reaches neither the stock nor the cost; plain table layout, exact arithmetic.
+#pragma once
+
+static_assert(SDP_COL_LEAN_ON && !SDP_COL_WIDE_ON && !SDP_COL_TOP2, "resident chunks: the lean first pass of 8-byte reals");
+static_assert(SDP_COL_WRES >= 1 && 2 * SDP_COL_WRES >= SDP_COL_W, "resident chunks: at least half of the points resident");
+
+// The reference's operations for ONE control over the perturbation points [w_lo, w_hi) (table rows w - t_base),
+// `acc` carried from call to call: what sdp_col_expected_cost<1> does for those points.
+SDP_DEV void sdp_colres_partial(const sdp_real *T, const SdpColWeights &k, const int w_lo, const int w_hi, const int t_base,
+                                int q0, sdp_real lam0, sdp_real oml0, sdp_real g, sdp_real &acc)
+{
+    constexpr int N0 = SDP_COL_ROWS;
+    constexpr int B = SDP_COL_BATCH;
+    // (two separate 8-byte reads per cell, kept apart by `volatile`: see sdp_col_expected_cost)
+    const volatile sdp_lds_real *row = (const volatile sdp_lds_real *)(T + q0);
+#pragma unroll SDP_COL_UNROLL_W
+    for (int w0 = w_lo; w0 < w_hi; w0 += B) {
+        sdp_real lo[B], hi[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (w0 + b < w_hi) {
+                lo[b] = row[(w0 + b - t_base) * N0];
+                hi[b] = row[(w0 + b - t_base) * N0 + 1];
+            }
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (w0 + b < w_hi) {
+                const sdp_real pw = SDP_COL_PW(k, w0 + b);
+                const sdp_real val = oml0 * lo[b] + lam0 * hi[b];     // pyx:88-300
+                const sdp_real jc = g + val;                          // stodynprog.py:677
+                acc = acc + jc * pw;                                  // stodynprog.py:681, w order
+            }
+    }
+}
+
+// cell of x0' along axis 0 and the cost of one control, as sdp_col_expected_cost computes them (pyx:75-81)
+SDP_DEV void sdp_colres_locate(const SdpLeadAxis &l, const sdp_real *x, const sdp_real *u, sdp_real t,
+                               int &q0, sdp_real &lam0, sdp_real &oml0, sdp_real &g)
+{
+    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+    const sdp_real sn = sdp_div_span<sdp_real>(xn0 - l.smin, l.span, l.rspan, l.pow2);   // pyx:75
+    const sdp_real p = sn * l.nm1;
+    q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);                                         // pyx:78
+    lam0 = p - (sdp_real)q0;                                                             // pyx:81
+    oml0 = (sdp_real)1 - lam0;
+    g = sdp_model_cost(x, u, (sdp_real)0, t);
+}
+
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
+{
+    __shared__ SdpColLds sdp_lds;
+    SDP_STAMP_BEGIN(a);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    constexpr int C = SDP_COL_WRES, R = Wn - C;            // resident head, rebuilt tail
+    sdp_trap_unless(a.n_lead == N0 && a.W == Wn && (int)blockDim.x == SDP_COL_THREADS);
+    const sdp_real t = (sdp_real)a.t_k;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+
+    SdpColShared s;
+    sdp_col_carve(sdp_lds, s);
+    SdpGrid<sdp_real, SDP_DT> tg;
+    sdp_col_trailing_grid(a, tg);
+    SdpLeadAxis lead;
+    sdp_col_lead_axis(a, lead);
+    SdpColWalk walk;
+    sdp_col_walk(a, walk);
+    SdpColWeights wts;
+    sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+    SdpColFilter filt;
+    sdp_col_filter_setup(a, filt);
+    const int axis_mode = __builtin_amdgcn_readfirstlane(sdp_col_axis_mode(lead));
+    const sdp_cst_real *pw = (const sdp_cst_real *)a.proba;
+    if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
+    int parity = 0;
+
+    // units of this XCD's share, claimed in order (see sdp_col_of_unit)
+    const int64_t u_base = walk.unit - (blockIdx.x >> 3), u_end = walk.end;
+    unsigned int *claim = a.claim + 32 * (blockIdx.x & 7);
+    if (threadIdx.x == 0) sdp_lds.next_unit = (int)atomicAdd(claim, 1u);
+    __syncthreads();
+    int64_t unit = u_base + sdp_lds.next_unit;
+    int upar = 0;                                          // parity buffer of the control table
+#if SDP_COL_UTAB
+    sdp_trap_unless(!a.box_per_node);
+#endif
+    // what stays the same from unit to unit (SDP_COL_HOIST)
+    SdpBox box_hold;
+    const SdpBox *box_c = nullptr;
+    const sdp_real *w_mine = nullptr;
+    sdp_real w_hold = (sdp_real)0;
+    if (SDP_COL_HOIST) {
+        if (!a.box_per_node) { sdp_load_box(a, 0, box_hold); box_c = &box_hold; }
+        if (lane < Wn) { w_hold = ((const sdp_real *)a.wgrid)[lane]; w_mine = &w_hold; }
+    }
+    if (unit < u_end) {                                    // trailing cells (and control table) of the first unit
+        sdp_real xn[SDP_D];
+        sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
+        sdp_col_phase_w(a, tg, s, xn, nullptr, t);
+#if SDP_COL_UTAB
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 0, box_c);
+#endif
+    }
+    while (unit < u_end) {
+        const int64_t col = sdp_col_of_unit(a, unit);
+        const int part = (int)(unit % a.col_splits);
+        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
+        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        sdp_real x[SDP_D];
+        sdp_col_coords(a, col, x);
+        const int r = (int)threadIdx.x;                    // the table row this thread reduces
+        // ---- tail of the table, partial sums of the reduced table
+        __syncthreads();                                   // the previous unit has left the table; this unit's cells are published
+        int nx = 0;
+        if (wave == waves - 1 && lane == 0) nx = (int)atomicAdd(claim, 1u);      // (its round trip hides under the builds)
+        sdp_col_phase_a<false>(a, tg, s, C, R);
+        __syncthreads();
+        sdp_real acc_t = (sdp_real)0, big = (sdp_real)0;
+        if (r < N0) {
+#pragma unroll SDP_COL_FILTER_RUNROLL
+            for (int w = 0; w < R; ++w) {
+                const sdp_real v = sdp_lds.T[w * N0 + r];
+                acc_t = acc_t + pw[C + w] * v;
+                big = sdp_vmax_abs(big, v);
+            }
+        }
+        __syncthreads();                                   // the tail has been read
+        // ---- head of the table, the reduced table
+        sdp_col_phase_a<false>(a, tg, s, 0, C);
+        if (wave == waves - 1 && lane == 0) sdp_lds.next_unit = nx;
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
+        {
+            sdp_real dmax = (sdp_real)0;
+            if (r < N0) {
+                sdp_real acc = (sdp_real)0;
+#pragma unroll SDP_COL_FILTER_RUNROLL
+                for (int w = 0; w < C; ++w) {
+                    const sdp_real v = sdp_lds.T[w * N0 + r];
+                    acc = acc + pw[w] * v;
+                    big = sdp_vmax_abs(big, v);
+                }
+                acc = acc + acc_t;
+                // (>= tiny / cu: the radius never drops below `tiny`; a NaN entry, which the max skips, shows in acc)
+                dmax = acc == acc ? filt.pcap * big + filt.floor : (sdp_real)INFINITY;
+                sdp_lds.ad[r] = acc;
+            }
+            dmax = sdp_wave_max(dmax);
+            if (lane == 0) atomicMax(&sdp_lds.dcol[parity], (unsigned long long)__double_as_longlong((double)dmax));
+        }
+        __syncthreads();                                   // A[r] and the column's bound are complete
+        const sdp_real dcol = sdp_col_filter_dcol(sdp_lds, parity);
+        parity ^= 1;
+        const int64_t next_unit = u_base + sdp_lds.next_unit;
+        // ---- first pass (every control of this lane's node), second pass over the head
+        const int i = i_lo + (int)threadIdx.x;
+        const bool live = i < i_hi;
+        const int64_t node = col * N0 + (live ? i : i_hi - 1);
+        SdpBox box;
+        if (box_c) box = *box_c;
+        else sdp_load_box(a, node, box);
+        sdp_real best = INFINITY, acc = (sdp_real)0, lam0 = (sdp_real)0, oml0 = (sdp_real)0, g = (sdp_real)0;
+        int ibest = INT_MAX, q0 = 0;
+        bool single = false;
+        if (live) {
+            x[0] = axis0[i];
+            SdpColBounds bd;
+            bd.f1 = bd.f2 = bd.f3 = INFINITY;
+            bd.s_max = bd.s_sum = bd.p_max = bd.b_max = (sdp_real)0;
+            bd.i1 = bd.i2 = INT_MAX;
+            const sdp_real *utab = sdp_lds.utab[upar];
+            const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
+            if (plain) {
+                if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+                else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+                else sdp_col_filter_pass1<true, 0>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+            } else {
+                if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+                else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+                else sdp_col_filter_pass1<false, 0>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+            }
+            // the radius of the lean first pass: sdp_col_lean_core
+            const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
+            const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
+            const bool bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
+            const sdp_real radius = filt.cu * s_node;
+            const sdp_real m_hi = bd.f1 + radius;              // >= the minimum of E over the node
+            single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
+            if (single) {
+                // the one survivor IS the reference's argmin: its cell and cost once, its cells of the head
+                sdp_real u[SDP_NU];
+                sdp_controls_at(box, bd.i1, u);
+                ibest = bd.i1;
+                sdp_colres_locate(lead, x, u, t, q0, lam0, oml0, g);
+                sdp_colres_partial(sdp_lds.T, wts, 0, C, 0, q0, lam0, oml0, g, acc);
+            } else {
+                // near-ties or special values: the candidates (all controls of a marked node) the long way, from
+                // global memory -- the same operations, no table needed -- compared like the reference compares
+                for (int ci = 0; ci < box.total; ++ci) {
+                    sdp_real u[SDP_NU];
+                    sdp_controls_at(box, ci, u);
+                    bool cand = bad;
+                    if (!cand) {
+                        sdp_real F, pm = (sdp_real)0, gm = (sdp_real)0, bm = (sdp_real)0;
+                        if (lead.pow2) sdp_col_lean_eval<1>(sdp_lds.ad, filt, lead, x, u, t, F, pm, gm, bm);
+                        else sdp_col_lean_eval<0>(sdp_lds.ad, filt, lead, x, u, t, F, pm, gm, bm);
+                        cand = !(F - radius > m_hi);
+                    }
+                    if (cand) {
+                        const sdp_real jc = sdp_col_cost_global<false>(a, tg, s, wts, lead, x, u, t);
+                        if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // the head has been read
+        // ---- the tail again, second pass over it
+        __builtin_amdgcn_s_setprio(0);
+        sdp_col_phase_a<false>(a, tg, s, C, R);
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
+        {
+            // the next unit's column-level tables, a wave each: nothing reads the cells from here on
+            const int nxu = __builtin_amdgcn_readfirstlane(sdp_lds.next_unit);
+            if (u_base + nxu < u_end) {
+                sdp_real xn[SDP_D];
+                sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
+                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
+#if SDP_COL_UTAB
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c);
+#endif
+            }
+        }
+        if (live) {
+            if (single) {
+                sdp_colres_partial(sdp_lds.T, wts, C, Wn, C, q0, lam0, oml0, g, acc);
+                best = acc;
+            }
+            sdp_col_store(a, node, box, best, ibest);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        upar ^= 1;
+        unit = next_unit;
+    }
+    // the last workgroup to run out of units leaves the counters at zero for the next launch
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(a.claim + 256, 1u) == gridDim.x - 1) {
+            for (int k = 0; k < 8; ++k) atomicExch(a.claim + 32 * k, 0u);
+            atomicExch(a.claim + 256, 0u);
+        }
+    }
+    SDP_STAMP_END(a);
+}
+
+// fixed-policy backup: the table a chunk of C perturbation points at a time, the node's expectation carried in a register
+extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(SdpSweepArgs a)
+{
+    __shared__ SdpColLds sdp_lds;
+    constexpr int N0 = SDP_COL_N0;
+    constexpr int Wn = SDP_COL_W;
+    constexpr int C = SDP_COL_WRES;
+    sdp_trap_unless(a.n_lead == N0 && a.W == Wn);
+    const sdp_real t = (sdp_real)a.t_k;
+    const sdp_real *__restrict__ axis0 = (const sdp_real *)a.axes + a.axis_off[0];
+    SdpColShared s;
+    sdp_col_carve(sdp_lds, s);
+    SdpGrid<sdp_real, SDP_DT> tg;
+    sdp_col_trailing_grid(a, tg);
+    // fused relative-DP shift of the previous step (see SdpLerp<.., SHIFT>)
+    tg.shift = a.shift_index >= 0 ? ((const sdp_real *)a.V)[a.shift_index] : (sdp_real)0;
+    if (a.ref_out && blockIdx.x == 0 && threadIdx.x == 0) *a.ref_out = (double)tg.shift;
+    SdpLeadAxis lead;
+    sdp_col_lead_axis(a, lead);
+    SdpColWalk walk;
+    sdp_col_walk(a, walk);
+    SdpColWeights wts;
+    sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
+    for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
+        const int64_t col = sdp_col_of_unit(a, unit);
+        const int part = (int)(unit % a.col_splits);
+        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
+        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        sdp_real x[SDP_D];
+        sdp_col_coords(a, col, x);
+        __syncthreads();
+        sdp_col_phase_w(a, tg, s, x, nullptr, t);
+        // (a launch with fewer threads than nodes walks them in rounds: each round builds the chunks again)
+        for (int i0 = i_lo; i0 < i_hi; i0 += (int)blockDim.x) {
+            const int i = i0 + (int)threadIdx.x;
+            const bool live = i < i_hi;
+            const int64_t node = col * N0 + (live ? i : i_hi - 1);
+            sdp_real u[SDP_NU], acc = (sdp_real)0, lam0, oml0, g;
+            int q0;
+            x[0] = axis0[live ? i : i_hi - 1];
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+            sdp_colres_locate(lead, x, u, t, q0, lam0, oml0, g);
+            for (int w0 = 0; w0 < Wn; w0 += C) {
+                const int cnt = min(C, Wn - w0);
+                __syncthreads();                           // the cells are published / the previous chunk has been read
+                sdp_col_phase_a<true>(a, tg, s, w0, cnt);
+                __syncthreads();
+                if (live) sdp_colres_partial(sdp_lds.T, wts, w0, w0 + cnt, w0, q0, lam0, oml0, g, acc);
+            }
+            if (live) sdp_store_J<sdp_real>(a, node, col, acc);
+        }
+    }
+}

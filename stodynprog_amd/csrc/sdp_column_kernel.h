@@ -185,6 +185,32 @@
 #ifndef SDP_COL_SHIFT_ROWS
 #define SDP_COL_SHIFT_ROWS (2 * SDP_COL_N0)     // rows of the shifted lattice held in LDS
 #endif
+#ifndef SDP_COL_WRES
+// Perturbation points the LDS table holds at a time (default: all SDP_COL_W).  Fewer = RESIDENT CHUNK form of
+// the filtered kernel (sdp_colres_kernel.h): the W x N0 table is what limits a CU to two workgroups (64 KiB each
+// at 256 x 32 x 8 B) -- two waves per SIMD, and the kernel's time halves when a second workgroup joins the first
+// (measured: 3.39 -> 1.67 ms), i.e. it is bound by how much there is to overlap, not by a unit.  With C < W
+// points resident the table shrinks to C x N0 (32 KiB at C = 16: four workgroups per CU), at the price of
+// building the tail W - C points twice per column: once for the reduced table, once more for the second pass
+// (whose accumulation runs in w order: head first, then the tail).  Same operations on the same operands in
+// the same order: same bits.
+#define SDP_COL_WRES SDP_COL_W
+#endif
+#if SDP_COL_WRES < SDP_COL_W && (!SDP_COL_FILTER || SDP_COL_SHIFT || SDP_COL_WPAIR || SDP_COST_HAS_W || SDP_COL_FUSED || \
+                                 SDP_COL_ROWS < SDP_COL_N0 || SDP_COL_THREADS < SDP_COL_N0 || 2 * SDP_COL_WRES < SDP_COL_W)
+#error "SDP_COL_WRES: lean filtered kernel, plain full-column table, one lane per node, at least half of the points resident"
+#endif
+#ifndef SDP_COL_LDS_PAD
+#define SDP_COL_LDS_PAD 0        // diagnostic builds: unused bytes in the LDS image (fewer workgroups per CU: occupancy A/B)
+#endif
+#ifndef SDP_COL_HOIST
+// 1: what does not change from unit to unit is fetched ONCE per workgroup instead of once per unit -- the control
+// box of a constant-box problem (its loads and the division of numpy.linspace's step sat at the head of every
+// first pass and of every control table), the perturbation point of a helper thread, the axis-0 coordinate of a
+// thread's node: global-memory round trips behind the co-resident workgroup's table build, each followed by a
+// dependent chain, several times per unit.  0: as in round 3 (A/B runs)
+#define SDP_COL_HOIST 1
+#endif
 #if SDP_COL_FILTER && (!SDP_HAS_W || (SDP_LEAD_HAS_W && !SDP_COL_SHIFT) || SDP_TRAIL_HAS_U || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
 #error "SDP_COL_FILTER needs a perturbation that reaches x0' through a final sum at most, and the plain full-column table"
 #endif
@@ -205,6 +231,9 @@ constexpr int SDP_DT = SDP_D - 1;
 // rows of the LDS table: perturbation points, rounded up to whole pairs for the pair layout
 constexpr int SDP_COL_TW = SDP_COL_WPAIR ? (SDP_COL_W + 1) / 2 * 2 : SDP_COL_W;
 
+#ifndef SDP_COL_WMODE
+#define SDP_COL_WMODE 1          // where the inner loop takes the perturbation weights from: see SdpColWeights
+#endif
 struct SdpColShared {
     sdp_real *T;        // [Wn][N0]
     int *w_off;         // [Wn][SDP_DT]   M[k]*q[k] of the trailing cell (x N0)
@@ -219,24 +248,32 @@ struct SdpColShared {
 #ifndef SDP_COL_WCHUNK
 #define SDP_COL_WCHUNK SDP_COL_W     // per-control table only: perturbation points tabulated at a time
 #endif
+// (members a build does not use shrink to one element: the image decides how many workgroups share a CU)
+constexpr int SDP_COL_LDS_WCOPY = SDP_COL_WMODE == 2 ? SDP_COL_W : 1;
+constexpr int SDP_COL_LDS_PART = (SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? 1 : SDP_COL_THREADS;
+// reals per row of the reduced table: A[r] alone in the lean form, (A[r], D[r]) otherwise, 16 bytes for 4-byte reals
+constexpr int SDP_COL_LDS_AD = sizeof(SDP_REAL) == 4 ? 4 : ((SDP_COL_LEAN != 0 && !SDP_COL_SHIFT) ? 1 : 2);
 struct __attribute__((aligned(16))) SdpColLds {
-    sdp_real T[(SDP_TRAIL_HAS_U ? SDP_COL_WCHUNK : SDP_COL_TW) * SDP_COL_ROWS];
+    sdp_real T[(SDP_TRAIL_HAS_U ? SDP_COL_WCHUNK : (SDP_COL_WRES < SDP_COL_W ? SDP_COL_WRES : SDP_COL_TW)) * SDP_COL_ROWS];
     sdp_real w_lam[SDP_COL_W * SDP_DT];
     sdp_real w_oml[SDP_COL_W * SDP_DT];
-    sdp_real pw[SDP_COL_W];                // weight / point copies (SDP_COL_WMODE 2)
-    sdp_real gw[SDP_COL_W];
-    sdp_real part_J[SDP_COL_THREADS];      // partial minima of the control chunks
-    int part_i[SDP_COL_THREADS];
+    sdp_real pw[SDP_COL_LDS_WCOPY];        // weight / point copies (SDP_COL_WMODE 2)
+    sdp_real gw[SDP_COL_LDS_WCOPY];
+    sdp_real part_J[SDP_COL_LDS_PART];     // partial minima of the control chunks (unfiltered sweep)
+    int part_i[SDP_COL_LDS_PART];
     int w_off[SDP_COL_W * SDP_DT];
     int win[2][2];                         // row window: per parity (min row, minus max row) of the unit
     int next_unit;                         // filtered kernel: the unit claimed for the next round
     unsigned long long dcol[2];            // lean filter: per parity of the unit, bits of max_r D[r] (>= 0: ordered as integers)
     // per parity of the unit: the tabulated values of every control of the column (SDP_COL_UTAB)
     sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N : 2] __attribute__((aligned(16)));
+#if SDP_COL_LDS_PAD
+    char pad_[SDP_COL_LDS_PAD];
+#endif
 #if SDP_COL_FILTER
     // filter: per row r of axis 0 the pair (A[r], D[r]) = (sum_w p_w T[w][r], Pcap max_w |T[w][r]|)
     // (wide first pass of 4-byte reals: 16 bytes per row -- A[r] as a double, then the bound B[r])
-    sdp_real ad[(sizeof(sdp_real) == 4 ? 4 : 2) * (SDP_COL_SHIFT ? SDP_COL_SHIFT_ROWS : SDP_COL_ROWS)] __attribute__((aligned(16)));
+    sdp_real ad[SDP_COL_LDS_AD * (SDP_COL_SHIFT ? SDP_COL_SHIFT_ROWS : SDP_COL_ROWS)] __attribute__((aligned(16)));
 #endif
 #if SDP_COL_SHIFT
     // per parity of the unit: the shift of every perturbation point in rows of axis 0 -- whole part, fraction
@@ -336,9 +373,10 @@ struct SdpColNest<SDP_DT - 1, SHIFT> {
 
 // phase W for column `c`: trailing cell of every perturbation point -> s.w_*
 // (`first`: the threads from `first` on do it, the others pass)
+// (`w_mine`: the perturbation point of this thread's first item, fetched by the caller -- or null)
 SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
                              const SdpColShared &s, const sdp_real *x, const sdp_real *u, sdp_real t,
-                             int first = 0, int count = 0)
+                             int first = 0, int count = 0, const sdp_real *w_mine = nullptr)
 {
     // (threads first .. first + count - 1 do the work; count = 0: all threads from `first` on)
     constexpr int Wn = SDP_COL_W;
@@ -350,7 +388,7 @@ SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
     for (int w = (int)threadIdx.x - first; w < Wn; w += count) {
         sdp_real xn[SDP_D];
 #if SDP_HAS_W
-        sdp_model_trail(x, u, wgrid[w], t, xn);
+        sdp_model_trail(x, u, (w_mine && w == (int)threadIdx.x - first) ? *w_mine : wgrid[w], t, xn);
 #else
         sdp_model_trail(x, u, (sdp_real)0, t, xn);
 #endif
@@ -377,12 +415,14 @@ extern "C" __device__ float __ockl_wfred_max_f32(float);
 SDP_DEV double sdp_wave_max(double v) { return __ockl_wfred_max_f64(v); }      // DPP row operations, no LDS traffic
 SDP_DEV float sdp_wave_max(float v) { return __ockl_wfred_max_f32(v); }
 
+// (w_begin, w_count: the perturbation points to tabulate, into table rows 0 .. w_count-1 -- all of them by
+// default; the resident-chunk kernel builds the table a part at a time)
 template <bool SHIFT = false>
 SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
-                             const SdpColShared &s)
+                             const SdpColShared &s, const int w_begin = 0, const int w_count = SDP_COL_W)
 {
     constexpr int N0 = SDP_COL_ROWS;        // rows held by the table (the whole axis without a window)
-    constexpr int Wn = SDP_COL_W;
+    const int Wn = w_begin + w_count;       // one past the last point
     const sdp_real *__restrict__ V = (const sdp_real *)a.V + s.r0;
     constexpr int G = SDP_COL_A_GROUP;
     constexpr int NV = 1 << SDP_DT;
@@ -395,7 +435,8 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
     constexpr int LW = SDP_COL_A_LW;                     // lanes (= consecutive rows) per perturbation point
     const int WPASS = blockDim.x / LW;                   // perturbation points handled side by side (the
     const int rl = threadIdx.x % LW;                     //  policy-evaluation launch has fewer threads)
-    for (int w = threadIdx.x / LW; w < Wn; w += WPASS) {
+    for (int w = w_begin + threadIdx.x / LW; w < Wn; w += WPASS) {
+        const int tw = w - w_begin;                      // row of the table
         int off[SDP_DT];
         sdp_real lam[SDP_DT], oml[SDP_DT];
 #pragma unroll
@@ -449,9 +490,9 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                         }
 #if SDP_COL_WPAIR
 #pragma unroll
-                        for (int c = 0; c < RPL; ++c) s.T[((w >> 1) * N0 + r + c) * 2 + (w & 1)] = e[c];
+                        for (int c = 0; c < RPL; ++c) s.T[((tw >> 1) * N0 + r + c) * 2 + (tw & 1)] = e[c];
 #else
-                        *(sdp_rows *)(s.T + w * N0 + r) = e;
+                        *(sdp_rows *)(s.T + tw * N0 + r) = e;
 #endif
                     }
                 }
@@ -481,9 +522,9 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                     const sdp_real entry = val;
 #endif
 #if SDP_COL_WPAIR
-                    s.T[((w >> 1) * N0 + r) * 2 + (w & 1)] = entry;
+                    s.T[((tw >> 1) * N0 + r) * 2 + (tw & 1)] = entry;
 #else
-                    s.T[w * N0 + r] = entry;
+                    s.T[tw * N0 + r] = entry;
 #endif
                 }
             }
@@ -496,9 +537,9 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
     // a strip comes from the CU's L1 instead of L2
     constexpr int LANES_R = SDP_COL_THREADS < N0 ? SDP_COL_THREADS : N0;   // threads along the rows
     constexpr int GROUPS = SDP_COL_THREADS / LANES_R;                        // thread groups along w
-    constexpr int W_PER = (Wn + GROUPS - 1) / GROUPS;
+    const int W_PER = (w_count + GROUPS - 1) / GROUPS;
     const int grp = threadIdx.x / LANES_R;
-    const int w_lo = grp * W_PER, w_hi = min(Wn, w_lo + W_PER);
+    const int w_lo = w_begin + grp * W_PER, w_hi = min(Wn, w_lo + W_PER);
     for (int r = threadIdx.x - grp * LANES_R; r < N0 && grp < GROUPS; r += LANES_R) {
         for (int w0 = w_lo; w0 < w_hi; w0 += G) {
             sdp_real vals[G][NV];
@@ -526,24 +567,26 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
 #else
                     const sdp_real entry = val;
 #endif
+                    const int tw = w - w_begin;
 #if SDP_COL_WPAIR
-                    s.T[((w >> 1) * N0 + r) * 2 + (w & 1)] = entry;
+                    s.T[((tw >> 1) * N0 + r) * 2 + (tw & 1)] = entry;
 #else
-                    s.T[w * N0 + r] = entry;
+                    s.T[tw * N0 + r] = entry;
 #endif
                 }
             }
         }
     }
 #else
-    constexpr int total = Wn * N0;
+    const int total = w_count * N0;
     for (int item0 = threadIdx.x; item0 < total; item0 += G * blockDim.x) {
         sdp_real vals[G][NV];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
             const int item = min(item0 + j * (int)blockDim.x, total - 1);   // clamp: result unused
-            const int w = item / N0;
-            const int r = item - w * N0;
+            const int tw = item / N0;
+            const int r = item - tw * N0;
+            const int w = w_begin + tw;
             int off[SDP_DT];
 #pragma unroll
             for (int k = 0; k < SDP_DT; ++k) off[k] = s.w_off[w * SDP_DT + k];
@@ -553,8 +596,9 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
         for (int j = 0; j < G; ++j) {
             const int item = item0 + j * (int)blockDim.x;
             if (item < total) {
-                const int w = item / N0;
-                const int r = item - w * N0;
+                const int tw = item / N0;
+                const int r = item - tw * N0;
+                const int w = w_begin + tw;
                 sdp_real lam[SDP_DT], oml[SDP_DT];
 #pragma unroll
                 for (int k = 0; k < SDP_DT; ++k) {
@@ -570,9 +614,9 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                 const sdp_real entry = val;
 #endif
 #if SDP_COL_WPAIR
-                s.T[((w >> 1) * N0 + r) * 2 + (w & 1)] = entry;
+                s.T[((tw >> 1) * N0 + r) * 2 + (tw & 1)] = entry;
 #else
-                s.T[w * N0 + r] = entry;
+                s.T[tw * N0 + r] = entry;
 #endif
             }
         }
@@ -627,10 +671,6 @@ SDP_DEV void sdp_col_lead_axis(const SdpSweepArgs &a, SdpLeadAxis &l)
 //      used directly as VALU operands: no VGPR cost
 //   2  LDS broadcast reads of a copy made at kernel start
 // Default: scalar loads (A/B on MI355X: as fast as VGPRs, and no register cost).
-#ifndef SDP_COL_WMODE
-#define SDP_COL_WMODE 1
-#endif
-
 
 struct SdpColWeights {
 #if SDP_COL_WMODE == 0 && SDP_HAS_W
@@ -1037,7 +1077,7 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real
 SDP_DEV void sdp_col_store(const SdpSweepArgs &a, int64_t node, const SdpBox &box,
                            sdp_real best, int ibest)
 {
-    ((sdp_real *)a.J)[node] = best;
+    sdp_store_J<sdp_real>(a, node, node / SDP_COL_N0, best);        // (N0 is a compile-time constant)
     if (a.idx) a.idx[node] = ibest;
     if (a.pol) {
         sdp_real u[SDP_NU];
@@ -1712,12 +1752,13 @@ SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, cons
 }
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
 SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0,
-                             int count = 0)
+                             int count = 0, const SdpBox *box_c = nullptr)
 {
     if (count == 0) count = (int)blockDim.x - first;
     if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     SdpBox box;
-    sdp_load_box(a, 0, box);                                // (one box for every node: checked at launch)
+    if (box_c) box = *box_c;
+    else sdp_load_box(a, 0, box);                           // (one box for every node: checked at launch)
     const int n_tab = min(box.total, SDP_COL_UTAB_N);        // (SDP_COL_UTAB_N is a capacity: the host checks total <= it)
     for (int ci = (int)threadIdx.x - first; ci < n_tab; ci += count) {
         sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
@@ -1948,7 +1989,8 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
                                   const SdpColFilter &filt, int axis_mode, const sdp_real *ad_tab,
                                   const sdp_real *utab, sdp_real dcol,
                                   int64_t col, int i_lo, int i_hi, int wave, int waves,
-                                  sdp_real *x, sdp_real t, SdpColDiag &diag
+                                  sdp_real *x, sdp_real t, SdpColDiag &diag,
+                                  const SdpBox *box_c, int i_pre, sdp_real x0_pre
 #if SDP_COL_SHIFT
                                   , const SdpColShiftCol &shc
 #endif
@@ -1980,8 +2022,9 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         const int i = live ? i_raw : i_hi - 1;
         const int64_t node = col * N0 + i;
         SdpBox box;
-        x[0] = axis0[i];
-        sdp_load_box(a, node, box);
+        x[0] = i == i_pre ? x0_pre : axis0[i];              // (i_pre: the node whose coordinate the caller holds)
+        if (box_c) box = *box_c;                            // (constant box, fetched once per workgroup)
+        else sdp_load_box(a, node, box);
         const int c_lo = (int)((int64_t)box.total * chunk / chunks);
         const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
         // pass 1: bounds of every control of this lane's range
@@ -2105,7 +2148,9 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
 }
 #endif  // SDP_COL_FILTER
 
-#if !SDP_TRAIL_HAS_U
+#if !SDP_TRAIL_HAS_U && SDP_COL_WRES < SDP_COL_W
+#include "sdp_colres_kernel.h"      // sdp_sweep_col / sdp_evalpol_col with the table a chunk of perturbation points at a time
+#elif !SDP_TRAIL_HAS_U
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
@@ -2162,12 +2207,28 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_UTAB
     sdp_trap_unless(!a.box_per_node);                      // (and SDP_COL_UTAB_N controls: sdp_meta, checked by the host)
 #endif
+    // what stays the same from unit to unit (SDP_COL_HOIST)
+    SdpBox box_hold;
+    const SdpBox *box_c = nullptr;
+    const sdp_real *w_mine = nullptr;
+    sdp_real w_hold = (sdp_real)0, x0_pre = (sdp_real)0;
+    int i_pre = -1;
+    if (SDP_COL_HOIST) {
+        if (!a.box_per_node) { sdp_load_box(a, 0, box_hold); box_c = &box_hold; }
+#if SDP_HAS_W
+        if (lane < Wn) { w_hold = ((const sdp_real *)a.wgrid)[lane]; w_mine = &w_hold; }
+#endif
+        if (a.col_splits == 1 && N0 <= (int)blockDim.x && (int)threadIdx.x < N0) {     // one lane per node, whole columns:
+            i_pre = (int)threadIdx.x;                                                   // this thread's node never changes
+            x0_pre = axis0[i_pre];
+        }
+    }
     if (unit < u_end) {                                    // trailing cells of the first unit
         sdp_real xn[SDP_D];
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
-        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t);
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 0, box_c);
 #endif
 #if SDP_COL_SHIFT
         sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
@@ -2212,9 +2273,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             if (u_base + nxu < u_end) {
                 sdp_real xn[SDP_D];
                 sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
-                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64);
+                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
 #if SDP_COL_UTAB
-                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64);
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c);
 #endif
 #if SDP_COL_SHIFT
                 sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);
@@ -2257,7 +2318,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         tr += m0 - t2;
 #endif
         // ---- phase B, filtered: sdp_col_filter_nodes
-        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, sdp_lds.utab[upar], dcol, col, i_lo, i_hi, wave, waves, x, t, diag
+        sdp_col_filter_nodes(a, tg, s, wts, lead, filt, axis_mode, sdp_lds.ad, sdp_lds.utab[upar], dcol, col, i_lo, i_hi, wave, waves, x, t, diag,
+                             box_c, i_pre, x0_pre
 #if SDP_COL_SHIFT
                              , shc
 #endif
@@ -2422,7 +2484,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
 #pragma unroll
             for (int c = 0; c < SDP_NU; ++c) u[0][c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
             sdp_col_expected_cost<1, true>(a, tg, s, wts, lead, x, u, t, jc);
-            ((sdp_real *)a.J)[node] = jc[0];
+            sdp_store_J<sdp_real>(a, node, col, jc[0]);
         }
     }
 }
@@ -2693,7 +2755,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
         x[0] = axis0[node % N0];
 #pragma unroll
         for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-        ((sdp_real *)a.J)[node] = sdp_expected_cost<true>(a, grid, V, x, u, t);
+        sdp_store_J<sdp_real>(a, node, node / N0, sdp_expected_cost<true>(a, grid, V, x, u, t));
     }
 }
 #endif  // SDP_TRAIL_HAS_U
@@ -2706,7 +2768,7 @@ __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
 #if SDP_COL_FILTER
         (SDP_COL_LEAN_ON ? SDP_META_F_LEAN : 0) | (SDP_COL_SHIFT ? SDP_META_F_SHIFT : 0) |
 #endif
-        ((SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? SDP_META_F_CLAIMS : 0),
+        ((SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? SDP_META_F_CLAIMS : 0) | SDP_META_F_PEER_STORES,
     SDP_COL_FILTER ? SDP_COL_UTAB : 0, SDP_COL_FILTER ? SDP_COL_UTAB_N : 0, SDP_COL_THREADS, SDP_COL_ROWS,
     0, 0, 0};
 }
@@ -2714,6 +2776,6 @@ __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
 #else   // SDP_D < 2: no column kernels; the unit is a node-order one after all
 extern "C" {
 __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
-    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1, 0, 0, 0, 256, 0, 0, 0, 0};
+    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1, SDP_META_F_PEER_STORES, 0, 0, 256, 0, 0, 0, 0};
 }
 #endif  // SDP_D >= 2

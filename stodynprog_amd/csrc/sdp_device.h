@@ -19,6 +19,22 @@
 // never fires in a correct program): abort the kernel instead of returning stale results
 SDP_DEV void sdp_trap_unless(bool ok) { if (!ok) __builtin_trap(); }
 
+// J[node] = v, on this GPU and -- direct exchange of a sharded backup -- in the J buffer of every rank that
+// reads the node (`unit`: its column in the column layout, where a mask says who does; ignored otherwise).
+// Plain stores over xGMI into IPC-mapped buffers: they are complete when the kernel is, and the ranks meet
+// (one tiny all-reduce per backup, sdp_hip.hip:finish_pushes) before anybody reads J or overwrites V.
+template <typename real>
+SDP_DEV void sdp_store_J(const SdpSweepArgs &a, int64_t node, int64_t unit, real v)
+{
+    ((real *)a.J)[node] = v;
+    if (a.n_peer) {
+        const unsigned m = a.peer_mask ? (unsigned)a.peer_mask[unit] : 0xffu;
+#pragma unroll
+        for (int q = 0; q < SDP_MAX_PEERS; ++q)
+            if (((m >> q) & 1u) && a.peer_J[q]) ((real *)a.peer_J[q])[node] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // <int>(p) of the Cython source is cvttsd2si / cvttss2si on the reference's
 // x86-64 build: NaN and out-of-range values give INT_MIN (then clamped to 0).

@@ -684,6 +684,19 @@ struct sdp_problem {
     // that rank q reads in a backup; J / V are then complete on a rank only there
     std::vector<std::vector<std::pair<int64_t, int64_t>>> need;
     bool sparse = false, J_partial = false, V_partial = false;
+    // direct exchange (sdp_problem_set_direct_exchange): the backup kernels themselves store J into the
+    // peers' mapped buffers (SdpSweepArgs.peer_J); sparse: per column the ranks that read it
+    bool direct = false, mask_valid = false, send_everything = false;
+    DevBuf peer_mask;
+    // reduced-array sweep (csrc/sdp_lead_kernel.h), sharded: rows of the first stock the controls of a node
+    // reach on either side (a guess of the host: too small costs time, not correctness); < 0: reduce everything
+    int64_t lead_halo = -1;
+    // what the plane-major arrays currently hold: the value buffer they were reduced from, its generation
+    // (bumped whenever the contents of V change), and the lead indices covered
+    const void *red_V = nullptr;
+    uint64_t red_gen = 0, V_gen = 1;
+    int64_t red_begin = 0, red_end = 0;
+    double red_t = 0;
     int cus = 256;
     int refs_cap = 0;
     int col_threads = 512;
@@ -708,6 +721,7 @@ struct sdp_problem {
         if (ev_enter) { (void)hipEventDestroy(ev_enter); ev_enter = nullptr; }
         if (ev_fence) { (void)hipEventDestroy(ev_fence); ev_fence = nullptr; }
         peer_exchange = false;
+        direct = false;
         peer_me = -1;
     }
     ~sdp_problem()
@@ -935,6 +949,7 @@ extern "C" int sdp_problem_set_params(sdp_problem *p, const void *values, int32_
     // on the problem's stream: ordered after the launches that still read the old values
     HIP_TRY(hipMemcpyAsync(p->prm_dev, values, bytes, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));        // `values` may be reused by the caller
+    p->red_V = nullptr;                               // (the reduced array was made with the old constants)
     return SDP_OK;
 }
 
@@ -993,6 +1008,7 @@ extern "C" int sdp_problem_set_value(sdp_problem *p, const void *host_V)
 {
     if (!p || !host_V) return fail(SDP_EINVAL, "NULL argument");
     p->V_partial = false;
+    ++p->V_gen;                              // (whatever was derived from the old contents is stale)
     return upload_nodes(p, p->V.p, host_V, real_size(p->dtype));
 }
 
@@ -1019,6 +1035,13 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     a.stamps = (unsigned long long *)p->stamps.p;
     a.claim = (unsigned int *)p->claim.p;
     a.aux_a = p->lead_a.p; a.aux_v = p->lead_v.p; a.aux_e = p->lead_e.p; a.aux_vmax = (unsigned long long *)p->lead_vmax.p;
+    a.aux_begin = p->red_begin; a.aux_end = p->red_end;
+    if (p->direct && p->comm && p->comm->nranks > 1 && p->peer_exchange) {
+        const int n = p->comm->nranks;
+        a.n_peer = n;
+        for (int q = 0; q < n && q < SDP_MAX_PEERS; ++q) a.peer_J[q] = q == p->comm->rank ? nullptr : p->peer_J[(size_t)q];
+        a.peer_mask = p->send_everything ? nullptr : (const unsigned char *)(p->sparse ? p->peer_mask.p : nullptr);
+    }
     if (p->layout == SDP_LAYOUT_COLUMNS) {
         a.n_lead = p->orders[0];
         a.col_begin = nb / p->orders[0];
@@ -1087,6 +1110,33 @@ static unsigned sweep_blocks(const sdp_problem *p, int64_t nodes)
     return (unsigned)blocks;
 }
 
+// reduced-array sweep: nodes per block of trailing coordinates, and the lead indices [lb, le) whose reduced
+// values a launch over the nodes [nb, ne) may read
+static int64_t lead_trailing_nodes(const sdp_problem *p)
+{
+    int64_t ts = 1;
+    for (int k = p->meta[SDP_META_LEAD_AXES]; k < p->d; ++k) ts *= p->orders[k];
+    return ts;
+}
+static void lead_reduce_range(const sdp_problem *p, int64_t nb, int64_t ne, int64_t &lb, int64_t &le)
+{
+    const int64_t ts = lead_trailing_nodes(p), ls = p->S / ts;
+    lb = 0; le = ls;
+    if (p->lead_halo < 0 || !p->comm || p->comm->nranks < 2) return;
+    // this rank's nodes over all phases of the backup (one contiguous slab with dist.slab_partition)
+    int64_t lo = nb, hi = ne;
+    const int n = p->comm->nranks, me = p->comm->rank;
+    for (int ph = 0; ph < p->n_phases; ++ph) {
+        const int64_t *b = p->parts.data() + (size_t)ph * (n + 1);
+        if (b[me + 1] > b[me]) { lo = b[me] < lo ? b[me] : lo; hi = b[me + 1] > hi ? b[me + 1] : hi; }
+    }
+    const int64_t row = ls / p->orders[0];                  // lead indices per row of the first stock
+    lb = lo / ts - (p->lead_halo + 1) * row;
+    le = (hi + ts - 1) / ts + (p->lead_halo + 2) * row;
+    if (lb < 0) lb = 0;
+    if (le > ls) le = ls;
+}
+
 static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
 {
     if (ne <= nb) return SDP_OK;
@@ -1107,13 +1157,24 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
         return launch_module(p->f_sweep, a, (unsigned)blocks, (unsigned)p->stg_threads, p->stream);
     }
     if (p->f_lead_reduce) {
-        // the array reduced over w, from the whole of V (every node's first pass reads it at other nodes)
+        // The array reduced over w (every node's first pass reads it at the nodes its controls reach): from
+        // the whole of V on one GPU; sharded, from this rank's rows of the first stock plus `lead_halo` rows
+        // on either side -- once per value array, however many launches (phases) the backup takes.
         if (p->V_partial) return fail(SDP_EINVAL, "the reduced-array sweep needs the whole cost-to-go array on this device");
-        HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 8, p->stream));
-        SdpSweepArgs r = a;
-        r.node_begin = 0; r.node_end = p->S;
-        int rc = launch_module(p->f_lead_reduce, r, sweep_blocks(p, p->S), 256, p->stream);
-        if (rc) return rc;
+        int64_t lb, le;
+        lead_reduce_range(p, nb, ne, lb, le);
+        if (!(p->red_V == p->V.p && p->red_gen == p->V_gen && p->red_t == t_k && p->red_begin <= lb && le <= p->red_end)) {
+            HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 8, p->stream));
+            const int64_t ts = lead_trailing_nodes(p);
+            SdpSweepArgs r = a;
+            r.n_peer = 0;
+            r.node_begin = lb * ts; r.node_end = le * ts;
+            r.aux_begin = lb; r.aux_end = le;
+            int rc = launch_module(p->f_lead_reduce, r, sweep_blocks(p, r.node_end - r.node_begin), 256, p->stream);
+            if (rc) return rc;
+            p->red_V = p->V.p; p->red_gen = p->V_gen; p->red_t = t_k; p->red_begin = lb; p->red_end = le;
+        }
+        a.aux_begin = p->red_begin; a.aux_end = p->red_end;
     }
     return launch_module(p->f_sweep, a, sweep_blocks(p, ne - nb), 256, p->stream);
 }
@@ -1221,6 +1282,8 @@ static int open_pushes(sdp_problem *p)
     HIP_TRY(hipEventRecord(p->ev_fence, cs));
     for (int q = 0; q < n; ++q)
         if (q != me) HIP_TRY(hipStreamWaitEvent(p->peer_stream[q], p->ev_fence, 0));
+    // direct exchange: the kernels themselves write into the peers
+    if (p->direct) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_fence, 0));
     p->peer_fence = false;
     return SDP_OK;
 }
@@ -1246,6 +1309,27 @@ static int finish_pushes(sdp_problem *p, hipEvent_t last_kernel)
     return SDP_OK;
 }
 
+// direct sparse exchange: per column of the column layout, the ranks that read it (need lists of
+// sdp_problem_set_peer_needs) as a bit mask the kernel looks up when it stores J
+static int build_peer_mask(sdp_problem *p)
+{
+    if (p->mask_valid) return SDP_OK;
+    if (p->layout != SDP_LAYOUT_COLUMNS) return fail(SDP_EINVAL, "the sparse direct exchange works on whole columns (column layout)");
+    const int64_t n0 = p->orders[0], cols = p->S / n0;
+    std::vector<unsigned char> mask((size_t)cols, 0);
+    const int n = p->comm->nranks, me = p->comm->rank;
+    for (int q = 0; q < n && q < SDP_MAX_PEERS; ++q) {
+        if (q == me) continue;
+        for (const auto &iv : p->need[(size_t)q])
+            for (int64_t c = iv.first / n0; c < iv.second / n0; ++c) mask[(size_t)c] |= (unsigned char)(1u << q);
+    }
+    int rc = p->peer_mask.alloc((size_t)cols);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(p->peer_mask.p, mask.data(), (size_t)cols, hipMemcpyHostToDevice));
+    p->mask_valid = true;
+    return SDP_OK;
+}
+
 static int gather_phase(sdp_problem *p, int phase)
 {
     return gather_phase_of(p, phase, p->J.p, real_size(p->dtype));
@@ -1267,6 +1351,9 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
     }
     const int n = p->comm->nranks, rank = p->comm->rank;
     if (n > 1 && p->peer_exchange && p->peer_fence && (rc = open_pushes(p))) return rc;
+    const bool direct = n > 1 && p->peer_exchange && p->direct;
+    if (direct && p->sparse && !everything && (rc = build_peer_mask(p))) return rc;
+    p->send_everything = everything;
     for (int ph = 0; ph < p->n_phases; ++ph) {
         const int64_t *b = p->parts.data() + (size_t)ph * (n + 1);
         rc = evalpol ? launch_evalpol(p, t_k, b[rank], b[rank + 1], shift_index, ref_out)
@@ -1274,7 +1361,9 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
         if (rc) return rc;
         if (n > 1) {
             HIP_TRY(hipEventRecord(p->ev_phase[ph], p->stream));
-            if (p->peer_exchange) {
+            if (direct) {
+                // (the kernel has stored its rows into the peers that read them: nothing to copy)
+            } else if (p->peer_exchange) {
                 if ((rc = push_phase(p, ph, p->ev_phase[ph], everything))) return rc;
             } else {
                 HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
@@ -1401,6 +1490,7 @@ static void swap_buffers(sdp_problem *p)
 {
     std::swap(p->V.p, p->J.p);
     std::swap(p->V_partial, p->J_partial);
+    ++p->V_gen;
     if (p->peer_exchange) p->peer_V.swap(p->peer_J);
 }
 
@@ -1541,6 +1631,7 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
     const size_t rs = real_size(p->dtype);
     if (host_V) {
         const size_t bytes = (size_t)p->S * rs;
+        ++p->V_gen;
         if (p->layout != SDP_LAYOUT_COLUMNS) {
             HIP_TRY(hipMemcpyAsync(p->V.p, host_V, bytes, hipMemcpyHostToDevice, p->stream));
         } else {
@@ -1862,7 +1953,7 @@ extern "C" int sdp_problem_complete_value(sdp_problem *p)
 extern "C" int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_off, const int64_t *ranges)
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
-    if (!need_off || !ranges) { p->sparse = false; p->need.clear(); return SDP_OK; }
+    if (!need_off || !ranges) { p->sparse = false; p->need.clear(); p->mask_valid = false; return SDP_OK; }
     if (!p->comm || !p->peer_exchange) return fail(SDP_EINVAL, "sparse exchange needs the peer exchange (sdp_problem_enable_peer_exchange)");
     if (p->J_partial || p->V_partial) return fail(SDP_EINVAL, "the value arrays are incomplete: fetch or set them first");
     const int n = p->comm->nranks;
@@ -1881,6 +1972,27 @@ extern "C" int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_of
     }
     p->need.swap(need);
     p->sparse = true;
+    p->mask_valid = false;
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_direct_exchange(sdp_problem *p, int on)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (!on) { p->direct = false; return SDP_OK; }
+    if (!p->comm || !p->peer_exchange) return fail(SDP_EINVAL, "the direct exchange needs the peers' buffers mapped (sdp_problem_enable_peer_exchange)");
+    if (p->comm->nranks > SDP_MAX_PEERS) return fail(SDP_EINVAL, "the direct exchange serves at most %d ranks (one node), the communicator has %d", SDP_MAX_PEERS, p->comm->nranks);
+    if (!(p->meta[SDP_META_FLAGS] & SDP_META_F_PEER_STORES)) return fail(SDP_EMODULE, "the code object's kernels do not store through sdp_store_J");
+    p->direct = true;
+    p->peer_fence = true;
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_lead_halo(sdp_problem *p, int64_t rows)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    p->lead_halo = rows;
+    p->red_V = nullptr;
     return SDP_OK;
 }
 
@@ -1914,5 +2026,7 @@ extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_ph
     p->comm_pending = false;
     p->sparse = false;                     // (a new partition: the need lists no longer apply)
     p->need.clear();
+    p->mask_valid = false;
+    p->red_V = nullptr;
     return SDP_OK;
 }

@@ -21,16 +21,19 @@ enum {
     SDP_META_UTAB,          // tabulated values per control (0: none)
     SDP_META_UTAB_N,        // controls the control table has room for (the lattice may be shorter)
     SDP_META_THREADS,       // workgroup size of the sweep kernel (column / staged units)
-    SDP_META_COL_ROWS       // rows of axis 0 the table holds (< COL_N0: row window)
+    SDP_META_COL_ROWS,      // rows of axis 0 the table holds (< COL_N0: row window)
+    SDP_META_LEAD_AXES      // SDP_META_F_LEAD units: controlled state variables (the plane-major arrays' "lead" axes)
 };
 enum {
     SDP_META_F_FILTER = 1, SDP_META_F_WINDOW = 2, SDP_META_F_TRAIL_HAS_U = 4, SDP_META_F_STAGED = 8,
     SDP_META_F_WPAIR = 16, SDP_META_F_LEAN = 32,
     SDP_META_F_CLAIMS = 64, // the sweep kernel's workgroups claim their units (persistent: a bounded grid)
     SDP_META_F_SHIFT = 128, // certified filter on the shifted lattice (a perturbation that reaches x0')
-    SDP_META_F_LEAD = 256   // node-order sweep with the filter on an array reduced over w (sdp_lead_kernel.h):
+    SDP_META_F_LEAD = 256,  // node-order sweep with the filter on an array reduced over w (sdp_lead_kernel.h):
                             // the code object also exports sdp_lead_reduce, launched before every sweep
+    SDP_META_F_PEER_STORES = 512   // the backup kernels store J through sdp_store_J (SdpSweepArgs.peer_J: direct exchange)
 };
+#define SDP_MAX_PEERS 8     // ranks of a direct exchange: the GPUs of one node
 #define SDP_MAXU 4   // control variables per system
 
 // One Bellman backup over a contiguous range of state nodes
@@ -79,6 +82,14 @@ struct SdpSweepArgs {
     void *aux_v;           // [S] copy of V, plane-major (the second pass reads it)
     void *aux_e;           // [nodes per block of trailing coordinates] bound factor of the trailing cells
     unsigned long long *aux_vmax;   // bits of max |V| as a double (zero before sdp_lead_reduce)
+    int64_t aux_begin;     // plane-major arrays: lead indices [aux_begin, aux_end) hold valid values (the part of the
+    int64_t aux_end;       //   grid sdp_lead_reduce was run on); a node whose controls reach outside takes the long way on V
+    // ---- direct exchange (several GPUs, sdp_problem_set_direct_exchange): the kernel that computes J[node] also
+    // stores it into the J buffers of the other ranks, mapped into this process (HIP IPC; xGMI stores) ----
+    void *peer_J[SDP_MAX_PEERS];        // null: no store (this rank itself, ranks beyond the communicator)
+    const unsigned char *peer_mask;     // column layout: [columns] bit q set = rank q reads the column; null: every peer gets every node
+    int32_t n_peer;                     // 0: single GPU or another exchange -- no peer stores at all
+    int32_t pad_;
 };
 
 // Batched closed-loop simulation (the user loop of the reference's examples, e.g.

@@ -129,7 +129,9 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
 #endif
     sdp_real vmax = (sdp_real)0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t node = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; node < a.S; node += stride) {
+    // (the launch covers the lead indices [aux_begin, aux_end): the whole grid on one GPU, a rank's slab of the
+    // first stock plus what its controls reach when the backup is sharded)
+    for (int64_t node = a.node_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; node < a.node_end; node += stride) {
         sdp_real x[SDP_D];
         sdp_node_coords(a, node, x);
         const int64_t lead = node / geo.ts, trail = node - lead * geo.ts;
@@ -156,7 +158,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
         const sdp_real vn = V[node];
         A[trail * geo.ls + lead] = acc;                   // plane-major: [trailing index][lead index]
         Vt[trail * geo.ls + lead] = vn;
-        if (lead == 0) E[trail] = emax;
+        if (lead == a.aux_begin) E[trail] = emax;
         vmax = sdp_lead_vmax_abs(vmax, vn);
     }
     vmax = __ockl_wfred_max_f64(vmax);
@@ -242,8 +244,10 @@ SDP_DEV void sdp_lead_walk_next(const SdpBox &b, SdpLeadWalk &w)
 // (W cost evaluations per control: the 2^d loads and the lerps of the long way are what is saved), and
 // gmax collects Gabs = max(sum_w |p_w g_w|, max_w |g_w|), which stands where |g| Pcap stood in the bound
 // (the raw magnitude too: a tiny weight must not hide a g_w that overflows g_w + val on the reference's path).
+// [lmin, lmax]: lead indices (positions inside a plane) the node's controls have read so far
 SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeom &geo, const SdpLeadConst &f,
-                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &lp, sdp_real &gmax)
+                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &lp, sdp_real &gmax,
+                                int &lmin, int &lmax)
 {
     sdp_real xl[SDP_LM], lam[SDP_LM];
     int off[SDP_LM];
@@ -259,6 +263,13 @@ SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeo
         prod = prod * fma((sdp_real)2, fabs(lam[k]), (sdp_real)1);
     }
     lp = sdp_lead_vmax(lp, prod);
+    {
+        int lo = 0, span = 0;
+#pragma unroll
+        for (int k = 0; k < SDP_LM; ++k) { lo += off[k]; span += geo.pm[k]; }
+        lmin = min(lmin, lo);
+        lmax = max(lmax, lo + span);
+    }
     const sdp_real h = SdpLeadLerp<0>::eval(A, off, geo.pm, lam, 0);
 #if SDP_LEAD_COST_HAS_W
     sdp_real G = (sdp_real)0, gabs = (sdp_real)0, graw = (sdp_real)0;
@@ -300,17 +311,25 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
     sdp_trap_unless(a.aux_a != nullptr && a.aux_e != nullptr && a.aux_v != nullptr);
     const sdp_real vmax = (sdp_real)__longlong_as_double((long long)*a.aux_vmax);
 
+    // the second pass of a node whose controls reach beyond the reduced part of the grid (sharded backups: the
+    // host's guess of the reach was too small) reads V itself, in node order
+    SdpGrid<sdp_real, SDP_D> grid_v;
+    sdp_grid_from_args(a, grid_v);
+
     // XCD-aware walk over tiles of 256 consecutive PLANE-MAJOR positions: an XCD takes a contiguous eighth,
-    // i.e. whole planes, whose reduced values then stay in its L2
-    const int64_t n_tiles = (a.S + blockDim.x - 1) / blockDim.x;
+    // i.e. whole planes, whose reduced values then stay in its L2.  A launch over part of the nodes (a rank's
+    // slab of the first stock, a phase of it) walks the lead indices of that part only.
+    const int64_t lead_lo = a.node_begin / geo.ts, lead_hi = (a.node_end + geo.ts - 1) / geo.ts, n_l = lead_hi - lead_lo;
+    const int64_t n_pos = n_l * geo.ts;
+    const int64_t n_tiles = (n_pos + blockDim.x - 1) / blockDim.x;
     const int xcd = blockIdx.x & 7;
     const int64_t per_xcd = (n_tiles + 7) / 8;
     const int64_t t_end = min((int64_t)(xcd + 1) * per_xcd, n_tiles);
     const int64_t stride = gridDim.x >> 3;
     for (int64_t tile = (int64_t)xcd * per_xcd + (blockIdx.x >> 3); tile < t_end; tile += stride) {
         const int64_t pos = tile * blockDim.x + threadIdx.x;
-        if (pos >= a.S) continue;
-        const int64_t trail = pos / geo.ls, lead = pos - trail * geo.ls;
+        if (pos >= n_pos) continue;
+        const int64_t trail = pos / n_l, lead = lead_lo + (pos - trail * n_l);
         const int64_t node = lead * geo.ts + trail;
         if (node < a.node_begin || node >= a.node_end) continue;
         sdp_real x[SDP_D];
@@ -321,12 +340,12 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         const sdp_real dabs = fc.pcap * (E[trail] * vmax) + fc.floor;
         // pass 1
         sdp_real f1 = INFINITY, f2 = INFINITY, fsum = (sdp_real)0, lp = (sdp_real)0, gmax = (sdp_real)0;
-        int i1 = INT_MAX;
+        int i1 = INT_MAX, lmin = INT_MAX, lmax = INT_MIN;
         SdpLeadWalk walk;
         sdp_lead_walk_begin(box, walk);
 #pragma unroll SDP_LEAD_UNROLL
         for (int ci = 0; ci < box.total; ++ci) {
-            const sdp_real F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp, gmax);
+            const sdp_real F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp, gmax, lmin, lmax);
             fsum = fsum + fabs(F);
             f2 = sdp_lead_vmin(f2, sdp_lead_vmax(f1, F));
             i1 = F < f1 ? ci : i1;
@@ -339,7 +358,10 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
 #else
         const sdp_real s_node = fma(fc.ratio, fsum + h_cap, h_cap);
 #endif
-        const bool bad = !fc.ok || !(s_node < (sdp_real)0x1p1000) || !(lp < (sdp_real)1073741824.0);
+        // the reduced array and the plane-major copy of V hold this rank's part of the grid: a control that reads
+        // outside it saw stale values -- the node then takes every control the long way on V itself
+        const bool outside = (int64_t)lmin < a.aux_begin || (int64_t)lmax >= a.aux_end;
+        const bool bad = outside || !fc.ok || !(s_node < (sdp_real)0x1p1000) || !(lp < (sdp_real)1073741824.0);
         const sdp_real radius = fc.cu * s_node;
         const sdp_real m_hi = f1 + radius;                 // >= the minimum of E over the node
         const bool single = !bad && i1 != INT_MAX && f2 - radius > m_hi;
@@ -353,15 +375,17 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
             bool cand = single || bad;
             if (!cand) {
                 sdp_real lq = (sdp_real)0, gq = (sdp_real)0;
-                cand = !(sdp_lead_first(A, geo, fc, x, walk.u, t, lq, gq) - radius > m_hi);
+                int l0 = 0, l1 = 0;
+                cand = !(sdp_lead_first(A, geo, fc, x, walk.u, t, lq, gq, l0, l1) - radius > m_hi);
             }
             if (cand) {
-                const sdp_real jc = sdp_expected_cost(a, grid, Vt, x, walk.u, t);
+                const sdp_real jc = outside ? sdp_expected_cost(a, grid_v, (const sdp_real *)a.V, x, walk.u, t)
+                                            : sdp_expected_cost(a, grid, Vt, x, walk.u, t);
                 if (ibest == INT_MAX || sdp_better_seq(jc, best)) { best = jc; ibest = ci; }
             }
             if (!single) sdp_lead_walk_next(box, walk);
         }
-        ((sdp_real *)a.J)[node] = best;
+        sdp_store_J<sdp_real>(a, node, 0, best);
         if (a.idx) a.idx[node] = ibest;
         if (a.pol) {
             sdp_real u[SDP_NU];

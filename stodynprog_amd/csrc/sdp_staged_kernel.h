@@ -389,7 +389,7 @@ extern "C" __global__ void __launch_bounds__(SDP_STG_THREADS, SDP_STG_THREADS / 
             }
         }
         if (live) {
-            ((sdp_real *)a.J)[node] = best;
+            sdp_store_J<sdp_real>(a, node, 0, best);
             if (a.idx) a.idx[node] = ibest;
             if (a.pol) {
                 sdp_real u[SDP_NU];

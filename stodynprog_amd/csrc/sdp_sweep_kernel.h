@@ -198,7 +198,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         }
         sdp_seg_argmin<sdp_real, L>(best, ibest);
         if (live && sub == 0) {
-            ((sdp_real *)a.J)[node] = best;
+            sdp_store_J<sdp_real>(a, node, 0, best);
             if (a.idx) a.idx[node] = ibest;
             if (a.pol) {
                 sdp_real u[SDP_NU];
@@ -228,7 +228,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_evalpol(SdpSweepArgs a)
         sdp_node_coords(a, node, x);
 #pragma unroll
         for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-        ((sdp_real *)a.J)[node] = sdp_expected_cost<true>(a, grid, V, x, u, t);
+        sdp_store_J<sdp_real>(a, node, 0, sdp_expected_cost<true>(a, grid, V, x, u, t));
     }
 }
 
@@ -292,12 +292,12 @@ extern "C" {
 __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
     SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1,
 #if defined(SDP_STG_THREADS)
-    SDP_META_F_STAGED, 0, 0, SDP_STG_THREADS, 0,
+    SDP_META_F_STAGED | SDP_META_F_PEER_STORES, 0, 0, SDP_STG_THREADS, 0, 0,
 #elif defined(SDP_LEAD_AXES)
-    SDP_META_F_LEAD | SDP_META_F_FILTER, 0, 0, 256, 0,
+    SDP_META_F_LEAD | SDP_META_F_FILTER | SDP_META_F_PEER_STORES, 0, 0, 256, 0, SDP_LEAD_AXES,
 #else
-    0, 0, 0, 256, 0,
+    SDP_META_F_PEER_STORES, 0, 0, 256, 0, 0,
 #endif
-    0, 0, 0};
+    0, 0};
 }
 #endif

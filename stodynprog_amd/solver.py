@@ -220,14 +220,17 @@ class DPSolver(object):
         self.comm_phases = 4               # multi-GPU: phases per backup (comm/compute overlap)
         # multi-GPU: how the J rows of a phase reach the other ranks -- 'rccl': in-place all-gather;
         # 'peer': every rank writes its rows straight into the others' buffers (HIP IPC mappings,
-        # device-to-device copies over xGMI, no compute units); falls back to 'rccl' when the
-        # buffers cannot be mapped (backend_info['exchange'] tells which one runs)
+        # device-to-device copies over xGMI, no compute units); 'direct': the backup kernel itself
+        # stores every J it computes into the buffers of the ranks that read it (xGMI stores spread
+        # over the whole sweep: one launch and one rendezvous per backup, nothing left to copy).
+        # Both fall back to 'rccl' when the buffers cannot be mapped (backend_info['exchange'] tells
+        # which one runs)
         self.comm_exchange = 'rccl'
         self.comm_taper = False            # multi-GPU: shrinking phases (smallest gather exposed)
-        # peer exchange only: every rank owns one slab of columns and is sent only the rows of J its
-        # own backups read (computed from the model: the cells its trailing next states fall in) --
-        # for a contracting exogenous process a fraction of the array.  J is completed on every
-        # rank when the host asks for it.  Plain column kernel, stationary systems.
+        # 'peer' / 'direct' exchange only: every rank owns one slab of columns and is sent only the rows
+        # of J its own backups read (computed from the model: the cells its trailing next states fall
+        # in) -- for a contracting exogenous process a fraction of the array.  J is completed on every
+        # rank when the host asks for it.  Full-table column kernels (all filter forms), stationary systems.
         self.comm_sparse = False
         # 'exact': every floating-point operation of the reference, same order (default);
         # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
@@ -614,24 +617,29 @@ class DPSolver(object):
         # with the time index gets a control table with room to spare (a capacity, checked by the library as
         # controls <= capacity), so that the steps of a horizon keep sharing one code object.
         n_controls = bp['max_u'] if box_t is None else 1 << max(int(bp['max_u']) - 1, 0).bit_length()
-        col_cfg, utab = None, None
+        col_cfg, utab, wres = None, None, 0
         if self.kernel in ('auto', 'column') and model.storage_separable:
             wpair = codegen.use_wpair(model, dt, debug)
             shift = bool(may_filter and codegen.column_shift_applies(model, dt, debug=debug))
             fr = codegen.control_table_plan(model, dt, bp['per_node'], n_controls, debug) if may_filter else None
             for frontier in ((fr, None) if fr is not None else (None,)):
-                col_cfg = codegen.column_config(shape[0], W, len(shape), dt, wpair, may_filter,
-                                                max_controls=n_controls, n_columns=int(np.prod(shape[1:])),
-                                                shift=shift, utab_values=len(frontier) * n_controls if frontier else 0,
-                                                debug=debug)
+                kw = dict(max_controls=n_controls, n_columns=int(np.prod(shape[1:])), shift=shift,
+                          utab_values=len(frontier) * n_controls if frontier else 0, debug=debug)
+                col_cfg = codegen.column_config(shape[0], W, len(shape), dt, wpair, may_filter, **kw)
                 if col_cfg is not None:                   # (else once more without the control table)
                     utab = (frontier, n_controls) if frontier is not None else None
+                    # the table a chunk of perturbation points at a time, where that lets more workgroups share a CU
+                    wres = codegen.column_resident_points(model, shape[0], W, len(shape), dt, may_filter, shift, wpair,
+                                                          col_cfg[0], kw['utab_values'], debug)
+                    if wres:
+                        col_cfg = codegen.column_config(shape[0], W, len(shape), dt, wpair, may_filter, wres=wres, **kw)
                     break
         column = col_cfg is not None
         # several controlled state variables next to an exogenous process: the node-order sweep with the
         # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h); one GPU for now
         lead_axes = 0
-        if (not column and self.kernel in ('auto', 'lead') and self.comm is None and W > 0
+        if (not column and self.kernel in ('auto', 'lead') and W > 0
+                and (self.comm is None or self.comm.is_device)
                 and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
             # (one stock whose table does not fit LDS too: measured 5.9 ms against 12.7 ms of the row-window
             # column kernel at 1024 x 128 x 128 x 64 x 32, tools/window_vs_lead.py)
@@ -640,7 +648,7 @@ class DPSolver(object):
         if self.kernel == 'lead' and not lead_axes:
             raise ValueError("kernel = 'lead' needs controlled state variables listed first, an exogenous process "
                              'after them, a perturbation that reaches only that process, 8-byte reals, the certified '
-                             'filter, exact arithmetic and a solver without a communicator (one GPU)')
+                             'filter and exact arithmetic (several GPUs: a device communicator)')
         if lead_axes:
             lanes = 1                                     # one lane per node, the control loop in-lane
         # trailing next states that depend on the control but not on x0: the nodes of a
@@ -692,7 +700,7 @@ class DPSolver(object):
                                           fused=(self.arithmetic == 'fused'), staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
                                           filtered=filtered, utab=utab, lead_axes=lead_axes,
-                                          col_cfg=col_cfg, debug=debug)
+                                          col_cfg=col_cfg, debug=debug, wres=wres if filtered else 0)
         filtered = filtered or bool(lead_axes)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
                     lead_axes=lead_axes,
@@ -713,7 +721,7 @@ class DPSolver(object):
                 return False
         return True
 
-    def _lead_reach_rows(self, model, bp, box_t=None, n_samples=4096):
+    def _lead_reach_rows(self, model, bp, box_t=None, n_samples=4096, around=False):
         """Rows of axis 0 the controls (and perturbation points) of ONE node span:
         max over sampled nodes of the distance, in grid rows, between the next
         values of the leading state variable at the ends of the node's control
@@ -742,6 +750,8 @@ class DPSolver(object):
                 p = (np.asarray(xn[0], dtype=float) - g0[0]) / (g0[-1] - g0[0]) * (len(g0) - 1)
                 rows.append(np.clip(np.nan_to_num(p, nan=0.0, posinf=1e9, neginf=-1e9), 0, len(g0) - 2))
         rows = np.array([np.broadcast_to(r, flat.shape) for r in rows])
+        if around:          # farthest row from the node's own, either side
+            return int(np.ceil(np.abs(rows - idx[0][None, :]).max())) + 1
         return int(np.ceil((rows.max(axis=0) - rows.min(axis=0)).max())) + 1
 
     def _problem(self, t_k=None, model=None):
@@ -793,13 +803,18 @@ class DPSolver(object):
             unit = shape[0] if column else 1
             bounds = phase_partition(S // unit, unit, self.comm.nranks, self.comm_phases,
                                      self.comm_taper)
-            sparse = (getattr(self, 'comm_sparse', False) and self.comm_exchange == 'peer'
+            sparse = (getattr(self, 'comm_sparse', False) and self.comm_exchange in ('peer', 'direct')
                       and self.comm.nranks > 1 and column and not plan['per_control']
                       and not plan['window'] and model.storage_separable and self.sys.stationnary
                       and len(shape) >= 2)
             if sparse:
                 dense_bounds = bounds
                 bounds = slab_partition(S // unit, unit, self.comm.nranks, self.comm_phases)
+            elif plan.get('lead_axes'):
+                # reduced-array sweep: a rank reduces what its nodes read -- its own rows of the first
+                # stock and a few around them -- so it gets ONE slab of whole rows
+                row = int(np.prod(shape[1:])) if shape[0] >= self.comm.nranks else 1
+                bounds = slab_partition(S // row, row, self.comm.nranks, self.comm_phases)
             node_range = (0, S)
         elif self.comm is not None:
             bounds = self.comm.slab_bounds(dev_shape)
@@ -830,7 +845,7 @@ class DPSolver(object):
         exchange = None
         if self.comm is not None and self.comm.is_device and self.comm.nranks > 1:
             exchange = 'rccl'
-            if self.comm_exchange == 'peer':
+            if self.comm_exchange in ('peer', 'direct'):
                 try:                                        # collective: all ranks succeed or none
                     nat.check(nat.lib().sdp_problem_enable_peer_exchange(prob.h))
                     exchange = 'peer'
@@ -851,8 +866,19 @@ class DPSolver(object):
                     nat.check(nat.lib().sdp_problem_set_peer_needs(prob.h, nat.ptr(off), nat.ptr(ranges)))
                     exchange = 'peer-sparse'
                     prob.need_fraction = float((ranges[:, 1] - ranges[:, 0]).sum()) / S / self.comm.nranks
+                if exchange.startswith('peer') and self.comm_exchange == 'direct':
+                    if self.comm.nranks <= 8:
+                        nat.check(nat.lib().sdp_problem_set_direct_exchange(prob.h, 1))
+                        exchange = exchange.replace('peer', 'direct')
+                    else:
+                        import warnings
+                        warnings.warn('the direct exchange serves the (at most 8) GPUs of one node: peer copies instead')
             elif self.comm_exchange != 'rccl':
-                raise ValueError("comm_exchange must be 'rccl' or 'peer'")
+                raise ValueError("comm_exchange must be 'rccl', 'peer' or 'direct'")
+        if plan.get('lead_axes') and self.comm is not None and self.comm.is_device and self.comm.nranks > 1:
+            # rows of the first stock a node's controls reach (sampled: the kernel notices a node that
+            # reaches further and evaluates it from the value array itself)
+            nat.check(nat.lib().sdp_problem_set_lead_halo(prob.h, self._lead_reach_rows(model, plan, None, around=True) + 1))
         prob.info = dict(mode='traced', exchange=exchange,
                          kernel='column' if column else ('staged' if plan['staged'] else
                                                          ('lead' if plan.get('lead_axes') else 'generic')),

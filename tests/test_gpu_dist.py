@@ -218,32 +218,51 @@ def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
 
-CASES = [('synthetic3d', dict(N=20), 4), ('synthetic3d', dict(N=20), 3), ('synthetic3d', dict(N=20), -4),
-         ('storage_ar1', dict(), 4),                  # 61 columns: uneven parts -> broadcasts
-         ('nas_demo', dict(), 4), ('inventory', dict(), 4),          # inventory: LDS-staged tiles, node ranges
-         ('synthetic3d_coupled', dict(N=20), 4),                     # column kernel, table per control
-         ('synthetic3d_coupled', dict(N=18, cross=0.2), 3)]          # staged tiles in 3-D, ragged
-EXCHANGES = os.environ.get('SDP_TEST_EXCHANGES', 'rccl,peer,sparse').split(',')
-for (name, kw, phases), exchange in [(c, e) for c in CASES for e in EXCHANGES]:
+F64, F32 = 'float64', 'float32'
+CASES = [('synthetic3d', dict(N=20), 4, F64), ('synthetic3d', dict(N=20), 3, F64), ('synthetic3d', dict(N=20), -4, F64),
+         ('storage_ar1', dict(), 4, F64),                  # 61 columns: uneven parts -> broadcasts
+         ('nas_demo', dict(), 4, F64), ('inventory', dict(), 4, F64),     # inventory: LDS-staged tiles, node ranges
+         ('synthetic3d_coupled', dict(N=20), 4, F64),                     # column kernel, table per control
+         ('synthetic3d_coupled', dict(N=18, cross=0.2), 3, F64),          # staged tiles in 3-D, ragged
+         # round 4: every fast family shards -- the filter on the shifted lattice (a perturbation that reaches
+         # the stock), the reduced-array sweep for two stocks (a rank reduces its own rows and their reach),
+         # 4-byte reals (pair table, wide first pass)
+         ('synthetic3d', dict(N=20, stock_noise=0.07), 2, F64),
+         ('two_reservoirs', dict(n_a=24, n_b=12, n_y=8, n_w=5, steps=(0.25, 0.25)), 2, F64),
+         ('two_reservoirs', dict(n_a=7, n_b=12, n_y=8, n_w=5, steps=(0.5, 0.25)), 1, F64),   # fewer rows than 8 ranks
+         ('synthetic3d', dict(N=24), 2, F32)]
+if os.environ.get('SDP_TEST_CASES'):
+    CASES = [CASES[int(k)] for k in os.environ['SDP_TEST_CASES'].split(',')]
+EXCHANGES = os.environ.get('SDP_TEST_EXCHANGES', 'rccl,peer,sparse,direct').split(',')
+SPARSE_OK = ('synthetic3d', 'storage_ar1', 'nas_demo')       # full-table column kernels: need lists
+for (name, kw, phases, dtype), exchange in [(c, e) for c in CASES for e in EXCHANGES]:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
+    one.dtype = two.dtype = np.dtype(dtype)
     two.comm = dev
     # 'peer': rows written into the peers' buffers (HIP IPC); 'sparse': one slab per rank, and a
-    # peer is sent only the rows it reads (plain column kernel; the others keep the full exchange)
+    # peer is sent only the rows it reads (full-table column kernels; the others keep the full exchange);
+    # 'direct': the backup kernel itself stores J into the ranks that read it (sparse where it applies)
     two.comm_exchange = 'peer' if exchange == 'sparse' else exchange
-    two.comm_sparse = exchange == 'sparse'
+    two.comm_sparse = exchange in ('sparse', 'direct')
     if exchange == 'sparse':
-        exchange = 'peer-sparse' if name in ('synthetic3d', 'storage_ar1', 'nas_demo') else 'peer'
+        exchange = 'peer-sparse' if name in SPARSE_OK else 'peer'
+    elif exchange == 'direct':
+        exchange = 'direct-sparse' if name in SPARSE_OK else 'direct'
     two.comm_phases, two.comm_taper = abs(phases), phases < 0          # negative: tapered phases
-    V0 = rng.standard_normal(one._state_grid_shape)
+    V0 = rng.standard_normal(one._state_grid_shape).astype(dtype).astype(float)
     J1, p1 = one.value_iteration(V0, report_time=False); i1 = one.last_policy_index
     J2, p2 = two.value_iteration(V0, report_time=False); i2 = two.last_policy_index
     prob = [v for k, v in two._cache.items() if k[0] == 'problem'][0]
     assert prob.parts is not None and prob.parts.shape[1] == dev.nranks + 1
     assert two.backend_info['exchange'] == exchange, two.backend_info
-    if exchange == 'peer-sparse':                        # strictly less than everybody else's rows
+    if exchange.endswith('-sparse'):                     # strictly less than everybody else's rows
         assert 0.0 < prob.need_fraction < (dev.nranks - 1.0) / dev.nranks + 1e-12, prob.need_fraction
         assert prob.parts.shape[0] == dev.nranks * min(abs(phases), prob.parts.shape[0])
+    if name == 'two_reservoirs':
+        assert two.backend_info['kernel'] == 'lead' == one.backend_info['kernel'], two.backend_info
+    if kw.get('stock_noise'):
+        assert two.backend_info['filter_form'] == 'shifted lattice', two.backend_info
     assert np.array_equal(J1, J2), name
     assert np.array_equal(p1, p2) and np.array_equal(i1, i2), name      # get_policy gathers
     ref = one._state_ref_ind
@@ -258,7 +277,7 @@ for (name, kw, phases), exchange in [(c, e) for c in CASES for e in EXCHANGES]:
     Ka, _ = quiet(one.value_iterations, V0, 3)
     Kb, _ = quiet(two.value_iterations, V0, 3)
     assert np.array_equal(Ka, Kb), name
-    print('rank', rank, name, phases, exchange, 'ok', flush=True)
+    print('rank', rank, name, phases, dtype, exchange, 'ok', flush=True)
 dev.barrier()
 for k in [k for k in list(two._cache) if k[0] == 'problem']:
     two._cache.pop(k).close()
@@ -267,15 +286,21 @@ print('rank', rank, 'all ok', flush=True)
 '''
 
 
+# (8 ranks: the partition / mapping / rendezvous logic with more ranks than rows or columns in some cases -- one
+# case per kernel family is enough there, every exchange; the blocking stand-in with 2 ranks only: the
+# asynchronous one is the stricter test.  Round 3 ran all cases in all five set-ups: 280 s of the suite.)
+EIGHT = '0,3,7,8,9,10,11'
+
+
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('world,asynchronous', [(2, False), (3, False), (8, False), (2, True), (3, True)])
-def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world, asynchronous):
+@pytest.mark.parametrize('world,asynchronous,cases', [(2, False, ''), (2, True, ''), (3, True, ''), (8, True, EIGHT)])
+def test_library_exchange_path_with_several_ranks_on_one_gpu(gpu, tmp_path, world, asynchronous, cases):
     """asynchronous: the stand-in only enqueues (staging copies + host-function rendezvous in
     stream order), so the library's events and stream joins carry the ordering, as with RCCL"""
     mock = _build_mock(tmp_path, asynchronous)
     script = tmp_path / 'lib_worker.py'
     script.write_text(LIB_WORKER.format(root=ROOT))
-    outs = _run_ranks(_with_hooks(tmp_path, script), world, dict(SDP_RCCL_LIBRARY=mock))
+    outs = _run_ranks(_with_hooks(tmp_path, script), world, dict(SDP_RCCL_LIBRARY=mock, SDP_TEST_CASES=cases))
     for rank, out in enumerate(outs):
         assert 'rank {} all ok'.format(rank) in out, out
 
@@ -300,8 +325,10 @@ def test_bench_multi_rank_path_on_one_gpu(gpu, tmp_path, asynchronous):
     # the RCCL plans are timed first (and reported whatever happens later), then the optional exchanges
     assert set(d['config']['comm_phase_tuning_ms_per_sweep']) == (
         {'1', '2', '4', '8', '16', '4t', '8t'} | {p + '/peer' for p in ('1', '2', '4', '8')}
-        | {p + '/sparse' for p in ('1', '2', '4')}), d['config']
-    assert d['config']['comm_exchange'] in ('rccl', 'peer', 'peer-sparse'), d['config']
+        | {p + '/sparse' for p in ('1', '2', '4')} | {p + '/direct' for p in ('1', '2')}), d['config']
+    assert d['config']['comm_exchange'] in ('rccl', 'peer', 'peer-sparse', 'direct-sparse'), d['config']
+    # the work-equivalent chain (every control the long way), sharded like the headline
+    assert d['every_control_the_long_way']['n_gpus'] == 2 and d['every_control_the_long_way']['sweeps_per_s'] > 0
     note = d['config']['comm_exchange_note']
     assert note is None or 'not faster in tuning' in note, note
     assert d['value'] > 0 and d['steps'] == 3 and d['warmup'] == 1
@@ -323,6 +350,7 @@ def test_bench_keeps_the_rccl_result_when_an_optional_exchange_fails(gpu, tmp_pa
     env = dict(SDP_RCCL_LIBRARY=mock, SDP_BENCH_FAULT='peer:{}:1'.format(kind), SDP_BENCH_OPTIONAL_TIMEOUT='45')
     if kind == 'hang':
         env['SDP_COMM_EXCHANGES'] = 'rccl,peer'
+        env['SDP_BENCH_OPTIONAL_TIMEOUT'] = '15'          # (what the test waits for)
     outs = _run_ranks(_with_hooks(tmp_path, os.path.join(ROOT, 'bench.py')), world, env,
                       argv=['--gpus', str(world), '--grid', '48', '--steps', '3', '--warmup', '1',
                             '--no-cpu-baseline'])
@@ -341,6 +369,7 @@ def test_bench_keeps_the_rccl_result_when_an_optional_exchange_fails(gpu, tmp_pa
         assert 'peer exchange not used' in note, note
     else:
         assert 'peer exchange abandoned' in note and d['config']['comm_exchange'] == 'rccl', note
+        assert d['config']['optional_exchange_hang'] == 'peer'
     import glob
     for leftover in glob.glob('/dev/shm/sdp_mock_*') + glob.glob('/dev/shm/sdp_rccl_uid_*'):
         try:

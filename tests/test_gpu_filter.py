@@ -339,3 +339,72 @@ def test_a_radius_far_too_small_is_noticed(gpu, debug_defines, dtype):
     assert (on[2] != off[2]).sum() > 0
     # ... while every J it returns is still the reference's value of SOME control: within rounding noise
     assert np.allclose(on[0], off[0], rtol=1e-5 if dtype == np.float32 else 1e-13, atol=0)
+
+
+# ---------------------------------------------------------------------------
+# Resident-chunk form (csrc/sdp_colres_kernel.h, SDP_COL_WRES): the table holds a chunk of the
+# perturbation points at a time -- more workgroups per CU -- and the tail is built twice; the second
+# pass accumulates head then tail in w order.  Same bits as the plain filtered kernel and as the kernel
+# without the filter.
+# ---------------------------------------------------------------------------
+def _wres(debug_defines, make, V, k, **kw):
+    debug_defines.set(SDP_COL_WRES=str(k))
+    try:
+        out = _sweep(make, True, V, **kw)
+        assert ('#define SDP_COL_WRES {}'.format(k) in out[3]._kernel_plan()['source']) == (k > 0)
+    finally:
+        debug_defines.unset('SDP_COL_WRES')
+    return out
+
+
+@pytest.mark.parametrize('case', ['benchmark', 'stock', 'stock_box_on_state', 'nan', 'inf', 'huge', 'ties', 'near_ties'])
+def test_resident_chunks_give_the_same_bits(gpu, debug_defines, case):
+    if case == 'benchmark':
+        make, k = (lambda: models.synthetic3d(N=24)), 16                 # 32 points: 16 resident, 16 built twice
+        V = models.synthetic3d_V0(make()[1].state_grid)
+    else:
+        make, k = (lambda: _stock(box_on_state=(case == 'stock_box_on_state'), cost_has_u=(case != 'ties'))), 4
+        shape = make()[1]._state_grid_shape                               # 7 points: 4 resident, 3 built twice
+        V = np.random.default_rng(5).standard_normal(shape)
+        if case == 'nan':
+            V[10:14, 2:5] = np.nan
+        elif case == 'inf':
+            V[40:, :] = np.inf
+        elif case == 'huge':
+            V *= 1e302
+        elif case == 'ties':
+            V = np.full(shape, 2.5)                                       # every control survives: the global path
+        elif case == 'near_ties':
+            V = 1.37 * np.asarray(make()[1].state_grid[0])[:, None] + 0.0 * V
+    plain, off = _sweep(make, True, V), _sweep(make, False, V)
+    res = _wres(debug_defines, make, V, k)
+    assert res[3].backend_info['certified_filter']
+    _same(res, plain)
+    _same(res, off)
+
+
+def test_resident_chunks_chained_sweeps_relative_dp_and_policy_evaluation(gpu, debug_defines):
+    """the chunked fixed-policy kernel (sdp_evalpol_col of sdp_colres_kernel.h) and chains of sweeps"""
+    make = lambda: models.synthetic3d(N=24)
+    _, a = make()
+    _, b = make()
+    V = models.synthetic3d_V0(a.state_grid)
+    debug_defines.set(SDP_COL_WRES='16')
+    Ja, pa = b.value_iterations(V, 3, report_time=False)
+    Ea, fa = b.eval_policy(pa, 4, rel_dp=True, report_time=False, J_ref_full=True)
+    assert '#define SDP_COL_WRES 16' in b._kernel_plan()['source']
+    debug_defines.unset('SDP_COL_WRES')
+    Jb, pb = a.value_iterations(V, 3, report_time=False)
+    Eb, fb = a.eval_policy(pb, 4, rel_dp=True, report_time=False, J_ref_full=True)
+    assert np.array_equal(Ja, Jb) and np.array_equal(pa, pb)
+    assert np.array_equal(Ea, Eb) and np.array_equal(fa, fb)
+
+
+def test_resident_chunks_only_where_they_apply(gpu, debug_defines):
+    """a column longer than a workgroup, 4-byte reals, a cost that sees the perturbation: the plain kernel"""
+    debug_defines.set(SDP_COL_WRES='4')
+    for make, dtype in ((lambda: _stock(n_x=600), np.float64), (lambda: _stock(), np.float32),
+                        (lambda: _stock_cost_w(), np.float64)):
+        _, s = make()
+        s.dtype = np.dtype(dtype)
+        assert 'SDP_COL_WRES' not in s._kernel_plan()['source']
