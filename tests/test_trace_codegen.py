@@ -373,7 +373,12 @@ def test_certified_filter_planning_without_a_gpu():
     assert plan['column'] and plan['filtered']
     src = plan['source']
     assert '#define SDP_COL_FILTER 1' in src and '#define SDP_COL_THREADS 256' in src
-    assert '#define SDP_COL_MIN_WAVES 1' in src
+    # the benchmark grid: half of the 32 perturbation points resident (32 KiB instead of 64: four workgroups per
+    # CU, registers capped to match); a table that lets three workgroups share a CU anyway stays whole
+    assert '#define SDP_COL_WRES 16' in src and '#define SDP_COL_MIN_WAVES 4' in src
+    _, small = models.synthetic3d(N=128)
+    src128 = small._kernel_plan()['source']
+    assert 'SDP_COL_WRES' not in src128 and '#define SDP_COL_MIN_WAVES 1' in src128
     s.certified_filter = False                           # every control the long way: the round-1 shape
     src = s._kernel_plan()['source']
     assert 'SDP_COL_FILTER' not in src and '#define SDP_COL_THREADS 512' in src

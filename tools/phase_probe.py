@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from stodynprog_amd import models, DPSolver, _native as nat
 # diagnostic build (clock stamps), and whatever other switches the command line names as K=V
-DPSolver.debug_defines = dict([('SDP_STAMP', '2')] + [a.split('=', 1) for a in sys.argv[1:] if a.startswith('SDP_') and '=' in a])
+DPSolver.debug_defines = dict([('SDP_STAMP', '2'), ('SDP_COL_WRES', '0')] + [a.split('=', 1) for a in sys.argv[1:] if a.startswith('SDP_') and '=' in a])
 sys.argv = [a for a in sys.argv if not (a.startswith('SDP_') and '=' in a)]
 
 _, s = models.synthetic3d(N=256, stock_noise=float(os.environ.get('SDP_STOCK_NOISE', 0)))
