@@ -180,6 +180,15 @@ def load_pmc(key):
         return None, None
 
 
+def load_issue_classes(key):
+    """profiles/issue_classes_<key>.json (tools/issue_model.py), or None"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'issue_classes_{}.json'.format(key))) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def load_clock():
     """in-kernel clock of the sweep kernel (s_memtime / s_memrealtime stamps of the
     diagnostic build, tools/clock_probe.py -> profiles/clock.json)"""
@@ -561,6 +570,16 @@ def report(args, env):
         count_source = ('{}: per {} dispatch (rocprofv3 --pmc of this command) SQ_INSTS_VALU {:.4g} (fp64 ADD/MUL/FMA '
                         '{:.4g} of them); issue cycles = 4 x all vector instructions'.format(
                             pmc_path, kname, valu_all, valu_f64))
+        # Round 4: the same total priced BY INSTRUCTION CLASS where a class table of this very kernel is committed
+        # (tools/issue_model.py: disassembly of the code object, hot loops weighted by their trip counts, the rest
+        # at the slowest class; clocks per class from profiles/r03_ubench_valu_rate.txt)
+        classes = load_issue_classes(pmc_key)
+        if classes and classes.get('kernel_source_key') == source_key and classes.get('issue_cycles_per_launch') \
+                and classes.get('pmc_kernel_source_key') == source_key:
+            class_cycles = float(classes['issue_cycles_per_launch'])
+            counted = class_cycles
+            count_source += ('; priced by class (profiles/issue_classes_{}.json: fp64 / VOP3 4.3 clk, plain 32-bit '
+                             'VOP2 2.4 clk): {:.4g} issue cycles'.format(pmc_key, class_cycles))
     elif filtered:
         counted = None
         count_source = 'no PMC summary committed for this workload'
@@ -609,6 +628,8 @@ def report(args, env):
                        'per-cell gathers: bound by vector-memory/LDS gather issue, see DESIGN.md section 4',
     }
     if filtered and valu_all is not None:
+        roof['frac_uniform_4clk'] = 4.0 * valu_all * share / k_s / issue_peak
+        roof['priced_by_class'] = bool(counted != 4.0 * valu_all)
         roof['valu_wave_instr_fp64_arith'] = valu_f64 * share
         roof['frac_r02_accounting'] = (4.0 * valu_f64 + 2.0 * (valu_all - valu_f64)) * share / k_s / issue_peak
         # what the filtered algorithm cannot do without, in wave64 instructions per launch: per control
@@ -790,6 +811,26 @@ def finish_single(args, env, out):
                 s3._cache.pop(k_).close()
         except Exception as e:
             others['ar1_reference_size'] = {'error': repr(e)}
+        try:
+            # The reference's own calling convention (stodynprog.py:466, 530-533): numpy arrays in and out on EVERY
+            # call of value_iteration -- upload, sweep, downloads of J and the policy; PCIe-bound, never `value`.
+            _, s4 = models.synthetic3d(N=256)
+            J4, _u4 = s4.value_iteration(np.asarray(V0, dtype=np.float64), report_time=False)
+            J4, _u4 = s4.value_iteration(J4, report_time=False)
+            t4 = time.perf_counter()
+            for _ in range(5):
+                J4, _u4 = s4.value_iteration(J4, report_time=False)
+            t4 = (time.perf_counter() - t4) / 5
+            others['host_array_call_ms'] = t4 * 1e3
+            others['host_array_calls_per_s'] = 1.0 / t4
+            others['host_array_call_note'] = ('DPSolver.value_iteration(J_next) -> (J_k, pol_k) with numpy arrays every call '
+                                              '(the drop-in signature), 256^3 fp64: 134 MB up, 268 MB down per call')
+            for k_ in [k_ for k_ in s4._cache if k_[0] == 'problem']:
+                s4._cache.pop(k_).close()
+            del J4, _u4
+        except Exception as e:
+            others['host_array_call_ms'] = None
+            others['host_array_call_note'] = repr(e)
         out['other_configs'] = dict(others, note='steady state (sweeps 6..25 of a chain from a closed-form start), kernel '
                                     'time by HIP events; outside the timed region of `value`')
     if not args.no_cpu_baseline and world == 1:

@@ -261,23 +261,27 @@ def separable_functions_source(model):
     return '\n\n'.join(out)
 
 
-def lead_functions_source(model, m):
-    """C++ text of the slices csrc/sdp_lead_kernel.h uses for a model whose first `m` state variables
-    are controlled stocks and whose other state variables are exogenous (TracedModel.controlled_axes)."""
+def lead_functions_source(model, m, order=None):
+    """C++ text of the slices csrc/sdp_lead_kernel.h uses for a model with `m` controlled stocks next to an
+    exogenous process (TracedModel.controlled_order): `order` lists the state variables, stocks first
+    (default: as they are listed)."""
     d = model.n_state
+    order = tuple(order) if order is not None else tuple(range(d))
+    leads = [model.x_next[k] for k in order[:m]]
+    trails = [model.x_next[k] for k in order[m:]]
     out = []
     lines = ['SDP_DEV void sdp_model_leads(const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real *xl)',
              '{', '    (void)x; (void)u; (void)t;']
-    names = _emit_body(model, model.slice_nodes(model.x_next[:m]), lines)
-    for k, n in enumerate(model.x_next[:m]):
+    names = _emit_body(model, model.slice_nodes(leads), lines)
+    for k, n in enumerate(leads):
         lines.append('    xl[{}] = {};'.format(k, names[n.id]))
     lines.append('}')
     out.append('\n'.join(lines))
     if m < d:
         lines = ['SDP_DEV void sdp_model_trails(const sdp_real *x, sdp_real w, sdp_real t, sdp_real *xt)',
                  '{', '    (void)x; (void)w; (void)t;']
-        names = _emit_body(model, model.slice_nodes(model.x_next[m:]), lines)
-        for k, n in enumerate(model.x_next[m:]):
+        names = _emit_body(model, model.slice_nodes(trails), lines)
+        for k, n in enumerate(trails):
             lines.append('    xt[{}] = {};'.format(k, names[n.id]))
         lines.append('}')
         out.append('\n'.join(lines))
@@ -302,6 +306,18 @@ def lead_filter_applies(model, dtype, min_axes=2, debug=None):
         return 0
     m = model.controlled_axes()
     return int(m) if m is not None and m >= min_axes else 0
+
+
+def lead_order(model, dtype, debug=None):
+    """(m, order) for the reduced-array sweep of a model whose stocks are NOT listed first (the order of the
+    state variables is the user's: reference stodynprog.py:119-131), or None: TracedModel.controlled_order
+    with at least one exogenous variable, 8-byte reals, one perturbation."""
+    if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0' or model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
+        return None
+    co = model.controlled_order()
+    if co is None or co[1] == tuple(range(model.n_state)) or co[0] >= model.n_state:
+        return None
+    return co
 
 
 UTAB_MAX_VALUES = 4          # tabulated sub-expressions per control
@@ -452,7 +468,8 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
 
 
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
-                     per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None, wres=0):
+                     per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None, wres=0,
+                     lead_perm=None):
     """column: None for the generic node-order kernels, or (N0, W[, controls, columns]) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
@@ -503,11 +520,15 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
         # several controlled state variables: node-order sweep with the filter on an array reduced over w
         head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes)),
                  '#define SDP_LEAD_COST_HAS_W {}'.format(1 if model.cost_depends_on_w else 0)]
+        if lead_perm is not None and tuple(lead_perm) != tuple(range(model.n_state)):
+            full = tuple(lead_perm) + tuple(range(model.n_state, 4))
+            head.append('#define SDP_LEAD_PERM {{{}}}     // state variable of logical axis j: the stocks are not listed first'.format(
+                ', '.join(str(int(k)) for k in full)))
         if _dbg(debug, 'SDP_LEAD_FILTER_SCALE'):
             head.append('#define SDP_LEAD_FILTER_SCALE {}'.format(float(_dbg(debug, 'SDP_LEAD_FILTER_SCALE'))))
         if _dbg(debug, 'SDP_LEAD_UNROLL'):
             head.append('#define SDP_LEAD_UNROLL {}'.format(int(_dbg(debug, 'SDP_LEAD_UNROLL'))))
-        head += [lead_functions_source(model, int(lead_axes)), '',
+        head += [lead_functions_source(model, int(lead_axes), lead_perm), '',
                  '#include "sdp_sweep_kernel.h"    // brings in sdp_lead_kernel.h', '']
     else:
         head += ['#include "sdp_sweep_kernel.h"', '']

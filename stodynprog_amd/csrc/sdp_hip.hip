@@ -741,6 +741,8 @@ struct sdp_problem {
     }
 };
 
+static int64_t lead_trailing_nodes(const sdp_problem *p);
+
 extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **out)
 {
     if (!desc || !out) return fail(SDP_EINVAL, "NULL argument");
@@ -903,7 +905,7 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         if (p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
         int rc = p->lead_a.alloc((size_t)p->S * rs);
         if (!rc) rc = p->lead_v.alloc((size_t)p->S * rs);
-        if (!rc) rc = p->lead_e.alloc((size_t)p->S * rs / (size_t)p->orders[0]);      // (>= nodes per trailing block)
+        if (!rc) rc = p->lead_e.alloc((size_t)lead_trailing_nodes(p) * rs);            // (a value per trailing index)
         if (!rc) rc = p->lead_vmax.alloc(8);
         if (rc) return rc;
     }
@@ -1115,14 +1117,21 @@ static unsigned sweep_blocks(const sdp_problem *p, int64_t nodes)
 static int64_t lead_trailing_nodes(const sdp_problem *p)
 {
     int64_t ts = 1;
-    for (int k = p->meta[SDP_META_LEAD_AXES]; k < p->d; ++k) ts *= p->orders[k];
+    for (int k = p->meta[SDP_META_LEAD_AXES]; k < p->d; ++k) ts *= p->orders[(p->meta[SDP_META_LEAD_PERM] >> (4 * k)) & 15];
     return ts;
+}
+static bool lead_permuted(const sdp_problem *p)
+{
+    for (int k = 0; k < p->d; ++k)
+        if (((p->meta[SDP_META_LEAD_PERM] >> (4 * k)) & 15) != k) return true;
+    return false;
 }
 static void lead_reduce_range(const sdp_problem *p, int64_t nb, int64_t ne, int64_t &lb, int64_t &le)
 {
     const int64_t ts = lead_trailing_nodes(p), ls = p->S / ts;
     lb = 0; le = ls;
-    if (p->lead_halo < 0 || !p->comm || p->comm->nranks < 2) return;
+    // (stocks not listed first: a slab of nodes is no range of lead indices -- everything is reduced)
+    if (p->lead_halo < 0 || !p->comm || p->comm->nranks < 2 || lead_permuted(p)) return;
     // this rank's nodes over all phases of the backup (one contiguous slab with dist.slab_partition)
     int64_t lo = nb, hi = ne;
     const int n = p->comm->nranks, me = p->comm->rank;

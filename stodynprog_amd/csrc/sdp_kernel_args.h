@@ -22,7 +22,8 @@ enum {
     SDP_META_UTAB_N,        // controls the control table has room for (the lattice may be shorter)
     SDP_META_THREADS,       // workgroup size of the sweep kernel (column / staged units)
     SDP_META_COL_ROWS,      // rows of axis 0 the table holds (< COL_N0: row window)
-    SDP_META_LEAD_AXES      // SDP_META_F_LEAD units: controlled state variables (the plane-major arrays' "lead" axes)
+    SDP_META_LEAD_AXES,     // SDP_META_F_LEAD units: controlled state variables (the plane-major arrays' "lead" axes)
+    SDP_META_LEAD_PERM      // ... and which state variable logical axis j is (nibble j; stocks first)
 };
 enum {
     SDP_META_F_FILTER = 1, SDP_META_F_WINDOW = 2, SDP_META_F_TRAIL_HAS_U = 4, SDP_META_F_STAGED = 8,

@@ -54,6 +54,18 @@ static_assert(sizeof(sdp_real) == 8, "the global-memory filter is built for 8-by
 #define SDP_LEAD_FILTER_SCALE 1      // test knob: multiplies the radius (any value >= 1: same bits)
 #endif
 constexpr int SDP_LM = SDP_LEAD_AXES, SDP_LT = SDP_D - SDP_LEAD_AXES;
+// The controlled state variables need not be listed first (the reference takes the order of the state variables
+// from dyn's signature, stodynprog.py:119-131): logical axis j of this kernel -- stocks first, then the exogenous
+// process -- is state variable SDP_LP[j].  Only the FILTER works in the logical order (reduced array, first
+// pass: free to reorder, the bound holds for any nest); the second pass evaluates the reference's nest in the
+// reference's own axis order (sdp_expected_cost: the strides alone know about the plane-major copy).
+#ifdef SDP_LEAD_PERM
+constexpr int SDP_LP[SDP_MAXD] = SDP_LEAD_PERM;
+constexpr bool SDP_LEAD_PERMUTED = true;
+#else
+constexpr int SDP_LP[SDP_MAXD] = {0, 1, 2, 3};
+constexpr bool SDP_LEAD_PERMUTED = false;
+#endif
 
 SDP_DEV double sdp_lead_vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 SDP_DEV double sdp_lead_vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -66,6 +78,9 @@ struct SdpLeadGeom {
     int64_t ls;                 // nodes per plane = prod orders[..m-1]
     int64_t lm[SDP_LM];         // strides of the lead axes in node order
     int pm[SDP_LM];             // strides of the lead axes inside a plane (plane-major arrays)
+    int64_t nstr[SDP_D];        // node-order stride of LOGICAL axis j (state variable SDP_LP[j])
+    int tm[SDP_LT > 0 ? SDP_LT : 1];   // strides of the trailing axes inside the trailing index
+    int ord[SDP_D];             // points of logical axis j
     sdp_real smin[SDP_LM], span[SDP_LM], rspan[SDP_LM], nm1[SDP_LM];
     int ordm2[SDP_LM];
     int pow2;
@@ -73,41 +88,85 @@ struct SdpLeadGeom {
 SDP_DEV void sdp_lead_geom(const SdpSweepArgs &a, SdpLeadGeom &g)
 {
     const sdp_real *axes = (const sdp_real *)a.axes;
-    int64_t m = 1;
+    int64_t phys[SDP_D];                                   // node-order strides of the state variables
+    {
+        int64_t acc = 1;
 #pragma unroll
-    for (int k = SDP_D - 1; k >= SDP_LM; --k) m *= a.orders[k];
+        for (int p = SDP_D - 1; p >= 0; --p) { phys[p] = acc; acc *= a.orders[p]; }
+    }
+#pragma unroll
+    for (int j = 0; j < SDP_D; ++j) { g.ord[j] = a.orders[SDP_LP[j]]; g.nstr[j] = phys[SDP_LP[j]]; }
+    int64_t m = 1;
+    int tmul = 1;
+#pragma unroll
+    for (int k = SDP_D - 1; k >= SDP_LM; --k) { g.tm[k - SDP_LM] = tmul; tmul *= g.ord[k]; m *= g.ord[k]; }
     g.ts = m;
     g.pow2 = 0;
     int pm = 1;
 #pragma unroll
     for (int k = SDP_LM - 1; k >= 0; --k) {
-        g.lm[k] = m;
-        m *= a.orders[k];
+        const int ax = SDP_LP[k];
+        g.lm[k] = g.nstr[k];
         g.pm[k] = pm;
-        pm *= a.orders[k];
-        g.smin[k] = axes[a.axis_off[k]];
-        g.span[k] = axes[a.axis_off[k] + a.orders[k] - 1] - g.smin[k];
+        pm *= g.ord[k];
+        g.smin[k] = axes[a.axis_off[ax]];
+        g.span[k] = axes[a.axis_off[ax] + a.orders[ax] - 1] - g.smin[k];
         g.rspan[k] = (sdp_real)1 / g.span[k];
-        g.nm1[k] = (sdp_real)(a.orders[k] - 1);
-        g.ordm2[k] = a.orders[k] - 2;
+        g.nm1[k] = (sdp_real)(a.orders[ax] - 1);
+        g.ordm2[k] = a.orders[ax] - 2;
         if (sdp_is_pow2(g.span[k])) g.pow2 |= 1 << k;
     }
     g.ls = pm;
     g.pow2 = __builtin_amdgcn_readfirstlane(g.pow2);
 }
+// node <-> (lead index, trailing index).  Stocks listed first: node = lead * ts + trail.
+SDP_DEV void sdp_lead_split(const SdpLeadGeom &g, int64_t node, int64_t &lead, int64_t &trail)
+{
+    if (!SDP_LEAD_PERMUTED) { lead = node / g.ts; trail = node - lead * g.ts; return; }
+    lead = 0; trail = 0;
+#pragma unroll
+    for (int j = 0; j < SDP_D; ++j) {
+        const int i = (int)((node / g.nstr[j]) % g.ord[j]);
+        if (j < SDP_LM) lead += (int64_t)i * g.pm[j];
+        else trail += (int64_t)i * g.tm[j - SDP_LM];
+    }
+}
+SDP_DEV int64_t sdp_lead_join(const SdpLeadGeom &g, int64_t lead, int64_t trail)
+{
+    if (!SDP_LEAD_PERMUTED) return lead * g.ts + trail;
+    int64_t node = 0;
+#pragma unroll
+    for (int j = SDP_LM - 1; j >= 0; --j) { node += (lead % g.ord[j]) * g.nstr[j]; lead /= g.ord[j]; }
+#pragma unroll
+    for (int j = SDP_D - 1; j >= SDP_LM; --j) { node += (trail % g.ord[j]) * g.nstr[j]; trail /= g.ord[j]; }
+    return node;
+}
+// node-order offset of the trailing block of a lead index (all trailing indices zero)
+SDP_DEV int64_t sdp_lead_base(const SdpLeadGeom &g, int64_t lead)
+{
+    if (!SDP_LEAD_PERMUTED) return lead * g.ts;
+    int64_t base = 0;
+#pragma unroll
+    for (int j = SDP_LM - 1; j >= 0; --j) { base += (lead % g.ord[j]) * g.nstr[j]; lead /= g.ord[j]; }
+    return base;
+}
 #if SDP_LEAD_AXES < SDP_D
-SDP_DEV void sdp_lead_trail_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_LT> &tg)
+// the trailing axes as a grid of their own over the value array in NODE order (their own strides there)
+SDP_DEV void sdp_lead_trail_grid(const SdpSweepArgs &a, const SdpLeadGeom &geo, SdpGrid<sdp_real, SDP_LT> &tg)
 {
     const sdp_real *axes = (const sdp_real *)a.axes;
     sdp_real smin[SDP_LT], smax[SDP_LT];
     int32_t ord[SDP_LT];
 #pragma unroll
     for (int k = 0; k < SDP_LT; ++k) {
-        ord[k] = a.orders[SDP_LM + k];
-        smin[k] = axes[a.axis_off[SDP_LM + k]];
-        smax[k] = axes[a.axis_off[SDP_LM + k] + ord[k] - 1];
+        const int ax = SDP_LP[SDP_LM + k];
+        ord[k] = a.orders[ax];
+        smin[k] = axes[a.axis_off[ax]];
+        smax[k] = axes[a.axis_off[ax] + ord[k] - 1];
     }
     sdp_make_grid<sdp_real, SDP_LT>(tg, ord, smin, smax);
+#pragma unroll
+    for (int k = 0; k < SDP_LT; ++k) tg.M[k] = (int)geo.nstr[SDP_LM + k];
 }
 #endif
 
@@ -125,7 +184,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
     sdp_lead_geom(a, geo);
 #if SDP_LEAD_AXES < SDP_D
     SdpGrid<sdp_real, SDP_LT> tg;
-    sdp_lead_trail_grid(a, tg);
+    sdp_lead_trail_grid(a, geo, tg);
 #endif
     sdp_real vmax = (sdp_real)0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -134,7 +193,8 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
     for (int64_t node = a.node_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; node < a.node_end; node += stride) {
         sdp_real x[SDP_D];
         sdp_node_coords(a, node, x);
-        const int64_t lead = node / geo.ts, trail = node - lead * geo.ts;
+        int64_t lead, trail;
+        sdp_lead_split(geo, node, lead, trail);
         sdp_real acc = (sdp_real)0, emax = (sdp_real)0;
         for (int wi = 0; wi < a.W; ++wi) {
 #if SDP_LEAD_AXES < SDP_D
@@ -147,7 +207,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
                 sdp_locate_axis<sdp_real, SDP_LT, sdp_real>(tg, k, xt[k], c);      // (the reference's cell: pyx:75-81)
                 ew = ew * (fabs(c.oml[k]) + fabs(c.lam[k]));
             }
-            const sdp_real inner = SdpLerp<sdp_real, SDP_LT, sdp_real, 0>::eval(V + lead * geo.ts, tg, c, 0);
+            const sdp_real inner = SdpLerp<sdp_real, SDP_LT, sdp_real, 0>::eval(V + sdp_lead_base(geo, lead), tg, c, 0);
             emax = ew > emax || ew != ew ? ew : emax;                              // (a NaN sticks)
 #else
             const sdp_real inner = V[node];
@@ -299,11 +359,11 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
     SdpGrid<sdp_real, SDP_D> grid;
     sdp_grid_from_args(a, grid);
     {
-        int m = (int)geo.ls;
+        // (grid.M is indexed by STATE VARIABLE: sdp_expected_cost keeps the reference's axis order)
 #pragma unroll
-        for (int k = SDP_D - 1; k >= SDP_LM; --k) { grid.M[k] = m; m *= a.orders[k]; }
+        for (int k = SDP_D - 1; k >= SDP_LM; --k) grid.M[SDP_LP[k]] = (int)geo.ls * geo.tm[k - SDP_LM];
 #pragma unroll
-        for (int k = 0; k < SDP_LM; ++k) grid.M[k] = geo.pm[k];
+        for (int k = 0; k < SDP_LM; ++k) grid.M[SDP_LP[k]] = geo.pm[k];
     }
     SdpLeadConst fc;
     sdp_lead_const(a, fc);
@@ -319,7 +379,9 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
     // XCD-aware walk over tiles of 256 consecutive PLANE-MAJOR positions: an XCD takes a contiguous eighth,
     // i.e. whole planes, whose reduced values then stay in its L2.  A launch over part of the nodes (a rank's
     // slab of the first stock, a phase of it) walks the lead indices of that part only.
-    const int64_t lead_lo = a.node_begin / geo.ts, lead_hi = (a.node_end + geo.ts - 1) / geo.ts, n_l = lead_hi - lead_lo;
+    // (with the stocks not listed first a node range is no range of lead indices: every position, filtered below)
+    const int64_t lead_lo = SDP_LEAD_PERMUTED ? 0 : a.node_begin / geo.ts;
+    const int64_t lead_hi = SDP_LEAD_PERMUTED ? geo.ls : (a.node_end + geo.ts - 1) / geo.ts, n_l = lead_hi - lead_lo;
     const int64_t n_pos = n_l * geo.ts;
     const int64_t n_tiles = (n_pos + blockDim.x - 1) / blockDim.x;
     const int xcd = blockIdx.x & 7;
@@ -330,7 +392,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         const int64_t pos = tile * blockDim.x + threadIdx.x;
         if (pos >= n_pos) continue;
         const int64_t trail = pos / n_l, lead = lead_lo + (pos - trail * n_l);
-        const int64_t node = lead * geo.ts + trail;
+        const int64_t node = sdp_lead_join(geo, lead, trail);
         if (node < a.node_begin || node >= a.node_end) continue;
         sdp_real x[SDP_D];
         SdpBox box;

@@ -292,12 +292,14 @@ extern "C" {
 __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
     SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1,
 #if defined(SDP_STG_THREADS)
-    SDP_META_F_STAGED | SDP_META_F_PEER_STORES, 0, 0, SDP_STG_THREADS, 0, 0,
+    SDP_META_F_STAGED | SDP_META_F_PEER_STORES, 0, 0, SDP_STG_THREADS, 0, 0, 0,
 #elif defined(SDP_LEAD_AXES)
     SDP_META_F_LEAD | SDP_META_F_FILTER | SDP_META_F_PEER_STORES, 0, 0, 256, 0, SDP_LEAD_AXES,
+    // (state variable of logical axis j in nibble j: the host sizes the plane-major arrays with it)
+    SDP_LP[0] | (SDP_LP[1] << 4) | (SDP_LP[2] << 8) | (SDP_LP[3] << 12),
 #else
-    SDP_META_F_PEER_STORES, 0, 0, 256, 0, 0,
+    SDP_META_F_PEER_STORES, 0, 0, 256, 0, 0, 0,
 #endif
-    0, 0};
+    0};
 }
 #endif

@@ -638,16 +638,26 @@ class DPSolver(object):
         # several controlled state variables next to an exogenous process: the node-order sweep with the
         # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h); one GPU for now
         lead_axes = 0
-        if (not column and self.kernel in ('auto', 'lead') and W > 0
+        if (not column and self.kernel in ('auto', 'lead') and W > 0 and not self._cache.get('no_lead')
                 and (self.comm is None or self.comm.is_device)
                 and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
             # (one stock whose table does not fit LDS too: measured 5.9 ms against 12.7 ms of the row-window
             # column kernel at 1024 x 128 x 128 x 64 x 32, tools/window_vs_lead.py)
             lead_axes = codegen.lead_filter_applies(
                 model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2, debug)
+        # the stocks need not be listed first (the order of the state variables is the user's, reference
+        # stodynprog.py:119-131): the filter then works on a permuted view of the axes, the second pass keeps the
+        # reference's own axis order
+        lead_perm = None
+        if (not column and not lead_axes and self.kernel in ('auto', 'lead') and W > 0 and not self._cache.get('no_lead')
+                and (self.comm is None or self.comm.is_device)
+                and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
+            co = codegen.lead_order(model, dt, debug)
+            if co is not None:
+                lead_axes, lead_perm = co
         if self.kernel == 'lead' and not lead_axes:
-            raise ValueError("kernel = 'lead' needs controlled state variables listed first, an exogenous process "
-                             'after them, a perturbation that reaches only that process, 8-byte reals, the certified '
+            raise ValueError("kernel = 'lead' needs controlled state variables next to an exogenous process, "
+                             'a perturbation that reaches only that process, 8-byte reals, the certified '
                              'filter and exact arithmetic (several GPUs: a device communicator)')
         if lead_axes:
             lanes = 1                                     # one lane per node, the control loop in-lane
@@ -669,7 +679,7 @@ class DPSolver(object):
             window = codegen.column_window_config(shape[0], W, len(shape), dt,
                                                   self._lead_reach_rows(model, bp, box_t))
             column = window is not None
-        if (not column or per_control) and self.kernel in ('auto', 'column'):
+        if (not column or per_control) and not lead_perm and self.kernel in ('auto', 'column'):
             k = model.separable_axis_hint()
             if k is not None and not self._cache.get('hinted'):
                 self._cache['hinted'] = True
@@ -700,10 +710,11 @@ class DPSolver(object):
                                           fused=(self.arithmetic == 'fused'), staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
                                           filtered=filtered, utab=utab, lead_axes=lead_axes,
-                                          col_cfg=col_cfg, debug=debug, wres=wres if filtered else 0)
+                                          col_cfg=col_cfg, debug=debug, wres=wres if filtered else 0,
+                                          lead_perm=lead_perm)
         filtered = filtered or bool(lead_axes)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
-                    lead_axes=lead_axes,
+                    lead_axes=lead_axes, lead_perm=lead_perm,
                     window=window, per_control=per_control,
                     col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
@@ -770,7 +781,21 @@ class DPSolver(object):
               codegen.source_key(plan['source']))
         prob = self._cache.get(fp)
         if prob is None:
-            prob = self._create_problem(fp, plan)
+            try:
+                prob = self._create_problem(fp, plan)
+            except MemoryError:
+                # the reduced-array sweep keeps two more arrays of the size of the grid (the reduced array and a
+                # plane-major copy of the cost-to-go): where they no longer fit, the families that need no extra
+                # memory take over (row window / table per control / staged tiles) -- slower, same bits
+                if not plan.get('lead_axes') or self.kernel == 'lead':
+                    raise
+                import warnings
+                warnings.warn('not enough device memory for the reduced-array sweep (2 extra arrays of the grid\'s '
+                              'size): using the kernels that need none')
+                self._cache['no_lead'] = True
+                plan = self._kernel_plan(box_t, model)
+                fp = ('problem', self._fingerprint(None), plan['box_digest'], codegen.source_key(plan['source']))
+                prob = self._create_problem(fp, plan)
         if model.param_index is not None:
             prob.set_params(model.param_values())
         self.backend_info = dict(prob.info, time_specialized=model.t_value is not None,
@@ -883,6 +908,8 @@ class DPSolver(object):
                          kernel='column' if column else ('staged' if plan['staged'] else
                                                          ('lead' if plan.get('lead_axes') else 'generic')),
                          controlled_axes=int(plan.get('lead_axes') or (1 if column else 0)),
+                         # state variables in the order the filter sees them (stocks first) when they are not listed first
+                         controlled_order=(list(plan['lead_perm']) if plan.get('lead_perm') else None),
                          staged=plan['staged'],
                          row_window=(dict(rows=plan['window'][2], segment_nodes=plan['window'][3])
                                      if plan['window'] else None),

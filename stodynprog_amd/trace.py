@@ -704,6 +704,30 @@ class TracedModel(object):
                 return m
         return None
 
+    def controlled_order(self):
+        """(m, order): the state variables split into m 'stocks' -- next values that may depend on the whole
+        state and on the control but not on the perturbation -- and an exogenous process -- next values that
+        depend on the exogenous variables, the perturbation and the time only -- WHEREVER they are listed
+        (the reference takes the order of the state variables from dyn's signature, stodynprog.py:119-131);
+        `order` lists the stocks first, then the exogenous variables, each group in the listed order.
+        controlled_axes() is the case order == (0, 1, ..).  None when no such split exists."""
+        d = self.n_state
+        reach = [self.var_reach(n) for n in self.x_next]
+        # the largest closed set of variables that evolve on their own: start from those the control does not
+        # reach, drop what depends on a variable outside the set, repeat
+        exo = set(k for k in range(d) if not any(v.startswith('u') for v in reach[k]))
+        changed = True
+        while changed:
+            changed = False
+            for k in sorted(exo):
+                if any(v.startswith('x') and int(v[1:]) not in exo for v in reach[k]):
+                    exo.discard(k)
+                    changed = True
+        stocks = [k for k in range(d) if k not in exo]
+        if not stocks or any(any(v.startswith('w') for v in reach[k]) for k in stocks):
+            return None
+        return len(stocks), tuple(stocks + sorted(exo))
+
     LEAD_SPLIT_MAX_TERMS = 4
 
     def lead_split(self):

@@ -204,3 +204,66 @@ def test_policy_evaluation_and_iteration_run_on_the_same_problem(gpu):
     with contextlib.redirect_stdout(io.StringIO()):
         E2 = g.eval_policy(pol, 3, False, V)
     assert np.array_equal(E1, E2)
+
+
+# ---------------------------------------------------------------------------
+# Round 4: the stocks need not be listed first.  The reference takes the order of the state variables from
+# dyn's signature (stodynprog.py:119-131) and its lerp nest follows that order (multilinear_cython.pyx:177-208);
+# the filter works on a permuted view of the axes (stocks first), the second pass evaluates the reference's
+# nest in the reference's own order.
+# ---------------------------------------------------------------------------
+def _stock_not_first(three=False, cost_w=False):
+    if three:
+        s = SysDescription((3, 1, 1), name='stock in the middle')
+        s.dyn = lambda a, y, b, u, w: (0.8 * a + w, y + 0.7 * u, 0.5 * b - 0.3 * w + 0.1 * a)
+        if cost_w:
+            s.cost = lambda a, y, b, u, w: (a - 0.3 + 0.4 * w) * u + 0.2 * u * u + 0.05 * y + 0.1 * b * b
+        else:
+            s.cost = lambda a, y, b, u, w: (a - 0.3) * u + 0.2 * u * u + 0.05 * y + 0.1 * b * b
+        s.control_box = lambda a, y, b: ((-1.0, 1.0 + 0.2 * a * a),)
+    else:
+        s = SysDescription((2, 1, 1), name='stock listed last')
+        s.dyn = lambda a, y, u, w: (0.8 * a + w, y + 0.7 * u)
+        s.cost = lambda a, y, u, w: (a - 0.3) * u + 0.2 * u * u + 0.05 * y
+        s.control_box = lambda a, y: ((-1.0, 1.0),)
+    s.perturb_laws = [NormalLaw(0, 0.2)]
+    sol = DPSolver(s)
+    if three:
+        sol.discretize_state(-1, 1, 9, 0, 3, 40, -1, 1, 7)
+    else:
+        sol.discretize_state(-1, 1, 9, 0, 3, 40)
+    sol.discretize_perturb(-0.5, 0.5, 7)
+    sol.control_steps = (0.0625,)
+    return s, sol
+
+
+@pytest.mark.parametrize('three,cost_w', [(False, False), (True, False), (True, True)])
+def test_a_stock_that_is_not_listed_first(gpu, three, cost_w, recwarn):
+    from oracle import vi_numpy
+    make = lambda: _stock_not_first(three, cost_w)
+    _, a = make()
+    shape = a._state_grid_shape
+    V = np.random.default_rng(12).standard_normal(shape)
+    Ja, pa = a.value_iterations(V, 3, report_time=False)
+    assert a.backend_info['kernel'] == 'lead' and a.backend_info['certified_filter']
+    assert a.backend_info['controlled_order'] == ([1, 0, 2] if three else [1, 0])
+    assert not [w for w in recwarn.list if 'listing it' in str(w.message)]          # no "list it FIRST" advice any more
+    src = a._kernel_plan()['source']
+    assert '#define SDP_LEAD_PERM {1, 0, 2, 3}' in src and '#define SDP_LEAD_AXES 1' in src
+    _, b = make()
+    b.kernel = 'generic'
+    Jb, pb = b.value_iterations(V, 3, report_time=False)
+    assert np.array_equal(Ja, Jb) and np.array_equal(pa, pb)
+    assert np.array_equal(a.last_policy_index, b.last_policy_index)
+    # and the numpy oracle (the reference's nest order, its own callables) on one sweep
+    J1, _ = a.value_iteration(V, report_time=False)
+    Jo, _, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(a), V)
+    assert np.array_equal(J1, Jo) and np.array_equal(a.last_policy_index, io)
+    # special values take the long way on V itself
+    V2 = V.copy()
+    V2[(2,) * V.ndim] = np.nan
+    V2[(0,) + (5,) * (V.ndim - 1)] = np.inf
+    with np.errstate(all='ignore'):
+        Jn, _ = a.value_iteration(V2, report_time=False)
+        Jg, _ = b.value_iteration(V2, report_time=False)
+    assert np.array_equal(Jn, Jg, equal_nan=True) and np.array_equal(a.last_policy_index, b.last_policy_index)

@@ -152,9 +152,19 @@ def test_hint_when_the_controlled_stock_is_not_listed_first():
         warnings.simplefilter('always')
         plan = solver._kernel_plan()
         solver._kernel_plan()                          # only once
-    # as written the model still has a column structure (the trailing axis depends on the
-    # control, not on the leading state): the per-control table runs, and the hint says
-    # that listing the stock first would run the much cheaper separable kernel
+    # Round 4: the order of the state variables is the user's (reference stodynprog.py:119-131) -- a stock the
+    # perturbation does not reach runs the reduced-array sweep on a permuted view of the axes (stocks first for the
+    # filter, the reference's own order for the second pass), without a word
+    assert plan['lead_axes'] == 1 and plan['lead_perm'] == (1, 0) and plan['filtered'] and not plan['column']
+    assert '#define SDP_LEAD_PERM {1, 0, 2, 3}' in plan['source'] and not rec
+    # 4-byte reals (and a stock that sees the perturbation) keep the column structure the model still has as
+    # written (the trailing axis depends on the control, not on the leading state: table per control), and the
+    # hint says that listing the stock first would run the much cheaper separable kernel
+    solver.dtype = np.dtype(np.float32)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        plan = solver._kernel_plan()
+        solver._kernel_plan()                          # only once
     assert plan['column'] and plan['per_control']
     assert len(rec) == 1 and '"e"' in str(rec[0].message) and 'FIRST' in str(rec[0].message)
     # a genuinely coupled model gets no hint
