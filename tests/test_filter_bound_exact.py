@@ -1,0 +1,160 @@
+"""The error radius of the certified filter, checked in EXACT arithmetic (no GPU).
+
+The filter of csrc/sdp_column_kernel.h skips a control when its short value F -- two fused operations on a table
+reduced over the perturbation -- lies further than a radius above the smallest F of the node; that is sound if
+|E - F| <= radius for every control, E being the reference's value (W x 6 separately rounded operations,
+stodynprog.py:677-681 on multilinear_cython.pyx:88).  DESIGN.md section 3.1c derives the radius to first order in
+the unit roundoff with a factor 2 to spare; the GPU tests back it empirically (same bits at the proven radius and at
+half of it).  Here both values are computed with Python floats, operation by operation as the kernels round
+(`fma` = one rounding of the exact a*b + c through fractions.Fraction), their difference is taken EXACTLY, and
+compared with the radius the kernel would use -- on random tables of every magnitude regime the special-value
+tests use short of overflow, on weights that are negative or do not sum to one, on positions far outside the grid
+(extrapolation: |lam| >> 1), for the plain reduction order and for the resident-chunk one (tail first, then head).
+VERDICT r03, "what's weak" 1(b).
+"""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+U = 2.0 ** -53
+TINY = 2.2250738585072014e-308
+
+
+def fma(a, b, c):
+    return float(Fraction(a) * Fraction(b) + Fraction(c))          # correctly rounded (round-half-even)
+
+
+def reference_value(T, p, g, q0, lam0):
+    """E: sdp_col_expected_cost<1> / stodynprog.py:677-681, sequential in w"""
+    oml0 = 1.0 - lam0
+    acc = 0.0
+    for w in range(len(p)):
+        val = oml0 * T[w][q0] + lam0 * T[w][q0 + 1]
+        jc = g + val
+        acc = acc + jc * p[w]
+    return acc
+
+
+def reduced_table(T, p, chunked):
+    """A[r] as sdp_col_filter_reduce accumulates it (acc + p_w * v, separately rounded), or as the resident-chunk
+    kernel does: the tail's partial sum first, then the head, then their sum"""
+    W, N0 = T.shape
+    A = np.zeros(N0)
+    for r in range(N0):
+        if chunked:
+            C = (W + 1) // 2
+            tail = 0.0
+            for w in range(C, W):
+                tail = tail + p[w] * T[w][r]
+            head = 0.0
+            for w in range(C):
+                head = head + p[w] * T[w][r]
+            A[r] = head + tail
+        else:
+            acc = 0.0
+            for w in range(W):
+                acc = acc + p[w] * T[w][r]
+            A[r] = acc
+    return A
+
+
+def filter_constants(p):
+    """sdp_col_filter_setup"""
+    ps = 0.0
+    pa = 0.0
+    for v in p:
+        ps = ps + v
+        pa = pa + abs(v)
+    pcap = pa if pa > 1.0 else 1.0
+    cu = 1.0 * float(2 * (len(p) + 8)) * 2.0 ** -52
+    return dict(psum=ps, pcap=pcap, cu=cu, floor=2.0 * TINY / cu, ratio=pcap / abs(ps))
+
+
+def node_check(T, p, controls, chunked):
+    """controls: (position p along axis 0, cost g) of every control of one node.  Returns (worst |E - F| / radius,
+    radius, scale) with everything but the final division exact."""
+    W, N0 = T.shape
+    fc = filter_constants(p)
+    A = reduced_table(T, p, chunked)
+    dcol = 0.0
+    for r in range(N0):
+        big = max(abs(T[w][r]) for w in range(W))
+        dcol = max(dcol, fc['pcap'] * big + fc['floor'])
+    F, E, lmax, fsum = [], [], 0.0, 0.0
+    for pos, g in controls:
+        q0 = max(min(int(pos), N0 - 2), 0)                 # pyx:78 (trunc, clamp)
+        lam0 = pos - float(q0)                             # pyx:81
+        lmax = max(lmax, abs(lam0))
+        f = fma(g, fc['psum'], fma(lam0, A[q0 + 1] - A[q0], A[q0]))     # sdp_col_lean_core
+        fsum = fsum + abs(f)
+        F.append(f)
+        E.append(reference_value(T, p, g, q0, lam0))
+    h_cap = (1.0 + 2.0 * lmax) * dcol
+    s_node = fma(fc['ratio'], fsum + h_cap, h_cap)
+    radius = fc['cu'] * s_node
+    worst = max(abs(Fraction(e) - Fraction(f)) for e, f in zip(E, F))
+    return float(worst / Fraction(radius)), radius, s_node
+
+
+def random_problem(rng, regime):
+    W = int(rng.integers(1, 9))
+    N0 = int(rng.integers(3, 14))
+    T = rng.standard_normal((W, N0))
+    if regime == 'large':
+        T *= 10.0 ** rng.uniform(100, 290)
+    elif regime == 'small':
+        T *= 10.0 ** rng.uniform(-300, -100)
+    elif regime == 'mixed':
+        T *= 10.0 ** rng.uniform(-12, 12, size=T.shape)
+    elif regime == 'cancel':
+        T = 1e6 + 1e-6 * T                                  # A[q0+1] - A[q0] cancels almost completely
+    p = np.abs(rng.standard_normal(W)) + 1e-3
+    p /= p.sum()
+    if regime == 'weights':
+        p = rng.standard_normal(W) * 3.7                   # negative weights, a sum far from one
+        if abs(p.sum()) < 0.2:
+            p[0] += 1.0
+    scale = float(np.abs(T).max())
+    n_u = int(rng.integers(2, 12))
+    controls = []
+    for _ in range(n_u):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            pos = float(rng.uniform(0, N0 - 1))
+        elif kind == 1:
+            pos = float(rng.integers(0, N0))               # exactly on a node
+        elif kind == 2:
+            pos = float(rng.uniform(-3 * N0, 4 * N0))      # extrapolation: |lam| up to ~3 N0
+        else:
+            pos = float(rng.uniform(0, N0 - 1)) * (1.0 + U)
+        g = float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3)
+        controls.append((pos, g))
+    return T, p, controls
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+@pytest.mark.parametrize('chunked', [False, True])
+def test_the_radius_covers_the_difference_exactly(regime, chunked):
+    rng = np.random.default_rng(['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime) * 2 + int(chunked))
+    worst = 0.0
+    for _ in range(300):
+        T, p, controls = random_problem(rng, regime)
+        ratio, radius, s_node = node_check(T, p, controls, chunked)
+        assert np.isfinite(radius) and radius > 0.0
+        assert ratio <= 1.0, (regime, chunked, ratio, T.shape, len(controls))
+        worst = max(worst, ratio)
+    # the bound is meant to be generous (a factor ~2 over first order, a node-wide sum in place of a per-control
+    # term): the worst case seen stays well inside it -- and is not absurdly far from it either
+    assert worst < 0.6, worst
+
+
+def test_a_radius_a_thousand_times_smaller_would_not_cover_it():
+    """(the check above has teeth: the same difference against 1e-3 of the radius fails somewhere)"""
+    rng = np.random.default_rng(7)
+    seen = 0.0
+    for _ in range(300):
+        T, p, controls = random_problem(rng, 'cancel')
+        ratio, _, _ = node_check(T, p, controls, False)
+        seen = max(seen, ratio)
+    assert seen > 1e-3, seen
