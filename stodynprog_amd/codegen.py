@@ -733,14 +733,15 @@ def column_config(n0, w, n_state, dtype, wpair=False, filtered=False, max_contro
         # (threads, lds_bytes, rows of the shifted lattice): as many rows as LDS has room for beside the table
         # and the control table while two workgroups share a CU -- at least n0 + n0 / 8, so that
         # shifts spread over an eighth of the axis still fit --, else one workgroup per CU and 2 n0 rows
-        for per_cu in (2, 1):
+        # (`wres`: the resident-chunk form -- the table holds that many points -- may get a third workgroup per CU)
+        for per_cu in ((3, 2, 1) if wres else (2, 1)):
             for threads in sizes:
-                if per_cu == 2 and threads > 512:
+                if per_cu >= 2 and threads > 512:
                     continue
-                base = _column_lds(tw, w, n0, n_state, rs, threads, shift=True, shift_rows=0, utab_values=utab_values)
+                base = _column_lds(int(wres) or tw, w, n0, n_state, rs, threads, shift=True, shift_rows=0, utab_values=utab_values)
                 rows = min(2 * int(n0) + 16, (COLUMN_LDS_MAX // per_cu - base - 1024) // (2 * rs))
                 if rows >= int(n0) + max(8, int(n0) // 8):
-                    return (threads, _column_lds(tw, w, n0, n_state, rs, threads, shift=True, shift_rows=rows,
+                    return (threads, _column_lds(int(wres) or tw, w, n0, n_state, rs, threads, shift=True, shift_rows=rows,
                                                  utab_values=utab_values), int(rows))
         return None
     for threads in sizes:
@@ -763,7 +764,7 @@ def column_resident_points(model, n0, w, n_state, dtype, filtered, shift, wpair,
     see the perturbation, one lane per node.  (`debug`: SDP_COL_WRES = 0 switches it off, k > 0 forces k.)"""
     rs = np.dtype(dtype).itemsize
     w = int(w)
-    ok = (filtered and rs == 8 and not shift and not wpair and not model.cost_depends_on_w and w >= 4
+    ok = (filtered and rs == 8 and not wpair and not model.cost_depends_on_w and w >= 4
           and int(threads) >= int(n0) and _dbg(debug, 'SDP_COL_LEAN', '-1') != '0')
     forced = _dbg(debug, 'SDP_COL_WRES')
     if forced is not None:
@@ -771,9 +772,17 @@ def column_resident_points(model, n0, w, n_state, dtype, filtered, shift, wpair,
         return k if (ok and 0 < k < w and 2 * k >= w) else 0
     if not ok:
         return 0
-    whole = _column_lds(w, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
     half = (w + 1) // 2
-    part = _column_lds(half, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
+    if shift:
+        # (the shifted lattice sits beside the table: ask the planner of that image)
+        both = [column_config(n0, w, n_state, dtype, wpair, True, shift=True, utab_values=utab_values, debug=debug, wres=k)
+                for k in (0, half)]
+        if None in both:
+            return 0
+        whole, part = both[0][1], both[1][1]
+    else:
+        whole = _column_lds(w, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
+        part = _column_lds(half, w, n0, n_state, rs, threads, reduced=True, utab_values=utab_values)
     if COLUMN_LDS_MAX // whole < 3 <= COLUMN_LDS_MAX // part:
         return half if RESIDENT_CHUNKS_DEFAULT else 0
     return 0

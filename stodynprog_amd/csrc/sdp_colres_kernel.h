@@ -23,52 +23,83 @@
 // candidates from global memory (sdp_col_cost_global: the same operations), which needs no table at all.
 //
 // One lane per node (SDP_COL_THREADS >= SDP_COL_N0); 8-byte lean first pass (with or without the control table);
-// the perturbation reaches neither the stock nor the cost; plain table layout, exact arithmetic.
+// the perturbation does not reach the cost; plain table layout, exact arithmetic.
+// The perturbation may reach the stock through final sums (SDP_COL_SHIFT, the filter on the shifted lattice of
+// sdp_col_shift_reduce): the reduced table is then accumulated chunk by chunk into the same lattice (its LDS atomics
+// do not care in how many pieces the points arrive), the second pass locates the cell along axis 0 per perturbation
+// point as sdp_col_expected_cost does, and a node with exactly TWO survivors -- one in a hundred on the benchmark
+// problem with noise in the stock, hence about every other wave -- carries both through the rebuild.
 #pragma once
 
-static_assert(SDP_COL_LEAN_ON && !SDP_COL_WIDE_ON && !SDP_COL_TOP2, "resident chunks: the lean first pass of 8-byte reals");
+static_assert(SDP_COL_LEAN_ON && !SDP_COL_WIDE_ON, "resident chunks: the lean first pass of 8-byte reals");
+static_assert(!SDP_COL_TOP2 || SDP_COL_SHIFT, "resident chunks: two carried survivors only on the shifted lattice");
 static_assert(SDP_COL_WRES >= 1 && 2 * SDP_COL_WRES >= SDP_COL_W, "resident chunks: at least half of the points resident");
+constexpr int SDP_COLRES_K = SDP_COL_TOP2 ? 2 : 1;        // survivors a lane can carry through the rebuild of the tail
 
-// The reference's operations for ONE control over the perturbation points [w_lo, w_hi) (table rows w - t_base),
-// `acc` carried from call to call: what sdp_col_expected_cost<1> does for those points.
-SDP_DEV void sdp_colres_partial(const sdp_real *T, const SdpColWeights &k, const int w_lo, const int w_hi, const int t_base,
-                                int q0, sdp_real lam0, sdp_real oml0, sdp_real g, sdp_real &acc)
+// cell of x0' along axis 0 of one control for the perturbation point value `wv`, as sdp_col_expected_cost computes it (pyx:75-81)
+SDP_DEV void sdp_colres_cell(const SdpLeadAxis &l, const sdp_real *x, const sdp_real *u, sdp_real wv, sdp_real t,
+                             int &q0, sdp_real &lam0, sdp_real &oml0)
 {
-    constexpr int N0 = SDP_COL_ROWS;
-    constexpr int B = SDP_COL_BATCH;
-    // (two separate 8-byte reads per cell, kept apart by `volatile`: see sdp_col_expected_cost)
-    const volatile sdp_lds_real *row = (const volatile sdp_lds_real *)(T + q0);
-#pragma unroll SDP_COL_UNROLL_W
-    for (int w0 = w_lo; w0 < w_hi; w0 += B) {
-        sdp_real lo[B], hi[B];
-#pragma unroll
-        for (int b = 0; b < B; ++b)
-            if (w0 + b < w_hi) {
-                lo[b] = row[(w0 + b - t_base) * N0];
-                hi[b] = row[(w0 + b - t_base) * N0 + 1];
-            }
-#pragma unroll
-        for (int b = 0; b < B; ++b)
-            if (w0 + b < w_hi) {
-                const sdp_real pw = SDP_COL_PW(k, w0 + b);
-                const sdp_real val = oml0 * lo[b] + lam0 * hi[b];     // pyx:88-300
-                const sdp_real jc = g + val;                          // stodynprog.py:677
-                acc = acc + jc * pw;                                  // stodynprog.py:681, w order
-            }
-    }
-}
-
-// cell of x0' along axis 0 and the cost of one control, as sdp_col_expected_cost computes them (pyx:75-81)
-SDP_DEV void sdp_colres_locate(const SdpLeadAxis &l, const sdp_real *x, const sdp_real *u, sdp_real t,
-                               int &q0, sdp_real &lam0, sdp_real &oml0, sdp_real &g)
-{
-    const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
+    const sdp_real xn0 = sdp_model_lead(x, u, wv, t);
     const sdp_real sn = sdp_div_span<sdp_real>(xn0 - l.smin, l.span, l.rspan, l.pow2);   // pyx:75
     const sdp_real p = sn * l.nm1;
     q0 = max(min(sdp_trunc_i32(p), l.ordm2), 0);                                         // pyx:78
     lam0 = p - (sdp_real)q0;                                                             // pyx:81
     oml0 = (sdp_real)1 - lam0;
-    g = sdp_model_cost(x, u, (sdp_real)0, t);
+}
+
+// What a lane carries of its surviving controls from the second pass over the head to the one over the tail
+struct SdpColresCand {
+    sdp_real u[SDP_COLRES_K][SDP_NU], g[SDP_COLRES_K], acc[SDP_COLRES_K];
+    sdp_real lam0[SDP_COLRES_K], oml0[SDP_COLRES_K];       // (a stock the perturbation does not reach: located once)
+    int q0[SDP_COLRES_K], idx[SDP_COLRES_K];
+    int n;                                                 // 0 (decided already), 1 or 2
+};
+
+// The reference's operations for K controls over the perturbation points [w_lo, w_hi) (table rows w - t_base), the
+// expectations `acc` carried from call to call: what sdp_col_expected_cost<K> does for those points, chains interleaved.
+template <int K>
+SDP_DEV void sdp_colres_partial(const sdp_real *T, const SdpColWeights &k, const SdpLeadAxis &l, const sdp_real *x,
+                                sdp_real t, const int w_lo, const int w_hi, const int t_base, SdpColresCand &c)
+{
+    constexpr int N0 = SDP_COL_ROWS;
+    constexpr int B = SDP_COL_BATCH;
+    // (two separate 8-byte reads per cell, kept apart by `volatile`: see sdp_col_expected_cost)
+    const volatile sdp_lds_real *tab = (const volatile sdp_lds_real *)T;
+#pragma unroll SDP_COL_UNROLL_W
+    for (int w0 = w_lo; w0 < w_hi; w0 += B) {
+        sdp_real lo[B][K], hi[B][K];
+#if SDP_LEAD_HAS_W
+        sdp_real lam_b[B][K], oml_b[B][K];
+#endif
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (w0 + b < w_hi) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+#if SDP_LEAD_HAS_W
+                    sdp_colres_cell(l, x, c.u[j], SDP_COL_GW(k, w0 + b), t, c.q0[j], lam_b[b][j], oml_b[b][j]);
+#endif
+                    lo[b][j] = tab[(w0 + b - t_base) * N0 + c.q0[j]];
+                    hi[b][j] = tab[(w0 + b - t_base) * N0 + c.q0[j] + 1];
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (w0 + b < w_hi) {
+                const sdp_real pw = SDP_COL_PW(k, w0 + b);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+#if SDP_LEAD_HAS_W
+                    const sdp_real val = oml_b[b][j] * lo[b][j] + lam_b[b][j] * hi[b][j];
+#else
+                    const sdp_real val = c.oml0[j] * lo[b][j] + c.lam0[j] * hi[b][j];     // pyx:88-300
+#endif
+                    const sdp_real jc = c.g[j] + val;                                  // stodynprog.py:677
+                    c.acc[j] = c.acc[j] + jc * pw;                                     // stodynprog.py:681, w order
+                }
+            }
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
@@ -121,12 +152,19 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         if (!a.box_per_node) { sdp_load_box(a, 0, box_hold); box_c = &box_hold; }
         if (lane < Wn) { w_hold = ((const sdp_real *)a.wgrid)[lane]; w_mine = &w_hold; }
     }
-    if (unit < u_end) {                                    // trailing cells (and control table) of the first unit
+#if SDP_COL_SHIFT
+    if (threadIdx.x < 2) sdp_col_shift_reset(sdp_lds, threadIdx.x);
+    __syncthreads();
+#endif
+    if (unit < u_end) {                                    // trailing cells (and control table, shifts) of the first unit
         sdp_real xn[SDP_D];
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
         sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 0, box_c);
+#endif
+#if SDP_COL_SHIFT
+        sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
 #endif
     }
     while (unit < u_end) {
@@ -141,8 +179,17 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         __syncthreads();                                   // the previous unit has left the table; this unit's cells are published
         int nx = 0;
         if (wave == waves - 1 && lane == 0) nx = (int)atomicAdd(claim, 1u);      // (its round trip hides under the builds)
+#if SDP_COL_SHIFT
+        if (threadIdx.x == 0) sdp_col_shift_reset(sdp_lds, upar ^ 1);            // (its readers left at the barrier above)
+        SdpColShiftCol shc;
+        sdp_col_shift_col(sdp_lds, lead, upar, shc);
+        sdp_col_shift_zero(sdp_lds, shc);
+#endif
         sdp_col_phase_a<false>(a, tg, s, C, R);
         __syncthreads();
+#if SDP_COL_SHIFT
+        sdp_col_shift_reduce(a, sdp_lds, filt, shc, parity, upar, C, R);         // (adds into the cleared lattice)
+#else
         sdp_real acc_t = (sdp_real)0, big = (sdp_real)0;
         if (r < N0) {
 #pragma unroll SDP_COL_FILTER_RUNROLL
@@ -152,12 +199,16 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 big = sdp_vmax_abs(big, v);
             }
         }
+#endif
         __syncthreads();                                   // the tail has been read
         // ---- head of the table, the reduced table
         sdp_col_phase_a<false>(a, tg, s, 0, C);
         if (wave == waves - 1 && lane == 0) sdp_lds.next_unit = nx;
         __syncthreads();
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
+#if SDP_COL_SHIFT
+        sdp_col_shift_reduce(a, sdp_lds, filt, shc, parity, upar, 0, C);
+#else
         {
             sdp_real dmax = (sdp_real)0;
             if (r < N0) {
@@ -176,20 +227,37 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             dmax = sdp_wave_max(dmax);
             if (lane == 0) atomicMax(&sdp_lds.dcol[parity], (unsigned long long)__double_as_longlong((double)dmax));
         }
+#endif
+        (void)r;
         __syncthreads();                                   // A[r] and the column's bound are complete
         const sdp_real dcol = sdp_col_filter_dcol(sdp_lds, parity);
         parity ^= 1;
         const int64_t next_unit = u_base + sdp_lds.next_unit;
         // ---- first pass (every control of this lane's node), second pass over the head
+        // the axis the FIRST pass locates its positions on: axis 0, or the shifted lattice of this column
+        SdpLeadAxis lead1 = lead;
+#if SDP_COL_SHIFT
+        lead1.koff = (sdp_real)shc.kmin;
+        lead1.ordm2 = shc.ok ? shc.rows - 2 : 0;
+#endif
         const int i = i_lo + (int)threadIdx.x;
         const bool live = i < i_hi;
         const int64_t node = col * N0 + (live ? i : i_hi - 1);
         SdpBox box;
         if (box_c) box = *box_c;
         else sdp_load_box(a, node, box);
-        sdp_real best = INFINITY, acc = (sdp_real)0, lam0 = (sdp_real)0, oml0 = (sdp_real)0, g = (sdp_real)0;
-        int ibest = INT_MAX, q0 = 0;
-        bool single = false;
+        sdp_real best = INFINITY;
+        int ibest = INT_MAX;
+        SdpColresCand cd;                                  // survivors this lane carries through the rebuild, in lattice order
+        cd.n = 0;
+#pragma unroll
+        for (int j = 0; j < SDP_COLRES_K; ++j) {
+            cd.acc[j] = cd.g[j] = cd.lam0[j] = cd.oml0[j] = (sdp_real)0;
+            cd.q0[j] = 0;
+            cd.idx[j] = INT_MAX;
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c) cd.u[j][c] = (sdp_real)0;
+        }
         if (live) {
             x[0] = axis0[i];
             SdpColBounds bd;
@@ -199,28 +267,45 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             const sdp_real *utab = sdp_lds.utab[upar];
             const bool plain = SDP_NU == 1 && box.n[0] > 1 && box.step[0] != (sdp_real)0;
             if (plain) {
-                if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
-                else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
-                else sdp_col_filter_pass1<true, 0>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+                if (axis_mode == 2) sdp_col_filter_pass1<true, 2>(sdp_lds.ad, utab, filt, lead1, box, x, t, 0, box.total, bd);
+                else if (axis_mode == 1) sdp_col_filter_pass1<true, 1>(sdp_lds.ad, utab, filt, lead1, box, x, t, 0, box.total, bd);
+                else sdp_col_filter_pass1<true, 0>(sdp_lds.ad, utab, filt, lead1, box, x, t, 0, box.total, bd);
             } else {
-                if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
-                else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
-                else sdp_col_filter_pass1<false, 0>(sdp_lds.ad, utab, filt, lead, box, x, t, 0, box.total, bd);
+                if (axis_mode == 2) sdp_col_filter_pass1<false, 2>(sdp_lds.ad, utab, filt, lead1, box, x, t, 0, box.total, bd);
+                else if (axis_mode == 1) sdp_col_filter_pass1<false, 1>(sdp_lds.ad, utab, filt, lead1, box, x, t, 0, box.total, bd);
+                else sdp_col_filter_pass1<false, 0>(sdp_lds.ad, utab, filt, lead1, box, x, t, 0, box.total, bd);
             }
-            // the radius of the lean first pass: sdp_col_lean_core
+            // the radius of the lean first pass (sdp_col_lean_core), on the shifted lattice with its H and B' (sdp_col_shift_reduce)
+#if SDP_COL_SHIFT
+            const sdp_real h_cap = (((sdp_real)1 + (sdp_real)2 * (bd.p_max + shc.lc)) * ((sdp_real)3 + shc.es)) * dcol;
+            const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
+            const bool bad = !filt.ok || !shc.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max + shc.lc < (sdp_real)1073741824.0);
+            const sdp_real radius = fma(filt.cu, s_node, (sdp_real)(SDP_COL_FILTER_SCALE) * bd.b_max);
+#else
             const sdp_real h_cap = ((sdp_real)1 + (sdp_real)2 * bd.p_max) * dcol;        // (1 + 2L) D
             const sdp_real s_node = fma(filt.ratio, bd.s_sum + h_cap, h_cap);
             const bool bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
             const sdp_real radius = filt.cu * s_node;
+#endif
             const sdp_real m_hi = bd.f1 + radius;              // >= the minimum of E over the node
-            single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
-            if (single) {
-                // the one survivor IS the reference's argmin: its cell and cost once, its cells of the head
-                sdp_real u[SDP_NU];
-                sdp_controls_at(box, bd.i1, u);
-                ibest = bd.i1;
-                sdp_colres_locate(lead, x, u, t, q0, lam0, oml0, g);
-                sdp_colres_partial(sdp_lds.T, wts, 0, C, 0, q0, lam0, oml0, g, acc);
+            const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
+            // exactly two survivors (the lattice points either side of the continuous optimum): both carried
+            const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
+            if (single || pair) {
+                // the survivors ARE the only candidates for the reference's argmin
+                // (their controls, cost and -- a stock the perturbation does not reach -- cell: once)
+                cd.n = single ? 1 : 2;
+                cd.idx[0] = single ? bd.i1 : min(bd.i1, bd.i2);
+                if (SDP_COLRES_K > 1) cd.idx[SDP_COLRES_K - 1] = single ? bd.i1 : max(bd.i1, bd.i2);
+                else ibest = bd.i1;
+#pragma unroll
+                for (int j = 0; j < SDP_COLRES_K; ++j) {
+                    sdp_controls_at(box, cd.idx[j], cd.u[j]);
+                    cd.g[j] = sdp_model_cost(x, cd.u[j], (sdp_real)0, t);
+#if !SDP_LEAD_HAS_W
+                    sdp_colres_cell(lead, x, cd.u[j], (sdp_real)0, t, cd.q0[j], cd.lam0[j], cd.oml0[j]);
+#endif
+                }
             } else {
                 // near-ties or special values: the candidates (all controls of a marked node) the long way, from
                 // global memory -- the same operations, no table needed -- compared like the reference compares
@@ -230,8 +315,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                     bool cand = bad;
                     if (!cand) {
                         sdp_real F, pm = (sdp_real)0, gm = (sdp_real)0, bm = (sdp_real)0;
-                        if (lead.pow2) sdp_col_lean_eval<1>(sdp_lds.ad, filt, lead, x, u, t, F, pm, gm, bm);
-                        else sdp_col_lean_eval<0>(sdp_lds.ad, filt, lead, x, u, t, F, pm, gm, bm);
+                        if (lead.pow2) sdp_col_lean_eval<1>(sdp_lds.ad, filt, lead1, x, u, t, F, pm, gm, bm);
+                        else sdp_col_lean_eval<0>(sdp_lds.ad, filt, lead1, x, u, t, F, pm, gm, bm);
                         cand = !(F - radius > m_hi);
                     }
                     if (cand) {
@@ -241,6 +326,10 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 }
             }
         }
+        // (the lanes of a wave run the same code: two chains where any lane carries two survivors)
+        const bool two = SDP_COLRES_K > 1 && __any(cd.n == 2);
+        if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
+        else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
         __syncthreads();                                   // the head has been read
         // ---- the tail again, second pass over it
         __builtin_amdgcn_s_setprio(0);
@@ -257,12 +346,19 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_UTAB
                 sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c);
 #endif
+#if SDP_COL_SHIFT
+                sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);
+#endif
             }
         }
+        if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
+        else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
         if (live) {
-            if (single) {
-                sdp_colres_partial(sdp_lds.T, wts, C, Wn, C, q0, lam0, oml0, g, acc);
-                best = acc;
+            // the carried survivors in lattice order, compared like the reference compares
+#pragma unroll
+            for (int j = 0; j < SDP_COLRES_K; ++j) {
+                if (SDP_COLRES_K == 1) { if (cd.n) best = cd.acc[0]; }          // (its index is in ibest already)
+                else if (j < cd.n && (ibest == INT_MAX || sdp_better_seq(cd.acc[j], best))) { best = cd.acc[j]; ibest = cd.idx[j]; }
             }
             sdp_col_store(a, node, box, best, ibest);
         }
@@ -318,19 +414,26 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
             const int i = i0 + (int)threadIdx.x;
             const bool live = i < i_hi;
             const int64_t node = col * N0 + (live ? i : i_hi - 1);
-            sdp_real u[SDP_NU], acc = (sdp_real)0, lam0, oml0, g;
-            int q0;
+            SdpColresCand cd;
+            cd.n = 1;
+            cd.acc[0] = (sdp_real)0;
+            cd.idx[0] = 0;
             x[0] = axis0[live ? i : i_hi - 1];
 #pragma unroll
-            for (int c = 0; c < SDP_NU; ++c) u[c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
-            sdp_colres_locate(lead, x, u, t, q0, lam0, oml0, g);
+            for (int c = 0; c < SDP_NU; ++c) cd.u[0][c] = ((const sdp_real *)a.pol_in)[node * SDP_NU + c];
+            cd.g[0] = sdp_model_cost(x, cd.u[0], (sdp_real)0, t);
+            cd.q0[0] = 0; cd.lam0[0] = cd.oml0[0] = (sdp_real)0;
+#if !SDP_LEAD_HAS_W
+            sdp_colres_cell(lead, x, cd.u[0], (sdp_real)0, t, cd.q0[0], cd.lam0[0], cd.oml0[0]);
+#endif
             for (int w0 = 0; w0 < Wn; w0 += C) {
                 const int cnt = min(C, Wn - w0);
                 __syncthreads();                           // the cells are published / the previous chunk has been read
                 sdp_col_phase_a<true>(a, tg, s, w0, cnt);
                 __syncthreads();
-                if (live) sdp_colres_partial(sdp_lds.T, wts, w0, w0 + cnt, w0, q0, lam0, oml0, g, acc);
+                sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, w0, w0 + cnt, w0, cd);
             }
+            const sdp_real acc = cd.acc[0];
             if (live) sdp_store_J<sdp_real>(a, node, col, acc);
         }
     }

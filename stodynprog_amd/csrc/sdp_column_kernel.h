@@ -196,7 +196,7 @@
 // the same order: same bits.
 #define SDP_COL_WRES SDP_COL_W
 #endif
-#if SDP_COL_WRES < SDP_COL_W && (!SDP_COL_FILTER || SDP_COL_SHIFT || SDP_COL_WPAIR || SDP_COST_HAS_W || SDP_COL_FUSED || \
+#if SDP_COL_WRES < SDP_COL_W && (!SDP_COL_FILTER || SDP_COL_WPAIR || SDP_COST_HAS_W || SDP_COL_FUSED || \
                                  SDP_COL_ROWS < SDP_COL_N0 || SDP_COL_THREADS < SDP_COL_N0 || 2 * SDP_COL_WRES < SDP_COL_W)
 #error "SDP_COL_WRES: lean filtered kernel, plain full-column table, one lane per node, at least half of the points resident"
 #endif
@@ -1518,8 +1518,11 @@ SDP_DEV void sdp_col_shift_zero(SdpColLds &m, const SdpColShiftCol &c)
 // lane and block): the positions rarely fill a whole number of thread-per-position rounds, the (block, w)
 // items do.  Blocks whose positions stay inside the axis for every perturbation point -- all but the first
 // and the last ones -- skip the clamps.
+// (w_lo, w_cnt: the perturbation points held by table rows 0 .. w_cnt-1 -- all of them by default; the resident-chunk
+// kernel adds the points to the lattice a part of the table at a time)
 SDP_DEV void sdp_col_shift_reduce(const SdpSweepArgs &a, SdpColLds &m, const SdpColFilter &f,
-                                  const SdpColShiftCol &c, int parity, int par)
+                                  const SdpColShiftCol &c, int parity, int par, const int w_lo = 0,
+                                  const int w_cnt = SDP_COL_W)
 {
     constexpr int N0 = SDP_COL_N0;
     if (!c.ok) return;
@@ -1527,10 +1530,11 @@ SDP_DEV void sdp_col_shift_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sdp
     const int lane = threadIdx.x & 63;
     // (compile-time trip counts; the shifts of a wave's perturbation points are fetched once, so that the table
     // reads of a block do not wait for them one after the other: the loop is bound by LDS latency, not by issue)
-    constexpr int waves = SDP_COL_THREADS / 64, rounds = (SDP_COL_W + waves - 1) / waves, CH = rounds < 8 ? rounds : 8;
+    constexpr int waves = SDP_COL_THREADS / 64, rounds_all = (SDP_COL_W + waves - 1) / waves, CH = rounds_all < 8 ? rounds_all : 8;
+    const int rounds = (w_cnt + waves - 1) / waves;
     sdp_trap_unless(blockDim.x == SDP_COL_THREADS);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave >= SDP_COL_W) return;
+    if (wave >= w_cnt) return;
     const int blocks = (c.rows + 63) >> 6;
     sdp_real dmax = (sdp_real)0;
     for (int i0 = 0; i0 < rounds; i0 += CH) {
@@ -1538,10 +1542,10 @@ SDP_DEV void sdp_col_shift_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sdp
         sdp_real tf[CH], tc[CH], tp[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int w = wave + (i0 + i) * waves;
-            const bool valid = w < SDP_COL_W;                          // (past the end: this wave's first point
-            const int wv = valid ? w : wave;                           //  again, with weights zero)
-            tq[i] = wv * N0 + __builtin_amdgcn_readfirstlane(m.sh_q[par][wv]);
+            const int w = w_lo + wave + (i0 + i) * waves;
+            const bool valid = w < w_lo + w_cnt;                       // (past the end: this wave's first point
+            const int wv = valid ? w : w_lo + wave;                    //  again, with weights zero)
+            tq[i] = (wv - w_lo) * N0 + __builtin_amdgcn_readfirstlane(m.sh_q[par][wv]);
             tf[i] = m.sh_f[par][wv];
             tc[i] = valid ? m.sh_c[par][wv] : (sdp_real)0;
             tp[i] = valid ? (sdp_real)p[wv] : (sdp_real)0;
@@ -1570,12 +1574,12 @@ SDP_DEV void sdp_col_shift_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sdp
             } else {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    const int w = min(wave + (i0 + i) * waves, SDP_COL_W - 1);
-                    const int wrow = w < wave + (i0 + i) * waves ? wave : w;
-                    const int j = k + (tq[i] - wrow * N0);
+                    const int wq = w_lo + wave + (i0 + i) * waves;
+                    const int trow = (wq < w_lo + w_cnt ? wq : w_lo + wave) - w_lo;        // table row of the point
+                    const int j = k + (tq[i] - trow * N0);
                     const int q = max(min(j, N0 - 2), 0);
                     const sdp_real lam = (sdp_real)(j - q) + tf[i];
-                    const sdp_real *row = m.T + wrow * N0 + q;
+                    const sdp_real *row = m.T + trow * N0 + q;
                     const sdp_real t0 = row[0], t1 = row[1], t2 = row[q + 2 < N0 ? 2 : 1];
                     acc = fma(tp[i], fma(lam, t1 - t0, t0), acc);
                     const sdp_real d2 = (t2 - t1) - (t1 - t0);

@@ -272,3 +272,78 @@ def test_near_ties_keep_the_bits_at_the_proven_radius_and_at_half_of_it(gpu, deb
         _same(on, off)
         if tilt == 0.0:                          # (the case is what it claims to be: no clear winner)
             assert len(np.unique(off[2])) > 3
+
+
+# ---------------------------------------------------------------------------
+# Round 4: the shifted lattice in the resident-chunk kernel (csrc/sdp_colres_kernel.h): the table holds half of the
+# perturbation points at a time, the lattice is accumulated in two pieces, the second pass locates its cell per
+# perturbation point and carries up to TWO survivors through the rebuild of the tail.  Forced here on small
+# problems (the planner picks it where the whole table leaves fewer than three workgroups per CU).
+# ---------------------------------------------------------------------------
+def _chunked(debug_defines, make, V, k, sweeps=1):
+    debug_defines.set(SDP_COL_WRES=str(k))
+    try:
+        out = _sweep(make, True, V, sweeps=sweeps)
+        src = out[3]._kernel_plan()['source']
+        assert '#define SDP_COL_WRES {}'.format(k) in src and '#define SDP_COL_SHIFT 1' in src
+    finally:
+        debug_defines.unset('SDP_COL_WRES')
+    return out
+
+
+@pytest.mark.parametrize('case', ['smooth', 'rough', 'box_on_state', 'plus', 'leaves_the_grid', 'wide_shifts',
+                                  'shifts_beyond_the_lattice', 'nan', 'inf', 'huge', 'constant', 'benchmark'])
+def test_resident_chunks_on_the_shifted_lattice_give_the_same_bits(gpu, debug_defines, case):
+    sweeps, k = 1, 4                                     # 7 points: 4 resident, 3 built twice
+    if case == 'benchmark':
+        make, k, sweeps = (lambda: models.synthetic3d(N=24, stock_noise=0.07)), 16, 2
+        V = models.synthetic3d_V0(make()[1].state_grid)
+    else:
+        kw = {}
+        if case == 'box_on_state':
+            kw = dict(box_on_state=True)
+        elif case == 'plus':
+            kw = dict(sign=1)
+        elif case == 'leaves_the_grid':
+            kw = dict(x_range=(0., 8.))
+        elif case == 'wide_shifts':
+            kw = dict(w_gain=8.0)
+        elif case == 'shifts_beyond_the_lattice':
+            kw = dict(w_gain=40.0)                         # more rows than LDS holds: the column takes the long way
+        make = lambda: _shop(**kw)
+        s = make()[1]
+        V = _smooth(s)
+        rng = np.random.default_rng(3)
+        if case == 'rough':
+            V = rng.standard_normal(s._state_grid_shape)
+        elif case == 'nan':
+            V[10:14, 2:5] = np.nan
+        elif case == 'inf':
+            V[40:, :] = np.inf
+        elif case == 'huge':
+            V = V * 1e302
+        elif case == 'constant':
+            V = np.full(s._state_grid_shape, 2.5)
+    plain, off = _sweep(make, True, V, sweeps=sweeps), _sweep(make, False, V, sweeps=sweeps)
+    res = _chunked(debug_defines, make, V, k, sweeps)
+    assert res[3].backend_info['filter_form'] == 'shifted lattice'
+    _same(res, plain)
+    _same(res, off)
+
+
+@pytest.mark.parametrize('scale', [None, '0.5', '1e9'])
+def test_resident_chunks_carry_two_survivors(gpu, debug_defines, scale):
+    """an objective flat in the control (near-ties: nodes with exactly two survivors, and with many) at the proven
+    radius, at half of it and at a radius that leaves every control standing"""
+    for tilt in (0.0, 1e-15, 1e-13):
+        make = lambda: _flat_shop(tilt)[:2]
+        V = _flat_shop(tilt)[2]
+        off = _sweep(make, False, V)
+        if scale:
+            debug_defines.set(SDP_COL_FILTER_SCALE=scale)
+        try:
+            res = _chunked(debug_defines, make, V, 4)
+        finally:
+            if scale:
+                debug_defines.unset('SDP_COL_FILTER_SCALE')
+        _same(res, off)
