@@ -34,12 +34,13 @@ DEBUG_INT_MACROS = ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_
                     'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO',
                     'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE',
                     'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP', 'SDP_COL_LDS_PAD', 'SDP_COL_HOIST')
+# (SDP_COL_LEAN2 = 0 keeps the resident-chunk kernel on the first pass of section 3.1c: an A/B switch of short_pass_source)
 # (SDP_COL_WRES is a planning switch: it sizes the LDS image -- column_config)
 # every name a `debug` dict may carry (a typo must not pass silently)
 DEBUG_NAMES = frozenset(DEBUG_INT_MACROS + (
     'SDP_STAMP', 'SDP_NO_POW2', 'SDP_EXTRA_DEFINES', 'SDP_COL_FILTER_SCALE', 'SDP_LEAD_FILTER_SCALE',
     'SDP_LEAD_UNROLL', 'SDP_COL_A_LW', 'SDP_COL_FILTER', 'SDP_COL_SHIFT', 'SDP_COL_UTAB', 'SDP_LEAD_FILTER',
-    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES'))
+    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES', 'SDP_COL_LEAN2'))
 
 
 def check_debug(debug):
@@ -370,6 +371,32 @@ def control_table_source(model, frontier):
     return '\n\n'.join(out)
 
 
+def short_pass_source(model, frontier):
+    """C++ text for the short first pass of the resident-chunk kernel (SDP_COL_LEAN2 of csrc/sdp_colres_kernel.h), or
+    None when the model does not have the shape: x0' = X(x, t) +- a, cost = K(x, t) +- h with a, h in the control
+    table (TracedModel.additive_control_split).  X and K as functions of the node alone, the slots of a and h, and
+    how they enter."""
+    sp = model.additive_control_split(frontier)
+    if sp is None:
+        return None
+    (x_node, a_slot, a_form), (k_node, h_slot, h_form) = sp['lead'], sp['cost']
+    out = ['#define SDP_COL_LEAN2 1          // x0\' = X(x) +- a(u), cost = K(x) +- h(u): the short first pass',
+           '#define SDP_LEAN2_A_SLOT {}'.format(int(a_slot)),
+           '#define SDP_LEAN2_H_SLOT {}'.format(-1 if h_slot is None else int(h_slot)),
+           '#define SDP_LEAN2_LEAD(X, A) {}'.format({'add': '((X) + (A))', 'sub': '((X) - (A))', 'rsub': '((A) - (X))'}[a_form]),
+           '#define SDP_LEAN2_HNEG {}           // the part of the cost that depends on the control enters negated (K - h)'.format(
+               1 if (h_slot is not None and h_form == 'sub') else 0)]
+    for fname, node in (('sdp_model_lead_x', x_node), ('sdp_model_cost_x', k_node)):
+        lines = ['SDP_DEV sdp_real {}(const sdp_real *x, sdp_real t)'.format(fname), '{', '    (void)x; (void)t;']
+        if node is None:
+            lines += ['    return (sdp_real)0;', '}']
+        else:
+            names = _emit_body(model, model.slice_nodes([node]), lines)
+            lines += ['    return {};'.format(names[node.id]), '}']
+        out.append('\n'.join(lines))
+    return '\n'.join(out)
+
+
 def lanes_for(max_controls):
     """Lanes per state node: the power of two covering the largest control
     lattice, capped at the 64 lanes of a wavefront."""
@@ -463,6 +490,10 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
         lines += ['#define SDP_COL_UTAB {}'.format(len(utab[0])),
                   '#define SDP_COL_UTAB_N {}'.format(int(utab[1])),
                   control_table_source(model, utab[0]), '']
+        short = short_pass_source(model, utab[0]) if (wres and rs == 8 and not shifted and _dbg(debug, 'SDP_COL_LEAN') != '0'
+                                                      and _dbg(debug, 'SDP_COL_LEAN2') != '0') else None
+        if short:
+            lines += [short, '']
     lines += ['#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h', '']
     return lines
 
@@ -846,7 +877,7 @@ def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False, s
                (rs, part, rs), (4, part, 4),                 # part_J, part_i
                (4, w * dt, 4),                               # w_off
                (4, 4, 4), (4, 1, 4), (8, 2, 8),              # win, next_unit, dcol
-               (rs, 2 * (int(utab_values) or 2), 16)]        # utab[2][..]
+               (rs, 2 * (int(utab_values) + 4 if utab_values else 2), 16)]        # utab[2][.. + 4 column statistics]
     if reduced or shift:
         per_row = 4 if rs == 4 else (2 if shift else 1)      # SDP_COL_LDS_AD (8-byte reals: the lean form is the default)
         members.append((rs, per_row * int(shift_rows if shift else rows), 16))    # ad

@@ -102,6 +102,98 @@ SDP_DEV void sdp_colres_partial(const sdp_real *T, const SdpColWeights &k, const
     }
 }
 
+#if SDP_COL_LEAN2
+// ---------------------------------------------------------------------------
+// The short first pass (generated where x0' = X(x) +- a and cost = K(x) +- h, a and h entries of the column's control
+// table: codegen.short_pass_source).  Vector issue binds this kernel and the first pass is half of its instructions
+// (DESIGN.md section 3.1e), so it sheds what need not be per control:
+//   * K does not change the argmin over the controls of a node: the pass orders  F' = fma(+-h, psum, lerp)  -- an
+//     approximation of E - K P*, P* the exact sum of the weights -- instead of F (one addition less);
+//   * |g| <= (|K| + max |h|)(1 + u), max |h| of the column from sdp_col_phase_u, replaces the running sum of the |F|
+//     as the bound on the cost (one addition less), and S_node = Pcap (|K| + max |h|) + (1 + 2 L) D bounds
+//     |g| Pcap + (1 + 2 |lam0|) D of section 3.1c directly;
+//   * x0' is monotone in a, and so is every rounded step from it to the position p (a sum with X, a difference with
+//     smin, a division by / product with positive numbers): the positions of all controls lie between those of the
+//     column's smallest and largest a, so L = max(1, |lam0| at either end) >= every |lam0| of the node (one maximum less);
+//   * the control's index rides in the low `bits` mantissa bits of F' (bits = ceil(log2(controls))), so the running
+//     minimum carries it: no compare, no select.  That moves F' by < 2^bits ulp <= 2^(bits+1) u |F'| <= 2^(bits+1) u
+//     S_node (1 + 3u)  (|F'| <= |h| |psum| + (1 + 2L) D (1 + 3u)).
+// Error: |E - R| as before; R - K P* = (g - K) P* + lerp*, g = fl(K +- h) so |(g - K) -+ h| <= u (|K| + |h|);
+// F' against +-h P* + lerp*: (W-1) u |h| P for psum, the lerp's terms as in 3.1c, one rounding of the outer fma.  In sum
+//     |E - K P* - F'| <= (2W+8) u [ (|K| + |h|)(1 + u) P + (1 + 2 |lam0|) D ]  <=  (2W+8) u S_node (1 + 2u)
+// and the radius (cu + 2^(bits+2) u) S_node, cu = 4 (W+8) u, covers it with the same factor 2 to spare, the packing
+// with its own.  What is not finite: a or h (poisoned statistics: sdp_col_phase_u), K, the table (D), X (L) -- each
+// makes S_node or L fail its test and the node `bad`; and S_node < 2^1000 keeps every F' finite (|lam0 (A1 - A0)| <= 2 L D),
+// so the packing never meets an infinity.  tests/test_filter_bound_exact.py checks the inequality in exact arithmetic.
+static_assert(!SDP_COL_SHIFT && !SDP_COST_HAS_W && !SDP_COL_TOP2 && SDP_COL_UTAB && sizeof(sdp_real) == 8,
+              "short first pass: 8-byte reals, control table, a perturbation that reaches neither the stock nor the cost");
+template <int AXIS>
+SDP_DEV void sdp_lean2_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_real &lam0)
+{
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);   // pyx:75
+    const sdp_real p = sn * l.nm1;
+    q0 = (int)p;                                            // (saturating conversion; NaN -> 0)
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // pyx:78
+    lam0 = p - (sdp_real)q0;                                // pyx:81
+}
+template <int AXIS>
+SDP_DEV sdp_real sdp_lean2_value(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                                 sdp_real X, int ci)
+{
+    int q0;
+    sdp_real lam0;
+    sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, utab[ci * SDP_COL_UTAB + SDP_LEAN2_A_SLOT]), q0, lam0);
+    const sdp_real a0 = A[q0], a1 = A[q0 + 1];
+    const sdp_real h = fma(lam0, a1 - a0, a0);
+    if (SDP_LEAN2_H_SLOT < 0) return h;
+    const sdp_real hv = utab[ci * SDP_COL_UTAB + (SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT)];
+    return fma(SDP_LEAN2_HNEG ? -hv : hv, f.psum, h);
+}
+// the two smallest F' over the controls [0, n) of one node, the index of each in its low bits.
+// A group of SDP_LEAN2_GROUP controls at a time, in stages -- every cell first, then every read of the reduced table,
+// then the values: the reads of a group are in flight together (written control by control the compiler waits for
+// each read before it starts the next control's cell, and a wave spends its time in LDS latency: the pass was bound by
+// that, not by its instruction count -- removing a fifth of its instructions bought 2 %).
+#ifndef SDP_LEAN2_GROUP
+#define SDP_LEAN2_GROUP 4
+#endif
+template <int AXIS>
+SDP_DEV void sdp_lean2_pass1(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                             sdp_real X, int n, int mask, sdp_real &f1, sdp_real &f2)
+{
+    auto insert = [&](sdp_real F, int ci) {
+        const sdp_real Fp = __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci);
+        f2 = sdp_vmin(f2, sdp_vmax(f1, Fp));
+        f1 = sdp_vmin(f1, Fp);
+    };
+    constexpr int K = SDP_LEAN2_GROUP;
+    constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
+    int ci = 0;
+    for (; ci + K <= n; ci += K) {
+        int q0[K];
+        sdp_real av[K], lam0[K], hv[K], a0[K], a1[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            av[j] = utab[(ci + j) * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+            hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[(ci + j) * SDP_COL_UTAB + HS];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            a0[j] = A[q0[j]];
+            a1[j] = A[q0[j] + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const sdp_real h = fma(lam0[j], a1[j] - a0[j], a0[j]);
+            insert(SDP_LEAN2_H_SLOT < 0 ? h : fma(SDP_LEAN2_HNEG ? -hv[j] : hv[j], f.psum, h), ci + j);
+        }
+    }
+    for (; ci < n; ++ci) insert(sdp_lean2_value<AXIS>(A, utab, f, l, X, ci), ci);
+}
+#endif
+
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
     __shared__ SdpColLds sdp_lds;
@@ -161,7 +253,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
-        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 0, box_c);
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 64, box_c);      // (one wave: it also reduces the table's statistics)
 #endif
 #if SDP_COL_SHIFT
         sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
@@ -260,6 +352,37 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         }
         if (live) {
             x[0] = axis0[i];
+#if SDP_COL_LEAN2
+            const sdp_real *utab = sdp_lds.utab[upar];
+            const sdp_real *ust = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;          // a_lo, a_hi, max |h| (or NaN)
+            const sdp_real X = sdp_model_lead_x(x, t), K = sdp_model_cost_x(x, t);
+            const int bits = 32 - __clz(max(box.total - 1, 1));
+            const int mask = (1 << bits) - 1;
+            struct { sdp_real f1, f2; int i1, i2; } bd;
+            bd.f1 = bd.f2 = INFINITY;
+            bd.i2 = INT_MAX;
+            int q_e;
+            sdp_real lam_lo, lam_hi;
+            if (axis_mode == 2) {
+                sdp_lean2_pass1<2>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
+                sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            } else if (axis_mode == 1) {
+                sdp_lean2_pass1<1>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
+                sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            } else {
+                sdp_lean2_pass1<0>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
+                sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            }
+            bd.i1 = bd.f1 < (sdp_real)INFINITY ? (__double2loint(bd.f1) & mask) : INT_MAX;
+            const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
+            const sdp_real s_node = fma(filt.pcap, fabs(K) + ust[2], ((sdp_real)1 + (sdp_real)2 * l_cap) * dcol);
+            const bool bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(fabs(lam_lo) + fabs(lam_hi) < (sdp_real)1073741824.0) ||
+                             bits > 24 || box.total > SDP_COL_UTAB_N;
+            const sdp_real radius = (filt.cu + (sdp_real)(SDP_COL_FILTER_SCALE) * ldexp(SDP_COL_FILTER_EPS, bits + 1)) * s_node;
+#else
             SdpColBounds bd;
             bd.f1 = bd.f2 = bd.f3 = INFINITY;
             bd.s_max = bd.s_sum = bd.p_max = bd.b_max = (sdp_real)0;
@@ -287,10 +410,15 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             const bool bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)1073741824.0);
             const sdp_real radius = filt.cu * s_node;
 #endif
+#endif  // SDP_COL_LEAN2
             const sdp_real m_hi = bd.f1 + radius;              // >= the minimum of E over the node
             const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
             // exactly two survivors (the lattice points either side of the continuous optimum): both carried
+#if SDP_COL_LEAN2
+            const bool pair = false;
+#else
             const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
+#endif
             if (single || pair) {
                 // the survivors ARE the only candidates for the reference's argmin
                 // (their controls, cost and -- a stock the perturbation does not reach -- cell: once)
@@ -314,9 +442,14 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                     sdp_controls_at(box, ci, u);
                     bool cand = bad;
                     if (!cand) {
+#if SDP_COL_LEAN2
+                        const sdp_real F = lead.pow2 ? sdp_lean2_value<1>(sdp_lds.ad, utab, filt, lead, X, ci)
+                                                     : sdp_lean2_value<0>(sdp_lds.ad, utab, filt, lead, X, ci);
+#else
                         sdp_real F, pm = (sdp_real)0, gm = (sdp_real)0, bm = (sdp_real)0;
                         if (lead.pow2) sdp_col_lean_eval<1>(sdp_lds.ad, filt, lead1, x, u, t, F, pm, gm, bm);
                         else sdp_col_lean_eval<0>(sdp_lds.ad, filt, lead1, x, u, t, F, pm, gm, bm);
+#endif
                         cand = !(F - radius > m_hi);
                     }
                     if (cand) {

@@ -200,6 +200,9 @@
                                  SDP_COL_ROWS < SDP_COL_N0 || SDP_COL_THREADS < SDP_COL_N0 || 2 * SDP_COL_WRES < SDP_COL_W)
 #error "SDP_COL_WRES: lean filtered kernel, plain full-column table, one lane per node, at least half of the points resident"
 #endif
+#ifndef SDP_COL_LEAN2
+#define SDP_COL_LEAN2 0          // generated: x0' = X(x) +- a(u), cost = K(x) +- h(u) -- the short first pass of sdp_colres_kernel.h
+#endif
 #ifndef SDP_COL_LDS_PAD
 #define SDP_COL_LDS_PAD 0        // diagnostic builds: unused bytes in the LDS image (fewer workgroups per CU: occupancy A/B)
 #endif
@@ -266,7 +269,8 @@ struct __attribute__((aligned(16))) SdpColLds {
     int next_unit;                         // filtered kernel: the unit claimed for the next round
     unsigned long long dcol[2];            // lean filter: per parity of the unit, bits of max_r D[r] (>= 0: ordered as integers)
     // per parity of the unit: the tabulated values of every control of the column (SDP_COL_UTAB)
-    sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N : 2] __attribute__((aligned(16)));
+    // (+ 4: statistics of the column's table for the short first pass, SDP_COL_LEAN2 -- sdp_col_phase_u)
+    sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N + 4 : 2] __attribute__((aligned(16)));
 #if SDP_COL_LDS_PAD
     char pad_[SDP_COL_LDS_PAD];
 #endif
@@ -396,7 +400,11 @@ SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
 #pragma unroll
         for (int k = 0; k < SDP_DT; ++k) {
             sdp_locate_axis<sdp_real, SDP_DT, sdp_real>(tg, k, xn[k + 1], c);
+#ifdef SDP_DIAG_SAME_CELL      // timing diagnostic (WRONG results): every perturbation point reads the strips of one cell
+            s.w_off[w * SDP_DT + k] = 0;
+#else
             s.w_off[w * SDP_DT + k] = c.off[k];
+#endif
             s.w_lam[w * SDP_DT + k] = c.lam[k];
             s.w_oml[w * SDP_DT + k] = c.oml[k];
         }
@@ -411,6 +419,8 @@ SDP_DEV void sdp_col_phase_w(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
 // meanwhile; the interpolation weights are re-read from LDS afterwards -- so one
 // memory round trip serves SDP_COL_A_GROUP entries.
 extern "C" __device__ double __ockl_wfred_max_f64(double);
+extern "C" __device__ double __ockl_wfred_min_f64(double);
+extern "C" __device__ double __ockl_wfred_add_f64(double);
 extern "C" __device__ float __ockl_wfred_max_f32(float);
 SDP_DEV double sdp_wave_max(double v) { return __ockl_wfred_max_f64(v); }      // DPP row operations, no LDS traffic
 SDP_DEV float sdp_wave_max(float v) { return __ockl_wfred_max_f32(v); }
@@ -1764,13 +1774,40 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
     if (box_c) box = *box_c;
     else sdp_load_box(a, 0, box);                           // (one box for every node: checked at launch)
     const int n_tab = min(box.total, SDP_COL_UTAB_N);        // (SDP_COL_UTAB_N is a capacity: the host checks total <= it)
+#if SDP_COL_LEAN2
+    // the short first pass bounds what it no longer tracks per control by the column's smallest and largest a and
+    // largest |h| (x0' = X +- a, cost = K +- h: sdp_colres_kernel.h); a value that is not finite poisons them.
+    // ONE wave builds the table there (count == 64), so a wave reduction completes them.
+    sdp_real a_lo = INFINITY, a_hi = -INFINITY, h_abs = (sdp_real)0, fin = (sdp_real)0;
+#endif
     for (int ci = (int)threadIdx.x - first; ci < n_tab; ci += count) {
         sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
         sdp_controls_at(box, ci, u);
         sdp_model_utab(x, u, t, tab);
 #pragma unroll
         for (int k = 0; k < SDP_COL_UTAB; ++k) utab[ci * SDP_COL_UTAB + k] = tab[k];
+#if SDP_COL_LEAN2
+        a_lo = sdp_vmin(a_lo, tab[SDP_LEAN2_A_SLOT]);
+        a_hi = sdp_vmax(a_hi, tab[SDP_LEAN2_A_SLOT]);
+        fin = fin + fabs(tab[SDP_LEAN2_A_SLOT]);
+        if (SDP_LEAN2_H_SLOT >= 0) {
+            h_abs = sdp_vmax_abs(h_abs, tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT]);
+            fin = fin + fabs(tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT]);
+        }
+#endif
     }
+#if SDP_COL_LEAN2
+    a_lo = __ockl_wfred_min_f64(a_lo);
+    a_hi = __ockl_wfred_max_f64(a_hi);
+    h_abs = __ockl_wfred_max_f64(h_abs);
+    fin = __ockl_wfred_add_f64(fin);
+    if ((int)threadIdx.x == first) {
+        sdp_real *st = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;
+        st[0] = a_lo;
+        st[1] = a_hi;
+        st[2] = (count == 64 && fin < SDP_COL_FILTER_LIMIT) ? h_abs : (sdp_real)NAN;     // (NaN: every node the long way)
+    }
+#endif
 }
 #endif
 

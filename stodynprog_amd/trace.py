@@ -577,6 +577,36 @@ class TracedModel(object):
             return None
         return fr
 
+    def additive_control_split(self, frontier):
+        """The shape the short first pass of the certified filter can use (csrc/sdp_colres_kernel.h,
+        SDP_COL_LEAN2): x0' = X(x, t) +- a  and  cost = K(x, t) +- h  (or h alone, or no control in it), a and h
+        nodes of the control table `frontier` (control_uniform_frontier), X and K free of the control and of the
+        perturbation.  The argmin over the controls of a node does not see K, |K| + max |h| bounds the cost, and
+        x0' is monotone in a -- so the smallest and the largest a of the column bound every position of the node.
+        Returns None or a dict: lead = (X node, slot of a, form), cost = (K node or None, slot of h or None, form);
+        form: 'add' (X + a), 'sub' (X - a) or 'rsub' (a - X)."""
+        slot = {n.id: k for k, n in enumerate(frontier)}
+        if self.lead_depends_on_w or self.cost_depends_on_w:
+            return None
+
+        def split(node, need_control):
+            if node.id in slot:
+                return (None, slot[node.id], 'add')
+            if not (node.deps & DEP_U):
+                return None if need_control else (node, None, 'add')
+            if node.op not in ('add', 'sub') or node.kind != 'r':
+                return None
+            l, r = node.args
+            for part, other, form in ((r, l, node.op), (l, r, 'add' if node.op == 'add' else 'rsub')):
+                if part.id in slot and not (other.deps & (DEP_U | DEP_W)) and other.kind == 'r':
+                    return (other, slot[part.id], form)
+            return None
+        lead = split(self.x_next[0], True)
+        cost = split(self.cost, False)
+        if lead is None or cost is None or lead[0] is None:
+            return None
+        return dict(lead=lead, cost=cost)
+
     @property
     def storage_separable(self):
         """True when the next values of all state axes but the LEADING one

@@ -158,3 +158,95 @@ def test_a_radius_a_thousand_times_smaller_would_not_cover_it():
         ratio, _, _ = node_check(T, p, controls, False)
         seen = max(seen, ratio)
     assert seen > 1e-3, seen
+
+
+# ---------------------------------------------------------------------------
+# The short first pass of the resident-chunk kernel (csrc/sdp_colres_kernel.h, SDP_COL_LEAN2): x0' = X + a(u),
+# cost = K + h(u).  It orders F'' = pack(fma(h, psum, lerp), index) -- an approximation of E - K P*, P* the EXACT sum
+# of the weights -- and bounds the node by S = Pcap (|K| + max |h|) + (1 + 2 L) D with L from the column's smallest and
+# largest a.  Checked here: |E - K P* - F''| <= (cu + 2^(bits+2) u) S for every control, exactly.
+# ---------------------------------------------------------------------------
+import struct
+
+
+def pack_index(F, ci, mask):
+    (b,) = struct.unpack('<q', struct.pack('<d', F))
+    lo = (b & 0xffffffff & ~mask) | ci
+    (out,) = struct.unpack('<d', struct.pack('<q', (b & ~0xffffffff) | lo))
+    return out
+
+
+def cell_of(xn0, nm1, n0):
+    p = xn0 * nm1                                            # (grid [0, 1]: axis mode 2; pyx:75)
+    q0 = max(min(int(p), n0 - 2), 0)                         # pyx:78
+    return q0, p - float(q0)                                 # pyx:81
+
+
+def short_pass_check(T, p, X, K, a, h, chunked, sign=1.0):
+    """a, h: the control table of the column (one entry per control).  Returns (worst |E - K P* - F''| / radius, radius)."""
+    W, N0 = T.shape
+    fc = filter_constants(p)
+    A = reduced_table(T, p, chunked)
+    nm1 = float(N0 - 1)
+    dcol = 0.0
+    for r in range(N0):
+        big = max(abs(T[w][r]) for w in range(W))
+        dcol = max(dcol, fc['pcap'] * big + fc['floor'])
+    n = len(a)
+    bits = max((n - 1).bit_length(), 1)
+    mask = (1 << bits) - 1
+    lam_lo = cell_of(X + min(a), nm1, N0)[1]
+    lam_hi = cell_of(X + max(a), nm1, N0)[1]
+    L = max(1.0, abs(lam_lo), abs(lam_hi))
+    s_node = fma(fc['pcap'], abs(K) + max(abs(v) for v in h), (1.0 + 2.0 * L) * dcol)
+    radius = (fc['cu'] + 2.0 ** (bits + 1 - 52)) * s_node
+    p_exact = sum(Fraction(v) for v in p)
+    worst = Fraction(0)
+    for ci in range(n):
+        q0, lam0 = cell_of(X + a[ci], nm1, N0)
+        assert abs(lam0) <= L
+        g = K + sign * h[ci]                                 # the reference's cost, one rounding
+        E = reference_value(T, p, g, q0, lam0)
+        F = fma(sign * h[ci], fc['psum'], fma(lam0, A[q0 + 1] - A[q0], A[q0]))
+        Fp = pack_index(F, ci, mask)
+        assert abs(Fraction(Fp) - Fraction(F)) <= Fraction(2.0 ** (bits + 1 - 53)) * Fraction(s_node) * (1 + Fraction(3, 2 ** 53))
+        worst = max(worst, abs(Fraction(E) - Fraction(K) * p_exact - Fraction(Fp)))
+    return float(worst / Fraction(radius)), radius
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+@pytest.mark.parametrize('chunked', [False, True])
+def test_the_short_pass_radius_covers_the_difference_exactly(regime, chunked):
+    rng = np.random.default_rng(100 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime) * 2 + int(chunked))
+    worst = 0.0
+    for trial in range(250):
+        T, p, _ = random_problem(rng, regime)
+        W, N0 = T.shape
+        scale = float(np.abs(T).max())
+        n = int(rng.integers(1, 70))
+        X = float(rng.uniform(0, 1))
+        spread = float(10.0 ** rng.uniform(-3, 0.7))          # controls within a cell ... far outside the grid
+        a = [float(v) for v in rng.uniform(-spread, spread, size=n)]
+        if trial % 5 == 0:
+            a[0] = float(rng.integers(0, N0)) / (N0 - 1) - X  # (about) exactly on a node
+        K = float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3)
+        h = [float(v) * scale * 10.0 ** rng.uniform(-3, 3) for v in rng.standard_normal(n)]
+        sign = -1.0 if trial % 3 == 0 else 1.0                # cost = K - h
+        ratio, radius = short_pass_check(T, p, X, K, a, h, chunked, sign)
+        assert np.isfinite(radius) and radius > 0.0
+        assert ratio <= 1.0, (regime, chunked, trial, ratio)
+        worst = max(worst, ratio)
+    assert worst < 0.8, worst
+
+
+def test_the_packed_index_comes_back_and_the_order_survives():
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        F = float(rng.standard_normal()) * 10.0 ** rng.uniform(-300, 300)
+        bits = int(rng.integers(1, 14))
+        ci = int(rng.integers(0, 1 << bits))
+        Fp = pack_index(F, ci, (1 << bits) - 1)
+        (b,) = struct.unpack('<q', struct.pack('<d', Fp))
+        assert (b & ((1 << bits) - 1)) == ci
+        assert abs(Fp - F) <= 2.0 ** bits * abs(F) * 2.0 ** -52
+        assert (Fp < 0) == (F < 0)

@@ -351,7 +351,8 @@ def _wres(debug_defines, make, V, k, **kw):
     debug_defines.set(SDP_COL_WRES=str(k))
     try:
         out = _sweep(make, True, V, **kw)
-        assert ('#define SDP_COL_WRES {}'.format(k) in out[3]._kernel_plan()['source']) == (k > 0)
+        out[3].wres_source = out[3]._kernel_plan()['source']           # (the plan follows the switches: kept for the caller)
+        assert ('#define SDP_COL_WRES {}'.format(k) in out[3].wres_source) == (k > 0)
     finally:
         debug_defines.unset('SDP_COL_WRES')
     return out
@@ -408,3 +409,116 @@ def test_resident_chunks_only_where_they_apply(gpu, debug_defines):
         _, s = make()
         s.dtype = np.dtype(dtype)
         assert 'SDP_COL_WRES' not in s._kernel_plan()['source']
+
+
+# ---------------------------------------------------------------------------
+# Short first pass of the resident-chunk kernel (SDP_COL_LEAN2, codegen.short_pass_source): x0' = X(x) +- a(u),
+# cost = K(x) +- h(u).  K left out of the ordered value, the cost and the positions bounded from the column's
+# control table, the index packed into the low mantissa bits.  Same bits as the first pass of section 3.1c
+# (SDP_COL_LEAN2 = 0) and as the kernel without the filter.
+# ---------------------------------------------------------------------------
+def _shaped(form, n_x=96, n_y=9, n_w=7):
+    sysd = SysDescription((2, 1, 1), name='stock, ' + form)
+    dyn = {'add': lambda x, y, u, w: (x + 0.7 * u, 0.8 * y + w),
+           'sub': lambda x, y, u, w: (x - 0.7 * u, 0.8 * y + w),
+           'rsub': lambda x, y, u, w: (0.7 * u - (0.0 - x), 0.8 * y + w),
+           'h_only': lambda x, y, u, w: (x + 0.7 * u, 0.8 * y + w),
+           'no_u_cost': lambda x, y, u, w: (0.7 * u + x, 0.8 * y + w),
+           'not_additive': lambda x, y, u, w: (x * (1.0 + 0.01 * u) + 0.7 * u, 0.8 * y + w)}[form]
+    cost = {'add': lambda x, y, u, w: 0.05 * x + ((y - 0.3) * u + 0.2 * u * u),
+            'sub': lambda x, y, u, w: (0.05 * x + y) - ((0.3 - y) * u - 0.2 * u * u),
+            'rsub': lambda x, y, u, w: ((y - 0.3) * u + 0.2 * u * u) - 0.05 * x,
+            'h_only': lambda x, y, u, w: (y - 0.3) * u + 0.2 * u * u,
+            'no_u_cost': lambda x, y, u, w: 0.05 * x + y * y,
+            'not_additive': lambda x, y, u, w: 0.05 * x + ((y - 0.3) * u + 0.2 * u * u)}[form]
+    sysd.dyn, sysd.cost = dyn, cost
+    sysd.control_box = lambda x, y: ((-1.0, 1.0),)
+    sysd.perturb_laws = [NormalLaw(0, 0.2)]
+    s = DPSolver(sysd)
+    s.discretize_state(0, 3, n_x, -1, 1, n_y)
+    s.discretize_perturb(-0.5, 0.5, n_w)
+    s.control_steps = (0.0625,)
+    return sysd, s
+
+
+# (form 'add' with NaN / infinite / huge values, ties and near-ties: test_resident_chunks_give_the_same_bits above --
+# its stock model has the shape, so it runs the short first pass)
+@pytest.mark.parametrize('form,values', [(f, v) for f in ('sub', 'rsub', 'h_only', 'no_u_cost') for v in ('random', 'nan', 'ties')] +
+                         [('add', 'random'), ('not_additive', 'random'), ('sub', 'inf'), ('sub', 'huge')])
+def test_the_short_first_pass_gives_the_same_bits(gpu, debug_defines, form, values):
+    make = lambda: _shaped(form)
+    shape = make()[1]._state_grid_shape
+    V = np.random.default_rng(11).standard_normal(shape)
+    if values == 'nan':
+        V[10:14, 2:5] = np.nan
+    elif values == 'inf':
+        V[40:, :] = np.inf
+    elif values == 'huge':
+        V *= 1e302
+    elif values == 'ties':
+        V = np.full(shape, 2.5)
+    off = _sweep(make, False, V)
+    short = _wres(debug_defines, make, V, 4)
+    assert ('#define SDP_COL_LEAN2 1' in short[3].wres_source) == (form != 'not_additive')
+    debug_defines.set(SDP_COL_LEAN2='0')
+    try:
+        long_ = _wres(debug_defines, make, V, 4)
+        assert '#define SDP_COL_LEAN2 1' not in long_[3].wres_source
+    finally:
+        debug_defines.unset('SDP_COL_LEAN2')
+    _same(short, off)
+    _same(short, long_)
+
+
+@pytest.mark.parametrize('special', ['nan_in_h', 'inf_in_h', 'nan_in_K', 'huge_a', 'extrapolation'])
+def test_the_short_first_pass_with_special_values_in_the_model(gpu, debug_defines, special):
+    """what the statistics of the control table must catch: a cost or a position that is not finite for SOME control /
+    node; controls that leave the grid by many cells (L >> 1)"""
+    def make():
+        sysd, s = _shaped('add')
+        if special == 'nan_in_h':
+            sysd.cost = lambda x, y, u, w: 0.05 * x + ((y - 0.3) * u + 0.2 * u * u) / (1.0 + 0.0 * np.sqrt(0.5 - u * u * u))
+        elif special == 'inf_in_h':
+            sysd.cost = lambda x, y, u, w: 0.05 * x + ((y - 0.3) * u + 0.2 / (u * u))      # u = 0 is a lattice point
+        elif special == 'nan_in_K':
+            sysd.cost = lambda x, y, u, w: np.sqrt(x - 0.5) + ((y - 0.3) * u + 0.2 * u * u)
+        elif special == 'huge_a':
+            sysd.dyn = lambda x, y, u, w: (x + 1e300 * (u * u * u * u * u * u * u * u * u), 0.8 * y + w)
+        elif special == 'extrapolation':
+            sysd.dyn = lambda x, y, u, w: (x + 40.0 * u, 0.8 * y + w)
+        return sysd, s
+    V = np.random.default_rng(12).standard_normal(make()[1]._state_grid_shape)
+    off = _sweep(make, False, V)
+    short = _wres(debug_defines, make, V, 4)
+    assert '#define SDP_COL_LEAN2 1' in short[3].wres_source
+    _same(short, off)
+
+
+@pytest.mark.parametrize('scale', [None, '0.5'])
+def test_the_short_first_pass_on_near_ties(gpu, debug_defines, scale):
+    for tilt in NEAR_TIE_TILTS[np.float64]:
+        make = lambda: _flat(tilt)[:2]
+        V = _flat(tilt)[2]
+        off = _sweep(make, False, V)
+        if scale:
+            debug_defines.set(SDP_COL_FILTER_SCALE=scale)
+        try:
+            on = _wres(debug_defines, make, V, 4)
+        finally:
+            debug_defines.unset('SDP_COL_FILTER_SCALE')
+        assert '#define SDP_COL_LEAN2 1' in on[3].wres_source
+        _same(on, off)
+
+
+def test_the_short_first_pass_notices_a_radius_far_too_small(gpu, debug_defines):
+    make = lambda: _flat(0.0)[:2]
+    V = _flat(0.0)[2]
+    off = _sweep(make, False, V)
+    debug_defines.set(SDP_COL_FILTER_SCALE='1e-6')
+    try:
+        on = _wres(debug_defines, make, V, 4)
+    finally:
+        debug_defines.unset('SDP_COL_FILTER_SCALE')
+    assert '#define SDP_COL_LEAN2 1' in on[3].wres_source
+    assert (on[2] != off[2]).sum() > 0
+    assert np.allclose(on[0], off[0], rtol=1e-13, atol=0)

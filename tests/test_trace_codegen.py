@@ -590,3 +590,54 @@ def test_the_planned_lds_image_is_the_compiled_one():
     # both sides by shrinking the budget the planner may use
     cfg = codegen.column_config(256, 32, 3, np.float64, False, True, max_controls=64, n_columns=65536, utab_values=128)
     assert cfg == (256, codegen._column_lds(32, 32, 256, 3, 8, 256, reduced=True, utab_values=128))
+
+
+def test_the_short_first_pass_is_planned_where_the_model_has_its_shape():
+    """x0' = X(x) +- a(u) and cost = K(x) +- h(u) (TracedModel.additive_control_split): the resident-chunk kernel of
+    8-byte reals then gets codegen.short_pass_source (SDP_COL_LEAN2 of csrc/sdp_colres_kernel.h)"""
+    from stodynprog_amd import codegen
+    from stodynprog_amd.trace import DEP_U
+    _, s = models.synthetic3d(N=256)
+    plan = s._kernel_plan()
+    m = plan['model']
+    sp = m.additive_control_split(m.control_uniform_frontier())
+    (X, a_slot, a_form), (K, h_slot, h_form) = sp['lead'], sp['cost']
+    assert (a_slot, a_form, h_slot, h_form) == (0, 'add', 1, 'add') and not (X.deps | K.deps) & DEP_U
+    src = plan['source']
+    assert '#define SDP_COL_WRES 16' in src and '#define SDP_COL_LEAN2 1' in src
+    assert '#define SDP_LEAN2_LEAD(X, A) ((X) + (A))' in src and '#define SDP_LEAN2_HNEG 0' in src
+    lead_x = src[src.index('sdp_model_lead_x'):src.index('sdp_model_cost_x')]
+    assert 'return x[0];' in lead_x and 'u[' not in lead_x
+    assert _compiles(src)
+    # the switch of A/B runs, 4-byte reals, a table that stays whole: the first pass of section 3.1c
+    s.debug_defines = {'SDP_COL_LEAN2': '0'}
+    assert 'SDP_COL_LEAN2' not in s._kernel_plan()['source']
+    s.debug_defines = None
+    s.dtype = np.dtype(np.float32)
+    assert 'SDP_COL_LEAN2' not in s._kernel_plan()['source']
+    _, s2 = models.synthetic3d(N=32)
+    assert 'SDP_COL_WRES' not in s2._kernel_plan()['source'] and 'SDP_COL_LEAN2' not in s2._kernel_plan()['source']
+    # the forms: X - a, a - X, K - h (the control enters negated), h alone, a cost without the control
+    tm = lambda dyn0, cost: trace_model(lambda x, y, u, w: (dyn0(x, y, u), 0.5 * y + w), lambda x, y, u, w: cost(x, y, u), 2, 1, 1)
+    for dyn0, cost, want in (
+            (lambda x, y, u: x - 0.5 * u, lambda x, y, u: x * x - (y - u) * (y - u), ('sub', 'sub')),
+            (lambda x, y, u: 0.5 * u - x, lambda x, y, u: (y - u) * (y - u) - x, ('rsub', 'rsub')),
+            (lambda x, y, u: x + 0.5 * u, lambda x, y, u: (y - u) * (y - u), ('add', 'add')),
+            (lambda x, y, u: x * y + y * u, lambda x, y, u: x * x + y, ('add', 'add'))):
+        m = tm(dyn0, cost)
+        sp = m.additive_control_split(m.control_uniform_frontier())
+        assert sp is not None and (sp['lead'][2], sp['cost'][2]) == want
+        assert codegen.short_pass_source(m, m.control_uniform_frontier()) is not None
+    assert tm(lambda x, y, u: x + 0.5 * u, lambda x, y, u: (y - u) * (y - u))\
+        .additive_control_split(tm(lambda x, y, u: x + 0.5 * u, lambda x, y, u: (y - u) * (y - u)).control_uniform_frontier())['cost'][0] is None
+    m = tm(lambda x, y, u: x * y + y * u, lambda x, y, u: x * x + y)
+    assert m.additive_control_split(m.control_uniform_frontier())['cost'][1] is None     # no control in the cost
+    # not the shape: the control multiplies the stock; the cost couples them; the perturbation reaches the stock
+    for dyn0, cost in ((lambda x, y, u: x * (1.0 + 0.1 * u) + u, lambda x, y, u: x + u * u),
+                       (lambda x, y, u: x + u, lambda x, y, u: (x - u) * (x - u)),
+                       (lambda x, y, u: (x + u) * 0.5, lambda x, y, u: x + u * u)):
+        m = tm(dyn0, cost)
+        fr = m.control_uniform_frontier()
+        assert fr is None or m.additive_control_split(fr) is None
+    m = trace_model(lambda x, y, u, w: ((x + 0.5 * u) - 0.1 * w, 0.5 * y + w), lambda x, y, u, w: x + u * u, 2, 1, 1)
+    assert m.additive_control_split(m.control_uniform_frontier(m.lead_split()[0])) is None
