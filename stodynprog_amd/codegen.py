@@ -371,7 +371,7 @@ def control_table_source(model, frontier):
     return '\n\n'.join(out)
 
 
-def short_pass_source(model, frontier):
+def short_pass_source(model, frontier, macro='SDP_COL_LEAN2'):
     """C++ text for the short first pass of the resident-chunk kernel (SDP_COL_LEAN2 of csrc/sdp_colres_kernel.h), or
     None when the model does not have the shape: x0' = X(x, t) +- a, cost = K(x, t) +- h with a, h in the control
     table (TracedModel.additive_control_split).  X and K as functions of the node alone, the slots of a and h, and
@@ -380,7 +380,7 @@ def short_pass_source(model, frontier):
     if sp is None:
         return None
     (x_node, a_slot, a_form), (k_node, h_slot, h_form) = sp['lead'], sp['cost']
-    out = ['#define SDP_COL_LEAN2 1          // x0\' = X(x) +- a(u), cost = K(x) +- h(u): the short first pass',
+    out = ['#define {} 1          // x0\' = X(x) +- a(u), cost = K(x) +- h(u): the short first pass'.format(macro),
            '#define SDP_LEAN2_A_SLOT {}'.format(int(a_slot)),
            '#define SDP_LEAN2_H_SLOT {}'.format(-1 if h_slot is None else int(h_slot)),
            '#define SDP_LEAN2_LEAD(X, A) {}'.format({'add': '((X) + (A))', 'sub': '((X) - (A))', 'rsub': '((A) - (X))'}[a_form]),
@@ -490,8 +490,15 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
         lines += ['#define SDP_COL_UTAB {}'.format(len(utab[0])),
                   '#define SDP_COL_UTAB_N {}'.format(int(utab[1])),
                   control_table_source(model, utab[0]), '']
-        short = short_pass_source(model, utab[0]) if (wres and rs == 8 and not shifted and _dbg(debug, 'SDP_COL_LEAN') != '0'
-                                                      and _dbg(debug, 'SDP_COL_LEAN2') != '0') else None
+        # the short first passes: 8-byte reals in the resident-chunk kernel, 4-byte reals (wide form) in the full-table one
+        short = None
+        if not shifted and not model.cost_depends_on_w and window is None and per_control is None and not fused \
+                and _dbg(debug, 'SDP_COL_LEAN2') != '0':
+            if rs == 8 and wres and _dbg(debug, 'SDP_COL_LEAN') != '0':
+                short = short_pass_source(model, utab[0], 'SDP_COL_LEAN2')
+            elif rs == 4 and not wres and _dbg(debug, 'SDP_COL_WIDE') != '0' and _dbg(debug, 'SDP_COL_LEAN') in (None, '0') \
+                    and _dbg(debug, 'SDP_COL_FILTER_TOP2') in (None, '1'):
+                short = short_pass_source(model, utab[0], 'SDP_COL_WIDE2')
         if short:
             lines += [short, '']
     lines += ['#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h', '']

@@ -128,15 +128,6 @@ SDP_DEV void sdp_colres_partial(const sdp_real *T, const SdpColWeights &k, const
 static_assert(!SDP_COL_SHIFT && !SDP_COST_HAS_W && !SDP_COL_TOP2 && SDP_COL_UTAB && sizeof(sdp_real) == 8,
               "short first pass: 8-byte reals, control table, a perturbation that reaches neither the stock nor the cost");
 template <int AXIS>
-SDP_DEV void sdp_lean2_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_real &lam0)
-{
-    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);   // pyx:75
-    const sdp_real p = sn * l.nm1;
-    q0 = (int)p;                                            // (saturating conversion; NaN -> 0)
-    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // pyx:78
-    lam0 = p - (sdp_real)q0;                                // pyx:81
-}
-template <int AXIS>
 SDP_DEV sdp_real sdp_lean2_value(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
                                  sdp_real X, int ci)
 {

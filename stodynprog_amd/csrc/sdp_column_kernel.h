@@ -203,6 +203,10 @@
 #ifndef SDP_COL_LEAN2
 #define SDP_COL_LEAN2 0          // generated: x0' = X(x) +- a(u), cost = K(x) +- h(u) -- the short first pass of sdp_colres_kernel.h
 #endif
+#ifndef SDP_COL_WIDE2
+#define SDP_COL_WIDE2 0          // generated, 4-byte reals: the same shape -- the short wide first pass of sdp_col_filter_nodes
+#endif
+#define SDP_COL_SHORT (SDP_COL_LEAN2 || SDP_COL_WIDE2)
 #ifndef SDP_COL_LDS_PAD
 #define SDP_COL_LDS_PAD 0        // diagnostic builds: unused bytes in the LDS image (fewer workgroups per CU: occupancy A/B)
 #endif
@@ -422,8 +426,14 @@ extern "C" __device__ double __ockl_wfred_max_f64(double);
 extern "C" __device__ double __ockl_wfred_min_f64(double);
 extern "C" __device__ double __ockl_wfred_add_f64(double);
 extern "C" __device__ float __ockl_wfred_max_f32(float);
+extern "C" __device__ float __ockl_wfred_min_f32(float);
+extern "C" __device__ float __ockl_wfred_add_f32(float);
 SDP_DEV double sdp_wave_max(double v) { return __ockl_wfred_max_f64(v); }      // DPP row operations, no LDS traffic
 SDP_DEV float sdp_wave_max(float v) { return __ockl_wfred_max_f32(v); }
+SDP_DEV double sdp_wave_min(double v) { return __ockl_wfred_min_f64(v); }
+SDP_DEV float sdp_wave_min(float v) { return __ockl_wfred_min_f32(v); }
+SDP_DEV double sdp_wave_sum(double v) { return __ockl_wfred_add_f64(v); }
+SDP_DEV float sdp_wave_sum(float v) { return __ockl_wfred_add_f32(v); }
 
 // (w_begin, w_count: the perturbation points to tabulate, into table rows 0 .. w_count-1 -- all of them by
 // default; the resident-chunk kernel builds the table a part at a time)
@@ -1774,7 +1784,7 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
     if (box_c) box = *box_c;
     else sdp_load_box(a, 0, box);                           // (one box for every node: checked at launch)
     const int n_tab = min(box.total, SDP_COL_UTAB_N);        // (SDP_COL_UTAB_N is a capacity: the host checks total <= it)
-#if SDP_COL_LEAN2
+#if SDP_COL_SHORT
     // the short first pass bounds what it no longer tracks per control by the column's smallest and largest a and
     // largest |h| (x0' = X +- a, cost = K +- h: sdp_colres_kernel.h); a value that is not finite poisons them.
     // ONE wave builds the table there (count == 64), so a wave reduction completes them.
@@ -1786,7 +1796,7 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         sdp_model_utab(x, u, t, tab);
 #pragma unroll
         for (int k = 0; k < SDP_COL_UTAB; ++k) utab[ci * SDP_COL_UTAB + k] = tab[k];
-#if SDP_COL_LEAN2
+#if SDP_COL_SHORT
         a_lo = sdp_vmin(a_lo, tab[SDP_LEAN2_A_SLOT]);
         a_hi = sdp_vmax(a_hi, tab[SDP_LEAN2_A_SLOT]);
         fin = fin + fabs(tab[SDP_LEAN2_A_SLOT]);
@@ -1796,11 +1806,11 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         }
 #endif
     }
-#if SDP_COL_LEAN2
-    a_lo = __ockl_wfred_min_f64(a_lo);
-    a_hi = __ockl_wfred_max_f64(a_hi);
-    h_abs = __ockl_wfred_max_f64(h_abs);
-    fin = __ockl_wfred_add_f64(fin);
+#if SDP_COL_SHORT
+    a_lo = sdp_wave_min(a_lo);
+    a_hi = sdp_wave_max(a_hi);
+    h_abs = sdp_wave_max(h_abs);
+    fin = sdp_wave_sum(fin);
     if ((int)threadIdx.x == first) {
         sdp_real *st = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;
         st[0] = a_lo;
@@ -1988,6 +1998,93 @@ SDP_DEV void sdp_col_filter_pass1(const sdp_real *ad_tab, const sdp_real *utab, 
     if (PLAIN && c_hi > last && c_lo <= last) eval(last, box.hi);
 }
 
+#if SDP_COL_SHORT
+// ---------------------------------------------------------------------------
+// Short first passes (generated where x0' = X(x) +- a(u) and cost = K(x) +- h(u), a and h entries of the column's
+// control table: codegen.short_pass_source).  The cell of a control as the reference computes it:
+template <int AXIS>
+SDP_DEV void sdp_lean2_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_real &lam0)
+{
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);   // pyx:75
+    const sdp_real p = sn * l.nm1;
+    q0 = (int)p;                                            // (saturating conversion; NaN -> 0)
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // pyx:78
+    lam0 = p - (sdp_real)q0;                                // pyx:81
+}
+#endif
+#if SDP_COL_WIDE2
+// Short WIDE first pass (4-byte reals; the 8-byte one is in sdp_colres_kernel.h, where the reasoning is spelled out).
+// Per control: the reference's cell (q0, lam0), then in 8-byte arithmetic on A[r] accumulated in 8-byte reals
+//     F' = fma(+-h, P, fma(lam0, A[q0+1] - A[q0], A[q0]))          ~  R - K P*,   R = g P* + oml0 A0* + lam0 A1*
+// with the index of the control in the low mantissa bits.  Nothing else per control: one bound for the node,
+//     S = (Gc + Pcap) [ |K| + max |h| + (1 + 2 L) max |T| ]
+// covers  Gc |g| + |oml0| B[q0] + |lam0| B[q0+1]  of sdp_col_wide_core (|g| <= (|K| + |h|)(1 + u), B[r] <= Gc max |T|,
+// |oml0| + |lam0| <= (1 + 2 L)(1 + u)) and the two liberties F' takes with the reference's inputs: g = fl(K +- h)
+// differs from K +- h by u (|K| + |h|), times P; and F' uses the exact 1 - lam0 where R has oml0 = fl(1 - lam0):
+// u |1 - lam0| |A0*| <= u (1 + L) P max |T|.  L = max(1, |lam0| at the column's smallest and largest a) as in the
+// 8-byte pass.  Radius u' (S + floor) + 2^(bits+1) 2^-52 S (the packing).  Values that are not finite: the same net.
+template <int AXIS>
+SDP_DEV double sdp_wide2_value(const sdp_real *ad, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                               sdp_real X, int ci)
+{
+    int q0;
+    sdp_real lam0;
+    sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, utab[ci * SDP_COL_UTAB + SDP_LEAN2_A_SLOT]), q0, lam0);
+    const sdp_real *row = ad + 4 * q0;
+    const double a0 = *(const double *)row, a1 = *(const double *)(row + 4);
+    const double h = fma((double)lam0, a1 - a0, a0);
+    if (SDP_LEAN2_H_SLOT < 0) return h;
+    const sdp_real hv = utab[ci * SDP_COL_UTAB + (SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT)];
+    return fma((double)(SDP_LEAN2_HNEG ? -hv : hv), f.psum64, h);
+}
+struct SdpShortBounds { double f1, f2, f3; };
+SDP_DEV void sdp_short_insert(SdpShortBounds &b, double F)
+{
+    b.f3 = sdp_vmin(b.f3, sdp_vmax(b.f2, F));
+    b.f2 = sdp_vmin(b.f2, sdp_vmax(b.f1, F));
+    b.f1 = sdp_vmin(b.f1, F);
+}
+#ifndef SDP_WIDE2_GROUP
+#define SDP_WIDE2_GROUP 4
+#endif
+// the three smallest F' over the controls [c_lo, c_hi) of one node, groups of controls in stages (all cells, all reads
+// of the reduced table, all values: the reads of a group are in flight together)
+template <int AXIS>
+SDP_DEV void sdp_wide2_pass1(const sdp_real *ad, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                             sdp_real X, int c_lo, int c_hi, int mask, SdpShortBounds &b)
+{
+    auto insert = [&](double F, int ci) {
+        sdp_short_insert(b, __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci));
+    };
+    constexpr int K = SDP_WIDE2_GROUP;
+    constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
+    int ci = c_lo;
+    for (; ci + K <= c_hi; ci += K) {
+        int q0[K];
+        sdp_real av[K], hv[K], lam0[K];
+        double a0[K], a1[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            av[j] = utab[(ci + j) * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+            hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[(ci + j) * SDP_COL_UTAB + HS];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            a0[j] = *(const double *)(ad + 4 * q0[j]);
+            a1[j] = *(const double *)(ad + 4 * q0[j] + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const double h = fma((double)lam0[j], a1[j] - a0[j], a0[j]);
+            insert(SDP_LEAN2_H_SLOT < 0 ? h : fma((double)(SDP_LEAN2_HNEG ? -hv[j] : hv[j]), f.psum64, h), ci + j);
+        }
+    }
+    for (; ci < c_hi; ++ci) insert(sdp_wide2_value<AXIS>(ad, utab, f, l, X, ci), ci);
+}
+#endif
+
 SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
 {
     const sdp_fkey o_f1 = sdp_shfl_xor(b.f1, d), o_f2 = sdp_shfl_xor(b.f2, d);
@@ -2070,6 +2167,54 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         const int c_hi = (int)((int64_t)box.total * (chunk + 1) / chunks);
         // pass 1: bounds of every control of this lane's range
         SDP_COL_MARK(diag.m1);
+#if SDP_COL_WIDE2
+        static_assert(SDP_COL_WIDE_ON && SDP_COL_TOP2 && !SDP_COST_HAS_W && !SDP_COL_SHIFT && SDP_COL_UTAB,
+                      "short first pass of the full-table kernel: the wide form of 4-byte reals");
+        struct { double f1, f2, f3; int i1, i2; } bd;
+        bool bad;
+        sdp_fkey radius;
+        const sdp_real X = sdp_model_lead_x(x, t);
+        {
+            const sdp_real *ust = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;          // a_lo, a_hi, max |h| (or NaN)
+            const sdp_real K = sdp_model_cost_x(x, t);
+            const int bits = 32 - __clz(max(box.total - 1, 1));
+            const int mask = (1 << bits) - 1;
+            SdpShortBounds sb;
+            sb.f1 = sb.f2 = sb.f3 = INFINITY;
+            int q_e;
+            sdp_real lam_lo, lam_hi;
+            if (axis_mode == 2) {
+                sdp_wide2_pass1<2>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
+                sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            } else if (axis_mode == 1) {
+                sdp_wide2_pass1<1>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
+                sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            } else {
+                sdp_wide2_pass1<0>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
+                sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            }
+            for (int d = npw; d < 64; d <<= 1) {           // the lanes that share the node (ranges of its lattice)
+                const double o1 = sdp_shfl_xor(sb.f1, d), o2 = sdp_shfl_xor(sb.f2, d), o3 = sdp_shfl_xor(sb.f3, d);
+                sdp_short_insert(sb, o1);
+                sdp_short_insert(sb, o2);
+                sdp_short_insert(sb, o3);
+            }
+            bd.f1 = sb.f1; bd.f2 = sb.f2; bd.f3 = sb.f3;
+            bd.i1 = sb.f1 < (double)INFINITY ? (__double2loint(sb.f1) & mask) : INT_MAX;
+            bd.i2 = sb.f2 < (double)INFINITY ? (__double2loint(sb.f2) & mask) : INT_MAX;
+            const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
+            // (dcol: the largest |T| of the column, raw -- sdp_col_filter_reduce)
+            const sdp_real s_node = (filt.gc + filt.pcap) * ((fabs(K) + ust[2]) + ((sdp_real)1 + (sdp_real)2 * l_cap) * dcol);
+            bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(fabs(lam_lo) + fabs(lam_hi) < (sdp_real)1073741824.0) ||
+                  bits > 24 || box.total > SDP_COL_UTAB_N;
+            radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)s_node + (sdp_fkey)filt.floor) +
+                     ldexp((sdp_fkey)s_node, bits - 51);
+        }
+        SDP_COL_MARK(diag.m2);
+#else
         SdpColBounds bd;
         bd.f1 = bd.f2 = bd.f3 = INFINITY;
         bd.s_max = bd.s_sum = bd.p_max = bd.b_max = (sdp_real)0;
@@ -2127,6 +2272,7 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             bad = !filt.ok || !(bd.s_sum < SDP_COL_FILTER_LIMIT) || !(bd.p_max < (sdp_real)2147483648.0);
             radius = filt.cu * (SDP_COL_RADIUS_FROM_SUM ? (sdp_real)bd.s_sum : bd.s_max);
         }
+#endif  // SDP_COL_WIDE2
         const sdp_fkey m_hi = bd.f1 + radius;                  // >= the minimum of E over the node
         const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
         // exactly two survivors (TOP2): the lanes of the node take one each (a lane alone takes both)
@@ -2147,6 +2293,13 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             sdp_real u[1][SDP_NU], jc[1];
             sdp_controls_at(box, ci, u[0]);
             bool cand = single || pair || bad;
+#if SDP_COL_WIDE2
+            if (!cand) {
+                const double Fw = lead.pow2 ? sdp_wide2_value<1>(ad_tab, utab, filt, lead, X, ci)
+                                            : sdp_wide2_value<0>(ad_tab, utab, filt, lead, X, ci);
+                cand = !((sdp_fkey)Fw - radius > m_hi);
+            }
+#else
             if (!cand && SDP_COL_WIDE_ON) {
                 double Fw;
                 sdp_real bnd, pm = (sdp_real)0;
@@ -2164,6 +2317,7 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
                 else sdp_col_filter_eval<0>(ad_tab, filt, lead, x, u[0], t, F, S, pm);
                 cand = !(F - radius > m_hi);
             }
+#endif
             if (cand) {
 #if SDP_STAMP == 3
                 if (live) ++diag.n_exact;
@@ -2269,7 +2423,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
-        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 0, box_c);
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, SDP_COL_SHORT ? 64 : 0, box_c);   // (one wave: it also reduces the table's statistics)
 #endif
 #if SDP_COL_SHIFT
         sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);

@@ -250,3 +250,109 @@ def test_the_packed_index_comes_back_and_the_order_survives():
         assert (b & ((1 << bits) - 1)) == ci
         assert abs(Fp - F) <= 2.0 ** bits * abs(F) * 2.0 ** -52
         assert (Fp < 0) == (F < 0)
+
+
+# ---------------------------------------------------------------------------
+# The short WIDE first pass (4-byte reals, SDP_COL_WIDE2 of csrc/sdp_column_kernel.h): the reference runs in 4-byte
+# arithmetic, F' in 8-byte arithmetic on A[r] accumulated in 8-byte reals, one bound per node:
+#     S = (Gc + Pcap) [ |K| + max |h| + (1 + 2 L) max |T| ],   radius = 1.001 2^-24 (S + floor) + 2^(bits-51) S
+# ---------------------------------------------------------------------------
+f32 = np.float32
+
+
+def reference_value32(T, p, g, q0, lam0):
+    """the reference's operations on 4-byte reals (multilinear_cython.pyx with floats; stodynprog.py:677-681)"""
+    oml0 = f32(f32(1) - lam0)
+    acc = f32(0)
+    for w in range(len(p)):
+        val = f32(f32(oml0 * T[w][q0]) + f32(lam0 * T[w][q0 + 1]))
+        jc = f32(g + val)
+        acc = f32(acc + f32(jc * p[w]))
+    return acc
+
+
+def wide_short_check(T, p, X, K, a, h, sign=1.0):
+    W, N0 = T.shape
+    nm1 = f32(N0 - 1)
+    # sdp_col_filter_setup / sdp_col_filter_reduce, wide form
+    pa, gc, ps64 = f32(0), f32(0), 0.0
+    for w in range(W):
+        pa = f32(pa + abs(p[w]))
+        nw = f32(W + 3 if w == 0 else W - w + 4)
+        gc = f32(gc + f32(nw * abs(p[w])))
+        ps64 = ps64 + float(p[w])
+    gc = f32(gc * f32(1.0001))
+    pcap = pa if pa > f32(1) else f32(1)
+    cu = f32(f32(2 * (W + 8)) * f32(2.0 ** -23))
+    floor = f32(f32(2) * f32(1.17549435e-38) / cu)
+    A = np.zeros(N0)
+    for r in range(N0):
+        acc = 0.0
+        for w in range(W):
+            acc = acc + float(p[w]) * float(T[w][r])          # (the product of two 4-byte reals is exact in 8 bytes)
+        A[r] = acc
+    tmax = f32(np.abs(T).max())
+
+    def cell(xn0):
+        pos = f32(xn0 * nm1)
+        q0 = max(min(int(pos), N0 - 2), 0)
+        return q0, f32(pos - f32(q0))
+    n = len(a)
+    bits = max((n - 1).bit_length(), 1)
+    mask = (1 << bits) - 1
+    lam_lo, lam_hi = cell(f32(X + min(a)))[1], cell(f32(X + max(a)))[1]
+    L = max(f32(1), abs(lam_lo), abs(lam_hi))
+    habs = max(abs(v) for v in h)
+    s_node = f32(f32(gc + pcap) * f32(f32(abs(K) + habs) + f32(f32(f32(1) + f32(f32(2) * L)) * tmax)))
+    radius = 1.001 * 2.0 ** -24 * (float(s_node) + float(floor)) + float(s_node) * 2.0 ** (bits - 51)
+    p_exact = sum(Fraction(float(v)) for v in p)
+    worst = Fraction(0)
+    for ci in range(n):
+        q0, lam0 = cell(f32(X + a[ci]))
+        assert abs(lam0) <= L
+        g = f32(K + f32(sign) * h[ci])
+        E = reference_value32(T, p, g, q0, lam0)
+        F = fma(float(f32(sign) * h[ci]), ps64, fma(float(lam0), A[q0 + 1] - A[q0], A[q0]))
+        Fp = pack_index(F, ci, mask)
+        worst = max(worst, abs(Fraction(float(E)) - Fraction(float(K)) * p_exact - Fraction(Fp)))
+    return float(worst / Fraction(radius)), radius
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+def test_the_short_wide_pass_radius_covers_the_difference_exactly(regime):
+    rng = np.random.default_rng(200 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime))
+    worst = 0.0
+    with np.errstate(all='ignore'):
+        for trial in range(250):
+            W = int(rng.integers(1, 9))
+            N0 = int(rng.integers(3, 14))
+            T = rng.standard_normal((W, N0))
+            if regime == 'large':
+                T *= 10.0 ** rng.uniform(10, 28)
+            elif regime == 'small':
+                T *= 10.0 ** rng.uniform(-30, -10)
+            elif regime == 'mixed':
+                T *= 10.0 ** rng.uniform(-4, 4, size=T.shape)
+            elif regime == 'cancel':
+                T = 1e3 + 1e-2 * T
+            T = T.astype(f32)
+            p = np.abs(rng.standard_normal(W)) + 1e-3
+            p /= p.sum()
+            if regime == 'weights':
+                p = rng.standard_normal(W) * 3.7
+                if abs(p.sum()) < 0.2:
+                    p[0] += 1.0
+            p = p.astype(f32)
+            scale = float(np.abs(T).max())
+            n = int(rng.integers(1, 70))
+            X = f32(rng.uniform(0, 1))
+            spread = float(10.0 ** rng.uniform(-3, 0.7))
+            a = [f32(v) for v in rng.uniform(-spread, spread, size=n)]
+            K = f32(float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3))
+            h = [f32(float(v) * scale * 10.0 ** rng.uniform(-3, 3)) for v in rng.standard_normal(n)]
+            sign = -1.0 if trial % 3 == 0 else 1.0
+            ratio, radius = wide_short_check(T, p, X, K, a, h, sign)
+            assert np.isfinite(radius) and radius > 0.0
+            assert ratio <= 1.0, (regime, trial, ratio)
+            worst = max(worst, ratio)
+    assert worst < 0.9, worst

@@ -296,7 +296,7 @@ print('rank', rank, 'all ok', flush=True)
 # (8 ranks: the partition / mapping / rendezvous logic with more ranks than rows or columns in some cases -- one
 # case per kernel family is enough there, every exchange; the blocking stand-in with 2 ranks only: the
 # asynchronous one is the stricter test.  Round 3 ran all cases in all five set-ups: 280 s of the suite.)
-EIGHT = '0,3,9,10'                   # (the shifted lattice, case 8: 2 and 3 ranks)
+EIGHT = '0,3,10'                     # (the shifted lattice and the larger two-stock case, 8 and 9: 2 and 3 ranks)
 REST8 = 'rccl,direct'                # every case but the first: the all-gather and the direct exchange
 
 

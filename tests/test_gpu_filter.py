@@ -522,3 +522,66 @@ def test_the_short_first_pass_notices_a_radius_far_too_small(gpu, debug_defines)
     assert '#define SDP_COL_LEAN2 1' in on[3].wres_source
     assert (on[2] != off[2]).sum() > 0
     assert np.allclose(on[0], off[0], rtol=1e-13, atol=0)
+
+
+# the same shape with 4-byte reals: the short WIDE first pass of the full-table kernel (SDP_COL_WIDE2 of
+# sdp_col_filter_nodes): F' in 8-byte arithmetic, one bound per node from the table's statistics and the column's
+# largest |T|, both survivors' indices in the low mantissa bits
+@pytest.mark.parametrize('form,values', [(f, v) for f in ('sub', 'rsub', 'no_u_cost') for v in ('random', 'nan')] +
+                         [('h_only', 'random'), ('not_additive', 'random'), ('add', 'ties'), ('add', 'inf'), ('add', 'huge')])
+def test_the_short_wide_first_pass_gives_the_same_bits(gpu, debug_defines, form, values):
+    make = lambda: _shaped(form)
+    shape = make()[1]._state_grid_shape
+    V = np.random.default_rng(13).standard_normal(shape)
+    if values == 'nan':
+        V[10:14, 2:5] = np.nan
+    elif values == 'inf':
+        V[40:, :] = np.inf
+    elif values == 'huge':
+        V *= 1e37
+    elif values == 'ties':
+        V = np.full(shape, 2.5)
+    off = _sweep(make, False, V, np.float32)
+    short = _sweep(make, True, V, np.float32)
+    assert ('#define SDP_COL_WIDE2 1' in short[3]._kernel_plan()['source']) == (form != 'not_additive')
+    debug_defines.set(SDP_COL_LEAN2='0')
+    try:
+        long_ = _sweep(make, True, V, np.float32)
+        assert 'SDP_COL_WIDE2' not in long_[3]._kernel_plan()['source']
+    finally:
+        debug_defines.unset('SDP_COL_LEAN2')
+    _same(short, off)
+    _same(short, long_)
+
+
+@pytest.mark.parametrize('special', ['nan_in_h', 'inf_in_h', 'nan_in_K', 'huge_a', 'extrapolation'])
+def test_the_short_wide_first_pass_with_special_values_in_the_model(gpu, special):
+    def make():
+        sysd, s = _shaped('add')
+        if special == 'nan_in_h':
+            sysd.cost = lambda x, y, u, w: 0.05 * x + ((y - 0.3) * u + 0.2 * u * u) / (1.0 + 0.0 * np.sqrt(0.5 - u * u * u))
+        elif special == 'inf_in_h':
+            sysd.cost = lambda x, y, u, w: 0.05 * x + ((y - 0.3) * u + 0.2 / (u * u))
+        elif special == 'nan_in_K':
+            sysd.cost = lambda x, y, u, w: np.sqrt(x - 0.5) + ((y - 0.3) * u + 0.2 * u * u)
+        elif special == 'huge_a':
+            sysd.dyn = lambda x, y, u, w: (x + 1e37 * (u * u * u * u * u * u * u * u * u), 0.8 * y + w)
+        elif special == 'extrapolation':
+            sysd.dyn = lambda x, y, u, w: (x + 40.0 * u, 0.8 * y + w)
+        return sysd, s
+    V = np.random.default_rng(14).standard_normal(make()[1]._state_grid_shape)
+    off = _sweep(make, False, V, np.float32)
+    short = _sweep(make, True, V, np.float32)
+    assert '#define SDP_COL_WIDE2 1' in short[3]._kernel_plan()['source']
+    _same(short, off)
+
+
+def test_the_short_wide_first_pass_when_lanes_share_a_node(gpu):
+    """a column shorter than the workgroup's waves x 64: the lattice of a node is cut into ranges, a lane each, and
+    the three smallest values of the ranges meet through shuffles -- indices still in their low bits"""
+    make = lambda: _stock(n_x=40)
+    V = np.random.default_rng(15).standard_normal(make()[1]._state_grid_shape)
+    off = _sweep(make, False, V, np.float32)
+    short = _sweep(make, True, V, np.float32)
+    assert '#define SDP_COL_WIDE2 1' in short[3]._kernel_plan()['source']
+    _same(short, off)

@@ -613,8 +613,13 @@ def test_the_short_first_pass_is_planned_where_the_model_has_its_shape():
     s.debug_defines = {'SDP_COL_LEAN2': '0'}
     assert 'SDP_COL_LEAN2' not in s._kernel_plan()['source']
     s.debug_defines = None
-    s.dtype = np.dtype(np.float32)
-    assert 'SDP_COL_LEAN2' not in s._kernel_plan()['source']
+    s.dtype = np.dtype(np.float32)             # 4-byte reals: the short WIDE pass of the full-table kernel instead
+    src32 = s._kernel_plan()['source']
+    assert 'SDP_COL_LEAN2' not in src32 and '#define SDP_COL_WIDE2 1' in src32 and 'SDP_COL_WRES' not in src32
+    assert _compiles(src32)
+    s.debug_defines = {'SDP_COL_LEAN2': '0'}
+    assert 'SDP_COL_WIDE2' not in s._kernel_plan()['source']
+    s.debug_defines = None
     _, s2 = models.synthetic3d(N=32)
     assert 'SDP_COL_WRES' not in s2._kernel_plan()['source'] and 'SDP_COL_LEAN2' not in s2._kernel_plan()['source']
     # the forms: X - a, a - X, K - h (the control enters negated), h alone, a cost without the control
