@@ -1371,7 +1371,9 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
                 const sdp_real v = m.T[w * N0 + r];
 #endif
                 acc = fma((double)p[w], (double)v, acc);
+#if !SDP_COL_WIDE2                                            // (the short wide pass bounds B[r] by Gc max |T|)
                 bsum = fma(sdp_col_wide_nw(w) * fabs(p[w]), fabs(v), bsum);
+#endif
                 tmax = sdp_vmax_abs(tmax, v);
             }
             *(double *)(m.ad + 4 * r) = acc;
