@@ -362,6 +362,17 @@ def run_sharded(args, env):
             warnings.simplefilter('ignore')
             return solver._problem()
 
+    def release_trials():
+        """Every plan is its own problem on the device (value / J / policy buffers, and for the peer exchanges the
+        mappings of every peer's buffers: 2 (nranks - 1) HIP IPC handles each).  Sixteen of them alive at once
+        exhausted the IPC exports of a rank at 256^3 with 8 ranks on one GPU (`hipIpcGetMemHandle` failing on
+        the third sparse plan, then processes dying inside the runtime): a plan is released as soon as it has
+        been timed, by all ranks at the same point."""
+        sync_all()
+        for k_ in [k_ for k_ in list(solver._cache) if k_[0] == 'problem']:
+            solver._cache.pop(k_).close()
+        sync_all()
+
     def tune(exch):
         """3 sweeps per plan, the maximum over the ranks decides; the J of the first plan must equal
         the RCCL one bit for bit on every rank.  Returns (best plan, its time) or (None, reason)."""
@@ -405,6 +416,11 @@ def run_sharded(args, env):
                             local_error = 'rejected: J differs from the RCCL result'
             except Exception as e:                              # this rank's trouble: the ranks agree below
                 local_error = '{}: {}'.format(type(e).__name__, e)
+            trial = None
+            try:
+                release_trials()
+            except Exception as e:
+                local_error = local_error or '{}: {}'.format(type(e).__name__, e)
             # every rank gets here for every plan (a rank stuck inside a collective does not: watchdog)
             failed = dev_comm.allreduce_max(1.0 if local_error else 0.0) > 0
             if failed:

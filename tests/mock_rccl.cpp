@@ -29,7 +29,9 @@
 #include <sched.h>
 
 namespace {
-#ifdef SDP_MOCK_ASYNC
+#ifdef SDP_MOCK_SLOT_MB
+constexpr size_t SLOT = (size_t)SDP_MOCK_SLOT_MB << 20;   // (tools/mock8_bench.py: 512^3 slabs)
+#elif defined(SDP_MOCK_ASYNC)
 constexpr size_t SLOT = (size_t)16 << 20;          // staging bytes per rank (the segment is page-locked)
 #else
 constexpr size_t SLOT = (size_t)96 << 20;          // staging bytes per rank

@@ -154,7 +154,7 @@ def test_real_rccl_without_torch_and_two_runtime_guard(gpu, tmp_path):
 # blocking) through SDP_RCCL_LIBRARY.  Everything above the collective calls is
 # the product code that runs on the multi-GPU node.
 # ---------------------------------------------------------------------------
-def _build_mock(tmp_path, asynchronous=False):
+def _build_mock(tmp_path, asynchronous=False, slot_mb=None):
     """the collective stand-in (tests/mock_rccl.cpp); `asynchronous`: the build whose calls only
     enqueue work on the stream, like the real library"""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -163,6 +163,7 @@ def _build_mock(tmp_path, asynchronous=False):
     out = str(tmp_path / ('libmock_rccl_async.so' if asynchronous else 'libmock_rccl.so'))
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', '-std=c++17']
                           + (['-DSDP_MOCK_ASYNC'] if asynchronous else [])
+                          + (['-DSDP_MOCK_SLOT_MB={}'.format(int(slot_mb))] if slot_mb else [])
                           + ['-o', out, os.path.join(ROOT, 'tests', 'mock_rccl.cpp'), '-lrt'])
     return out
 
@@ -207,8 +208,9 @@ def _run_ranks(script, world, extra_env, timeout=300, argv=()):
     if os.environ.get('SDP_TEST_DUMP'):                   # (where the time of a multi-rank run goes: the ranks' own lines)
         with open(os.environ['SDP_TEST_DUMP'], 'a') as f:
             f.write('--- {} ranks, {}\n{}\n'.format(world, extra_env, outs[0][0].decode()))
-    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, 'rank {} failed:\n{}\n{}'.format(rank, so.decode(), se.decode()[-3000:])
+    bad = [(rank, p.returncode, so.decode()[-1500:], se.decode()[-2500:])
+           for rank, (p, (so, se)) in enumerate(zip(procs, outs)) if p.returncode != 0]
+    assert not bad, '\n'.join('rank {} failed (status {}):\n{}\n{}'.format(*b) for b in bad)
     return [so.decode() for so, _ in outs]
 
 
