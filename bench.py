@@ -338,6 +338,14 @@ def run_sharded(args, env):
              'direct': ((1, False), (2, False)),
              'peer': ((2, False), (1, False), (4, False), (8, False)),
              'sparse': ((1, False), (2, False), (4, False))}
+    if dev_comm.nranks >= 8:
+        # Tapered plans are not tried with 8 ranks: under the tests' collective stand-in (8 processes on one GPU) a
+        # tapered plan -- uneven parts, hence one broadcast per rank and phase instead of an all-gather -- stalled in
+        # 3 runs of 12 with every rank waiting in its second batch of sweeps (round 4, tools/mock_loop.sh; never with
+        # 2 or 4 ranks, never in another plan).  Whether the stall is the stand-in's or the library's is not known;
+        # what tapering could win with 8 ranks (the tail of the last exchange: < 0.04 ms) is not worth finding out
+        # inside the driver's scaling run.
+        PLANS['rccl'] = tuple(pl for pl in PLANS['rccl'] if not pl[1])
     if os.environ.get('SDP_COMM_PHASES'):
         forced = (int(os.environ['SDP_COMM_PHASES']), False)
         PLANS = {k: (forced,) for k in PLANS}
@@ -364,13 +372,18 @@ def run_sharded(args, env):
 
     def release_trials():
         """Every plan is its own problem on the device (value / J / policy buffers, and for the peer exchanges the
-        mappings of every peer's buffers: 2 (nranks - 1) HIP IPC handles each).  Sixteen of them alive at once
-        exhausted the IPC exports of a rank at 256^3 with 8 ranks on one GPU (`hipIpcGetMemHandle` failing on
-        the third sparse plan, then processes dying inside the runtime): a plan is released as soon as it has
-        been timed, by all ranks at the same point."""
+        mappings of every peer's buffers).  A plan is released as soon as it has been timed, by all ranks at the
+        same point and in two steps: every rank unmaps, then the buffers go (the library parks buffers that were
+        ever exported instead of freeing them: csrc/sdp_hip.hip, park_exported -- nine problems with mappings, one
+        after the other, ended in `hipIpcGetMemHandle: invalid argument` or a GPU page fault in a peer's stores
+        about once in seven full-size runs while freed addresses were reused)."""
         sync_all()
-        for k_ in [k_ for k_ in list(solver._cache) if k_[0] == 'problem']:
-            solver._cache.pop(k_).close()
+        old = [solver._cache.pop(k_) for k_ in [k_ for k_ in list(solver._cache) if k_[0] == 'problem']]
+        for prob in old:
+            prob.unmap_peers()          # every rank lets go of the peers' buffers ...
+        sync_all()
+        for prob in old:
+            prob.close()                # ... before anybody frees its own
         sync_all()
 
     def tune(exch):
@@ -392,7 +405,9 @@ def run_sharded(args, env):
             try:
                 if f_exch == exch and f_kind == 'hang' and str(rank) == f_rank:
                     time.sleep(1e6)
+                _trace('plan', key_of(exch, ph, taper), 'configure')
                 trial = configure(exch, ph, taper)
+                _trace('plan', key_of(exch, ph, taper), 'configured')
                 got = solver.backend_info.get('exchange') or 'rccl'        # (None with one rank)
                 if got not in {'sparse': ('peer-sparse',), 'direct': ('direct-sparse', 'direct')}.get(exch, (exch,)):
                     local_error = ('not available on this node: {}'.format(getattr(trial, 'peer_failure', 'buffers not mappable'))
@@ -401,11 +416,13 @@ def run_sharded(args, env):
                     trial.set_value(V0)
                     trial.bench_sweeps(2)
                     trial.swap()
+                    _trace('plan', key_of(exch, ph, taper), 'warm')
                     sync_all()
                     t0 = time.perf_counter()
                     trial.bench_sweeps(3)
                     sync_all()
                     t = time.perf_counter() - t0
+                    _trace('plan', key_of(exch, ph, taper), 'timed')
                     if n == 0:                                  # one result check per exchange
                         J_now = trial.get_value()
                         if f_exch == exch and f_kind == 'reject' and str(rank) == f_rank:
@@ -418,6 +435,7 @@ def run_sharded(args, env):
                 local_error = '{}: {}'.format(type(e).__name__, e)
             trial = None
             try:
+                _trace('plan', key_of(exch, ph, taper), 'release')
                 release_trials()
             except Exception as e:
                 local_error = local_error or '{}: {}'.format(type(e).__name__, e)

@@ -293,6 +293,12 @@ int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_phases,
  */
 int sdp_problem_enable_peer_exchange(sdp_problem *p);
 /*
+ * Unmaps the peers' buffers again (the RCCL exchange is back in place).  Local, but when problems are torn down
+ * the order matters across the ranks: every rank unmaps, THEN (after a barrier of the caller's) the buffers are
+ * freed by sdp_problem_destroy -- memory a peer process still maps must not be freed under it.
+ */
+int sdp_problem_disable_peer_exchange(sdp_problem *p);
+/*
  * Sparse peer exchange (after sdp_problem_enable_peer_exchange): a backup sends a peer only the
  * rows of J that peer READS in its own backups -- for a column q of need_off, the sorted,
  * disjoint node ranges ranges[2k], ranges[2k+1], k in [need_off[q], need_off[q+1]) (whole columns

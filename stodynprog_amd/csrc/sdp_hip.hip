@@ -147,6 +147,32 @@ struct DevBuf {
     }
 };
 
+// Buffers that were exported to other processes (hipIpcGetMemHandle) are not handed back to the allocator when their
+// problem goes: a later allocation at the same address gets an IPC handle the peers may still hold a stale mapping for
+// -- seen as `hipIpcGetMemHandle: invalid argument`, and as GPU page faults in a peer's stores a few plans later,
+// roughly once in seven runs of bench.py's exchange tuning (nine problems with mappings, one after the other) even
+// with "every rank unmaps, barrier, then free".  They rest here instead; the oldest are freed once more than a
+// quarter of the device's memory is parked (by then nobody has mapped them for a long time).
+struct Parked { void *p; size_t bytes; };
+static std::vector<Parked> g_parked;
+static size_t g_parked_bytes = 0;
+static void park_exported(DevBuf &b, size_t bytes)
+{
+    if (!b.p) return;
+    g_parked.push_back({b.p, bytes});
+    g_parked_bytes += bytes;
+    b.p = nullptr;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    size_t k = 0;
+    while (k < g_parked.size() && g_parked_bytes > total_b / 4) {
+        (void)hipFree(g_parked[k].p);
+        g_parked_bytes -= g_parked[k].bytes;
+        ++k;
+    }
+    g_parked.erase(g_parked.begin(), g_parked.begin() + (long)k);
+}
+
 static int upload(DevBuf &b, const void *host, size_t bytes)
 {
     int rc = b.alloc(bytes);
@@ -703,6 +729,7 @@ struct sdp_problem {
     int col_occupancy = 8;                 // workgroups of sdp_sweep_col a CU holds at once
     int32_t meta[SDP_META_WORDS] = {0};    // `sdp_meta` of the code object
     int peer_me = -1;                      // this rank, as of sdp_problem_enable_peer_exchange
+    bool exported = false;                 // V / J have been handed to other processes (HIP IPC): see park_exported
     void release_peers()
     {
         // (the rank is the one recorded when the mappings were made: the communicator is not
@@ -726,6 +753,11 @@ struct sdp_problem {
     }
     ~sdp_problem()
     {
+        if (exported) {
+            const size_t bytes = (size_t)S * (dtype == SDP_F64 ? 8 : 4);
+            park_exported(V, bytes);
+            park_exported(J, bytes);
+        }
         if (mod) (void)hipModuleUnload(mod);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1868,6 +1900,7 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     {
         hipError_t e = hipIpcGetMemHandle(&all[2 * me], p->V.p);
         if (e == hipSuccess) e = hipIpcGetMemHandle(&all[2 * me + 1], p->J.p);
+        p->exported = true;
         if (e != hipSuccess) {
             failed = 1;
             snprintf(why, sizeof(why), "exporting this rank's buffers: %s", hipGetErrorString(e));
@@ -1956,6 +1989,17 @@ extern "C" int sdp_problem_complete_value(sdp_problem *p)
     int rc;
     if ((rc = complete_J(p))) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_disable_peer_exchange(sdp_problem *p)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL handle");
+    HIP_TRY(hipDeviceSynchronize());                       // (nothing of this rank is still writing into a peer)
+    // (a value array that the sparse exchange left incomplete stays marked so: this call is for tearing a problem
+    // down, not for switching exchanges in the middle of a chain)
+    p->release_peers();
+    p->mask_valid = false;
     return SDP_OK;
 }
 

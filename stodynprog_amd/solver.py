@@ -87,6 +87,12 @@ class _DeviceProblem(object):
             nat.lib().sdp_problem_destroy(self.h)
             self.h = None
 
+    def unmap_peers(self):
+        """first half of tearing down a sharded problem: the peers' buffers leave this process (every rank does
+        this, then a barrier, then close(): memory a peer still maps must not be freed under it)"""
+        if getattr(self, 'h', None):
+            nat.check(nat.lib().sdp_problem_disable_peer_exchange(self.h))
+
     def __del__(self):
         try:
             self.close()

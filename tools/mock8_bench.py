@@ -15,7 +15,7 @@ argv = sys.argv[2:] or ['--config', 'synth512f32', '--steps', '5', '--warmup', '
 tmp = pathlib.Path(tempfile.mkdtemp(prefix='mock8_'))
 mock = td._build_mock(tmp, asynchronous=True, slot_mb=int(os.environ.get('MOCK_SLOT_MB', '96')))
 outs = td._run_ranks(td._with_hooks(tmp, os.path.join(root, 'bench.py')), world, dict(SDP_RCCL_LIBRARY=mock),
-                     timeout=1500, argv=['--gpus', str(world)] + argv)
+                     timeout=int(os.environ.get('MOCK_TIMEOUT', '1500')), argv=['--gpus', str(world)] + argv)
 line = [l for l in outs[0].strip().splitlines() if l.startswith('{')][-1]
 d = json.loads(line)
 print(json.dumps({k: d[k] for k in ('metric', 'value', 'n_gpus', 'ms_per_step', 'scaling', 'dtype', 'sharded_matches_single_gpu') if k in d}))
