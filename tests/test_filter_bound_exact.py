@@ -356,3 +356,82 @@ def test_the_short_wide_pass_radius_covers_the_difference_exactly(regime):
             assert ratio <= 1.0, (regime, trial, ratio)
             worst = max(worst, ratio)
     assert worst < 0.9, worst
+
+
+# ---------------------------------------------------------------------------
+# The wide first pass of section 3.1c (4-byte reals, models WITHOUT the additive shape, per-node control boxes):
+#     F = fma(g, P, fma(oml0, A[q0], lam0 A[q0+1]))   in 8-byte arithmetic, q0 / lam0 / oml0 / g the reference's 4-byte values
+#     bound(u) = Gc |g| + |oml0| B[q0] + |lam0| B[q0+1],   B[r] = sum_w n_w |p_w| |T[w][r]|,   n_w = W - w + 4 (W + 3 for w = 0)
+#     radius = 1.001 2^-24 (max_u bound(u) + floor)
+# (sdp_col_wide_core, sdp_col_filter_reduce, sdp_col_filter_nodes of csrc/sdp_column_kernel.h)
+# ---------------------------------------------------------------------------
+def wide_check(T, p, controls):
+    """controls: (position p as the reference computes it in 4-byte reals, cost g) per control"""
+    W, N0 = T.shape
+    gc, ps64 = f32(0), 0.0
+    nw = [f32(W + 3 if w == 0 else W - w + 4) for w in range(W)]
+    for w in range(W):
+        gc = f32(gc + f32(nw[w] * abs(p[w])))
+        ps64 = ps64 + float(p[w])
+    gc = f32(gc * f32(1.0001))
+    cu = f32(f32(2 * (W + 8)) * f32(2.0 ** -23))
+    floor = f32(f32(2) * f32(1.17549435e-38) / cu)
+    A, B = np.zeros(N0), np.zeros(N0, dtype=f32)
+    for r in range(N0):
+        acc, bs = 0.0, f32(0)
+        for w in range(W):
+            acc = acc + float(p[w]) * float(T[w][r])
+            bs = f32(np.float64(f32(nw[w] * abs(p[w]))) * np.float64(abs(T[w][r])) + np.float64(bs))     # fma in 4-byte reals
+        A[r], B[r] = acc, bs
+    p_exact = sum(Fraction(float(v)) for v in p)
+    smax, worst = f32(0), []
+    for pos, g in controls:
+        q0 = max(min(int(pos), N0 - 2), 0)
+        lam0 = f32(pos - f32(q0))
+        oml0 = f32(f32(1) - lam0)
+        E = reference_value32(T, p, g, q0, lam0)
+        F = fma(float(g), ps64, fma(float(oml0), A[q0], float(lam0) * A[q0 + 1]))
+        inner = f32(np.float64(abs(oml0)) * np.float64(B[q0]) + np.float64(f32(abs(lam0) * B[q0 + 1])))
+        bound = f32(np.float64(abs(g)) * np.float64(gc) + np.float64(inner))
+        smax = max(smax, bound)
+        worst.append(abs(Fraction(float(E)) - Fraction(F)))
+    radius = 1.001 * 2.0 ** -24 * (float(smax) + float(floor))
+    return float(max(worst) / Fraction(radius)), radius
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+def test_the_wide_pass_radius_covers_the_difference_exactly(regime):
+    rng = np.random.default_rng(300 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime))
+    worst = 0.0
+    with np.errstate(all='ignore'):
+        for trial in range(250):
+            W = int(rng.integers(1, 9))
+            N0 = int(rng.integers(3, 14))
+            T = rng.standard_normal((W, N0))
+            if regime == 'large':
+                T *= 10.0 ** rng.uniform(10, 28)
+            elif regime == 'small':
+                T *= 10.0 ** rng.uniform(-30, -10)
+            elif regime == 'mixed':
+                T *= 10.0 ** rng.uniform(-4, 4, size=T.shape)
+            elif regime == 'cancel':
+                T = 1e3 + 1e-2 * T
+            T = T.astype(f32)
+            p = np.abs(rng.standard_normal(W)) + 1e-3
+            p /= p.sum()
+            if regime == 'weights':
+                p = rng.standard_normal(W) * 3.7
+                if abs(p.sum()) < 0.2:
+                    p[0] += 1.0
+            p = p.astype(f32)
+            scale = float(np.abs(T).max())
+            controls = []
+            for _ in range(int(rng.integers(1, 12))):
+                kind = rng.integers(0, 3)
+                pos = f32(rng.uniform(0, N0 - 1) if kind == 0 else (rng.integers(0, N0) if kind == 1 else rng.uniform(-3 * N0, 4 * N0)))
+                controls.append((pos, f32(float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3))))
+            ratio, radius = wide_check(T, p, controls)
+            assert np.isfinite(radius) and radius > 0.0
+            assert ratio <= 1.0, (regime, trial, ratio)
+            worst = max(worst, ratio)
+    assert 0.01 < worst < 0.9, worst          # (tight as intended: the 4-byte radius follows the reference's roundings one by one)
