@@ -435,3 +435,113 @@ def test_the_wide_pass_radius_covers_the_difference_exactly(regime):
             assert ratio <= 1.0, (regime, trial, ratio)
             worst = max(worst, ratio)
     assert 0.01 < worst < 0.9, worst          # (tight as intended: the 4-byte radius follows the reference's roundings one by one)
+
+
+# ---------------------------------------------------------------------------
+# The filter on the SHIFTED LATTICE (8-byte reals; a perturbation that reaches the stock through a final sum:
+# x0' = (X + a_u) - b_w; sdp_col_phase_shift / sdp_col_shift_col / sdp_col_shift_reduce /
+# sdp_col_lean_core of csrc/sdp_column_kernel.h).  Here the filter value differs from the reference's even in exact
+# arithmetic -- G is tabulated at whole positions and interpolated -- and the radius is cu S_node + max B'[q0]:
+# both parts are checked together, exactly.  Grid [0, 1] (axis mode 2), one term b.
+# ---------------------------------------------------------------------------
+def shifted_check(T, p, X, a, g, b, order):
+    """a, g: per control; b: per perturbation point (x0' = (X + a_u) - b_w); order: the order in which the partial
+    sums of the perturbation points reach the lattice (LDS atomics: any order is possible)"""
+    W, N0 = T.shape
+    nm1 = float(N0 - 1)
+    fc = filter_constants(p)
+    # sdp_col_phase_shift
+    q_w, f_w, c_w, pbabs = [], [], [], 0
+    for w in range(W):
+        pb = (-b[w]) * nm1                                   # the signed sum of the b_i, in rows
+        fl = float(np.floor(pb))
+        q_w.append(int(fl))
+        f_w.append(pb - fl)                                  # exact, in [0, 1)
+        c_w.append(abs(p[w]) * (f_w[-1] * (1.0 - f_w[-1])))
+        pbabs = max(pbabs, int(abs(abs(b[w]) * nm1)) + 1)
+    flmax, nflmin = max(q_w), max(-q for q in q_w)
+    kmin, rows = -(flmax + 1), N0 + flmax + nflmin + 1
+    pbmax = float(max(abs(flmax), abs(nflmin), pbabs) + 1)
+    lc = float(rows) + float(abs(kmin)) + pbmax + 0.0 + float(N0 + 1)
+    es = float(1 + 2 * (flmax + nflmin + 2))
+    # sdp_col_shift_reduce (general branch: the clamps are no-ops inside the axis)
+    Ap, Bp, big = np.zeros(rows), np.zeros(rows), 0.0
+    for ki in range(rows):
+        k = kmin + ki
+        for w in order:
+            j = k + q_w[w]
+            q = max(min(j, N0 - 2), 0)
+            lam = float(j - q) + f_w[w]
+            t0, t1 = T[w][q], T[w][q + 1]
+            t2 = T[w][q + 2] if q + 2 < N0 else T[w][q + 1]
+            Ap[ki] = fma(p[w], fma(lam, t1 - t0, t0), Ap[ki])
+            d2 = (t2 - t1) - (t1 - t0)
+            Bp[ki] = fma(c_w[w], abs(d2) if 0 <= j <= N0 - 3 else 0.0, Bp[ki])
+            big = max(big, abs(t0), abs(t1))
+    dcol = fc['pcap'] * big + fc['floor']
+    # first pass: sdp_col_lean_core on the lattice
+    F, E, lmax, fsum, bmax = [], [], 0.0, 0.0, 0.0
+    for u in range(len(a)):
+        xa = X + a[u]                                        # sdp_model_lead_a
+        pk = xa * nm1 - float(kmin)
+        q0 = max(min(int(pk), rows - 2), 0)
+        lam0 = pk - float(q0)
+        lmax = max(lmax, abs(lam0))
+        bmax = max(bmax, Bp[q0])
+        f = fma(g[u], fc['psum'], fma(lam0, Ap[q0 + 1] - Ap[q0], Ap[q0]))
+        fsum = fsum + abs(f)
+        F.append(f)
+        # the reference: its own position per perturbation point (pyx:75-81), stodynprog.py:677-681
+        acc = 0.0
+        for w in range(W):
+            s = (xa - b[w]) * nm1
+            qr = max(min(int(s), N0 - 2), 0)
+            lr = s - float(qr)
+            val = (1.0 - lr) * T[w][qr] + lr * T[w][qr + 1]
+            acc = acc + (g[u] + val) * p[w]
+        E.append(acc)
+    h_cap = ((1.0 + 2.0 * (lmax + lc)) * (3.0 + es)) * dcol
+    s_node = fma(fc['ratio'], fsum + h_cap, h_cap)
+    radius = fma(fc['cu'], s_node, bmax)
+    worst = max(abs(Fraction(e) - Fraction(f)) for e, f in zip(E, F))
+    return float(worst / Fraction(radius)), float(Fraction(bmax) / Fraction(radius))
+
+
+@pytest.mark.parametrize('regime', ['smooth', 'rough', 'cancel', 'weights', 'large'])
+def test_the_shifted_lattice_radius_covers_the_difference_exactly(regime):
+    rng = np.random.default_rng(400 + ['smooth', 'rough', 'cancel', 'weights', 'large'].index(regime))
+    worst, model_part = 0.0, 0.0
+    for trial in range(200):
+        W = int(rng.integers(1, 8))
+        N0 = int(rng.integers(4, 16))
+        r = np.arange(N0) / (N0 - 1.0)
+        if regime == 'smooth':                               # a cost-to-go with curvature: B' is what decides
+            T = np.stack([(r - rng.uniform(0, 1)) ** 2 * rng.uniform(0.5, 3) + rng.uniform(-1, 1) * r for _ in range(W)])
+        elif regime == 'cancel':
+            T = 1e6 + 1e-6 * rng.standard_normal((W, N0))
+        else:
+            T = rng.standard_normal((W, N0))
+            if regime == 'large':
+                T *= 10.0 ** rng.uniform(100, 250)
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        if regime == 'weights':
+            p = rng.standard_normal(W) * 2.1
+            if abs(p.sum()) < 0.2:
+                p[0] += 1.0
+        scale = float(np.abs(T).max())
+        n = int(rng.integers(1, 12))
+        X = float(rng.uniform(0, 1))
+        spread = float(10.0 ** rng.uniform(-2, 0.5))          # controls inside the grid ... far outside it
+        a = [float(v) for v in rng.uniform(-spread, spread, size=n)]
+        g = [float(v) * scale * 10.0 ** rng.uniform(-3, 2) for v in rng.standard_normal(n)]
+        b = [float(v) for v in rng.uniform(-1, 1, size=W) * 10.0 ** rng.uniform(-2.5, 0.3)]
+        if trial % 4 == 0:
+            b[0] = float(rng.integers(-3, 4)) / (N0 - 1)      # a shift of a whole number of rows
+        order = list(rng.permutation(W))
+        ratio, share = shifted_check(T, p, X, a, g, b, order)
+        assert ratio <= 1.0, (regime, trial, ratio)
+        worst, model_part = max(worst, ratio), max(model_part, share)
+    assert worst > 0.05, worst                               # the chord bound B' is close to what the lerp leaves out ...
+    if regime in ('smooth', 'rough'):
+        assert model_part > 0.9, model_part                  # ... and it is what the radius is made of there
