@@ -1,4 +1,8 @@
-"""The error radius of the certified filter, checked in EXACT arithmetic (no GPU).
+"""The error radii of the certified filters, checked in EXACT arithmetic (no GPU): the lean first pass of 8-byte reals
+(section 3.1c), the short first passes of round 4 (8-byte, and the wide one of 4-byte reals), the wide first pass of
+4-byte reals, the shifted lattice (3.1d) and the reduced array (3.3c) -- every form whose radius DESIGN.md derives to
+first order with a factor to spare.  The first block below explains the method on the lean pass.
+
 
 The filter of csrc/sdp_column_kernel.h skips a control when its short value F -- two fused operations on a table
 reduced over the perturbation -- lies further than a radius above the smallest F of the node; that is sound if
@@ -545,3 +549,98 @@ def test_the_shifted_lattice_radius_covers_the_difference_exactly(regime):
     assert worst > 0.05, worst                               # the chord bound B' is close to what the lerp leaves out ...
     if regime in ('smooth', 'rough'):
         assert model_part > 0.9, model_part                  # ... and it is what the radius is made of there
+
+
+# ---------------------------------------------------------------------------
+# The filter on the REDUCED ARRAY (csrc/sdp_lead_kernel.h): two controlled stocks next to one
+# exogenous axis (d = 3, m = 2), grids [0, 1].  sdp_lead_reduce: A[i0, i1] = sum_w p_w inner_w(i0, i1) with the reference's
+# lerp along the trailing axis; first pass F = fma(g, psum, bilerp(A)) with fused lerps; bound per node
+#     S = ratio (sum |F| + Lp Dabs) + Lp Dabs,   Lp = max_u prod_k (1 + 2 |lam_k|),   Dabs = Pcap (max_w E_w) max |V| + floor,
+#     radius = 4 (W + 3 d + 4) u S.
+# The reference: the full nest of multilinear_cython.pyx per perturbation point (axis 0 outermost), stodynprog.py:677-681.
+# ---------------------------------------------------------------------------
+def lead_check(V, p, lam2, q2, controls):
+    """V[n0][n1][n2]; per perturbation point the trailing cell (q2[w], lam2[w]); controls: (pos0, pos1, g) per control"""
+    n0, n1, n2 = V.shape
+    W, d = len(p), 3
+    ps, pa = 0.0, 0.0
+    for v in p:
+        ps, pa = ps + v, pa + abs(v)
+    pcap = pa if pa > 1.0 else 1.0
+    ratio = pcap / abs(ps)
+    cu = 1.0 * float(4 * (W + 3 * d + 4)) * 2.0 ** -53
+    floor = 2.0 * TINY / cu
+    oml2 = [1.0 - l for l in lam2]
+    A = np.zeros((n0, n1))
+    for i0 in range(n0):
+        for i1 in range(n1):
+            acc = 0.0
+            for w in range(W):
+                inner = oml2[w] * V[i0][i1][q2[w]] + lam2[w] * V[i0][i1][q2[w] + 1]       # pyx:88 (one axis)
+                acc = fma(p[w], inner, acc)
+            A[i0][i1] = acc
+    emax = max(abs(oml2[w]) + abs(lam2[w]) for w in range(W))
+    dabs = pcap * (emax * float(np.abs(V).max())) + floor
+    F, E, lp, fsum = [], [], 0.0, 0.0
+    for pos0, pos1, g in controls:
+        q0 = max(min(int(pos0), n0 - 2), 0)
+        q1 = max(min(int(pos1), n1 - 2), 0)
+        l0, l1 = pos0 - float(q0), pos1 - float(q1)
+        lp = max(lp, (1.0 * fma(2.0, abs(l0), 1.0)) * fma(2.0, abs(l1), 1.0))
+        lo = fma(l1, A[q0][q1 + 1] - A[q0][q1], A[q0][q1])                  # SdpLeadLerp: last lead axis innermost, fused
+        hi = fma(l1, A[q0 + 1][q1 + 1] - A[q0 + 1][q1], A[q0 + 1][q1])
+        f = fma(g, ps, fma(l0, hi - lo, lo))
+        fsum = fsum + abs(f)
+        F.append(f)
+        o0, o1 = 1.0 - l0, 1.0 - l1
+        acc = 0.0
+        for w in range(W):
+            def z(i0, i1):
+                return oml2[w] * V[i0][i1][q2[w]] + lam2[w] * V[i0][i1][q2[w] + 1]
+            val = o0 * (o1 * z(q0, q1) + l1 * z(q0, q1 + 1)) + l0 * (o1 * z(q0 + 1, q1) + l1 * z(q0 + 1, q1 + 1))
+            acc = acc + (g + val) * p[w]
+        E.append(acc)
+    h_cap = lp * dabs
+    s_node = fma(ratio, fsum + h_cap, h_cap)
+    radius = cu * s_node
+    worst = max(abs(Fraction(e) - Fraction(f)) for e, f in zip(E, F))
+    return float(worst / Fraction(radius)), radius
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+def test_the_reduced_array_radius_covers_the_difference_exactly(regime):
+    rng = np.random.default_rng(500 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime))
+    worst = 0.0
+    for trial in range(120):
+        n0, n1, n2 = (int(v) for v in rng.integers(3, 8, size=3))
+        W = int(rng.integers(1, 7))
+        V = rng.standard_normal((n0, n1, n2))
+        if regime == 'large':
+            V *= 10.0 ** rng.uniform(100, 280)
+        elif regime == 'small':
+            V *= 10.0 ** rng.uniform(-300, -100)
+        elif regime == 'mixed':
+            V *= 10.0 ** rng.uniform(-10, 10, size=V.shape)
+        elif regime == 'cancel':
+            V = 1e6 + 1e-6 * V
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        if regime == 'weights':
+            p = rng.standard_normal(W) * 2.9
+            if abs(p.sum()) < 0.2:
+                p[0] += 1.0
+        pos2 = [float(v) for v in rng.uniform(-1.5, n2 + 0.5, size=W)]          # (the exogenous axis extrapolates too)
+        q2 = [max(min(int(v), n2 - 2), 0) for v in pos2]
+        lam2 = [v - float(q) for v, q in zip(pos2, q2)]
+        scale = float(np.abs(V).max())
+        controls = []
+        for _ in range(int(rng.integers(1, 10))):
+            kind = rng.integers(0, 3)
+            pos = [float(rng.uniform(0, n - 1)) if kind == 0 else (float(rng.integers(0, n)) if kind == 1 else float(rng.uniform(-2 * n, 3 * n)))
+                   for n in (n0, n1)]
+            controls.append((pos[0], pos[1], float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3)))
+        ratio, radius = lead_check(V, [float(v) for v in p], lam2, q2, controls)
+        assert np.isfinite(radius) and radius > 0.0
+        assert ratio <= 1.0, (regime, trial, ratio)
+        worst = max(worst, ratio)
+    assert worst < 0.6, worst
