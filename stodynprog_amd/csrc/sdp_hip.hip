@@ -1690,7 +1690,7 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
     const int64_t units = (p->node_end - p->node_begin) / unit;
     const int n_ph = 4;
     if (!p->comm && p->S * (int64_t)rs >= ((int64_t)8 << 20) && units >= 64 * n_ph &&
-        p->node_begin == 0 && p->node_end == p->S && !getenv("SDP_HOST_NO_OVERLAP")) {
+        p->node_begin == 0 && p->node_end == p->S) {
         if (!p->copy_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
             for (auto &e : p->ev_host) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
