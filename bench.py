@@ -338,14 +338,8 @@ def run_sharded(args, env):
              'direct': ((1, False), (2, False)),
              'peer': ((2, False), (1, False), (4, False), (8, False)),
              'sparse': ((1, False), (2, False), (4, False))}
-    if dev_comm.nranks >= 8:
-        # Tapered plans are not tried with 8 ranks: under the tests' collective stand-in (8 processes on one GPU) a
-        # tapered plan -- uneven parts, hence one broadcast per rank and phase instead of an all-gather -- stalled in
-        # 3 runs of 12 with every rank waiting in its second batch of sweeps (round 4, tools/mock_loop.sh; never with
-        # 2 or 4 ranks, never in another plan).  Whether the stall is the stand-in's or the library's is not known;
-        # what tapering could win with 8 ranks (the tail of the last exchange: < 0.04 ms) is not worth finding out
-        # inside the driver's scaling run.
-        PLANS['rccl'] = tuple(pl for pl in PLANS['rccl'] if not pl[1])
+    # (tapered plans have uneven parts: padded to the longest part and gathered with ONE ncclAllGather since round 5 --
+    # the grouped broadcasts of rounds 1-4, which stalled under the 8-rank stand-in, are gone: csrc/sdp_hip.hip gather_phase_of)
     if os.environ.get('SDP_COMM_PHASES'):
         forced = (int(os.environ['SDP_COMM_PHASES']), False)
         PLANS = {k: (forced,) for k in PLANS}

@@ -193,6 +193,13 @@ int sdp_problem_eval_policy(sdp_problem *p, int32_t n_iter, int rel_dp, int64_t 
 int sdp_problem_backup_host(sdp_problem *p, const void *host_V, double t_k, int rel_dp,
                             int64_t ref_index, void *host_J, void *host_pol, int32_t *host_idx,
                             double *J_ref_out);
+/*
+ * on != 0 (the default): on one GPU, grids of 8 MiB and more run the backup of
+ * sdp_problem_backup_host in a few phases of the node range and send the finished rows of a
+ * phase to the host under the kernel of the next one.  on == 0: one launch, then the downloads.
+ * Same arrays either way.
+ */
+int sdp_problem_set_host_overlap(sdp_problem *p, int on);
 int sdp_host_alloc(size_t bytes, void **out);      /* page-locked host memory */
 int sdp_host_free(void *ptr);
 

@@ -26,6 +26,7 @@ _ERR = {-1: ValueError, -2: Exception, -3: RuntimeError, -4: MemoryError,
         -5: RuntimeError, -6: RuntimeError}
 
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+codegen.HIPCC_PATH = HIPCC
 LIB_FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-fast-math',
              '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value']
 
@@ -105,6 +106,7 @@ def _declare(lib):
         'sdp_problem_bench_sweeps': (C.c_int, [vp, i32, C.c_int, i64, P(dbl), P(dbl)]),
         'sdp_problem_debug_stamps': (C.c_int, [vp, C.c_int, vp, i64]),
         'sdp_problem_backup_host': (C.c_int, [vp, vp, dbl, C.c_int, i64, vp, vp, vp, P(dbl)]),
+        'sdp_problem_set_host_overlap': (C.c_int, [vp, C.c_int]),
         'sdp_problem_simulate': (C.c_int, [vp, vp, i64, i64, vp, vp, dbl, vp, vp, vp]),
         'sdp_host_alloc': (C.c_int, [C.c_size_t, P(vp)]),
         'sdp_host_free': (C.c_int, [vp]),

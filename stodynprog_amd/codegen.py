@@ -965,9 +965,33 @@ def _headers_digest():
     return h.copy()
 
 
+_compiler_id = None
+HIPCC_PATH = '/opt/rocm/bin/hipcc'       # (_native.py, which reads HIPCC from the environment, sets it)
+
+
+def compiler_identity():
+    """What `hipcc --version` prints (HIP version, clang version and commit), once per process: part of every
+    cache key, so that code objects built by another compiler -- a cache that travelled from a container with a
+    different ROCm -- are never picked up (the key named the source, headers and flags only).
+    Without a runnable hipcc the identity is a fixed string: nothing can be compiled then anyway."""
+    global _compiler_id
+    if _compiler_id is None:
+        import subprocess
+        try:
+            out = subprocess.run([HIPCC_PATH, '--version'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 timeout=60).stdout.decode(errors='replace')
+            # (the lines that name the compiler; not the installation directory, which may be a symlink)
+            keep = [ln.strip() for ln in out.splitlines() if ln.startswith(('HIP version', 'AMD clang version', 'clang version'))]
+            _compiler_id = '\n'.join(keep) or 'hipcc without a version'
+        except (OSError, subprocess.SubprocessError):
+            _compiler_id = 'no hipcc'
+    return _compiler_id
+
+
 def source_key(source):
-    """Cache key of a code object: generated text + kernel headers + flags."""
+    """Cache key of a code object: generated text + kernel headers + flags + the compiler's identity."""
     h = _headers_digest()
     h.update(source.encode())
     h.update(' '.join(HIPCC_FLAGS[:-1]).encode())
+    h.update(compiler_identity().encode())
     return h.hexdigest()[:24]

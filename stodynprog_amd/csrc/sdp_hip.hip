@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -134,38 +135,90 @@ static int launch_mlinterp(const SdpInterpArgs &a, hipStream_t stream)
     return SDP_OK;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        if (bytes == 0) bytes = 8;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return fail(SDP_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
-        return SDP_OK;
-    }
-};
-
 // Buffers that were exported to other processes (hipIpcGetMemHandle) are not handed back to the allocator when their
 // problem goes: a later allocation at the same address gets an IPC handle the peers may still hold a stale mapping for
 // -- seen as `hipIpcGetMemHandle: invalid argument`, and as GPU page faults in a peer's stores a few plans later,
 // roughly once in seven runs of bench.py's exchange tuning (nine problems with mappings, one after the other) even
-// with "every rank unmaps, barrier, then free".  They rest here instead; the oldest are freed once more than a
-// quarter of the device's memory is parked (by then nobody has mapped them for a long time).
-struct Parked { void *p; size_t bytes; };
+// with "every rank unmaps, barrier, then free" (tools/ubench/ipc_reexport.hip is the two-process probe of that
+// sequence; DESIGN section 5 has what it showed).  They rest here instead, and the NEXT problem that needs a buffer of
+// that size on that device takes one back (the same live allocation exports to the same handle: nothing stale about
+// it), so a process that re-plans with one grid holds two such buffers however often it re-plans.  Bounded: beyond
+// PARK_CAP_BYTES the oldest are freed; an allocation that fails for lack of memory frees all of them and tries again.
+struct Parked { void *p; size_t bytes; int device; };
+static std::mutex g_park_mu;
 static std::vector<Parked> g_parked;
 static size_t g_parked_bytes = 0;
+static const size_t PARK_CAP_BYTES = (size_t)4 << 30;
+
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
+
+// free every parked buffer of the current device (all of them with any_device); returns the bytes released
+static size_t drain_parked(bool any_device = false)
+{
+    std::lock_guard<std::mutex> lock(g_park_mu);
+    const int dev = current_device();
+    size_t freed = 0;
+    std::vector<Parked> keep;
+    for (auto &q : g_parked) {
+        if (any_device || q.device == dev) { (void)hipFree(q.p); freed += q.bytes; }
+        else keep.push_back(q);
+    }
+    g_parked.swap(keep);
+    g_parked_bytes -= freed;
+    return freed;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    bool ever_exported = false;            // handed to another process once (this allocation): park it, never free it early
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        ever_exported = false;
+        if (bytes == 0) bytes = 8;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipErrorOutOfMemory && drain_parked() > 0) {          // (parked buffers are the first to go)
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(SDP_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+        return SDP_OK;
+    }
+    // a buffer that may be exported later (V, J of a problem): a parked one of this size if there is one
+    int alloc_exportable(size_t bytes)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        {
+            std::lock_guard<std::mutex> lock(g_park_mu);
+            const int dev = current_device();
+            for (size_t k = 0; k < g_parked.size(); ++k)
+                if (g_parked[k].bytes == bytes && g_parked[k].device == dev) {
+                    p = g_parked[k].p;
+                    ever_exported = true;
+                    g_parked_bytes -= bytes;
+                    g_parked.erase(g_parked.begin() + (long)k);
+                    return SDP_OK;
+                }
+        }
+        return alloc(bytes);
+    }
+};
+
 static void park_exported(DevBuf &b, size_t bytes)
 {
-    if (!b.p) return;
-    g_parked.push_back({b.p, bytes});
+    if (!b.p || !b.ever_exported) return;                  // (never exported: its destructor frees it)
+    std::lock_guard<std::mutex> lock(g_park_mu);
+    g_parked.push_back({b.p, bytes, current_device()});
     g_parked_bytes += bytes;
     b.p = nullptr;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     size_t k = 0;
-    while (k < g_parked.size() && g_parked_bytes > total_b / 4) {
+    while (k + 1 < g_parked.size() && g_parked_bytes > PARK_CAP_BYTES) {     // (the newest stays)
         (void)hipFree(g_parked[k].p);
         g_parked_bytes -= g_parked[k].bytes;
         ++k;
@@ -535,10 +588,7 @@ struct RcclApi {
     int (*CommInitRank)(nccl_comm_t *, int, nccl_uid, int) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
-    int (*Broadcast)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
-    int (*GroupStart)(void) = nullptr;
-    int (*GroupEnd)(void) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -581,10 +631,7 @@ static int rccl_load()
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllGather, "ncclAllGather");
-    SYM(Broadcast, "ncclBroadcast");
     SYM(AllReduce, "ncclAllReduce");
-    SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.h = h;
@@ -672,6 +719,8 @@ struct sdp_problem {
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
     DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps, claim;
+    DevBuf gstage;                         // gather buffer of phases with uneven parts (gather_phase_of)
+    size_t gstage_bytes = 0;
     DevBuf stage[3];                       // layout-conversion buffers of the fused host call (J, pol, idx)
     size_t stage_bytes[3] = {0, 0, 0};
     // peer-write exchange (sdp_problem_enable_peer_exchange): the other ranks' value / J buffers
@@ -686,6 +735,7 @@ struct sdp_problem {
     hipStream_t copy_stream = nullptr;     // downloads of finished phases, under the next phase's kernel
     hipEvent_t ev_host[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_copy = nullptr;
+    int host_overlap = 1;                  // sdp_problem_set_host_overlap
     int64_t stamp_words = 0;
     size_t scratch_bytes = 0;
     hipModule_t mod = nullptr;
@@ -729,7 +779,6 @@ struct sdp_problem {
     int col_occupancy = 8;                 // workgroups of sdp_sweep_col a CU holds at once
     int32_t meta[SDP_META_WORDS] = {0};    // `sdp_meta` of the code object
     int peer_me = -1;                      // this rank, as of sdp_problem_enable_peer_exchange
-    bool exported = false;                 // V / J have been handed to other processes (HIP IPC): see park_exported
     void release_peers()
     {
         // (the rank is the one recorded when the mappings were made: the communicator is not
@@ -753,9 +802,9 @@ struct sdp_problem {
     }
     ~sdp_problem()
     {
-        if (exported) {
+        {
             const size_t bytes = (size_t)S * (dtype == SDP_F64 ? 8 : 4);
-            park_exported(V, bytes);
+            park_exported(V, bytes);                       // (no-ops for buffers that never left this process)
             park_exported(J, bytes);
         }
         if (mod) (void)hipModuleUnload(mod);
@@ -839,8 +888,8 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         if ((rc = upload(p->box_hi, desc->box_hi, nbox * rs))) return rc;
         if ((rc = upload(p->box_n, desc->box_n, nbox * 4))) return rc;
     }
-    if ((rc = p->V.alloc(S * rs))) return rc;
-    if ((rc = p->J.alloc(S * rs))) return rc;
+    if ((rc = p->V.alloc_exportable(S * rs))) return rc;       // (a parked, once-exported buffer of this size if there is one)
+    if ((rc = p->J.alloc_exportable(S * rs))) return rc;
     if ((rc = p->pol.alloc((size_t)S * p->nu * rs))) return rc;
     if ((rc = p->idx.alloc(S * 4))) return rc;
     HIP_TRY(hipMemset(p->V.p, 0, S * rs));
@@ -1243,30 +1292,49 @@ static int launch_evalpol(sdp_problem *p, double t_k, int64_t nb, int64_t ne,
 
 // Exchange of one phase of a per-node array (in place) on the communicator's
 // stream: rank r owns nodes [b[r], b[r+1]) of the phase, elem_bytes bytes per
-// node; equal parts go through one ncclAllGather, uneven ones through grouped
-// broadcasts.  Moved as raw bytes, so it serves J, the policy and the index.
+// node.  Equal parts: one in-place ncclAllGather.  Uneven parts (a column count
+// that is no multiple of ranks x phases -- Searev's 61 x 61 columns on 8 GPUs --, tapered
+// plans): every part padded to the longest one in a gather buffer, ONE
+// ncclAllGather there, and the parts copied to their places ("pad, or
+// use grouped ncclBroadcast" -- round 4 used the grouped broadcasts, one per rank
+// and phase; with 8 ranks a tapered plan stalled in 3 of 12 full-size runs under the
+// stand-in, cause not found: the path is gone).  Moved as raw bytes, so it serves J,
+// the policy and the index.
 static int gather_phase_of(sdp_problem *p, int phase, void *buffer, size_t elem_bytes)
 {
-    const int n = p->comm->nranks;
+    const int n = p->comm->nranks, me = p->comm->rank;
     const int64_t *b = p->parts.data() + (size_t)phase * (n + 1);
     bool even = true;
     const int64_t len0 = b[1] - b[0];
-    for (int r = 0; r < n; ++r) even = even && (b[r + 1] - b[r] == len0);
+    int64_t longest = 0;
+    for (int r = 0; r < n; ++r) {
+        even = even && (b[r + 1] - b[r] == len0);
+        longest = std::max(longest, b[r + 1] - b[r]);
+    }
     if (b[n] == b[0]) return SDP_OK;
     char *base = (char *)buffer;
     hipStream_t cs = p->comm->stream;
     if (even) {
-        NCCL_TRY(g_rccl.AllGather(base + b[p->comm->rank] * elem_bytes, base + b[0] * elem_bytes,
+        NCCL_TRY(g_rccl.AllGather(base + b[me] * elem_bytes, base + b[0] * elem_bytes,
                                   (size_t)len0 * elem_bytes, NCCL_INT8, p->comm->comm, cs));
-    } else {
-        NCCL_TRY(g_rccl.GroupStart());
-        for (int r = 0; r < n; ++r) {
-            const int64_t cnt = b[r + 1] - b[r];
-            if (cnt == 0) continue;
-            void *ptr = base + b[r] * elem_bytes;
-            NCCL_TRY(g_rccl.Broadcast(ptr, ptr, (size_t)cnt * elem_bytes, NCCL_INT8, r, p->comm->comm, cs));
-        }
-        NCCL_TRY(g_rccl.GroupEnd());
+        return SDP_OK;
+    }
+    const size_t slot = (size_t)longest * elem_bytes;
+    if (p->gstage_bytes < slot * (size_t)n) {
+        // (sdp_problem_attach_comm sizes the buffer for the J exchange of every phase; only the policy
+        // gather -- on request, nothing in flight -- can come here.  hipFree waits for the device.)
+        int rc = p->gstage.alloc(slot * (size_t)n);
+        if (rc) { p->gstage_bytes = 0; return rc; }
+        p->gstage_bytes = slot * (size_t)n;
+    }
+    char *g = (char *)p->gstage.p;
+    const size_t mine = (size_t)(b[me + 1] - b[me]) * elem_bytes;
+    if (mine) HIP_TRY(hipMemcpyAsync(g + (size_t)me * slot, base + b[me] * elem_bytes, mine, hipMemcpyDeviceToDevice, cs));
+    NCCL_TRY(g_rccl.AllGather(g + (size_t)me * slot, g, slot, NCCL_INT8, p->comm->comm, cs));
+    for (int r = 0; r < n; ++r) {
+        const size_t cnt = (size_t)(b[r + 1] - b[r]) * elem_bytes;
+        if (r == me || cnt == 0) continue;
+        HIP_TRY(hipMemcpyAsync(base + b[r] * elem_bytes, g + (size_t)r * slot, cnt, hipMemcpyDeviceToDevice, cs));
     }
     return SDP_OK;
 }
@@ -1530,6 +1598,7 @@ extern "C" int sdp_problem_vi_sweep(sdp_problem *p, double t_k, int rel_dp, int6
 static void swap_buffers(sdp_problem *p)
 {
     std::swap(p->V.p, p->J.p);
+    std::swap(p->V.ever_exported, p->J.ever_exported);
     std::swap(p->V_partial, p->J_partial);
     ++p->V_gen;
     if (p->peer_exchange) p->peer_V.swap(p->peer_J);
@@ -1689,7 +1758,7 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
     const int64_t unit = p->layout == SDP_LAYOUT_COLUMNS ? p->orders[0] : 1;
     const int64_t units = (p->node_end - p->node_begin) / unit;
     const int n_ph = 4;
-    if (!p->comm && p->S * (int64_t)rs >= ((int64_t)8 << 20) && units >= 64 * n_ph &&
+    if (p->host_overlap && !p->comm && p->S * (int64_t)rs >= ((int64_t)8 << 20) && units >= 64 * n_ph &&
         p->node_begin == 0 && p->node_end == p->S) {
         if (!p->copy_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
@@ -1735,6 +1804,13 @@ extern "C" int sdp_problem_backup_host(sdp_problem *p, const void *host_V, doubl
     HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->last_kernel_ms = ms;
     if (rel_dp && J_ref_out) HIP_TRY(hipMemcpy(J_ref_out, p->refs.p, 8, hipMemcpyDeviceToHost));
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_host_overlap(sdp_problem *p, int on)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    p->host_overlap = on ? 1 : 0;
     return SDP_OK;
 }
 
@@ -1840,6 +1916,36 @@ extern "C" int sdp_problem_debug_stamps(sdp_problem *p, int enable, unsigned lon
     return SDP_OK;
 }
 
+#ifdef SDP_TEST_HOOKS
+// TEST BUILD ONLY: fill the device arrays a backup writes (J, policy, index; the layout-conversion
+// buffers when they exist) with recognisable bytes, so that a row that reaches the host WITHOUT having
+// been written by the kernel / the conversion shows which buffer it came from (tools/host_phase_stress.py)
+extern "C" int sdp_problem_debug_poison(sdp_problem *p)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    const size_t rs = real_size(p->dtype);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(p->J.p, 0xF1, (size_t)p->S * rs));
+    HIP_TRY(hipMemset(p->pol.p, 0xF2, (size_t)p->S * rs * p->nu));
+    HIP_TRY(hipMemset(p->idx.p, 0xF3, (size_t)p->S * 4));
+    for (int k = 0; k < 3; ++k)
+        if (p->stage[k].p) HIP_TRY(hipMemset(p->stage[k].p, 0xE0 + k, p->stage_bytes[k]));
+    HIP_TRY(hipDeviceSynchronize());
+    return SDP_OK;
+}
+// TEST BUILD ONLY: leave `bytes` of freed device memory filled with `byte` behind (what a later
+// hipMalloc may hand out again)
+extern "C" int sdp_debug_pollute(size_t bytes, int byte)
+{
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, bytes));
+    HIP_TRY(hipMemset(q, byte, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(q));
+    return SDP_OK;
+}
+#endif
+
 extern "C" int sdp_problem_bench_sweeps(sdp_problem *p, int32_t reps, int rel_dp,
                                         int64_t ref_index, double *loop_ms, double *kernel_ms)
 {
@@ -1899,8 +2005,11 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     char why[256] = "";
     {
         hipError_t e = hipIpcGetMemHandle(&all[2 * me], p->V.p);
-        if (e == hipSuccess) e = hipIpcGetMemHandle(&all[2 * me + 1], p->J.p);
-        p->exported = true;
+        if (e == hipSuccess) {
+            p->V.ever_exported = true;
+            e = hipIpcGetMemHandle(&all[2 * me + 1], p->J.p);
+            if (e == hipSuccess) p->J.ever_exported = true;
+        }
         if (e != hipSuccess) {
             failed = 1;
             snprintf(why, sizeof(why), "exporting this rank's buffers: %s", hipGetErrorString(e));
@@ -2069,6 +2178,23 @@ extern "C" int sdp_problem_attach_comm(sdp_problem *p, sdp_comm *c, int32_t n_ph
         at = b[n];
     }
     if (at != p->S) return fail(SDP_EINVAL, "phases must cover all %lld nodes", (long long)p->S);
+    {
+        // gather buffer for the J exchange of phases whose parts are uneven (gather_phase_of): sized now, so
+        // that no backup ever allocates with collectives in flight
+        size_t need = 0;
+        for (int ph = 0; ph < n_phases; ++ph) {
+            const int64_t *b = parts.data() + (size_t)ph * (n + 1);
+            int64_t longest = 0;
+            bool even = true;
+            for (int r = 0; r < n; ++r) { longest = std::max(longest, b[r + 1] - b[r]); even = even && (b[r + 1] - b[r] == b[1] - b[0]); }
+            if (!even) need = std::max(need, (size_t)longest * (size_t)n * real_size(p->dtype));
+        }
+        if (need > p->gstage_bytes) {
+            int rc = p->gstage.alloc(need);
+            if (rc) { p->gstage_bytes = 0; return rc; }
+            p->gstage_bytes = need;
+        }
+    }
     for (auto &e : p->ev_phase) (void)hipEventDestroy(e);
     p->ev_phase.assign((size_t)n_phases, nullptr);
     for (auto &e : p->ev_phase) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -10,9 +10,9 @@ the J_k slabs are exchanged with ONE all-gather:
 
   * RcclCommunicator  -- device buffers, RCCL over xGMI, called inside
     sdp_problem_vi_sweep on the sweep's stream (include/sdp_hip.h);
-  * GlooCommunicator  -- host arrays over torch.distributed/gloo; used ONLY by
-    the tests of the slab logic (CPU, world_size 2).  The product never imports
-    torch: the RCCL unique id travels through a file (`FileRendezvous`).
+  * a HOST communicator (the `Communicator` interface below with is_device False) -- host arrays; the CPU tests
+    of the slab logic bring one over torch.distributed/gloo (tests/gloo_comm.py, world_size 2).  The product never
+    imports torch: the RCCL unique id travels through a file (`FileRendezvous`).
 
 Policies are gathered only on request (sdp_problem_get_policy is then a collective call);
 the timed sweep never pays for it.
@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-__all__ = ['slab_bounds', 'phase_partition', 'slab_partition', 'RcclCommunicator', 'GlooCommunicator',
+__all__ = ['slab_bounds', 'phase_partition', 'slab_partition', 'Communicator', 'RcclCommunicator',
            'FileRendezvous', 'from_env']
 
 
@@ -86,7 +86,12 @@ def intervals_of(mask):
     return d.reshape(-1, 2)
 
 
-class _Base(object):
+class Communicator(object):
+    """What DPSolver asks of a communicator.  `is_device` True: the library exchanges device buffers itself
+    (RcclCommunicator).  False: a HOST communicator -- the solver sweeps this rank's slab and calls
+    `all_gather_slabs(flat_array, bounds)` on host arrays; besides that `allreduce_max(value)` and `barrier()`.
+    The product ships the RCCL one only; the gloo one of the CPU tests (tests/gloo_comm.py) implements the host
+    interface over torch.distributed -- torch stays out of this package."""
     rank = 0
     nranks = 1
     is_device = False
@@ -95,48 +100,7 @@ class _Base(object):
         return slab_bounds(shape, self.nranks)
 
 
-class GlooCommunicator(_Base):
-    """Host-side collectives over an initialised torch.distributed group."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.nranks = dist.get_world_size(group)
-
-    def all_gather_slabs(self, J, bounds):
-        """Fill the flat view of `J` (complete array, own slab valid) with the
-        slabs of every rank, in place.  Slabs may have different lengths."""
-        import torch
-        flat = J.reshape(-1)
-        mine = torch.from_numpy(np.ascontiguousarray(flat[bounds[self.rank]:bounds[self.rank + 1]]))
-        for r in range(self.nranks):
-            n = int(bounds[r + 1] - bounds[r])
-            buf = mine.clone() if r == self.rank else torch.empty(n, dtype=mine.dtype)
-            if n:
-                self._dist.broadcast(buf, src=self._global_rank(r), group=self.group)
-                flat[bounds[r]:bounds[r + 1]] = buf.numpy()
-        return J
-
-    def _global_rank(self, r):
-        if self.group is None:
-            return r
-        return self._dist.get_global_rank(self.group, r)
-
-    def broadcast_bytes(self, payload, src=0):
-        obj = [payload if self.rank == src else None]
-        self._dist.broadcast_object_list(obj, src=self._global_rank(src), group=self.group)
-        return obj[0]
-
-    def allreduce_max(self, value):
-        import torch
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
-        return float(t[0])
-
-    def barrier(self):
-        self._dist.barrier(group=self.group)
+_Base = Communicator
 
 
 class RcclCommunicator(_Base):

@@ -71,7 +71,22 @@ class _DeviceProblem(object):
         d.node_begin, d.node_end = node_range
         d.module_path = module_path.encode()
         h = C.c_void_p()
-        nat.check(nat.lib().sdp_problem_create(C.byref(d), C.byref(h)))
+        rc = nat.lib().sdp_problem_create(C.byref(d), C.byref(h))
+        if comm is not None and comm.nranks > 1:
+            # What follows (attaching the communicator, mapping the peers' buffers, need lists) is collective, and so
+            # is what the caller does about a failure (DPSolver._problem re-plans without the reduced-array sweep when
+            # the device memory does not suffice): the ranks agree HERE whether every one of them has its problem --
+            # all go on or all raise (advisor, round 4: one rank out of memory left the others in a collective)
+            why = None if rc == 0 else nat.lib().sdp_last_error().decode(errors='replace')
+            if comm.allreduce_max(0.0 if rc == 0 else 1.0) > 0:
+                if rc == 0:
+                    nat.lib().sdp_problem_destroy(h)
+                    raise MemoryError('another rank could not create its problem (out of device memory there?)')
+                if rc != -4:
+                    raise nat._ERR.get(rc, RuntimeError)(why)
+                raise MemoryError(why)
+        else:
+            nat.check(rc)
         self.h = h
         self.node_range = tuple(node_range)
         self.parts = None
@@ -141,7 +156,7 @@ class _DeviceProblem(object):
                                                     int(ref_index), nat.ptr(refs)))
         return refs[:int(n_iter)]
 
-    def backup_host(self, V, t_k=0.0, rel_dp=False, ref_index=0):
+    def backup_host(self, V, t_k=0.0, rel_dp=False, ref_index=0, overlap=True):
         """value_iteration's device work with host arrays in and out in ONE library call
         (sdp_problem_backup_host): upload, sweep, relative-DP shift, download of J and of
         the policy values, one synchronisation.  Large outputs live in page-locked memory
@@ -154,6 +169,7 @@ class _DeviceProblem(object):
         J = new(self.shape, self.dtype)
         pol = new(self.shape + (self.nu,), self.dtype)
         ref = C.c_double(0.0)
+        nat.check(nat.lib().sdp_problem_set_host_overlap(self.h, int(bool(overlap))))
         nat.check(nat.lib().sdp_problem_backup_host(self.h, nat.ptr(V), float(t_k), int(bool(rel_dp)),
                                                     int(ref_index), nat.ptr(J), nat.ptr(pol), None,
                                                     C.byref(ref)))
@@ -201,6 +217,11 @@ class DPSolver(object):
     # nothing is ever read from the environment.  A radius scale below 1, say, voids the
     # bit-identity guarantee -- which is why it takes an explicit assignment to get one.
     debug_defines = None
+    # value_iteration with host arrays in and out on one GPU (sdp_problem_backup_host): True sends the finished
+    # rows of a phase to the host under the next phase's kernel (grids of 8 MiB and more), False runs one launch
+    # and then the downloads.  Same arrays either way.
+    host_overlap = True
+    _debug_after_create = None
 
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
@@ -873,6 +894,8 @@ class DPSolver(object):
                               self.comm if (self.comm is not None and self.comm.is_device) else None,
                               bounds, layout, plan['staged'], plan['col_seg_nodes'])
         self._cache[fp] = prob
+        if self._debug_after_create is not None:        # (tools/host_phase_stress.py: poison the fresh buffers)
+            self._debug_after_create(prob)
         exchange = None
         if self.comm is not None and self.comm.is_device and self.comm.nranks > 1:
             exchange = 'rccl'
@@ -1076,7 +1099,8 @@ class DPSolver(object):
         if self.comm is None:
             # single GPU: one library call, arrays through page-locked memory
             J_k, pol_k, J_ref = prob.backup_host(J_next, 0.0 if t_k is None else t_k, rel_dp,
-                                                 self._ref_flat(prob) if rel_dp else 0)
+                                                 self._ref_flat(prob) if rel_dp else 0,
+                                                 overlap=self.host_overlap)
             self._idx_cache, self._idx_source = None, prob
             return J_k, pol_k, J_ref
         prob.set_value(J_next)

@@ -43,13 +43,15 @@ WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, 'tests'))
 import torch.distributed as dist_t
+from gloo_comm import GlooCommunicator
 from stodynprog_amd import dist, models, solver as solver_mod
 from oracle import vi_numpy
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist_t.init_process_group('gloo', rank=rank, world_size=world)
-comm = dist.GlooCommunicator()
+comm = GlooCommunicator()
 assert comm.nranks == world and not comm.is_device
 
 sysd, ref = models.nas_demo(n_E=7, n_P=5, n_w=5)       # 7 planes over 2 ranks: uneven slabs

@@ -51,3 +51,34 @@ def test_a_code_object_without_metadata_is_refused(gpu, monkeypatch, tmp_path):
     with pytest.raises(RuntimeError) as e:
         s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
     assert 'sdp_meta' in str(e.value)
+
+
+def test_a_model_nobody_has_seen_is_compiled_on_this_box(gpu):
+    """The code-object cache travels with the tree (stodynprog_amd/_kcache, keys = source + kernel headers + flags +
+    `hipcc --version`), so a GPU run may never start the compiler (the driver's run did not).  This
+    model carries a constant drawn now: its unit cannot be cached, hipcc runs HERE, and the result is numpy's."""
+    import os
+    from oracle import vi_numpy
+    from stodynprog_amd import SysDescription, DPSolver, codegen
+    nonce = float(np.frombuffer(os.urandom(8), dtype=np.uint64)[0] % 10 ** 9) / 1e9 + 0.25
+    s = SysDescription((2, 1, 1))
+    s.dyn = lambda x, y, u, w: (x + 0.3 * u, 0.8 * y + w)
+    s.cost = lambda x, y, u, w: (x - nonce) ** 2 + 0.1 * u * u
+    s.control_box = lambda x, y: ((-1., 1.),)
+    s.perturb_laws = [models.NormalLaw(0, 0.1)]
+    solver = DPSolver(s)
+    solver.discretize_state(-1, 1, 33, -1, 1, 9)
+    solver.discretize_perturb(-0.3, 0.3, 5)
+    solver.control_steps = (0.1,)
+    source = solver._kernel_plan()['source']
+    assert float(nonce).hex() in source                                  # (constants are emitted as hexadecimal literals)
+    out = os.path.join(nat.KCACHE, codegen.source_key(source) + '.hsaco')
+    assert not os.path.exists(out)
+    assert codegen.compiler_identity().startswith('HIP version')
+    V = np.random.default_rng(9).standard_normal((33, 9))
+    J, u = solver.value_iteration(V, report_time=False)
+    assert os.path.exists(out) and os.path.getsize(out) > 10000          # compiled just now, on this machine
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(solver), V)
+    assert np.array_equal(J, Jo) and np.array_equal(u, uo)
+    for ext in ('.hsaco', '.hip'):                                        # (not worth keeping: never asked for again)
+        os.unlink(out[:-6] + ext)

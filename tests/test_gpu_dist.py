@@ -22,11 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
 import os, sys
 sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, 'tests'))
 import numpy as np
 import torch.distributed as tdist
 tdist.init_process_group('gloo', init_method='env://')
 from stodynprog_amd import models
-from stodynprog_amd.dist import GlooCommunicator
+from gloo_comm import GlooCommunicator
 
 comm = GlooCommunicator()
 rank = comm.rank
@@ -244,7 +245,10 @@ CASES = [('synthetic3d', dict(N=20), 4, F64), ('synthetic3d', dict(N=20), 3, F64
          ('synthetic3d', dict(N=20, stock_noise=0.07), 2, F64),
          ('two_reservoirs', dict(n_a=24, n_b=12, n_y=8, n_w=5, steps=(0.25, 0.25)), 2, F64),
          ('two_reservoirs', dict(n_a=7, n_b=12, n_y=8, n_w=5, steps=(0.5, 0.25)), 1, F64),   # fewer rows than 8 ranks
-         ('synthetic3d', dict(N=24), 2, F32)]
+         ('synthetic3d', dict(N=24), 2, F32),
+         # round 5: a column count that is no multiple of ranks x phases (the reference's Searev grid: 61 x 61 = 3721
+         # columns) -- uneven parts in every phase, padded and gathered with ONE all-gather -- over a chain of 20 sweeps
+         ('searev', dict(), 2, F64)]
 if os.environ.get('SDP_TEST_CASES'):
     CASES = [CASES[int(k)] for k in os.environ['SDP_TEST_CASES'].split(',')]
 EXCHANGES = os.environ.get('SDP_TEST_EXCHANGES', 'rccl,peer,sparse,direct').split(',')
@@ -295,6 +299,11 @@ for (name, kw, phases, dtype), exchange, light in PLAN:
     (Ja, ra), _ = one.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
     (Jb, rb), _ = two.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
     assert np.array_equal(Ja, Jb) and ra == rb, name
+    if name == 'searev':
+        assert any(len(set(np.diff(ph))) > 1 for ph in prob.parts), prob.parts       # uneven parts
+        Ka, _ = quiet(one.value_iterations, V0, 20)
+        Kb, _ = quiet(two.value_iterations, V0, 20)
+        assert np.array_equal(Ka, Kb), name
     if light:
         print('rank', rank, name, phases, dtype, exchange, 'ok (sweeps only)', round(time.time() - t_start, 1), flush=True)
         continue
@@ -317,7 +326,7 @@ print('rank', rank, 'all ok', flush=True)
 # (8 ranks: the partition / mapping / rendezvous logic with more ranks than rows or columns in some cases -- one
 # case per kernel family is enough there, every exchange; the blocking stand-in with 2 ranks only: the
 # asynchronous one is the stricter test.  Round 3 ran all cases in all five set-ups: 280 s of the suite.)
-EIGHT = '0,10'                       # (a column kernel with every exchange; two stocks with fewer rows than ranks)
+EIGHT = '0,10,12'                    # (a column kernel with every exchange; two stocks with fewer rows than ranks; uneven parts over 20 sweeps)
 REST8 = 'rccl,direct'                # every case but the first: the all-gather and the direct exchange
 
 
