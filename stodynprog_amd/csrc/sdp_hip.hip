@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 #include <memory>
 #include <mutex>
@@ -190,9 +191,14 @@ struct DevBuf {
         if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(SDP_ENOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
         return SDP_OK;
     }
-    // a buffer that may be exported later (V, J of a problem): a parked one of this size if there is one
+    // a buffer that may be exported later (V, J of a problem): a parked one of this size if there is one.
+    // Never less than EXPORT_MIN_BYTES: the runtime carves small allocations out of shared 2 MiB blocks, and
+    // a HIP IPC handle of such a fragment shares the whole BLOCK with the other process -- V, J and whatever
+    // else lives there, mapped once per handle.  A buffer of its own block is exported alone.
+    static constexpr size_t EXPORT_MIN_BYTES = (size_t)4 << 20;
     int alloc_exportable(size_t bytes)
     {
+        if (bytes < EXPORT_MIN_BYTES) bytes = EXPORT_MIN_BYTES;
         if (p) { (void)hipFree(p); p = nullptr; }
         {
             std::lock_guard<std::mutex> lock(g_park_mu);
@@ -210,9 +216,69 @@ struct DevBuf {
     }
 };
 
+// Mappings of other processes' buffers (hipIpcOpenMemHandle), ONE per remote allocation and process, counted.
+// Problems come and go in an order the ranks do not share (a Python object waiting for its garbage collector keeps
+// its mappings for a while), and a rank that re-plans takes its parked buffers back and exports them again: a second
+// problem here then maps what a first one still holds.  A second hipIpcOpenMemHandle of the same handle and the
+// first problem's hipIpcCloseMemHandle of it are exactly what corrupted things in round 5's first runs (the same
+// remote buffer at one address twice: the close of the old mapping took the new one with it -- wrong J, GPU page
+// faults, and `hipIpcGetMemHandle: invalid argument` once the runtime's own table of allocations was off).  So the
+// library opens a handle once, hands the same address to whoever asks again, and closes it with its last user.
+struct IpcMap { hipIpcMemHandle_t h; void *ptr; int refs; };
+static std::mutex g_ipc_mu;
+static std::vector<IpcMap> g_ipc_maps;
+
+static void ipc_trace(const char *what, const void *ptr, const hipIpcMemHandle_t *h, int refs)
+{
+#ifdef SDP_TEST_HOOKS
+    static const int on = getenv("SDP_IPC_TRACE") != nullptr;
+    if (!on) return;
+    unsigned long long sig = 0;
+    if (h) for (size_t k = 0; k < sizeof(*h); ++k) sig = sig * 1099511628211ull + ((const unsigned char *)h)[k];
+    fprintf(stderr, "[ipc %d] %s ptr %p handle %016llx refs %d\n", (int)getpid(), what, ptr, sig, refs);
+#else
+    (void)what; (void)ptr; (void)h; (void)refs;
+#endif
+}
+
+static hipError_t ipc_open(void **out, const hipIpcMemHandle_t &h)
+{
+    std::lock_guard<std::mutex> lock(g_ipc_mu);
+    for (auto &m : g_ipc_maps)
+        if (memcmp(&m.h, &h, sizeof(h)) == 0) {
+            ++m.refs;
+            *out = m.ptr;
+            ipc_trace("reuse", m.ptr, &h, m.refs);
+            return hipSuccess;
+        }
+    void *q = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { *out = nullptr; ipc_trace("open FAILED", nullptr, &h, 0); return e; }
+    g_ipc_maps.push_back({h, q, 1});
+    *out = q;
+    ipc_trace("open", q, &h, 1);
+    return hipSuccess;
+}
+
+static void ipc_close(void *ptr)
+{
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lock(g_ipc_mu);
+    for (size_t k = 0; k < g_ipc_maps.size(); ++k)
+        if (g_ipc_maps[k].ptr == ptr) {
+            if (--g_ipc_maps[k].refs > 0) { ipc_trace("release", ptr, &g_ipc_maps[k].h, g_ipc_maps[k].refs); return; }
+            ipc_trace("close", ptr, &g_ipc_maps[k].h, 0);
+            (void)hipIpcCloseMemHandle(ptr);
+            g_ipc_maps.erase(g_ipc_maps.begin() + (long)k);
+            return;
+        }
+    ipc_trace("close of an unknown mapping", ptr, nullptr, 0);
+}
+
 static void park_exported(DevBuf &b, size_t bytes)
 {
     if (!b.p || !b.ever_exported) return;                  // (never exported: its destructor frees it)
+    if (bytes < DevBuf::EXPORT_MIN_BYTES) bytes = DevBuf::EXPORT_MIN_BYTES;
     std::lock_guard<std::mutex> lock(g_park_mu);
     g_parked.push_back({b.p, bytes, current_device()});
     g_parked_bytes += bytes;
@@ -786,8 +852,8 @@ struct sdp_problem {
         const int me = peer_me;
         for (size_t r = 0; r < peer_V.size(); ++r) {
             if ((int)r == me) continue;
-            if (peer_V[r]) (void)hipIpcCloseMemHandle(peer_V[r]);
-            if (peer_J[r]) (void)hipIpcCloseMemHandle(peer_J[r]);
+            ipc_close(peer_V[r]);
+            ipc_close(peer_J[r]);
         }
         peer_V.clear(); peer_J.clear();
         for (auto &st : peer_stream) if (st) (void)hipStreamDestroy(st);
@@ -2005,9 +2071,11 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     char why[256] = "";
     {
         hipError_t e = hipIpcGetMemHandle(&all[2 * me], p->V.p);
+        ipc_trace(e == hipSuccess ? "export V" : "export V FAILED", p->V.p, &all[2 * me], 0);
         if (e == hipSuccess) {
             p->V.ever_exported = true;
             e = hipIpcGetMemHandle(&all[2 * me + 1], p->J.p);
+            ipc_trace(e == hipSuccess ? "export J" : "export J FAILED", p->J.p, &all[2 * me + 1], 0);
             if (e == hipSuccess) p->J.ever_exported = true;
         }
         if (e != hipSuccess) {
@@ -2059,10 +2127,10 @@ extern "C" int sdp_problem_enable_peer_exchange(sdp_problem *p)
     p->peer_V[me] = p->V.p; p->peer_J[me] = p->J.p;
     for (int r = 0; r < n && !failed; ++r) {
         if (r == me) continue;
-        hipError_t e = hipIpcOpenMemHandle(&p->peer_V[r], all[2 * r], hipIpcMemLazyEnablePeerAccess);
+        hipError_t e = ipc_open(&p->peer_V[r], all[2 * r]);
         if (e != hipSuccess) p->peer_V[r] = nullptr;
         if (e == hipSuccess) {
-            e = hipIpcOpenMemHandle(&p->peer_J[r], all[2 * r + 1], hipIpcMemLazyEnablePeerAccess);
+            e = ipc_open(&p->peer_J[r], all[2 * r + 1]);
             if (e != hipSuccess) p->peer_J[r] = nullptr;
         }
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->peer_stream[r], hipStreamNonBlocking);

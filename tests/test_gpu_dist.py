@@ -233,6 +233,12 @@ def quiet(fn, *a, **k):
     with contextlib.redirect_stdout(io.StringIO()):
         return fn(*a, **k)
 
+def where(a, b):
+    """for an assertion message: how many entries differ, and over which index ranges"""
+    bad = np.argwhere(np.asarray(a) != np.asarray(b))
+    return 'identical' if not len(bad) else '%d of %d entries differ, index ranges %s' % (
+        len(bad), np.asarray(a).size, [(int(lo), int(hi)) for lo, hi in zip(bad.min(axis=0), bad.max(axis=0))])
+
 F64, F32 = 'float64', 'float32'
 CASES = [('synthetic3d', dict(N=20), 4, F64), ('synthetic3d', dict(N=20), 3, F64), ('synthetic3d', dict(N=20), -4, F64),
          ('storage_ar1', dict(), 4, F64),                  # 61 columns: uneven parts -> broadcasts
@@ -261,7 +267,7 @@ REST_FROM = int(os.environ.get('SDP_TEST_REST_FROM', '1'))  # (the first REST_FR
 # per exchange with many phases, 0.1 s with two processes -- so the larger worlds keep what is about THEM: partitions,
 # mappings, need lists, the one-rendezvous exchange; the API surface is the 2-rank runs' job)
 FULL = [e for e in os.environ.get('SDP_TEST_FULL', '').split(',') if e]
-SPARSE_OK = ('synthetic3d', 'storage_ar1', 'nas_demo')       # full-table column kernels: need lists
+SPARSE_OK = ('synthetic3d', 'storage_ar1', 'nas_demo', 'searev')       # full-table column kernels: need lists
 PLAN = [(c, e, (bool(REST) and k >= REST_FROM) or (bool(FULL) and e not in FULL))
         for k, c in enumerate(CASES) for e in (REST if (REST and k >= REST_FROM) else EXCHANGES)]
 for (name, kw, phases, dtype), exchange, light in PLAN:
@@ -292,8 +298,8 @@ for (name, kw, phases, dtype), exchange, light in PLAN:
         assert two.backend_info['kernel'] == 'lead' == one.backend_info['kernel'], two.backend_info
     if kw.get('stock_noise'):
         assert two.backend_info['filter_form'] == 'shifted lattice', two.backend_info
-    assert np.array_equal(J1, J2), name
-    assert np.array_equal(p1, p2) and np.array_equal(i1, i2), name      # get_policy gathers
+    assert np.array_equal(J1, J2), (name, exchange, where(J1, J2), prob.parts.tolist())
+    assert np.array_equal(p1, p2) and np.array_equal(i1, i2), (name, exchange, where(p1, p2), where(i1, i2))      # get_policy gathers
     ref = one._state_ref_ind
     Jd = J1 - J1[ref]
     (Ja, ra), _ = one.value_iteration((Jd, 0.), rel_dp=True, report_time=False)
