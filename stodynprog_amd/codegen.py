@@ -40,7 +40,7 @@ DEBUG_INT_MACROS = ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_
 DEBUG_NAMES = frozenset(DEBUG_INT_MACROS + (
     'SDP_STAMP', 'SDP_NO_POW2', 'SDP_EXTRA_DEFINES', 'SDP_COL_FILTER_SCALE', 'SDP_LEAD_FILTER_SCALE',
     'SDP_LEAD_UNROLL', 'SDP_COL_A_LW', 'SDP_COL_FILTER', 'SDP_COL_SHIFT', 'SDP_COL_UTAB', 'SDP_LEAD_FILTER',
-    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES', 'SDP_COL_LEAN2'))
+    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES', 'SDP_COL_LEAN2', 'SDP_COL_BNB'))
 
 
 def check_debug(debug):
@@ -384,6 +384,7 @@ def short_pass_source(model, frontier, macro='SDP_COL_LEAN2'):
            '#define SDP_LEAN2_A_SLOT {}'.format(int(a_slot)),
            '#define SDP_LEAN2_H_SLOT {}'.format(-1 if h_slot is None else int(h_slot)),
            '#define SDP_LEAN2_LEAD(X, A) {}'.format({'add': '((X) + (A))', 'sub': '((X) - (A))', 'rsub': '((A) - (X))'}[a_form]),
+           '#define SDP_LEAN2_FORM {}            // 0: X + a, 1: X - a, 2: a - X'.format({'add': 0, 'sub': 1, 'rsub': 2}[a_form]),
            '#define SDP_LEAN2_HNEG {}           // the part of the cost that depends on the control enters negated (K - h)'.format(
                1 if (h_slot is not None and h_form == 'sub') else 0)]
     for fname, node in (('sdp_model_lead_x', x_node), ('sdp_model_cost_x', k_node)):
@@ -496,6 +497,9 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
                 and _dbg(debug, 'SDP_COL_LEAN2') != '0':
             if rs == 8 and wres and _dbg(debug, 'SDP_COL_LEAN') != '0':
                 short = short_pass_source(model, utab[0], 'SDP_COL_LEAN2')
+                if short and _dbg(debug, 'SDP_COL_BNB') != '0':
+                    short += ('\n#define SDP_COL_BNB 1          // the short first pass as a certified branch and bound over '
+                              'blocks of controls (sdp_lean2_bnb)')
             elif rs == 4 and not wres and _dbg(debug, 'SDP_COL_WIDE') != '0' and _dbg(debug, 'SDP_COL_LEAN') in (None, '0') \
                     and _dbg(debug, 'SDP_COL_FILTER_TOP2') in (None, '1'):
                 short = short_pass_source(model, utab[0], 'SDP_COL_WIDE2')
@@ -539,7 +543,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
                                     max_controls=column[2] if len(column) > 2 else None,
                                     n_columns=column[3] if len(column) > 3 else None,
                                     shift=filtered and column_shift_applies(model, dtype, debug=debug),
-                                    utab_values=(len(utab[0]) * int(utab[1]) if utab is not None and filtered else 0),
+                                    utab_values=(utab_reals(len(utab[0]), utab[1]) if utab is not None and filtered else 0),
                                     debug=debug)
         if col_cfg is None:
             raise ValueError('the column kernel does not fit this grid (its table exceeds the LDS of a CU)')
@@ -707,7 +711,7 @@ def column_shift_applies(model, dtype, table=None, debug=None):
               and dtype is not None and np.dtype(dtype).itemsize == 8)
     if ok and table is not None:       # (n0, w, n_state): the shifted lattice must fit LDS beside the table
         ok = column_config(table[0], table[1], table[2], dtype, False, True, shift=True,
-                           utab_values=UTAB_MAX_BYTES // np.dtype(dtype).itemsize,    # (whatever the control table takes)
+                           utab_values=UTAB_MAX_BYTES // np.dtype(dtype).itemsize + 256,    # (whatever the control table takes, block statistics included)
                            debug=debug) is not None
     return ok
 
@@ -864,6 +868,22 @@ def column_build_order(threads, w, rows, rows_per_lane=1):
         if util > best[2] + 1e-9:
             best = (2, lw, util)
     return (best[0], best[1]) if best[2] >= 0.85 else (0, 0)
+
+
+def bnb_words(n_controls):
+    """reals of block statistics kept beside a control table of `n_controls` controls (SDP_BNB_WORDS of
+    csrc/sdp_column_kernel.h: four per block of 8 controls, larger blocks beyond 64 of them)"""
+    n = max(int(n_controls), 1)
+    block = 8
+    while (n + block - 1) // block > 64:
+        block *= 2
+    return 4 * ((n + block - 1) // block)
+
+
+def utab_reals(n_values, n_controls):
+    """reals per parity buffer of a control table of `n_values` sub-expressions x `n_controls` controls, with the
+    block statistics of the branch and bound (what `utab_values` of the planning functions counts; 0: no table)"""
+    return int(n_values) * int(n_controls) + bnb_words(n_controls) if n_values else 0
 
 
 def _column_lds(tw, w, rows, n_state, rs, threads, reduced=False, shift=False, shift_rows=0, utab_values=0,

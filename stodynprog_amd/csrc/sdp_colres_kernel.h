@@ -183,7 +183,150 @@ SDP_DEV void sdp_lean2_pass1(const sdp_real *A, const sdp_real *utab, const SdpC
     }
     for (; ci < n; ++ci) insert(sdp_lean2_value<AXIS>(A, utab, f, l, X, ci), ci);
 }
+
+#if SDP_COL_BNB
+#ifndef SDP_BNB_CHUNK
+#define SDP_BNB_CHUNK 4
 #endif
+// ---------------------------------------------------------------------------
+// The short first pass as a certified BRANCH AND BOUND over blocks of controls (round 5).
+// A node's filter value is F'(c) = hp_c + L(p_c): hp_c = +-h_c psum from the control table, L the piecewise-linear
+// interpolant of the reduced table A along axis 0 (linear beyond the first and the last cell: the clamped cell with an
+// unclamped lam0), p_c the position of control c.  Over a BLOCK B of controls the positions lie between those of the
+// block's smallest and largest a (x0' = X +- a and every rounded step from it to the position are monotone in a:
+// see the short first pass above), and a piecewise-linear function takes its minimum over an interval at an end of
+// the interval or at a breakpoint inside it -- the breakpoints are the grid rows, where L = A[r].  So
+//     LB(B) = min_B hp  +  min( L(p_lo), L(p_hi), A[r] for the rows r strictly between the two positions )
+// bounds every F'(c), c in B, from below in real arithmetic; as evaluated, both sides are off by a few roundings of
+// numbers bounded by S_node (|hp| <= Pcap max |h|, |L| <= (1 + 2 L_cap) D), together < 16 u S_node.
+// A block with   LB(B) > f1 + 2 radius + 16 u S_node   (f1: the smallest F' seen so far, which only decreases) holds
+// only controls with F' - radius > f1 + radius >= m_hi: by the radius' own theorem none of them is the reference's
+// argmin or ties with it, exactly what the full pass concludes from F' itself (`single`, and the candidate test of the
+// multi-survivor path, which re-evaluates F' of EVERY control and does not depend on this pass).  Its controls are
+// never evaluated.  J, policy and index keep their bits: which controls are skipped is all that changes.
+// Order: the block of the lane's GUESS first (the node's best control in the previous unit of this workgroup: the
+// neighbouring column -- any guess is valid, a good one makes f1 tight at once), then the bounds of all blocks against
+// that f1, then the blocks that survive, lane by lane (a lane reads ITS blocks' entries of the control table; lanes
+// with nothing left idle through the trip).  On the benchmark problem 1.2 blocks of 8 per wave instead of 8.
+// Values that are not finite: a NaN bound fails its comparison (the block is evaluated); the node-level tests of the
+// caller (S_node, L) are unchanged.
+template <int AXIS>
+SDP_DEV void sdp_lean2_bnb(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                           sdp_real X, sdp_real k_rows, int n, int mask, sdp_real slack, int guess, sdp_real &f1, sdp_real &f2,
+                           sdp_real &sdp_diag_cnt)
+{
+    (void)sdp_diag_cnt;
+    constexpr int BS = SDP_BNB_BLOCK, NB = SDP_BNB_BLOCKS;
+    constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
+    static_assert(NB <= 64, "branch and bound: at most 64 blocks");
+    const sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
+    auto pack = [&](sdp_real F, int ci) { return __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci); };
+    auto insert = [&](sdp_real Fq) {
+        f2 = sdp_vmin(f2, sdp_vmax(f1, Fq));
+        f1 = sdp_vmin(f1, Fq);
+    };
+    const int n_blocks = (n + BS - 1) / BS;
+    const int g = guess < 0 ? (n >> 1) : min(guess, n - 1);              // (no guess yet: the middle of the lattice)
+    // ---- stage 1: what the bounds need from the LDS -- the guess's entry of the control table, the blocks' records
+    // ---- stage 2: the cells, the reads of the reduced table        (all of a stage's reads are in flight together)
+    // ---- stage 3: F' of the guess (an upper bound of the node's smallest F'), the bounds, the blocks to evaluate
+    const sdp_real ga = utab[g * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+    const sdp_real gh = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[g * SDP_COL_UTAB + HS];
+    const sdp_real pX = SDP_LEAN2_FORM == 2 ? -((X + l.smin) * k_rows) : (X - l.smin) * k_rows;
+    const int extra = __builtin_amdgcn_readfirstlane(__double2loint(rec[2 * n_blocks + 1]));
+    int gq;
+    sdp_real glam;
+    sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, ga), gq, glam);
+    const sdp_real gA0 = A[gq], gA1 = A[gq + 1];
+    unsigned long long need = 0ull;
+    sdp_real thresh = (sdp_real)0;
+    constexpr int CB = NB < SDP_BNB_CHUNK ? NB : SDP_BNB_CHUNK;
+    for (int b0 = 0; b0 < n_blocks; b0 += CB) {            // (uniform; one chunk on the benchmark lattice)
+        int q[CB + 1];
+        sdp_real P[CB + 1], hp[CB], Aq[CB + 1], Aq1[CB + 1], m[CB];
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            const int b = min(b0 + j, n_blocks);           // end j of the chunk: where block b0 + j starts, or the lattice ends
+            P[j] = pX + rec[2 * b];
+            if (j < CB) hp[j] = rec[2 * min(b, n_blocks - 1) + 1];
+        }
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            q[j] = (int)P[j];                              // (saturating conversion; NaN -> 0)
+            asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q[j]) : "s"(l.ordm2));
+        }
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            Aq[j] = A[q[j]];
+            Aq1[j] = A[q[j] + 1];
+        }
+        if (b0 == 0) {
+            // F' of the guess: its packed value is a first f1 (the block of the guess is evaluated like any other below)
+            const sdp_real h = fma(glam, gA1 - gA0, gA0);
+            const sdp_real Fg = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma(SDP_LEAN2_HNEG ? -gh : gh, f.psum, h), g);
+            thresh = Fg + slack;
+        }
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            const sdp_real lam = P[j] - (sdp_real)q[j];
+            P[j] = fma(lam, Aq1[j] - Aq[j], Aq[j]);        // (P: now L at the end)
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(sdp_vmin(P[j], P[j + 1]), sdp_vmin(Aq1[j], Aq[j + 1]));
+        for (int k = 0; k < extra; ++k) {                  // (one more row per block on the benchmark lattice)
+            sdp_real more[CB];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) more[j] = A[max(min(q[j] + 2 + k, q[j + 1] - 1), 0)];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(m[j], more[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            if (q[j + 1] - q[j] - 2 > extra) m[j] = -INFINITY;      // (never seen; a count too small must not cost a row)
+            const sdp_real lbv = hp[j] + m[j];
+            // pruned only on a comparison that HOLDS (a NaN anywhere keeps the block); the guess's own block always stays
+            if ((!(lbv > thresh) || b0 + j == g / BS) && b0 + j < n_blocks) need |= 1ull << (b0 + j);
+        }
+    }
+#ifdef SDP_DIAG_BNB_COUNT                                  // diagnostic: J := blocks asked for (+ 100 x the guess's block)
+    sdp_diag_cnt = (sdp_real)(__popcll(need) + 100 * (g / BS));
+#endif
+    // ---- the blocks that stay, lane by lane, groups of controls in stages (a lane reads ITS block's entries of the
+    // control table; lanes with nothing left idle through the trip)
+    while (__any(need != 0ull)) {
+        const bool on = need != 0ull;
+        const int b = on ? __ffsll((long long)need) - 1 : 0;
+        need &= need - 1ull;
+        constexpr int K = SDP_LEAN2_GROUP;
+        static_assert(BS % K == 0, "branch and bound: whole groups per block");
+        for (int j0 = 0; j0 < BS; j0 += K) {
+            int q0[K], ci[K];
+            sdp_real av[K], lam0[K], hv[K], a0[K], a1[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                ci[j] = min(b * BS + j0 + j, n - 1);       // (past the end: the last control again, not inserted)
+                av[j] = utab[ci[j] * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+                hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[ci[j] * SDP_COL_UTAB + HS];
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                a0[j] = A[q0[j]];
+                a1[j] = A[q0[j] + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const sdp_real h = fma(lam0[j], a1[j] - a0[j], a0[j]);
+                const sdp_real Fp = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma(SDP_LEAN2_HNEG ? -hv[j] : hv[j], f.psum, h), ci[j]);
+                // (a lane with nothing to evaluate in this trip, a control past the end: the largest finite number never wins)
+                insert(on && b * BS + j0 + j < n ? Fp : (sdp_real)0x1.fffffffffffffp+1023);
+            }
+        }
+    }
+}
+#endif  // SDP_COL_BNB
+#endif  // SDP_COL_LEAN2
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
 {
@@ -213,6 +356,13 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     sdp_col_filter_setup(a, filt);
     const int axis_mode = __builtin_amdgcn_readfirstlane(sdp_col_axis_mode(lead));
     const sdp_cst_real *pw = (const sdp_cst_real *)a.proba;
+    // (what is the same in every lane for the whole kernel lives in scalar registers: sdp_uniform)
+    lead.smin = sdp_uniform(lead.smin); lead.span = sdp_uniform(lead.span); lead.nm1 = sdp_uniform(lead.nm1); lead.rspan = sdp_uniform(lead.rspan);
+    filt.psum = sdp_uniform(filt.psum); filt.pcap = sdp_uniform(filt.pcap); filt.cu = sdp_uniform(filt.cu);
+    filt.floor = sdp_uniform(filt.floor); filt.ratio = sdp_uniform(filt.ratio);
+    const sdp_real k_rows = sdp_uniform(lead.nm1 / lead.span);        // rows of axis 0 per unit of x0 (branch and bound: positions relative to the node)
+    const sdp_real x_cap = sdp_uniform((sdp_real)0x1p30 / k_rows - fabs(lead.smin));
+    (void)k_rows; (void)x_cap;
     if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
     int parity = 0;
 
@@ -223,6 +373,14 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     __syncthreads();
     int64_t unit = u_base + sdp_lds.next_unit;
     int upar = 0;                                          // parity buffer of the control table
+#if SDP_STAMP == 2     // diagnostic: shader clocks of this thread in the table builds (+ their barriers), the first pass, the rest
+    unsigned long long tm_build = 0, tm_p1 = 0, tm_all = 0, tm_top = 0, tm0 = 0, tm1 = 0, tm_start = __builtin_amdgcn_s_memtime();
+#define SDP_RES_MARK(v) v = __builtin_amdgcn_s_memtime()
+#else
+#define SDP_RES_MARK(v)
+#endif
+    int guess = -1;                                        // branch and bound: this lane's best control in the previous unit of the workgroup
+    (void)guess;
 #if SDP_COL_UTAB
     sdp_trap_unless(!a.box_per_node);
 #endif
@@ -232,7 +390,17 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     const sdp_real *w_mine = nullptr;
     sdp_real w_hold = (sdp_real)0;
     if (SDP_COL_HOIST) {
-        if (!a.box_per_node) { sdp_load_box(a, 0, box_hold); box_c = &box_hold; }
+        if (!a.box_per_node) {
+            sdp_load_box(a, 0, box_hold);
+#pragma unroll
+            for (int c = 0; c < SDP_NU; ++c) {
+                box_hold.lo[c] = sdp_uniform(box_hold.lo[c]); box_hold.hi[c] = sdp_uniform(box_hold.hi[c]);
+                box_hold.step[c] = sdp_uniform(box_hold.step[c]); box_hold.delta[c] = sdp_uniform(box_hold.delta[c]);
+                box_hold.n[c] = sdp_uniform(box_hold.n[c]);
+            }
+            box_hold.total = sdp_uniform(box_hold.total);
+            box_c = &box_hold;
+        }
         if (lane < Wn) { w_hold = ((const sdp_real *)a.wgrid)[lane]; w_mine = &w_hold; }
     }
 #if SDP_COL_SHIFT
@@ -244,7 +412,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
-        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 64, box_c);      // (one wave: it also reduces the table's statistics)
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 64, box_c, filt.psum, k_rows, x_cap);      // (one wave: it also reduces the table's statistics)
 #endif
 #if SDP_COL_SHIFT
         sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
@@ -259,7 +427,11 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, col, x);
         const int r = (int)threadIdx.x;                    // the table row this thread reduces
         // ---- tail of the table, partial sums of the reduced table
+        SDP_RES_MARK(tm0);
         __syncthreads();                                   // the previous unit has left the table; this unit's cells are published
+#if SDP_STAMP == 2
+        { const unsigned long long tmb = __builtin_amdgcn_s_memtime(); tm_top += tmb - tm0; tm0 = tmb; }
+#endif
         int nx = 0;
         if (wave == waves - 1 && lane == 0) nx = (int)atomicAdd(claim, 1u);      // (its round trip hides under the builds)
 #if SDP_COL_SHIFT
@@ -313,6 +485,10 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
         (void)r;
         __syncthreads();                                   // A[r] and the column's bound are complete
+        SDP_RES_MARK(tm1);
+#if SDP_STAMP == 2
+        tm_build += tm1 - tm0;
+#endif
         const sdp_real dcol = sdp_col_filter_dcol(sdp_lds, parity);
         parity ^= 1;
         const int64_t next_unit = u_base + sdp_lds.next_unit;
@@ -330,6 +506,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         if (box_c) box = *box_c;
         else sdp_load_box(a, node, box);
         sdp_real best = INFINITY;
+        sdp_real diag_cnt = (sdp_real)-1;                  // (SDP_DIAG_BNB_COUNT builds)
+        (void)diag_cnt;
         int ibest = INT_MAX;
         SdpColresCand cd;                                  // survivors this lane carries through the rebuild, in lattice order
         cd.n = 0;
@@ -354,25 +532,40 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             bd.i2 = INT_MAX;
             int q_e;
             sdp_real lam_lo, lam_hi;
+            // (the node's bound and radius need nothing of the pass itself: they come first, the branch and bound uses them)
             if (axis_mode == 2) {
-                sdp_lean2_pass1<2>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
                 sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
             } else if (axis_mode == 1) {
-                sdp_lean2_pass1<1>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
                 sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
             } else {
-                sdp_lean2_pass1<0>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
                 sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
             }
-            bd.i1 = bd.f1 < (sdp_real)INFINITY ? (__double2loint(bd.f1) & mask) : INT_MAX;
             const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
             const sdp_real s_node = fma(filt.pcap, fabs(K) + ust[2], ((sdp_real)1 + (sdp_real)2 * l_cap) * dcol);
             const bool bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(fabs(lam_lo) + fabs(lam_hi) < (sdp_real)1073741824.0) ||
                              bits > 24 || box.total > SDP_COL_UTAB_N;
             const sdp_real radius = (filt.cu + (sdp_real)(SDP_COL_FILTER_SCALE) * ldexp(SDP_COL_FILTER_EPS, bits + 1)) * s_node;
+#if SDP_COL_BNB
+            // a block is skipped when its lower bound exceeds f1 by more than 2 radius + 16 u S_node (8 x EPS = 16 u).
+            // Only where the column's blocks are in order and |X| is small enough for the bounds' positions (ust[3]:
+            // sdp_col_phase_u); a wave with a node that does not qualify takes the full pass.
+            const sdp_real slack = fma((sdp_real)2, radius, ((sdp_real)8 * SDP_COL_FILTER_EPS) * s_node);
+            const bool bnb = fabs(X) < ust[3];
+            if (__all(bnb)) {                                  // (over the lanes that have a node)
+                if (axis_mode == 2) sdp_lean2_bnb<2>(sdp_lds.ad, utab, filt, lead, X, k_rows, box.total, mask, slack, guess, bd.f1, bd.f2, diag_cnt);
+                else if (axis_mode == 1) sdp_lean2_bnb<1>(sdp_lds.ad, utab, filt, lead, X, k_rows, box.total, mask, slack, guess, bd.f1, bd.f2, diag_cnt);
+                else sdp_lean2_bnb<0>(sdp_lds.ad, utab, filt, lead, X, k_rows, box.total, mask, slack, guess, bd.f1, bd.f2, diag_cnt);
+            } else
+#endif
+            {
+                if (axis_mode == 2) sdp_lean2_pass1<2>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
+                else if (axis_mode == 1) sdp_lean2_pass1<1>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
+                else sdp_lean2_pass1<0>(sdp_lds.ad, utab, filt, lead, X, box.total, mask, bd.f1, bd.f2);
+            }
+            bd.i1 = bd.f1 < (sdp_real)INFINITY ? (__double2loint(bd.f1) & mask) : INT_MAX;
 #else
             SdpColBounds bd;
             bd.f1 = bd.f2 = bd.f3 = INFINITY;
@@ -450,6 +643,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 }
             }
         }
+#if SDP_STAMP == 2
+        tm_p1 += __builtin_amdgcn_s_memtime() - tm1;
+#endif
         // (the lanes of a wave run the same code: two chains where any lane carries two survivors)
         const bool two = SDP_COLRES_K > 1 && __any(cd.n == 2);
         if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
@@ -460,21 +656,6 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_phase_a<false>(a, tg, s, C, R);
         __syncthreads();
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
-        {
-            // the next unit's column-level tables, a wave each: nothing reads the cells from here on
-            const int nxu = __builtin_amdgcn_readfirstlane(sdp_lds.next_unit);
-            if (u_base + nxu < u_end) {
-                sdp_real xn[SDP_D];
-                sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
-                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
-#if SDP_COL_UTAB
-                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c);
-#endif
-#if SDP_COL_SHIFT
-                sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);
-#endif
-            }
-        }
         if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
         else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
         if (live) {
@@ -484,7 +665,28 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 if (SDP_COLRES_K == 1) { if (cd.n) best = cd.acc[0]; }          // (its index is in ibest already)
                 else if (j < cd.n && (ibest == INT_MAX || sdp_better_seq(cd.acc[j], best))) { best = cd.acc[j]; ibest = cd.idx[j]; }
             }
+#ifdef SDP_DIAG_BNB_COUNT
+            best = diag_cnt;
+#endif
             sdp_col_store(a, node, box, best, ibest);
+            if (ibest != INT_MAX) guess = ibest;
+        }
+        {
+            // the next unit's column-level tables, a wave each (nothing reads the cells after the rebuild of the tail; here, after
+            // the stores, a wave holds next to nothing in registers: between the two halves of the second pass these tables
+            // cost the branch-and-bound build five reloads of spilled registers per unit, each a memory round trip)
+            const int nxu = __builtin_amdgcn_readfirstlane(sdp_lds.next_unit);
+            if (u_base + nxu < u_end) {
+                sdp_real xn[SDP_D];
+                sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
+                sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
+#if SDP_COL_UTAB
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, k_rows, x_cap);
+#endif
+#if SDP_COL_SHIFT
+                sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);
+#endif
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         upar ^= 1;
@@ -498,7 +700,15 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             atomicExch(a.claim + 256, 0u);
         }
     }
+#if SDP_STAMP == 2
+    if (a.stamps && (threadIdx.x & 63) == 0) {
+        tm_all = __builtin_amdgcn_s_memtime() - tm_start;
+        unsigned long long *o = a.stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
+        o[0] = tm_build; o[1] = tm_p1; o[2] = tm_top; o[3] = tm_all;
+    }
+#else
     SDP_STAMP_END(a);
+#endif
 }
 
 // fixed-policy backup: the table a chunk of C perturbation points at a time, the node's expectation carried in a register

@@ -207,6 +207,15 @@
 #define SDP_COL_WIDE2 0          // generated, 4-byte reals: the same shape -- the short wide first pass of sdp_col_filter_nodes
 #endif
 #define SDP_COL_SHORT (SDP_COL_LEAN2 || SDP_COL_WIDE2)
+#ifndef SDP_COL_BNB
+// 1 (generated with SDP_COL_LEAN2): the short first pass as a certified branch and bound over BLOCKS of controls
+// (sdp_lean2_bnb of sdp_colres_kernel.h): a block whose lower bound lies above the smallest F' seen so far by more than
+// twice the radius holds no survivor, and its controls are never evaluated.  0: every control (round 4; A/B runs)
+#define SDP_COL_BNB 0
+#endif
+// controls per block of the branch and bound, and the block statistics kept beside the control table (four reals per
+// block: smallest a, largest a, smallest +-h psum, unused): at most 64 blocks -- one lane of the table's wave each
+constexpr int sdp_bnb_block(int n) { int b = 8; while ((n + b - 1) / b > 64) b *= 2; return b; }
 #ifndef SDP_COL_LDS_PAD
 #define SDP_COL_LDS_PAD 0        // diagnostic builds: unused bytes in the LDS image (fewer workgroups per CU: occupancy A/B)
 #endif
@@ -259,6 +268,9 @@ struct SdpColShared {
 constexpr int SDP_COL_LDS_WCOPY = SDP_COL_WMODE == 2 ? SDP_COL_W : 1;
 constexpr int SDP_COL_LDS_PART = (SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? 1 : SDP_COL_THREADS;
 // reals per row of the reduced table: A[r] alone in the lean form, (A[r], D[r]) otherwise, 16 bytes for 4-byte reals
+constexpr int SDP_BNB_BLOCK = sdp_bnb_block(SDP_COL_UTAB_N);
+constexpr int SDP_BNB_BLOCKS = (SDP_COL_UTAB_N + SDP_BNB_BLOCK - 1) / SDP_BNB_BLOCK;
+constexpr int SDP_BNB_WORDS = SDP_COL_UTAB ? 4 * SDP_BNB_BLOCKS : 0;
 constexpr int SDP_COL_LDS_AD = sizeof(SDP_REAL) == 4 ? 4 : ((SDP_COL_LEAN != 0 && !SDP_COL_SHIFT) ? 1 : 2);
 struct __attribute__((aligned(16))) SdpColLds {
     sdp_real T[(SDP_TRAIL_HAS_U ? SDP_COL_WCHUNK : (SDP_COL_WRES < SDP_COL_W ? SDP_COL_WRES : SDP_COL_TW)) * SDP_COL_ROWS];
@@ -274,7 +286,8 @@ struct __attribute__((aligned(16))) SdpColLds {
     unsigned long long dcol[2];            // lean filter: per parity of the unit, bits of max_r D[r] (>= 0: ordered as integers)
     // per parity of the unit: the tabulated values of every control of the column (SDP_COL_UTAB)
     // (+ 4: statistics of the column's table for the short first pass, SDP_COL_LEAN2 -- sdp_col_phase_u)
-    sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N + 4 : 2] __attribute__((aligned(16)));
+    // (+ 4 per block of controls: statistics of the blocks for the branch and bound of the short first pass)
+    sdp_real utab[2][SDP_COL_UTAB ? SDP_COL_UTAB * SDP_COL_UTAB_N + 4 + SDP_BNB_WORDS : 2] __attribute__((aligned(16)));
 #if SDP_COL_LDS_PAD
     char pad_[SDP_COL_LDS_PAD];
 #endif
@@ -429,6 +442,23 @@ extern "C" __device__ float __ockl_wfred_max_f32(float);
 extern "C" __device__ float __ockl_wfred_min_f32(float);
 extern "C" __device__ float __ockl_wfred_add_f32(float);
 SDP_DEV double sdp_wave_max(double v) { return __ockl_wfred_max_f64(v); }      // DPP row operations, no LDS traffic
+// a value that is the same in every lane, moved to scalar registers (what the compiler will not conclude by itself for
+// numbers that came out of vector arithmetic or vector loads: kept in vector registers they crowd out the passes'
+// working set -- and what does not fit there goes to scratch memory, a memory round trip per use)
+SDP_DEV double sdp_uniform(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+SDP_DEV float sdp_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+SDP_DEV int sdp_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// the value of another lane of the row of 16 (DPP control CTRL: 0xB1 the neighbour, 0x4E the pair's partner, 0x141 the
+// mirrored lane of the half row): no LDS traffic
+template <int CTRL>
+SDP_DEV double sdp_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+SDP_DEV float sdp_dpp_f64(float v) { return __shfl_xor(v, CTRL == 0xB1 ? 1 : (CTRL == 0x4E ? 2 : 7), 64); }     // (4-byte builds never take this path)
 SDP_DEV float sdp_wave_max(float v) { return __ockl_wfred_max_f32(v); }
 SDP_DEV double sdp_wave_min(double v) { return __ockl_wfred_min_f64(v); }
 SDP_DEV float sdp_wave_min(float v) { return __ockl_wfred_min_f32(v); }
@@ -1650,6 +1680,10 @@ SDP_DEV void sdp_col_filter_eval(const sdp_real *ad_tab, const SdpColFilter &f, 
 }
 SDP_DEV int sdp_col_axis_mode(const SdpLeadAxis &l)
 {
+#ifdef SDP_COL_AXIS_MODE                                   // generated where the host knows axis 0 of the grid: one form of the passes instead of three
+    (void)l;
+    return SDP_COL_AXIS_MODE;
+#endif
     if (!l.pow2) return 0;
     return (l.smin == (sdp_real)0 && l.span == (sdp_real)1) ? 2 : 1;
 }
@@ -1778,8 +1812,10 @@ SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, cons
 }
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
 SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0,
-                             int count = 0, const SdpBox *box_c = nullptr)
+                             int count = 0, const SdpBox *box_c = nullptr, sdp_real psum = (sdp_real)0,
+                             sdp_real k_rows = (sdp_real)0, sdp_real x_cap = (sdp_real)0)
 {
+    (void)psum; (void)k_rows; (void)x_cap;
     if (count == 0) count = (int)blockDim.x - first;
     if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     SdpBox box;
@@ -1792,6 +1828,109 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
     // ONE wave builds the table there (count == 64), so a wave reduction completes them.
     sdp_real a_lo = INFINITY, a_hi = -INFINITY, h_abs = (sdp_real)0, fin = (sdp_real)0;
 #endif
+#if SDP_COL_BNB
+    // Records of the BLOCKS of controls for the branch and bound of the short first pass (sdp_lean2_bnb), made as the
+    // table is: in ROWS of axis 0 relative to the node -- a control's position is p = pX + pa, pX = +-(X -+ smin) k of
+    // the node, pa = +-a k of the control, k = (N0 - 1) / span (as real numbers; the kernel's own positions differ from
+    // that sum by roundings far below the margin DELTA the ends are moved out by).  Record b: (where block b starts:
+    // its smallest pa - DELTA;  its smallest +-h psum, as the first pass forms it); record n_blocks: (where the last
+    // block ends: its largest pa + DELTA;  how many rows beyond two can lie between the starts of two neighbouring
+    // blocks, as an integer).  The pass uses them only where the blocks are in order, each ending before the next
+    // starts (an ordinary lattice, a monotone in the control) and everything is finite: st[3] says so.
+    constexpr sdp_real BNB_DELTA = (sdp_real)0x1p-20;
+    sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
+    const int lane_u = (int)threadIdx.x - first;
+    bool bnb_fine = count == 64 && SDP_BNB_BLOCK <= 64;
+    sdp_real bnb_prev_hi = -INFINITY, bnb_prev_lo = (sdp_real)NAN, bnb_between = (sdp_real)0, bnb_amax = (sdp_real)0;
+    for (int c0 = 0; c0 < n_tab; c0 += 64) {               // (every lane of the wave takes part in every round: shuffles)
+        int ci = c0 + lane_u;
+        // (opaque to the optimiser: with a constant box the control of a lane and everything computed from it alone are
+        // the same in every unit, and the compiler hoists them out of the kernel's unit loop into registers it does not
+        // have -- measured: three reloads from scratch memory per unit in this helper wave, which the whole workgroup
+        // then waits for at the next barrier.  Recomputing them is a handful of instructions.)
+        asm volatile("" : "+v"(ci));
+        sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
+        sdp_controls_at(box, min(ci, n_tab - 1), u);
+        sdp_model_utab(x, u, t, tab);
+        if (ci < n_tab) {
+#pragma unroll
+            for (int k = 0; k < SDP_COL_UTAB; ++k) utab[ci * SDP_COL_UTAB + k] = tab[k];
+            a_lo = sdp_vmin(a_lo, tab[SDP_LEAN2_A_SLOT]);
+            a_hi = sdp_vmax(a_hi, tab[SDP_LEAN2_A_SLOT]);
+            fin = fin + fabs(tab[SDP_LEAN2_A_SLOT]);
+            if (SDP_LEAN2_H_SLOT >= 0) {
+                h_abs = sdp_vmax_abs(h_abs, tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT]);
+                fin = fin + fabs(tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT]);
+            }
+        }
+        const sdp_real av = tab[SDP_LEAN2_A_SLOT];
+        const sdp_real hv = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT];
+        const sdp_real pa = (SDP_LEAN2_FORM == 1 ? -av : av) * k_rows;
+        const sdp_real hpv = (SDP_LEAN2_HNEG ? -hv : hv) * psum;
+        const bool have = ci < n_tab;
+        bnb_fine = bnb_fine && (!have || (pa == pa && hpv == hpv && fabs(pa) < (sdp_real)INFINITY));
+        bnb_amax = sdp_vmax_abs(bnb_amax, have ? av : (sdp_real)0);
+        sdp_real lo = have ? pa : (sdp_real)INFINITY, hi = have ? pa : -(sdp_real)INFINITY, hp = have ? hpv : (sdp_real)INFINITY;
+        constexpr int SEG = SDP_BNB_BLOCK < 64 ? SDP_BNB_BLOCK : 64;
+        // minima / maxima over the aligned groups of SEG lanes: the blocks
+        if (SEG == 8 && sizeof(sdp_real) == 8) {
+            // (data-parallel primitives inside a row of 16 lanes: neighbours, pairs, the mirrored half -- no LDS round trips)
+            lo = sdp_vmin(lo, sdp_dpp_f64<0xB1>(lo)); hi = sdp_vmax(hi, sdp_dpp_f64<0xB1>(hi)); hp = sdp_vmin(hp, sdp_dpp_f64<0xB1>(hp));
+            lo = sdp_vmin(lo, sdp_dpp_f64<0x4E>(lo)); hi = sdp_vmax(hi, sdp_dpp_f64<0x4E>(hi)); hp = sdp_vmin(hp, sdp_dpp_f64<0x4E>(hp));
+            lo = sdp_vmin(lo, sdp_dpp_f64<0x141>(lo)); hi = sdp_vmax(hi, sdp_dpp_f64<0x141>(hi)); hp = sdp_vmin(hp, sdp_dpp_f64<0x141>(hp));
+        } else {
+#pragma unroll
+            for (int d = 1; d < SEG; d <<= 1) {
+                lo = sdp_vmin(lo, sdp_shfl_xor(lo, d));
+                hi = sdp_vmax(hi, sdp_shfl_xor(hi, d));
+                hp = sdp_vmin(hp, sdp_shfl_xor(hp, d));
+            }
+        }
+        // the block that follows in this round, or nothing (the last one of the round meets its successor next round)
+        const sdp_real next_lo = __shfl_down(lo, SEG, 64);
+        const bool head = have && (lane_u % SEG) == 0;
+        const bool has_next = lane_u + SEG < 64 && ci + SEG < n_tab;
+        if (head) {
+            const int b = ci / SDP_BNB_BLOCK;
+            rec[2 * b] = lo - BNB_DELTA;
+            rec[2 * b + 1] = hp;
+            if (has_next) {
+                bnb_fine = bnb_fine && hi <= next_lo;
+                bnb_between = sdp_vmax(bnb_between, next_lo - lo);
+            }
+            if (lane_u == 0 && c0 > 0) {                   // (against the last block of the previous round)
+                bnb_fine = bnb_fine && bnb_prev_hi <= lo;
+                bnb_between = sdp_vmax(bnb_between, lo - bnb_prev_lo);
+            }
+            if (ci + SDP_BNB_BLOCK >= n_tab) {             // the last block: where the lattice ends
+                rec[2 * (b + 1)] = hi + BNB_DELTA;
+                bnb_between = sdp_vmax(bnb_between, hi - lo);
+            }
+        }
+        if (c0 + 64 < n_tab) {                             // (another round follows)
+            bnb_prev_hi = __shfl(hi, 64 - SEG, 64);
+            bnb_prev_lo = __shfl(lo, 64 - SEG, 64);
+        }
+    }
+    {
+        const bool sorted = __all(bnb_fine);
+        bnb_between = sdp_wave_max(bnb_between);
+        bnb_amax = sdp_wave_max(bnb_amax);
+        if (lane_u == 0) {
+            const int n_blocks = (n_tab + SDP_BNB_BLOCK - 1) / SDP_BNB_BLOCK;
+            // rows strictly between the starts of two neighbouring blocks: at most floor(between) + 1, of which the ends'
+            // own cells bring two along (A[q+1] of the lower end, A[q] of the upper one): how many more the pass reads
+            const int extra = (bnb_between == bnb_between && bnb_between < (sdp_real)SDP_COL_N0)
+                                  ? max((int)(bnb_between + 4 * BNB_DELTA) - 1, 0) : SDP_COL_N0;
+            rec[2 * n_blocks + 1] = __hiloint2double(0, extra);
+            // st[3]: what |X| may be at most for the pass's positions to stay within DELTA / 2 of the kernel's own
+            // (8 u (|X| + |smin| + max |a|) k < DELTA / 2), or -1: no branch and bound in this column
+            sdp_real *st = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;
+            const sdp_real cap = x_cap - bnb_amax;         // (x_cap = 2^30 / k - |smin|: once per workgroup, by the caller)
+            st[3] = (sorted && cap == cap && extra < SDP_COL_N0) ? cap : (sdp_real)-1;
+        }
+    }
+#else
     for (int ci = (int)threadIdx.x - first; ci < n_tab; ci += count) {
         sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
         sdp_controls_at(box, ci, u);
@@ -1808,6 +1947,7 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         }
 #endif
     }
+#endif  // SDP_COL_BNB
 #if SDP_COL_SHORT
     a_lo = sdp_wave_min(a_lo);
     a_hi = sdp_wave_max(a_hi);

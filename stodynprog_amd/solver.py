@@ -651,7 +651,7 @@ class DPSolver(object):
             fr = codegen.control_table_plan(model, dt, bp['per_node'], n_controls, debug) if may_filter else None
             for frontier in ((fr, None) if fr is not None else (None,)):
                 kw = dict(max_controls=n_controls, n_columns=int(np.prod(shape[1:])), shift=shift,
-                          utab_values=len(frontier) * n_controls if frontier else 0, debug=debug)
+                          utab_values=codegen.utab_reals(len(frontier), n_controls) if frontier else 0, debug=debug)
                 col_cfg = codegen.column_config(shape[0], W, len(shape), dt, wpair, may_filter, **kw)
                 if col_cfg is not None:                   # (else once more without the control table)
                     utab = (frontier, n_controls) if frontier is not None else None

@@ -243,6 +243,73 @@ def test_the_short_pass_radius_covers_the_difference_exactly(regime, chunked):
     assert worst < 0.8, worst
 
 
+def block_bound_check(T, p, X, K, a, h, chunked, sign, block, lead='add'):
+    """The branch and bound of the short first pass (sdp_lean2_bnb of csrc/sdp_colres_kernel.h, round 5): for every
+    block of `block` controls the lower bound the kernel evaluates -- smallest fl(+-h psum) of the block plus the
+    smallest of L at the positions of the block's smallest and largest a and of the rows between them -- against the
+    PACKED F' of every control of the block, exactly.  Returns the largest (LB - F') / (16 u S_node) seen: a block is
+    skipped on LB > f1 + 2 radius + 16 u S_node, so any value <= 1 keeps the skipped controls above f1 + 2 radius."""
+    W, N0 = T.shape
+    fc = filter_constants(p)
+    A = reduced_table(T, p, chunked)
+    nm1 = float(N0 - 1)
+    dcol = max(fc['pcap'] * max(abs(T[w][r]) for w in range(W)) + fc['floor'] for r in range(N0))
+    n = len(a)
+    bits = max((n - 1).bit_length(), 1)
+    mask = (1 << bits) - 1
+    where = {'add': lambda v: X + v, 'sub': lambda v: X - v, 'rsub': lambda v: v - X}[lead]
+    lam_lo = cell_of(where(min(a)), nm1, N0)[1]
+    lam_hi = cell_of(where(max(a)), nm1, N0)[1]
+    L = max(1.0, abs(lam_lo), abs(lam_hi))
+    s_node = fma(fc['pcap'], abs(K) + max(abs(v) for v in h), (1.0 + 2.0 * L) * dcol)
+    worst = Fraction(-10 ** 9)
+    for b0 in range(0, n, block):
+        members = range(b0, min(b0 + block, n))
+        a_lo, a_hi = min(a[c] for c in members), max(a[c] for c in members)
+        hp = min((sign * h[c]) * fc['psum'] for c in members)             # one rounding each, as the table's wave forms them
+        (qa, la), (qb, lb) = cell_of(where(a_lo), nm1, N0), cell_of(where(a_hi), nm1, N0)
+        m = min(fma(la, A[qa + 1] - A[qa], A[qa]), fma(lb, A[qb + 1] - A[qb], A[qb]))
+        for r in range(min(qa, qb) + 1, max(qa, qb) + 1):
+            m = min(m, A[r])
+        lbv = hp + m
+        for ci in members:
+            q0, lam0 = cell_of(where(a[ci]), nm1, N0)
+            F = fma(sign * h[ci], fc['psum'], fma(lam0, A[q0 + 1] - A[q0], A[q0]))
+            Fp = pack_index(F, ci, mask)
+            # (the packing itself is inside the RADIUS: here the unpacked value decides, plus the packing's own bound)
+            worst = max(worst, (Fraction(lbv) - Fraction(F)) / (16 * Fraction(U) * Fraction(s_node)))
+            assert abs(Fraction(Fp) - Fraction(F)) <= Fraction(2.0 ** (bits + 1 - 53)) * Fraction(s_node) * (1 + Fraction(3, 2 ** 53))
+    return float(worst)
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+@pytest.mark.parametrize('lead', ['add', 'sub', 'rsub'])
+def test_the_block_bound_of_the_branch_and_bound_lies_below_every_control_of_its_block(regime, lead):
+    rng = np.random.default_rng(300 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime) * 3
+                                + ['add', 'sub', 'rsub'].index(lead))
+    worst = -1e9
+    for trial in range(120):
+        T, p, _ = random_problem(rng, regime)
+        W, N0 = T.shape
+        scale = float(np.abs(T).max())
+        n = int(rng.integers(1, 90))
+        X = float(rng.uniform(0, 1))
+        spread = float(10.0 ** rng.uniform(-3, 0.7))          # controls within a cell ... far outside the grid
+        if trial % 2:
+            a = sorted(float(v) for v in rng.uniform(-spread, spread, size=n))       # an ordinary lattice: blocks of neighbours
+        else:
+            a = [float(v) for v in rng.uniform(-spread, spread, size=n)]             # any order: blocks that span the axis
+        if lead == 'rsub':
+            a = [v + 2 * X for v in a]
+        K = float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3)
+        h = [float(v) * scale * 10.0 ** rng.uniform(-3, 3) for v in rng.standard_normal(n)]
+        sign = -1.0 if trial % 3 == 0 else 1.0
+        ratio = block_bound_check(T, p, X, K, a, h, bool(trial % 4 == 1), sign, 8 if trial % 5 else 16, lead)
+        assert ratio <= 1.0, (regime, lead, trial, ratio)
+        worst = max(worst, ratio)
+    assert worst < 0.5, worst                                  # (a handful of roundings against sixteen)
+
+
 def test_the_packed_index_comes_back_and_the_order_survives():
     rng = np.random.default_rng(5)
     for _ in range(2000):

@@ -1,0 +1,17 @@
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from stodynprog_amd import models, DPSolver
+DPSolver.debug_defines = {'SDP_EXTRA_DEFINES': 'SDP_DIAG_BNB_COUNT=1'}
+_, s = models.synthetic3d(N=256)
+V0 = models.synthetic3d_V0(s.state_grid)
+J, pol = s.value_iterations(V0, 1, report_time=False)
+idx = s.last_policy_index
+cnt = np.round(J).astype(int)
+need, bg = cnt % 100, cnt // 100
+print('need: mean %.3f, hist' % need.mean(), np.bincount(need.ravel(), minlength=9)[:9])
+print('guess block hist', np.bincount(bg.ravel(), minlength=8)[:8], ' best block hist', np.bincount((idx // 8).ravel(), minlength=8)[:8])
+print('guess block == best block: %.3f' % (bg == idx // 8).mean())
+w = need.reshape(256, -1)            # rows = axis 0 (lanes), columns
+per_wave = w.reshape(4, 64, -1).max(axis=1)
+print('max over the 64 lanes of a wave: mean %.3f' % per_wave.mean(), np.bincount(per_wave.ravel(), minlength=9)[:9])
