@@ -503,6 +503,9 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
             elif rs == 4 and not wres and _dbg(debug, 'SDP_COL_WIDE') != '0' and _dbg(debug, 'SDP_COL_LEAN') in (None, '0') \
                     and _dbg(debug, 'SDP_COL_FILTER_TOP2') in (None, '1'):
                 short = short_pass_source(model, utab[0], 'SDP_COL_WIDE2')
+                if short and _dbg(debug, 'SDP_COL_BNB') != '0':
+                    short += ('\n#define SDP_COL_BNB 1          // the short wide first pass as a certified branch and bound over '
+                              'blocks of controls (sdp_short_bnb)')
         if short:
             lines += [short, '']
     lines += ['#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h', '']
@@ -877,7 +880,7 @@ def bnb_words(n_controls):
     block = 8
     while (n + block - 1) // block > 64:
         block *= 2
-    return 4 * ((n + block - 1) // block)
+    return 4 * ((n + block - 1) // block + 1)
 
 
 def utab_reals(n_values, n_controls):

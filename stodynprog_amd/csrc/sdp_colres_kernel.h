@@ -184,148 +184,6 @@ SDP_DEV void sdp_lean2_pass1(const sdp_real *A, const sdp_real *utab, const SdpC
     for (; ci < n; ++ci) insert(sdp_lean2_value<AXIS>(A, utab, f, l, X, ci), ci);
 }
 
-#if SDP_COL_BNB
-#ifndef SDP_BNB_CHUNK
-#define SDP_BNB_CHUNK 4
-#endif
-// ---------------------------------------------------------------------------
-// The short first pass as a certified BRANCH AND BOUND over blocks of controls (round 5).
-// A node's filter value is F'(c) = hp_c + L(p_c): hp_c = +-h_c psum from the control table, L the piecewise-linear
-// interpolant of the reduced table A along axis 0 (linear beyond the first and the last cell: the clamped cell with an
-// unclamped lam0), p_c the position of control c.  Over a BLOCK B of controls the positions lie between those of the
-// block's smallest and largest a (x0' = X +- a and every rounded step from it to the position are monotone in a:
-// see the short first pass above), and a piecewise-linear function takes its minimum over an interval at an end of
-// the interval or at a breakpoint inside it -- the breakpoints are the grid rows, where L = A[r].  So
-//     LB(B) = min_B hp  +  min( L(p_lo), L(p_hi), A[r] for the rows r strictly between the two positions )
-// bounds every F'(c), c in B, from below in real arithmetic; as evaluated, both sides are off by a few roundings of
-// numbers bounded by S_node (|hp| <= Pcap max |h|, |L| <= (1 + 2 L_cap) D), together < 16 u S_node.
-// A block with   LB(B) > f1 + 2 radius + 16 u S_node   (f1: the smallest F' seen so far, which only decreases) holds
-// only controls with F' - radius > f1 + radius >= m_hi: by the radius' own theorem none of them is the reference's
-// argmin or ties with it, exactly what the full pass concludes from F' itself (`single`, and the candidate test of the
-// multi-survivor path, which re-evaluates F' of EVERY control and does not depend on this pass).  Its controls are
-// never evaluated.  J, policy and index keep their bits: which controls are skipped is all that changes.
-// Order: the block of the lane's GUESS first (the node's best control in the previous unit of this workgroup: the
-// neighbouring column -- any guess is valid, a good one makes f1 tight at once), then the bounds of all blocks against
-// that f1, then the blocks that survive, lane by lane (a lane reads ITS blocks' entries of the control table; lanes
-// with nothing left idle through the trip).  On the benchmark problem 1.2 blocks of 8 per wave instead of 8.
-// Values that are not finite: a NaN bound fails its comparison (the block is evaluated); the node-level tests of the
-// caller (S_node, L) are unchanged.
-template <int AXIS>
-SDP_DEV void sdp_lean2_bnb(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
-                           sdp_real X, sdp_real k_rows, int n, int mask, sdp_real slack, int guess, sdp_real &f1, sdp_real &f2,
-                           sdp_real &sdp_diag_cnt)
-{
-    (void)sdp_diag_cnt;
-    constexpr int BS = SDP_BNB_BLOCK, NB = SDP_BNB_BLOCKS;
-    constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
-    static_assert(NB <= 64, "branch and bound: at most 64 blocks");
-    const sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
-    auto pack = [&](sdp_real F, int ci) { return __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci); };
-    auto insert = [&](sdp_real Fq) {
-        f2 = sdp_vmin(f2, sdp_vmax(f1, Fq));
-        f1 = sdp_vmin(f1, Fq);
-    };
-    const int n_blocks = (n + BS - 1) / BS;
-    const int g = guess < 0 ? (n >> 1) : min(guess, n - 1);              // (no guess yet: the middle of the lattice)
-    // ---- stage 1: what the bounds need from the LDS -- the guess's entry of the control table, the blocks' records
-    // ---- stage 2: the cells, the reads of the reduced table        (all of a stage's reads are in flight together)
-    // ---- stage 3: F' of the guess (an upper bound of the node's smallest F'), the bounds, the blocks to evaluate
-    const sdp_real ga = utab[g * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
-    const sdp_real gh = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[g * SDP_COL_UTAB + HS];
-    const sdp_real pX = SDP_LEAN2_FORM == 2 ? -((X + l.smin) * k_rows) : (X - l.smin) * k_rows;
-    const int extra = __builtin_amdgcn_readfirstlane(__double2loint(rec[2 * n_blocks + 1]));
-    int gq;
-    sdp_real glam;
-    sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, ga), gq, glam);
-    const sdp_real gA0 = A[gq], gA1 = A[gq + 1];
-    unsigned long long need = 0ull;
-    sdp_real thresh = (sdp_real)0;
-    constexpr int CB = NB < SDP_BNB_CHUNK ? NB : SDP_BNB_CHUNK;
-    for (int b0 = 0; b0 < n_blocks; b0 += CB) {            // (uniform; one chunk on the benchmark lattice)
-        int q[CB + 1];
-        sdp_real P[CB + 1], hp[CB], Aq[CB + 1], Aq1[CB + 1], m[CB];
-#pragma unroll
-        for (int j = 0; j <= CB; ++j) {
-            const int b = min(b0 + j, n_blocks);           // end j of the chunk: where block b0 + j starts, or the lattice ends
-            P[j] = pX + rec[2 * b];
-            if (j < CB) hp[j] = rec[2 * min(b, n_blocks - 1) + 1];
-        }
-#pragma unroll
-        for (int j = 0; j <= CB; ++j) {
-            q[j] = (int)P[j];                              // (saturating conversion; NaN -> 0)
-            asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q[j]) : "s"(l.ordm2));
-        }
-#pragma unroll
-        for (int j = 0; j <= CB; ++j) {
-            Aq[j] = A[q[j]];
-            Aq1[j] = A[q[j] + 1];
-        }
-        if (b0 == 0) {
-            // F' of the guess: its packed value is a first f1 (the block of the guess is evaluated like any other below)
-            const sdp_real h = fma(glam, gA1 - gA0, gA0);
-            const sdp_real Fg = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma(SDP_LEAN2_HNEG ? -gh : gh, f.psum, h), g);
-            thresh = Fg + slack;
-        }
-#pragma unroll
-        for (int j = 0; j <= CB; ++j) {
-            const sdp_real lam = P[j] - (sdp_real)q[j];
-            P[j] = fma(lam, Aq1[j] - Aq[j], Aq[j]);        // (P: now L at the end)
-        }
-#pragma unroll
-        for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(sdp_vmin(P[j], P[j + 1]), sdp_vmin(Aq1[j], Aq[j + 1]));
-        for (int k = 0; k < extra; ++k) {                  // (one more row per block on the benchmark lattice)
-            sdp_real more[CB];
-#pragma unroll
-            for (int j = 0; j < CB; ++j) more[j] = A[max(min(q[j] + 2 + k, q[j + 1] - 1), 0)];
-#pragma unroll
-            for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(m[j], more[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            if (q[j + 1] - q[j] - 2 > extra) m[j] = -INFINITY;      // (never seen; a count too small must not cost a row)
-            const sdp_real lbv = hp[j] + m[j];
-            // pruned only on a comparison that HOLDS (a NaN anywhere keeps the block); the guess's own block always stays
-            if ((!(lbv > thresh) || b0 + j == g / BS) && b0 + j < n_blocks) need |= 1ull << (b0 + j);
-        }
-    }
-#ifdef SDP_DIAG_BNB_COUNT                                  // diagnostic: J := blocks asked for (+ 100 x the guess's block)
-    sdp_diag_cnt = (sdp_real)(__popcll(need) + 100 * (g / BS));
-#endif
-    // ---- the blocks that stay, lane by lane, groups of controls in stages (a lane reads ITS block's entries of the
-    // control table; lanes with nothing left idle through the trip)
-    while (__any(need != 0ull)) {
-        const bool on = need != 0ull;
-        const int b = on ? __ffsll((long long)need) - 1 : 0;
-        need &= need - 1ull;
-        constexpr int K = SDP_LEAN2_GROUP;
-        static_assert(BS % K == 0, "branch and bound: whole groups per block");
-        for (int j0 = 0; j0 < BS; j0 += K) {
-            int q0[K], ci[K];
-            sdp_real av[K], lam0[K], hv[K], a0[K], a1[K];
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                ci[j] = min(b * BS + j0 + j, n - 1);       // (past the end: the last control again, not inserted)
-                av[j] = utab[ci[j] * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
-                hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[ci[j] * SDP_COL_UTAB + HS];
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                a0[j] = A[q0[j]];
-                a1[j] = A[q0[j] + 1];
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const sdp_real h = fma(lam0[j], a1[j] - a0[j], a0[j]);
-                const sdp_real Fp = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma(SDP_LEAN2_HNEG ? -hv[j] : hv[j], f.psum, h), ci[j]);
-                // (a lane with nothing to evaluate in this trip, a control past the end: the largest finite number never wins)
-                insert(on && b * BS + j0 + j < n ? Fp : (sdp_real)0x1.fffffffffffffp+1023);
-            }
-        }
-    }
-}
-#endif  // SDP_COL_BNB
 #endif  // SDP_COL_LEAN2
 
 extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES) sdp_sweep_col(SdpSweepArgs a)
@@ -412,7 +270,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
-        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 64, box_c, filt.psum, k_rows, x_cap);      // (one wave: it also reduces the table's statistics)
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, 64, box_c, filt.psum, k_rows, x_cap, (double)filt.psum);      // (one wave: it also reduces the table's statistics)
 #endif
 #if SDP_COL_SHIFT
         sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
@@ -555,9 +413,13 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             const sdp_real slack = fma((sdp_real)2, radius, ((sdp_real)8 * SDP_COL_FILTER_EPS) * s_node);
             const bool bnb = fabs(X) < ust[3];
             if (__all(bnb)) {                                  // (over the lanes that have a node)
-                if (axis_mode == 2) sdp_lean2_bnb<2>(sdp_lds.ad, utab, filt, lead, X, k_rows, box.total, mask, slack, guess, bd.f1, bd.f2, diag_cnt);
-                else if (axis_mode == 1) sdp_lean2_bnb<1>(sdp_lds.ad, utab, filt, lead, X, k_rows, box.total, mask, slack, guess, bd.f1, bd.f2, diag_cnt);
-                else sdp_lean2_bnb<0>(sdp_lds.ad, utab, filt, lead, X, k_rows, box.total, mask, slack, guess, bd.f1, bd.f2, diag_cnt);
+                auto ins = [&](double Fq) {
+                    bd.f2 = sdp_vmin(bd.f2, sdp_vmax(bd.f1, Fq));
+                    bd.f1 = sdp_vmin(bd.f1, Fq);
+                };
+                if (axis_mode == 2) sdp_short_bnb<2, false>(sdp_lds.ad, utab, filt, lead, X, k_rows, 0, box.total, mask, slack, guess, ins, diag_cnt);
+                else if (axis_mode == 1) sdp_short_bnb<1, false>(sdp_lds.ad, utab, filt, lead, X, k_rows, 0, box.total, mask, slack, guess, ins, diag_cnt);
+                else sdp_short_bnb<0, false>(sdp_lds.ad, utab, filt, lead, X, k_rows, 0, box.total, mask, slack, guess, ins, diag_cnt);
             } else
 #endif
             {
@@ -681,7 +543,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
 #if SDP_COL_UTAB
-                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, k_rows, x_cap);
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, k_rows, x_cap, (double)filt.psum);
 #endif
 #if SDP_COL_SHIFT
                 sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);

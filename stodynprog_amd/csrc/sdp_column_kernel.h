@@ -270,7 +270,7 @@ constexpr int SDP_COL_LDS_PART = (SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? 1 : SDP_C
 // reals per row of the reduced table: A[r] alone in the lean form, (A[r], D[r]) otherwise, 16 bytes for 4-byte reals
 constexpr int SDP_BNB_BLOCK = sdp_bnb_block(SDP_COL_UTAB_N);
 constexpr int SDP_BNB_BLOCKS = (SDP_COL_UTAB_N + SDP_BNB_BLOCK - 1) / SDP_BNB_BLOCK;
-constexpr int SDP_BNB_WORDS = SDP_COL_UTAB ? 4 * SDP_BNB_BLOCKS : 0;
+constexpr int SDP_BNB_WORDS = SDP_COL_UTAB ? 4 * (SDP_BNB_BLOCKS + 1) : 0;      // (a record of 16 bytes per block and one for the end of the lattice: 4 x 4-byte or 2 x 8-byte reals)
 constexpr int SDP_COL_LDS_AD = sizeof(SDP_REAL) == 4 ? 4 : ((SDP_COL_LEAN != 0 && !SDP_COL_SHIFT) ? 1 : 2);
 struct __attribute__((aligned(16))) SdpColLds {
     sdp_real T[(SDP_TRAIL_HAS_U ? SDP_COL_WCHUNK : (SDP_COL_WRES < SDP_COL_W ? SDP_COL_WRES : SDP_COL_TW)) * SDP_COL_ROWS];
@@ -458,7 +458,7 @@ SDP_DEV double sdp_dpp_f64(double v)
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-SDP_DEV float sdp_dpp_f64(float v) { return __shfl_xor(v, CTRL == 0xB1 ? 1 : (CTRL == 0x4E ? 2 : 7), 64); }     // (4-byte builds never take this path)
+SDP_DEV float sdp_dpp_f64(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
 SDP_DEV float sdp_wave_max(float v) { return __ockl_wfred_max_f32(v); }
 SDP_DEV double sdp_wave_min(double v) { return __ockl_wfred_min_f64(v); }
 SDP_DEV float sdp_wave_min(float v) { return __ockl_wfred_min_f32(v); }
@@ -1326,6 +1326,8 @@ struct SdpColFilter {
     sdp_real gc;        // wide first pass: sum_w n_w |p_w| (rounded up), n_w = roundings the term of w passes through
     sdp_real glimit;    // min(1, sum_w |p_w|): a bound below LIMIT x glimit keeps |g| itself below LIMIT
     bool ok;            // weights are finite and of ordinary size
+    // branch and bound of the short first passes: rows of axis 0 per unit of x0, and what |X| + max |a| may be at most
+    sdp_real k_rows, x_cap;
 };
 constexpr bool SDP_COL_LEAN_ON = SDP_COL_LEAN < 0 ? sizeof(sdp_real) == 8 : SDP_COL_LEAN != 0;
 constexpr bool SDP_COL_WIDE_ON = sizeof(sdp_real) == 4 && !SDP_COL_LEAN_ON && SDP_COL_WIDE != 0;
@@ -1813,9 +1815,9 @@ SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, cons
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
 SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0,
                              int count = 0, const SdpBox *box_c = nullptr, sdp_real psum = (sdp_real)0,
-                             sdp_real k_rows = (sdp_real)0, sdp_real x_cap = (sdp_real)0)
+                             sdp_real k_rows = (sdp_real)0, sdp_real x_cap = (sdp_real)0, double psum_d = 0.0)
 {
-    (void)psum; (void)k_rows; (void)x_cap;
+    (void)psum; (void)k_rows; (void)x_cap; (void)psum_d;
     if (count == 0) count = (int)blockDim.x - first;
     if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     SdpBox box;
@@ -1837,7 +1839,8 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
     // block ends: its largest pa + DELTA;  how many rows beyond two can lie between the starts of two neighbouring
     // blocks, as an integer).  The pass uses them only where the blocks are in order, each ending before the next
     // starts (an ordinary lattice, a monotone in the control) and everything is finite: st[3] says so.
-    constexpr sdp_real BNB_DELTA = (sdp_real)0x1p-20;
+    constexpr sdp_real BNB_DELTA = sizeof(sdp_real) == 8 ? (sdp_real)0x1p-20 : (sdp_real)0x1p-8;      // (4-byte reals: the kernel's own positions are off by ~2^-15 rows)
+    constexpr bool BNB_WIDE = sizeof(sdp_real) == 4;       // records: (start as a 4-byte real, -, smallest +-h psum as an 8-byte real)
     sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
     const int lane_u = (int)threadIdx.x - first;
     bool bnb_fine = count == 64 && SDP_BNB_BLOCK <= 64;
@@ -1866,14 +1869,15 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         const sdp_real av = tab[SDP_LEAN2_A_SLOT];
         const sdp_real hv = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT];
         const sdp_real pa = (SDP_LEAN2_FORM == 1 ? -av : av) * k_rows;
-        const sdp_real hpv = (SDP_LEAN2_HNEG ? -hv : hv) * psum;
+        const double hpv = (double)(SDP_LEAN2_HNEG ? -hv : hv) * psum_d;
         const bool have = ci < n_tab;
         bnb_fine = bnb_fine && (!have || (pa == pa && hpv == hpv && fabs(pa) < (sdp_real)INFINITY));
         bnb_amax = sdp_vmax_abs(bnb_amax, have ? av : (sdp_real)0);
-        sdp_real lo = have ? pa : (sdp_real)INFINITY, hi = have ? pa : -(sdp_real)INFINITY, hp = have ? hpv : (sdp_real)INFINITY;
+        sdp_real lo = have ? pa : (sdp_real)INFINITY, hi = have ? pa : -(sdp_real)INFINITY;
+        double hp = have ? hpv : (double)INFINITY;
         constexpr int SEG = SDP_BNB_BLOCK < 64 ? SDP_BNB_BLOCK : 64;
         // minima / maxima over the aligned groups of SEG lanes: the blocks
-        if (SEG == 8 && sizeof(sdp_real) == 8) {
+        if (SEG == 8) {
             // (data-parallel primitives inside a row of 16 lanes: neighbours, pairs, the mirrored half -- no LDS round trips)
             lo = sdp_vmin(lo, sdp_dpp_f64<0xB1>(lo)); hi = sdp_vmax(hi, sdp_dpp_f64<0xB1>(hi)); hp = sdp_vmin(hp, sdp_dpp_f64<0xB1>(hp));
             lo = sdp_vmin(lo, sdp_dpp_f64<0x4E>(lo)); hi = sdp_vmax(hi, sdp_dpp_f64<0x4E>(hi)); hp = sdp_vmin(hp, sdp_dpp_f64<0x4E>(hp));
@@ -1881,9 +1885,9 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         } else {
 #pragma unroll
             for (int d = 1; d < SEG; d <<= 1) {
-                lo = sdp_vmin(lo, sdp_shfl_xor(lo, d));
-                hi = sdp_vmax(hi, sdp_shfl_xor(hi, d));
-                hp = sdp_vmin(hp, sdp_shfl_xor(hp, d));
+                lo = sdp_vmin(lo, __shfl_xor(lo, d, 64));
+                hi = sdp_vmax(hi, __shfl_xor(hi, d, 64));
+                hp = sdp_vmin(hp, __shfl_xor(hp, d, 64));
             }
         }
         // the block that follows in this round, or nothing (the last one of the round meets its successor next round)
@@ -1892,8 +1896,8 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         const bool has_next = lane_u + SEG < 64 && ci + SEG < n_tab;
         if (head) {
             const int b = ci / SDP_BNB_BLOCK;
-            rec[2 * b] = lo - BNB_DELTA;
-            rec[2 * b + 1] = hp;
+            if (BNB_WIDE) { rec[4 * b] = lo - BNB_DELTA; *(double *)(rec + 4 * b + 2) = hp; }
+            else { rec[2 * b] = lo - BNB_DELTA; rec[2 * b + 1] = (sdp_real)hp; }
             if (has_next) {
                 bnb_fine = bnb_fine && hi <= next_lo;
                 bnb_between = sdp_vmax(bnb_between, next_lo - lo);
@@ -1903,7 +1907,7 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
                 bnb_between = sdp_vmax(bnb_between, lo - bnb_prev_lo);
             }
             if (ci + SDP_BNB_BLOCK >= n_tab) {             // the last block: where the lattice ends
-                rec[2 * (b + 1)] = hi + BNB_DELTA;
+                rec[(BNB_WIDE ? 4 : 2) * (b + 1)] = hi + BNB_DELTA;
                 bnb_between = sdp_vmax(bnb_between, hi - lo);
             }
         }
@@ -1922,11 +1926,12 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
             // own cells bring two along (A[q+1] of the lower end, A[q] of the upper one): how many more the pass reads
             const int extra = (bnb_between == bnb_between && bnb_between < (sdp_real)SDP_COL_N0)
                                   ? max((int)(bnb_between + 4 * BNB_DELTA) - 1, 0) : SDP_COL_N0;
-            rec[2 * n_blocks + 1] = __hiloint2double(0, extra);
+            if (BNB_WIDE) rec[4 * n_blocks + 1] = (sdp_real)__int_as_float(extra);
+            else rec[2 * n_blocks + 1] = (sdp_real)__hiloint2double(0, extra);
             // st[3]: what |X| may be at most for the pass's positions to stay within DELTA / 2 of the kernel's own
             // (8 u (|X| + |smin| + max |a|) k < DELTA / 2), or -1: no branch and bound in this column
             sdp_real *st = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;
-            const sdp_real cap = x_cap - bnb_amax;         // (x_cap = 2^30 / k - |smin|: once per workgroup, by the caller)
+            const sdp_real cap = x_cap - bnb_amax;         // (x_cap = 2^30 / k - |smin| (2^13 / k for 4-byte reals): once per workgroup, by the caller)
             st[3] = (sorted && cap == cap && extra < SDP_COL_N0) ? cap : (sdp_real)-1;
         }
     }
@@ -2227,6 +2232,158 @@ SDP_DEV void sdp_wide2_pass1(const sdp_real *ad, const sdp_real *utab, const Sdp
 }
 #endif
 
+#if SDP_COL_BNB
+#ifndef SDP_SHORT_GROUP
+#define SDP_SHORT_GROUP 4
+#endif
+#ifndef SDP_BNB_CHUNK
+#define SDP_BNB_CHUNK (sizeof(SDP_REAL) == 8 ? 4 : 2)      // blocks whose bounds are evaluated together (registers: 8-byte values throughout)
+#endif
+// ---------------------------------------------------------------------------
+// The short first pass as a certified BRANCH AND BOUND over blocks of controls (round 5).
+// A node's filter value is F'(c) = hp_c + L(p_c): hp_c = +-h_c psum from the control table, L the piecewise-linear
+// interpolant of the reduced table A along axis 0 (linear beyond the first and the last cell: the clamped cell with an
+// unclamped lam0), p_c the position of control c.  Over a BLOCK B of controls the positions lie between those of the
+// block's smallest and largest a (x0' = X +- a and every rounded step from it to the position are monotone in a:
+// see the short first pass above), and a piecewise-linear function takes its minimum over an interval at an end of
+// the interval or at a breakpoint inside it -- the breakpoints are the grid rows, where L = A[r].  So
+//     LB(B) = min_B hp  +  min( L(p_lo), L(p_hi), A[r] for the rows r strictly between the two positions )
+// bounds every F'(c), c in B, from below in real arithmetic; as evaluated, both sides are off by a few roundings of
+// numbers bounded by S_node (|hp| <= Pcap max |h|, |L| <= (1 + 2 L_cap) D), together < 16 u S_node.
+// A block with   LB(B) > f1 + 2 radius + 16 u S_node   (f1: the smallest F' seen so far, which only decreases) holds
+// only controls with F' - radius > f1 + radius >= m_hi: by the radius' own theorem none of them is the reference's
+// argmin or ties with it, exactly what the full pass concludes from F' itself (`single`, and the candidate test of the
+// multi-survivor path, which re-evaluates F' of EVERY control and does not depend on this pass).  Its controls are
+// never evaluated.  J, policy and index keep their bits: which controls are skipped is all that changes.
+// Order: the block of the lane's GUESS first (the node's best control in the previous unit of this workgroup: the
+// neighbouring column -- any guess is valid, a good one makes f1 tight at once), then the bounds of all blocks against
+// that f1, then the blocks that survive, lane by lane (a lane reads ITS blocks' entries of the control table; lanes
+// with nothing left idle through the trip).  On the benchmark problem 1.2 blocks of 8 per wave instead of 8.
+// Values that are not finite: a NaN bound fails its comparison (the block is evaluated); the node-level tests of the
+// caller (S_node, L) are unchanged.
+// WIDE: the short wide first pass of 4-byte reals (positions and the control table in 4-byte reals, the reduced table and
+// F' in 8-byte reals; the block records hold the start as a 4-byte real and the smallest +-h psum as an 8-byte one; the
+// ends are moved out by 2^-8 rows there, which covers the 4-byte roundings of the kernel's own positions).
+// c_lo: the controls [c_lo, n) of the lattice are this lane's (0: all of them; the branch and bound runs with one lane
+// per node).  `insert` receives the packed F' of every control that is evaluated.
+template <int AXIS, bool WIDE, typename INSERT>
+SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                           sdp_real X, sdp_real k_rows, int c_lo, int n, int mask, double slack, int guess, INSERT &insert,
+                           sdp_real &sdp_diag_cnt)
+{
+    (void)sdp_diag_cnt; (void)c_lo;
+    constexpr int BS = SDP_BNB_BLOCK, NB = SDP_BNB_BLOCKS;
+    constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
+    static_assert(NB <= 64, "branch and bound: at most 64 blocks");
+    const sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
+    const double psum = WIDE ? f.psum64 : (double)f.psum;
+    auto pack = [&](double F, int ci) { return __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci); };
+    auto row = [&](int q) -> double { return WIDE ? *(const double *)(A + 4 * q) : (double)A[q]; };
+    auto start = [&](int b) -> sdp_real { return WIDE ? rec[4 * b] : rec[2 * b]; };
+    auto least = [&](int b) -> double { return WIDE ? *(const double *)(rec + 4 * b + 2) : (double)rec[2 * b + 1]; };
+    const int n_blocks = (n + BS - 1) / BS;
+    const int g = guess < 0 ? (n >> 1) : min(guess, n - 1);              // (no guess yet: the middle of the lattice)
+    // ---- stage 1: what the bounds need from the LDS -- the guess's entry of the control table, the blocks' records
+    // ---- stage 2: the cells, the reads of the reduced table        (all of a stage's reads are in flight together)
+    // ---- stage 3: F' of the guess (an upper bound of the node's smallest F'), the bounds, the blocks to evaluate
+    const sdp_real ga = utab[g * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+    const sdp_real gh = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[g * SDP_COL_UTAB + HS];
+    const sdp_real pX = SDP_LEAN2_FORM == 2 ? -((X + l.smin) * k_rows) : (X - l.smin) * k_rows;
+    const int extra = __builtin_amdgcn_readfirstlane(WIDE ? __float_as_int((float)rec[4 * n_blocks + 1]) : __double2loint((double)rec[2 * n_blocks + 1]));
+    int gq;
+    sdp_real glam;
+    sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, ga), gq, glam);
+    const double gA0 = row(gq), gA1 = row(gq + 1);
+    unsigned long long need = 0ull;
+    double thresh = 0.0;
+    constexpr int CB = NB < SDP_BNB_CHUNK ? NB : SDP_BNB_CHUNK;
+    for (int b0 = 0; b0 < n_blocks; b0 += CB) {            // (uniform; one chunk on the benchmark lattice)
+        int q[CB + 1];
+        double P[CB + 1], hp[CB], Aq[CB + 1], Aq1[CB + 1], m[CB];
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            const int b = min(b0 + j, n_blocks);           // end j of the chunk: where block b0 + j starts, or the lattice ends
+            P[j] = (double)(pX + start(b));
+            if (j < CB) hp[j] = least(min(b, n_blocks - 1));
+        }
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            q[j] = (int)P[j];                              // (saturating conversion; NaN -> 0)
+            asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q[j]) : "s"(l.ordm2));
+        }
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            Aq[j] = row(q[j]);
+            Aq1[j] = row(q[j] + 1);
+        }
+        if (b0 == 0) {
+            // F' of the guess: its packed value is a first f1 (the block of the guess is evaluated like any other below)
+            const double h = fma((double)glam, gA1 - gA0, gA0);
+            const double Fg = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma((double)(SDP_LEAN2_HNEG ? -gh : gh), psum, h), g);
+            thresh = Fg + slack;
+        }
+#pragma unroll
+        for (int j = 0; j <= CB; ++j) {
+            const double lam = P[j] - (double)q[j];
+            P[j] = fma(lam, Aq1[j] - Aq[j], Aq[j]);        // (P: now L at the end)
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(sdp_vmin(P[j], P[j + 1]), sdp_vmin(Aq1[j], Aq[j + 1]));
+        for (int k = 0; k < extra; ++k) {                  // (one more row per block on the benchmark lattice)
+            double more[CB];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) more[j] = row(max(min(q[j] + 2 + k, q[j + 1] - 1), 0));
+#pragma unroll
+            for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(m[j], more[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            if (q[j + 1] - q[j] - 2 > extra) m[j] = -(double)INFINITY;      // (never seen; a count too small must not cost a row)
+            const double lbv = hp[j] + m[j];
+            // pruned only on a comparison that HOLDS (a NaN anywhere keeps the block); the guess's own block always stays
+            if ((!(lbv > thresh) || b0 + j == g / BS) && b0 + j < n_blocks) need |= 1ull << (b0 + j);
+        }
+    }
+#ifdef SDP_DIAG_BNB_COUNT                                  // diagnostic: J := blocks asked for (+ 100 x the guess's block)
+    sdp_diag_cnt = (sdp_real)(__popcll(need) + 100 * (g / BS));
+#endif
+    // ---- the blocks that stay, lane by lane, groups of controls in stages (a lane reads ITS block's entries of the
+    // control table; lanes with nothing left idle through the trip)
+    while (__any(need != 0ull)) {
+        const bool on = need != 0ull;
+        const int b = on ? __ffsll((long long)need) - 1 : 0;
+        need &= need - 1ull;
+        constexpr int K = SDP_SHORT_GROUP;
+        static_assert(BS % K == 0, "branch and bound: whole groups per block");
+        for (int j0 = 0; j0 < BS; j0 += K) {
+            int q0[K], ci[K];
+            sdp_real av[K], lam0[K], hv[K];
+            double a0[K], a1[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                ci[j] = min(b * BS + j0 + j, n - 1);       // (past the end: the last control again, not inserted)
+                av[j] = utab[ci[j] * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+                hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[ci[j] * SDP_COL_UTAB + HS];
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                a0[j] = row(q0[j]);
+                a1[j] = row(q0[j] + 1);
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const double h = fma((double)lam0[j], a1[j] - a0[j], a0[j]);
+                const double Fp = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma((double)(SDP_LEAN2_HNEG ? -hv[j] : hv[j]), psum, h), ci[j]);
+                // (a lane with nothing to evaluate in this trip, a control past the end: the largest finite number never wins)
+                insert(on && b * BS + j0 + j < n ? Fp : 0x1.fffffffffffffp+1023);
+            }
+        }
+    }
+}
+#endif  // SDP_COL_BNB
+
 SDP_DEV void sdp_col_bounds_merge(SdpColBounds &b, int d)
 {
     const sdp_fkey o_f1 = sdp_shfl_xor(b.f1, d), o_f2 = sdp_shfl_xor(b.f2, d);
@@ -2274,8 +2431,10 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
 #if SDP_COL_SHIFT
                                   , const SdpColShiftCol &shc
 #endif
+                                  , int *guess_p = nullptr
                                   )
 {
+    (void)guess_p;
     constexpr int N0 = SDP_COL_N0;
     const int lane = threadIdx.x & 63;
     // the axis the FIRST pass locates its positions on: axis 0, or the shifted lattice of this column
@@ -2325,18 +2484,43 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             sb.f1 = sb.f2 = sb.f3 = INFINITY;
             int q_e;
             sdp_real lam_lo, lam_hi;
+            // (the node's bound and radius need nothing of the pass itself: they come first, the branch and bound uses them)
             if (axis_mode == 2) {
-                sdp_wide2_pass1<2>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
                 sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2_cell<2>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
             } else if (axis_mode == 1) {
-                sdp_wide2_pass1<1>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
                 sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2_cell<1>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
             } else {
-                sdp_wide2_pass1<0>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
                 sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2_cell<0>(lead, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+            }
+            const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
+            // (dcol: the largest |T| of the column, raw -- sdp_col_filter_reduce)
+            const sdp_real s_node = (filt.gc + filt.pcap) * ((fabs(K) + ust[2]) + ((sdp_real)1 + (sdp_real)2 * l_cap) * dcol);
+            bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(fabs(lam_lo) + fabs(lam_hi) < (sdp_real)1073741824.0) ||
+                  bits > 24 || box.total > SDP_COL_UTAB_N;
+            radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)s_node + (sdp_fkey)filt.floor) +
+                     ldexp((sdp_fkey)s_node, bits - 51);
+            bool full_pass = true;
+#if SDP_COL_BNB
+            // one lane per node, the column's blocks in order, |X| small enough for the bounds' positions (ust[3]:
+            // sdp_col_phase_u): a block is skipped when its lower bound exceeds f1 by more than 2 radius (+ 2^-40 S for the
+            // bound's own 8-byte roundings); a wave with a node that does not qualify takes the full pass
+            if (__all(chunks == 1 && fabs(X) < ust[3] && !bad)) {
+                full_pass = false;
+                sdp_real cnt_unused = (sdp_real)0;
+                const double slack = fma(2.0, (double)radius, 0x1p-40 * (double)s_node);
+                auto ins = [&](double Fq) { sdp_short_insert(sb, Fq); };
+                if (axis_mode == 2) sdp_short_bnb<2, true>(ad_tab, utab, filt, lead, X, filt.k_rows, c_lo, c_hi, mask, slack, *guess_p, ins, cnt_unused);
+                else if (axis_mode == 1) sdp_short_bnb<1, true>(ad_tab, utab, filt, lead, X, filt.k_rows, c_lo, c_hi, mask, slack, *guess_p, ins, cnt_unused);
+                else sdp_short_bnb<0, true>(ad_tab, utab, filt, lead, X, filt.k_rows, c_lo, c_hi, mask, slack, *guess_p, ins, cnt_unused);
+            }
+#endif
+            if (full_pass) {
+                if (axis_mode == 2) sdp_wide2_pass1<2>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
+                else if (axis_mode == 1) sdp_wide2_pass1<1>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
+                else sdp_wide2_pass1<0>(ad_tab, utab, filt, lead, X, c_lo, c_hi, mask, sb);
             }
             for (int d = npw; d < 64; d <<= 1) {           // the lanes that share the node (ranges of its lattice)
                 const double o1 = sdp_shfl_xor(sb.f1, d), o2 = sdp_shfl_xor(sb.f2, d), o3 = sdp_shfl_xor(sb.f3, d);
@@ -2347,13 +2531,6 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
             bd.f1 = sb.f1; bd.f2 = sb.f2; bd.f3 = sb.f3;
             bd.i1 = sb.f1 < (double)INFINITY ? (__double2loint(sb.f1) & mask) : INT_MAX;
             bd.i2 = sb.f2 < (double)INFINITY ? (__double2loint(sb.f2) & mask) : INT_MAX;
-            const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
-            // (dcol: the largest |T| of the column, raw -- sdp_col_filter_reduce)
-            const sdp_real s_node = (filt.gc + filt.pcap) * ((fabs(K) + ust[2]) + ((sdp_real)1 + (sdp_real)2 * l_cap) * dcol);
-            bad = !filt.ok || !(s_node < SDP_COL_FILTER_LIMIT) || !(fabs(lam_lo) + fabs(lam_hi) < (sdp_real)1073741824.0) ||
-                  bits > 24 || box.total > SDP_COL_UTAB_N;
-            radius = (sdp_fkey)(SDP_COL_FILTER_SCALE) * (sdp_fkey)(1.001 * 0x1p-24) * ((sdp_fkey)s_node + (sdp_fkey)filt.floor) +
-                     ldexp((sdp_fkey)s_node, bits - 51);
         }
         SDP_COL_MARK(diag.m2);
 #else
@@ -2477,6 +2654,7 @@ SDP_DEV void sdp_col_filter_nodes(const SdpSweepArgs &a, const SdpGrid<sdp_real,
         if (live && chunk == 0) { ++diag.n_all; if (!single && !pair) ++diag.n_slow; }
 #endif
         if (live && chunk == 0) sdp_col_store(a, node, box, best, ibest);
+        if (guess_p && live && ibest != INT_MAX) *guess_p = ibest;      // (branch and bound: where the next node of this lane starts)
 #if SDP_STAMP == 2
         diag.tp2 += __builtin_amdgcn_s_memtime() - diag.m2;
 #endif
@@ -2517,6 +2695,15 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     SdpColFilter filt;
     sdp_col_filter_setup(a, filt);
     const int axis_mode = __builtin_amdgcn_readfirstlane(sdp_col_axis_mode(lead));
+    // (what is the same in every lane for the whole kernel lives in scalar registers: sdp_uniform)
+    lead.smin = sdp_uniform(lead.smin); lead.span = sdp_uniform(lead.span); lead.nm1 = sdp_uniform(lead.nm1); lead.rspan = sdp_uniform(lead.rspan);
+    filt.psum = sdp_uniform(filt.psum); filt.pcap = sdp_uniform(filt.pcap); filt.cu = sdp_uniform(filt.cu);
+    filt.floor = sdp_uniform(filt.floor); filt.ratio = sdp_uniform(filt.ratio); filt.psum64 = sdp_uniform(filt.psum64);
+    filt.gc = sdp_uniform(filt.gc); filt.glimit = sdp_uniform(filt.glimit);
+    filt.k_rows = sdp_uniform(lead.nm1 / lead.span);
+    filt.x_cap = sdp_uniform((sizeof(sdp_real) == 8 ? (sdp_real)0x1p30 : (sdp_real)0x1p13) / filt.k_rows - fabs(lead.smin));
+    int guess = -1;                                        // branch and bound: this lane's best control at its previous node
+    (void)guess;
 #endif
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
@@ -2565,7 +2752,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_coords(a, sdp_col_of_unit(a, unit), xn);
         sdp_col_phase_w(a, tg, s, xn, nullptr, t);
 #if SDP_COL_UTAB
-        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, SDP_COL_SHORT ? 64 : 0, box_c);   // (one wave: it also reduces the table's statistics)
+        sdp_col_phase_u(a, sdp_lds.utab[0], xn, t, 0, SDP_COL_SHORT ? 64 : 0, box_c, filt.psum, filt.k_rows, filt.x_cap,
+                        sizeof(sdp_real) == 4 ? filt.psum64 : (double)filt.psum);   // (one wave: it also reduces the table's statistics)
 #endif
 #if SDP_COL_SHIFT
         sdp_col_phase_shift(a, sdp_lds, lead, xn, t, 0);
@@ -2612,7 +2800,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
 #if SDP_COL_UTAB
-                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c);
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, filt.k_rows, filt.x_cap,
+                                sizeof(sdp_real) == 4 ? filt.psum64 : (double)filt.psum);
 #endif
 #if SDP_COL_SHIFT
                 sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);
@@ -2660,6 +2849,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #if SDP_COL_SHIFT
                              , shc
 #endif
+                             , &guess
                              );
         upar ^= 1;
 #else
