@@ -329,6 +329,8 @@ SDP_DEV void sdp_col_carve(SdpColLds &m, SdpColShared &s)
 }
 
 // grid of the trailing axes over the axis-0-fastest array: strides in elements
+SDP_DEV double sdp_uniform_real(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+SDP_DEV float sdp_uniform_real(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 SDP_DEV void sdp_col_trailing_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_DT> &g)
 {
     const sdp_real *axes = (const sdp_real *)a.axes;
@@ -348,6 +350,12 @@ SDP_DEV void sdp_col_trailing_grid(const SdpSweepArgs &a, SdpGrid<sdp_real, SDP_
     }
     g.pow2 = __builtin_amdgcn_readfirstlane(g.pow2);
     g.shift = (sdp_real)0;
+    // (the same in every lane for the whole kernel: scalar registers -- sdp_uniform, defined below, is a template here)
+#pragma unroll
+    for (int k = 0; k < SDP_DT; ++k) {
+        g.smin[k] = sdp_uniform_real(g.smin[k]); g.span[k] = sdp_uniform_real(g.span[k]);
+        g.rspan[k] = sdp_uniform_real(g.rspan[k]); g.nm1[k] = sdp_uniform_real(g.nm1[k]);
+    }
 }
 
 // The nested lerp of SdpLerp<real, SDP_DT, real> (sdp_device.h; reference
@@ -1557,6 +1565,8 @@ SDP_DEV void sdp_col_shift_col(const SdpColLds &m, const SdpLeadAxis &l, int par
     c.lc = (sdp_real)c.rows + (sdp_real)abs(c.kmin) + pbmax + p0 * (sdp_real)1.001 + (sdp_real)(SDP_COL_N0 + 1);
     c.es = (sdp_real)(1 + 2 * (flmax + nflmin + 2));
     if (!(c.lc < (sdp_real)1073741824.0)) c.ok = false;              // (a NaN or an infinity of p0)
+    c.lc = sdp_uniform(c.lc);                               // (the same in every lane: scalar registers)
+    c.es = sdp_uniform(c.es);
 }
 
 // before phase A (the readers of the previous unit's table left at the barrier): clear the lattice
@@ -1899,11 +1909,12 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
             if (BNB_WIDE) { rec[4 * b] = lo - BNB_DELTA; *(double *)(rec + 4 * b + 2) = hp; }
             else { rec[2 * b] = lo - BNB_DELTA; rec[2 * b + 1] = (sdp_real)hp; }
             if (has_next) {
-                bnb_fine = bnb_fine && hi <= next_lo;
+                bnb_fine = bnb_fine && hi + 2 * BNB_DELTA <= next_lo;      // (a block's controls, each within DELTA / 2 of its
+                                                                           //  pa, stay below the start of the next block)
                 bnb_between = sdp_vmax(bnb_between, next_lo - lo);
             }
             if (lane_u == 0 && c0 > 0) {                   // (against the last block of the previous round)
-                bnb_fine = bnb_fine && bnb_prev_hi <= lo;
+                bnb_fine = bnb_fine && bnb_prev_hi + 2 * BNB_DELTA <= lo;
                 bnb_between = sdp_vmax(bnb_between, lo - bnb_prev_lo);
             }
             if (ci + SDP_BNB_BLOCK >= n_tab) {             // the last block: where the lattice ends
@@ -1936,7 +1947,9 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         }
     }
 #else
-    for (int ci = (int)threadIdx.x - first; ci < n_tab; ci += count) {
+    for (int ci_ = (int)threadIdx.x - first; ci_ < n_tab; ci_ += count) {
+        int ci = ci_;
+        asm volatile("" : "+v"(ci));                        // (opaque to the optimiser: see the loop above)
         sdp_real u[SDP_NU], tab[SDP_COL_UTAB];
         sdp_controls_at(box, ci, u);
         sdp_model_utab(x, u, t, tab);
