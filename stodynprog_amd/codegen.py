@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-from .trace import TracedModel
+from .trace import TracedModel, DEP_X
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 
@@ -385,6 +385,8 @@ def short_pass_source(model, frontier, macro='SDP_COL_LEAN2'):
            '#define SDP_LEAN2_H_SLOT {}'.format(-1 if h_slot is None else int(h_slot)),
            '#define SDP_LEAN2_LEAD(X, A) {}'.format({'add': '((X) + (A))', 'sub': '((X) - (A))', 'rsub': '((A) - (X))'}[a_form]),
            '#define SDP_LEAN2_FORM {}            // 0: X + a, 1: X - a, 2: a - X'.format({'add': 0, 'sub': 1, 'rsub': 2}[a_form]),
+           '#define SDP_LEAN2_A_FIXED {}         // a depends on the control alone: the same lattice of positions in every column'.format(
+               0 if (frontier[int(a_slot)].deps & DEP_X) else 1),
            '#define SDP_LEAN2_HNEG {}           // the part of the cost that depends on the control enters negated (K - h)'.format(
                1 if (h_slot is not None and h_form == 'sub') else 0)]
     for fname, node in (('sdp_model_lead_x', x_node), ('sdp_model_cost_x', k_node)):

@@ -238,6 +238,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #define SDP_RES_MARK(v)
 #endif
     int guess = -1;                                        // branch and bound: this lane's best control in the previous unit of the workgroup
+    int tables_made = 1;                                   // control tables made so far (the first one before the loop): see SDP_LEAN2_A_FIXED
+    (void)tables_made;
     (void)guess;
 #if SDP_COL_UTAB
     sdp_trap_unless(!a.box_per_node);
@@ -543,7 +545,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
 #if SDP_COL_UTAB
-                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, k_rows, x_cap, (double)filt.psum);
+                sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, k_rows, x_cap, (double)filt.psum,
+                                SDP_LEAN2_A_FIXED_ON && tables_made >= 2);
+                ++tables_made;
 #endif
 #if SDP_COL_SHIFT
                 sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);

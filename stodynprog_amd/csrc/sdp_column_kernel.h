@@ -215,6 +215,10 @@
 #endif
 // controls per block of the branch and bound, and the block statistics kept beside the control table (four reals per
 // block: smallest a, largest a, smallest +-h psum, unused): at most 64 blocks -- one lane of the table's wave each
+#ifndef SDP_LEAN2_A_FIXED
+#define SDP_LEAN2_A_FIXED 0      // generated: the part a of x0' = X +- a depends on the control alone (not on the column)
+#endif
+constexpr bool SDP_LEAN2_A_FIXED_ON = SDP_LEAN2_A_FIXED && SDP_COL_BNB;
 constexpr int sdp_bnb_block(int n) { int b = 8; while ((n + b - 1) / b > 64) b *= 2; return b; }
 #ifndef SDP_COL_LDS_PAD
 #define SDP_COL_LDS_PAD 0        // diagnostic builds: unused bytes in the LDS image (fewer workgroups per CU: occupancy A/B)
@@ -1825,9 +1829,13 @@ SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, cons
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..
 SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_real *x, sdp_real t, int first = 0,
                              int count = 0, const SdpBox *box_c = nullptr, sdp_real psum = (sdp_real)0,
-                             sdp_real k_rows = (sdp_real)0, sdp_real x_cap = (sdp_real)0, double psum_d = 0.0)
+                             sdp_real k_rows = (sdp_real)0, sdp_real x_cap = (sdp_real)0, double psum_d = 0.0,
+                             bool a_known = false)
 {
-    (void)psum; (void)k_rows; (void)x_cap; (void)psum_d;
+    // a_known (SDP_LEAN2_A_FIXED: the part a of x0' = X +- a depends on the control alone -- the same lattice of positions
+    // in every column): this parity buffer already holds what follows from a -- its smallest and largest value, the blocks'
+    // starts, their order, the row count -- from the table made here two units ago; only what follows from h is redone.
+    (void)psum; (void)k_rows; (void)x_cap; (void)psum_d; (void)a_known;
     if (count == 0) count = (int)blockDim.x - first;
     if ((int)threadIdx.x < first || (int)threadIdx.x >= first + count) return;
     SdpBox box;
@@ -1868,9 +1876,11 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         if (ci < n_tab) {
 #pragma unroll
             for (int k = 0; k < SDP_COL_UTAB; ++k) utab[ci * SDP_COL_UTAB + k] = tab[k];
-            a_lo = sdp_vmin(a_lo, tab[SDP_LEAN2_A_SLOT]);
-            a_hi = sdp_vmax(a_hi, tab[SDP_LEAN2_A_SLOT]);
-            fin = fin + fabs(tab[SDP_LEAN2_A_SLOT]);
+            if (!a_known) {
+                a_lo = sdp_vmin(a_lo, tab[SDP_LEAN2_A_SLOT]);
+                a_hi = sdp_vmax(a_hi, tab[SDP_LEAN2_A_SLOT]);
+                fin = fin + fabs(tab[SDP_LEAN2_A_SLOT]);
+            }
             if (SDP_LEAN2_H_SLOT >= 0) {
                 h_abs = sdp_vmax_abs(h_abs, tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT]);
                 fin = fin + fabs(tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT]);
@@ -1878,14 +1888,30 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         }
         const sdp_real av = tab[SDP_LEAN2_A_SLOT];
         const sdp_real hv = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : tab[SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT];
-        const sdp_real pa = (SDP_LEAN2_FORM == 1 ? -av : av) * k_rows;
         const double hpv = (double)(SDP_LEAN2_HNEG ? -hv : hv) * psum_d;
         const bool have = ci < n_tab;
+        double hp = have ? hpv : (double)INFINITY;
+        constexpr int SEG = SDP_BNB_BLOCK < 64 ? SDP_BNB_BLOCK : 64;
+        const bool head = have && (lane_u % SEG) == 0;
+        if (a_known) {
+            // (the smallest +-h psum of every block, nothing else)
+            if (SEG == 8) {
+                hp = sdp_vmin(hp, sdp_dpp_f64<0xB1>(hp)); hp = sdp_vmin(hp, sdp_dpp_f64<0x4E>(hp)); hp = sdp_vmin(hp, sdp_dpp_f64<0x141>(hp));
+            } else {
+#pragma unroll
+                for (int d = 1; d < SEG; d <<= 1) hp = sdp_vmin(hp, __shfl_xor(hp, d, 64));
+            }
+            if (head) {
+                const int b = ci / SDP_BNB_BLOCK;
+                if (BNB_WIDE) *(double *)(rec + 4 * b + 2) = hp;
+                else rec[2 * b + 1] = (sdp_real)hp;
+            }
+            continue;
+        }
+        const sdp_real pa = (SDP_LEAN2_FORM == 1 ? -av : av) * k_rows;
         bnb_fine = bnb_fine && (!have || (pa == pa && hpv == hpv && fabs(pa) < (sdp_real)INFINITY));
         bnb_amax = sdp_vmax_abs(bnb_amax, have ? av : (sdp_real)0);
         sdp_real lo = have ? pa : (sdp_real)INFINITY, hi = have ? pa : -(sdp_real)INFINITY;
-        double hp = have ? hpv : (double)INFINITY;
-        constexpr int SEG = SDP_BNB_BLOCK < 64 ? SDP_BNB_BLOCK : 64;
         // minima / maxima over the aligned groups of SEG lanes: the blocks
         if (SEG == 8) {
             // (data-parallel primitives inside a row of 16 lanes: neighbours, pairs, the mirrored half -- no LDS round trips)
@@ -1902,7 +1928,6 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
         }
         // the block that follows in this round, or nothing (the last one of the round meets its successor next round)
         const sdp_real next_lo = __shfl_down(lo, SEG, 64);
-        const bool head = have && (lane_u % SEG) == 0;
         const bool has_next = lane_u + SEG < 64 && ci + SEG < n_tab;
         if (head) {
             const int b = ci / SDP_BNB_BLOCK;
@@ -1927,6 +1952,7 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
             bnb_prev_lo = __shfl(lo, 64 - SEG, 64);
         }
     }
+    if (!a_known)
     {
         const bool sorted = __all(bnb_fine);
         bnb_between = sdp_wave_max(bnb_between);
@@ -1967,10 +1993,19 @@ SDP_DEV void sdp_col_phase_u(const SdpSweepArgs &a, sdp_real *utab, const sdp_re
     }
 #endif  // SDP_COL_BNB
 #if SDP_COL_SHORT
-    a_lo = sdp_wave_min(a_lo);
-    a_hi = sdp_wave_max(a_hi);
     h_abs = sdp_wave_max(h_abs);
     fin = sdp_wave_sum(fin);
+    if (a_known) {
+        // (what this buffer said two units ago about a stands; a poisoned entry stays poisoned)
+        if ((int)threadIdx.x == first) {
+            sdp_real *st = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;
+            const sdp_real before = st[2];
+            st[2] = (count == 64 && fin < SDP_COL_FILTER_LIMIT && before == before) ? h_abs : (sdp_real)NAN;
+        }
+        return;
+    }
+    a_lo = sdp_wave_min(a_lo);
+    a_hi = sdp_wave_max(a_hi);
     if ((int)threadIdx.x == first) {
         sdp_real *st = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;
         st[0] = a_lo;
@@ -2716,7 +2751,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     filt.k_rows = sdp_uniform(lead.nm1 / lead.span);
     filt.x_cap = sdp_uniform((sizeof(sdp_real) == 8 ? (sdp_real)0x1p30 : (sdp_real)0x1p13) / filt.k_rows - fabs(lead.smin));
     int guess = -1;                                        // branch and bound: this lane's best control at its previous node
-    (void)guess;
+    int tables_made = 1;                                   // control tables made so far (the first one before the loop): see SDP_LEAN2_A_FIXED
+    (void)guess; (void)tables_made;
 #endif
     if (SDP_COL_WINDOW && threadIdx.x < 4) sdp_lds.win[threadIdx.x >> 1][threadIdx.x & 1] = INT_MAX;
     if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
@@ -2814,7 +2850,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);
 #if SDP_COL_UTAB
                 sdp_col_phase_u(a, sdp_lds.utab[upar ^ 1], xn, t, max(waves - 2, 0) * 64, 64, box_c, filt.psum, filt.k_rows, filt.x_cap,
-                                sizeof(sdp_real) == 4 ? filt.psum64 : (double)filt.psum);
+                                sizeof(sdp_real) == 4 ? filt.psum64 : (double)filt.psum, SDP_LEAN2_A_FIXED_ON && tables_made >= 2);
+                ++tables_made;
 #endif
 #if SDP_COL_SHIFT
                 sdp_col_phase_shift(a, sdp_lds, lead, xn, t, upar ^ 1, max(waves - 3, 0) * 64, 64);

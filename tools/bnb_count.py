@@ -15,3 +15,5 @@ print('guess block == best block: %.3f' % (bg == idx // 8).mean())
 w = need.reshape(256, -1)            # rows = axis 0 (lanes), columns
 per_wave = w.reshape(4, 64, -1).max(axis=1)
 print('max over the 64 lanes of a wave: mean %.3f' % per_wave.mean(), np.bincount(per_wave.ravel(), minlength=9)[:9])
+for k in range(4):
+    print('wave', k, ': mean of the largest count of its lanes %.3f' % per_wave[k].mean(), ' mean count per lane %.3f' % w.reshape(4, 64, -1)[k].mean())
