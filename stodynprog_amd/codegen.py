@@ -972,6 +972,7 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
 
 
 _HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_colres_kernel.h',
+            'sdp_colfull_kernel.h', 'sdp_colu_kernel.h',
             'sdp_lead_kernel.h', 'sdp_staged_kernel.h')
 _digest_cache = {}
 
