@@ -30,7 +30,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 # so in backend_info['debug_defines'], and bench.py in config.debug_defines.
 # ---------------------------------------------------------------------------
 # macros copied into the generated unit as they are (integers)
-DEBUG_INT_MACROS = ('SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
+DEBUG_INT_MACROS = ('SDP_COL_SHARE_X2', 'SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
                     'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO',
                     'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE',
                     'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP', 'SDP_COL_LDS_PAD', 'SDP_COL_HOIST')

@@ -1175,8 +1175,32 @@ SDP_DEV void sdp_col_walk(const SdpSweepArgs &a, SdpColWalk &w)
 #ifndef SDP_COL_TILE
 #define SDP_COL_TILE 1
 #endif
+#ifndef SDP_COL_SHARE_X2
+// 1 (three state variables, a launch over the whole grid, x2 a multiple of 64 and x1 of 8 points): the eight
+// XCDs' shares of the columns are cut along x2 -- every XCD walks ALL rows of x1, an eighth of x2 each -- instead of
+// along x1.  The strips a column's table is built from lie around its next trailing state; with the shares cut along x1
+// the chip works on eight bands of x1 at once and their strips together (~70 MB per band at 512^3 x 4 bytes) do not fit
+// the cache, so every strip comes from HBM once per band that touches it (measured: 4.0 GB fetched per sweep for a
+// 0.54 GB array).  Cut along x2, the eight shares move through the SAME band of x1 together and share its strips:
+// 512^3 x 4 bytes 7.90 -> 7.54 ms, 256^3 x 8 bytes (which fits the cache) 1.336 -> 1.320 ms, same box.  0: along x1 (A/B runs)
+#define SDP_COL_SHARE_X2 1
+#endif
 SDP_DEV int64_t sdp_col_of_unit(const SdpSweepArgs &a, int64_t unit)
 {
+#if SDP_D == 3 && SDP_COL_SHARE_X2 && (SDP_COL_FILTER || SDP_TRAIL_HAS_U)
+    {
+        const int n1 = a.orders[1], n2 = a.orders[2];
+        const int64_t cols = (int64_t)n1 * n2;
+        if (a.col_splits == 1 && a.col_begin == 0 && a.col_end == cols && (n2 & 63) == 0 && (n1 & 7) == 0 && cols < ((int64_t)1 << 31)) {
+            const unsigned per = (unsigned)(cols >> 3), u = (unsigned)unit;      // units of an XCD's share (sdp_col_walk)
+            const unsigned k = u / per, v = u - k * per;
+            const unsigned w2 = (unsigned)n2 >> 3;                                // columns of x2 in a share
+            const unsigned band = v / (8u * w2), r = v - band * 8u * w2;
+            const unsigned tile = r >> 6, within = r & 63u;
+            return (int64_t)(band * 8u + (within >> 3)) * n2 + (k * w2 + tile * 8u + (within & 7u));
+        }
+    }
+#endif
     const int64_t col = a.col_begin + unit / a.col_splits;
 #if SDP_D == 3 && (SDP_COL_FILTER || SDP_TRAIL_HAS_U) && SDP_COL_TILE
     const int64_t n2 = a.orders[2];
