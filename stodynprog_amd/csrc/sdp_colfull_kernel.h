@@ -103,9 +103,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
 #endif
         const int64_t col = sdp_col_of_unit(a, unit);
-        const int part = (int)(unit % a.col_splits);
-        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
-        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        const int part = (int)((unsigned)unit % (unsigned)a.col_splits);      // (32-bit: units < 2^31)
+        const int i_lo = (int)((unsigned)(N0 * part) / (unsigned)a.col_splits);
+        const int i_hi = (int)((unsigned)(N0 * (part + 1)) / (unsigned)a.col_splits);
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
 #if SDP_COL_FILTER
@@ -330,9 +330,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS) sdp_evalpol_col(Sd
     int parity = 0;
     for (int64_t unit = walk.unit; unit < walk.end; unit += walk.stride) {
         const int64_t col = sdp_col_of_unit(a, unit);
-        const int part = (int)(unit % a.col_splits);
-        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
-        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        const int part = (int)((unsigned)unit % (unsigned)a.col_splits);      // (32-bit: units < 2^31)
+        const int i_lo = (int)((unsigned)(N0 * part) / (unsigned)a.col_splits);
+        const int i_hi = (int)((unsigned)(N0 * (part + 1)) / (unsigned)a.col_splits);
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
         __syncthreads();

@@ -155,9 +155,9 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         const int64_t unit = u_base + sdp_lds.next_unit;
         if (unit >= u_end) break;
         const int64_t col = sdp_col_of_unit(a, unit);
-        const int part = (int)(unit % a.col_splits);
-        const int i_lo = (int)((int64_t)N0 * part / a.col_splits);
-        const int i_hi = (int)((int64_t)N0 * (part + 1) / a.col_splits);
+        const int part = (int)((unsigned)unit % (unsigned)a.col_splits);      // (32-bit: units < 2^31)
+        const int i_lo = (int)((unsigned)(N0 * part) / (unsigned)a.col_splits);
+        const int i_hi = (int)((unsigned)(N0 * (part + 1)) / (unsigned)a.col_splits);
         sdp_real x[SDP_D];
         sdp_col_coords(a, col, x);
         // the controls of the column (every node of it has this box)

@@ -275,6 +275,11 @@ constexpr int SDP_COL_LDS_PART = (SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? 1 : SDP_C
 constexpr int SDP_BNB_BLOCK = sdp_bnb_block(SDP_COL_UTAB_N);
 constexpr int SDP_BNB_BLOCKS = (SDP_COL_UTAB_N + SDP_BNB_BLOCK - 1) / SDP_BNB_BLOCK;
 constexpr int SDP_BNB_WORDS = SDP_COL_UTAB ? 4 * (SDP_BNB_BLOCKS + 1) : 0;      // (a record of 16 bytes per block and one for the end of the lattice: 4 x 4-byte or 2 x 8-byte reals)
+// (the short wide first pass reads A[r] alone: there the 8-byte sums lie side by side in the first half of `ad` -- a lane
+// per row then reads conflict-free; at 16 bytes per row the same read hits every bank four times: 39 % of the LDS cycles
+// of config 5 were bank conflicts, profiles/r05_synth512f32_summary.txt)
+#define SDP_AD_A(ad, r) (SDP_COL_WIDE2 ? ((double *)(ad))[(r)] : *(double *)((ad) + 4 * (r)))
+#define SDP_AD_A_CONST(ad, r) (SDP_COL_WIDE2 ? ((const double *)(ad))[(r)] : *(const double *)((ad) + 4 * (r)))
 constexpr int SDP_COL_LDS_AD = sizeof(SDP_REAL) == 4 ? 4 : ((SDP_COL_LEAN != 0 && !SDP_COL_SHIFT) ? 1 : 2);
 struct __attribute__((aligned(16))) SdpColLds {
     sdp_real T[(SDP_TRAIL_HAS_U ? SDP_COL_WCHUNK : (SDP_COL_WRES < SDP_COL_W ? SDP_COL_WRES : SDP_COL_TW)) * SDP_COL_ROWS];
@@ -1201,12 +1206,12 @@ SDP_DEV int64_t sdp_col_of_unit(const SdpSweepArgs &a, int64_t unit)
         }
     }
 #endif
-    const int64_t col = a.col_begin + unit / a.col_splits;
+    const int64_t col = a.col_begin + (int64_t)((unsigned)unit / (unsigned)a.col_splits);     // (units < 2^31: see sdp_col_coords)
 #if SDP_D == 3 && (SDP_COL_FILTER || SDP_TRAIL_HAS_U) && SDP_COL_TILE
     const int64_t n2 = a.orders[2];
     if ((n2 & 7) == 0) {
         const int64_t blk = 8 * n2;
-        const int64_t b0 = col / blk * blk;
+        const int64_t b0 = (int64_t)((unsigned)col / (unsigned)blk) * blk;
         if (b0 >= a.col_begin && b0 + blk <= a.col_end) {
             const int64_t local = col - b0, tile = local >> 6, within = local & 63;
             return b0 + (within >> 3) * n2 + (tile << 3) + (within & 7);
@@ -1219,11 +1224,14 @@ SDP_DEV int64_t sdp_col_of_unit(const SdpSweepArgs &a, int64_t unit)
 SDP_DEV void sdp_col_coords(const SdpSweepArgs &a, int64_t col, sdp_real *x)
 {
     const sdp_real *axes = (const sdp_real *)a.axes;
-    int64_t r = col;
+    // (32-bit unsigned arithmetic: the grid has fewer than 2^31 nodes -- sdp_problem_create -- and a 64-bit division of
+    // uniform values is a hundred scalar instructions, several times per wave and unit)
+    unsigned r = (unsigned)col;
 #pragma unroll
     for (int k = SDP_D - 1; k >= 1; --k) {
-        const int i = (int)(r % a.orders[k]);
-        r /= a.orders[k];
+        const unsigned n = (unsigned)a.orders[k], q = r / n;
+        const int i = (int)(r - q * n);
+        r = q;
         x[k] = axes[a.axis_off[k] + i];
     }
     x[0] = (sdp_real)0;
@@ -1444,8 +1452,8 @@ SDP_DEV void sdp_col_filter_reduce(const SdpSweepArgs &a, SdpColLds &m, const Sd
 #endif
                 tmax = sdp_vmax_abs(tmax, v);
             }
-            *(double *)(m.ad + 4 * r) = acc;
-            m.ad[4 * r + 2] = bsum;
+            SDP_AD_A(m.ad, r) = acc;
+            if (!SDP_COL_WIDE2) m.ad[4 * r + 2] = bsum;
             if (!(acc == acc)) tmax = (sdp_real)INFINITY;        // (a NaN entry, which the maximum skips)
         }
         tmax = sdp_wave_max(tmax);
@@ -2249,8 +2257,7 @@ SDP_DEV double sdp_wide2_value(const sdp_real *ad, const sdp_real *utab, const S
     int q0;
     sdp_real lam0;
     sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, utab[ci * SDP_COL_UTAB + SDP_LEAN2_A_SLOT]), q0, lam0);
-    const sdp_real *row = ad + 4 * q0;
-    const double a0 = *(const double *)row, a1 = *(const double *)(row + 4);
+    const double a0 = SDP_AD_A_CONST(ad, q0), a1 = SDP_AD_A_CONST(ad, q0 + 1);
     const double h = fma((double)lam0, a1 - a0, a0);
     if (SDP_LEAN2_H_SLOT < 0) return h;
     const sdp_real hv = utab[ci * SDP_COL_UTAB + (SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT)];
@@ -2291,8 +2298,8 @@ SDP_DEV void sdp_wide2_pass1(const sdp_real *ad, const sdp_real *utab, const Sdp
         for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            a0[j] = *(const double *)(ad + 4 * q0[j]);
-            a1[j] = *(const double *)(ad + 4 * q0[j] + 4);
+            a0[j] = SDP_AD_A_CONST(ad, q0[j]);
+            a1[j] = SDP_AD_A_CONST(ad, q0[j] + 1);
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -2350,7 +2357,7 @@ SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpCol
     const sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
     const double psum = WIDE ? f.psum64 : (double)f.psum;
     auto pack = [&](double F, int ci) { return __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci); };
-    auto row = [&](int q) -> double { return WIDE ? *(const double *)(A + 4 * q) : (double)A[q]; };
+    auto row = [&](int q) -> double { return WIDE ? SDP_AD_A_CONST(A, q) : (double)A[q]; };
     auto start = [&](int b) -> sdp_real { return WIDE ? rec[4 * b] : rec[2 * b]; };
     auto least = [&](int b) -> double { return WIDE ? *(const double *)(rec + 4 * b + 2) : (double)rec[2 * b + 1]; };
     const int n_blocks = (n + BS - 1) / BS;
