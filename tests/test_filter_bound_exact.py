@@ -419,6 +419,120 @@ def wide_short_check(T, p, X, K, a, h, sign=1.0):
     return float(worst / Fraction(radius)), radius
 
 
+WIDE_DELTA = f32(2.0 ** -8)
+
+
+def wide_block_bound_check(T, p, X, K, a, h, sign, block):
+    """The branch and bound of the short WIDE first pass (4-byte reals: sdp_short_bnb<.., true>).  Positions and the control
+    table are 4-byte reals -- the blocks' starts pa - DELTA, the node's pX, their sum --, the reduced table A[r], the
+    smallest +-h psum of a block, L at the ends and F' are 8-byte reals; DELTA = 2^-8 rows covers the 4-byte roundings of
+    the kernel's own positions.  Exactly: every control's own (4-byte) position lies inside its block's interval of
+    the bounds, and LB lies below its F' up to the 2^-40 S_node the skip test allows for.  Returns the largest
+    (LB - F') / (2^-40 S_node), or None when the blocks are not 2 DELTA apart (no branch and bound then)."""
+    W, N0 = T.shape
+    nm1 = f32(N0 - 1)
+    pa_w, gc, ps64 = f32(0), f32(0), 0.0
+    for w in range(W):
+        pa_w = f32(pa_w + abs(p[w]))
+        nw = f32(W + 3 if w == 0 else W - w + 4)
+        gc = f32(gc + f32(nw * abs(p[w])))
+        ps64 = ps64 + float(p[w])
+    gc = f32(gc * f32(1.0001))
+    pcap = pa_w if pa_w > f32(1) else f32(1)
+    A = np.zeros(N0)
+    for r in range(N0):
+        acc = 0.0
+        for w in range(W):
+            acc = acc + float(p[w]) * float(T[w][r])
+        A[r] = acc
+    tmax = f32(np.abs(T).max())
+
+    def cell(xn0):
+        pos = f32(xn0 * nm1)
+        q0 = max(min(int(pos), N0 - 2), 0)
+        return q0, f32(pos - f32(q0))
+    n = len(a)
+    bits = max((n - 1).bit_length(), 1)
+    mask = (1 << bits) - 1
+    lam_lo, lam_hi = cell(f32(X + min(a)))[1], cell(f32(X + max(a)))[1]
+    L = max(f32(1), abs(lam_lo), abs(lam_hi))
+    habs = max(abs(v) for v in h)
+    s_node = f32(f32(gc + pcap) * f32(f32(abs(K) + habs) + f32(f32(f32(1) + f32(f32(2) * L)) * tmax)))
+    # the records of the table's wave (grid [0, 1]: k = N0 - 1)
+    blocks = [range(b0, min(b0 + block, n)) for b0 in range(0, n, block)]
+    pa = [f32(v * nm1) for v in a]
+    lo = [min(pa[c] for c in m) for m in blocks]
+    hi = [max(pa[c] for c in m) for m in blocks]
+    if any(f32(hi[b] + f32(2) * WIDE_DELTA) > lo[b + 1] for b in range(len(blocks) - 1)):
+        return None
+    starts = [f32(v - WIDE_DELTA) for v in lo] + [f32(hi[-1] + WIDE_DELTA)]
+    hp = [min(float(f32(sign) * h[c]) * ps64 for c in m) for m in blocks]
+    assert float(abs(X)) + float(max(abs(v) for v in a)) < 2.0 ** 13 / float(nm1)     # (the kernels' own condition)
+    pX = f32(X * nm1)
+
+    def at(P32):
+        P = float(P32)
+        q = max(min(int(P), N0 - 2), 0)
+        return q, fma(P - float(q), A[q + 1] - A[q], A[q])
+    ends = [at(f32(pX + v)) for v in starts]
+    worst = Fraction(-10 ** 9)
+    for b, members in enumerate(blocks):
+        (qa, La), (qb, Lb) = ends[b], ends[b + 1]
+        m = min(La, Lb, A[qa + 1], A[qb])
+        for r in range(qa + 2, qb):
+            m = min(m, A[r])
+        lbv = hp[b] + m
+        for ci in members:
+            q0, lam0 = cell(f32(X + a[ci]))
+            assert float(f32(pX + starts[b])) <= float(q0) + float(lam0) <= float(f32(pX + starts[b + 1])) or q0 in (0, N0 - 2), \
+                (float(f32(pX + starts[b])), float(q0) + float(lam0), float(f32(pX + starts[b + 1])))
+            F = fma(float(f32(sign) * h[ci]), ps64, fma(float(lam0), A[q0 + 1] - A[q0], A[q0]))
+            worst = max(worst, (Fraction(lbv) - Fraction(F)) / (Fraction(2.0 ** -40) * Fraction(float(s_node))))
+    return float(worst)
+
+
+@pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
+def test_the_block_bound_of_the_wide_branch_and_bound_lies_below_every_control_of_its_block(regime):
+    rng = np.random.default_rng(500 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime))
+    worst, checked = -1e9, 0
+    for trial in range(100):
+        W = int(rng.integers(1, 9))
+        N0 = int(rng.integers(3, 14))
+        T = rng.standard_normal((W, N0))
+        if regime == 'large':
+            T *= 10.0 ** rng.uniform(10, 28)
+        elif regime == 'small':
+            T *= 10.0 ** rng.uniform(-30, -10)
+        elif regime == 'mixed':
+            T *= 10.0 ** rng.uniform(-4, 4, size=T.shape)
+        elif regime == 'cancel':
+            T = 1e3 + 1e-2 * T
+        T = T.astype(f32)
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        if regime == 'weights':
+            p = rng.standard_normal(W) * 3.7
+            if abs(p.sum()) < 0.2:
+                p[0] += 1.0
+        p = p.astype(f32)
+        scale = float(np.abs(T).max())
+        n = int(rng.integers(1, 70))
+        X = f32(rng.uniform(0, 1))
+        spread = float(10.0 ** rng.uniform(-1.5, 0.5))
+        # an ordinary lattice: a monotone in the control, steps of at least 6 DELTA rows
+        a = [f32(v) for v in -spread + np.cumsum(rng.uniform(0.1, 1.0, size=n)) * (2 * spread / n) + np.arange(n) * 6 * float(WIDE_DELTA) / (N0 - 1)]
+        K = f32(float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-2, 2))
+        h = [f32(float(v) * scale * 10.0 ** rng.uniform(-2, 2)) for v in rng.standard_normal(n)]
+        sign = -1.0 if trial % 3 == 0 else 1.0
+        ratio = wide_block_bound_check(T, p, X, K, a, h, sign, 8 if trial % 5 else 16)
+        if ratio is None:
+            continue
+        checked += 1
+        assert ratio <= 1.0, (regime, trial, ratio)
+        worst = max(worst, ratio)
+    assert checked >= 80 and worst < 0.5, (checked, worst)
+
+
 @pytest.mark.parametrize('regime', ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'])
 def test_the_short_wide_pass_radius_covers_the_difference_exactly(regime):
     rng = np.random.default_rng(200 + ['ordinary', 'large', 'small', 'mixed', 'cancel', 'weights'].index(regime))

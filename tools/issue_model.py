@@ -58,6 +58,8 @@ def main():
     ins = kb.disassemble(nat.compile_model(plan['source']), 'sdp_sweep_col')
     N0, W, U = 256, 32, 64
     src = plan['source']
+    bnb = '#define SDP_COL_BNB 1' in src
+    bnb_blocks = float(os.environ.get('SDP_BNB_BLOCKS_PER_WAVE', '1.49'))
     threads = int(src.split('#define SDP_COL_THREADS ')[1].split()[0])
     wres = int(src.split('#define SDP_COL_WRES ')[1].split()[0]) if '#define SDP_COL_WRES ' in src else W
     waves = threads // 64
@@ -86,7 +88,9 @@ def main():
         n_r128 = count(body, 'ds_read_b128')
         n_r2 = count(body, 'ds_read2_b64')
         if n_cvt >= 4 and n_r128 + n_r2 >= n_cvt and not count(body, 'v_div_scale_f64') and not n_ld:
-            consider('first pass', body, n_cvt, U)                                   # controls per wave-node
+            # controls per wave-node: all of them, or -- branch and bound, SDP_COL_BNB -- those of the blocks a wave does
+            # evaluate (tools/bnb_count.py: 1.49 blocks of 8 per wave on this problem)
+            consider('first pass', body, n_cvt, bnb_blocks * 8 if bnb else U)
         elif n_ld >= 4 and count(body, 'ds_write') >= 1:
             # 2^(d-1) = 4 vertex loads of 16 bytes (two rows) per pair of entries
             consider('table build', body, n_ld, entries_per_unit * 4 / 2.0 / 64 / waves)
@@ -104,7 +108,8 @@ def main():
             per_wave_unit[c] = per_wave_unit.get(c, 0.0) + n * f['trips_per_wave_unit']
     launches = units * waves
     loops_total = {c: n * launches for c, n in per_wave_unit.items()}
-    out = dict(kernel='sdp_sweep_col', kernel_source_key=key, clocks_per_wave_instruction=CLOCKS,
+    out = dict(kernel='sdp_sweep_col', kernel_source_key=key, clocks_per_wave_instruction=CLOCKS, branch_and_bound=bnb,
+               first_pass_blocks_per_wave=(bnb_blocks if bnb else None),
                grid=dict(N0=N0, W=W, controls=U, threads=threads, resident_points=wres, units=units), loops=table,
                loops_wave_instructions_per_launch=loops_total)
     try:
