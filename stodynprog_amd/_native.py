@@ -214,9 +214,30 @@ def ptr(a):
 # ---------------------------------------------------------------------------
 # generated-model code objects
 # ---------------------------------------------------------------------------
+def _hipcc(cmd, src, verbose=False):
+    if verbose:
+        print(' '.join(cmd))
+    try:
+        subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    except FileNotFoundError:
+        raise NativeError('hipcc not found at {}: cannot compile the model kernel'.format(HIPCC))
+    except subprocess.CalledProcessError as e:
+        raise NativeError('hipcc failed on the generated model {}:\n{}'.format(
+            src, e.stdout.decode(errors='replace')))
+
+
+WAVES_CAPS = (4, 2, 1)        # waves per SIMD asked of the register allocator when a kernel's spill code is unsafe
+
+
 def compile_model(source, verbose=False):
     """Compile a generated translation unit to a gfx950 code object, cached
-    in-tree under stodynprog_amd/_kcache/<key>.hsaco.  Returns its path."""
+    in-tree under stodynprog_amd/_kcache/<key>.hsaco.  Returns its path.
+
+    A code object whose kernels spill vector registers is compiled to assembly as well and scanned for spill
+    code that runs before the execution mask is restored (codegen.spill_hazards: the compiler does that, and the
+    kernel then computes with registers of lanes that were never stored); such a kernel is rebuilt with fewer
+    waves per SIMD asked of the register allocator (-DSDP_WAVES_CAP) until the scan is clean -- what was done
+    is kept next to the code object in <key>.build.txt -- or refused."""
     key = codegen.source_key(source)
     os.makedirs(KCACHE, exist_ok=True)
     out = os.path.join(KCACHE, key + '.hsaco')
@@ -227,17 +248,37 @@ def compile_model(source, verbose=False):
         f.write(source)
     os.replace(f.name, src)
     tmp = out + '.tmp.{}'.format(os.getpid())
-    cmd = [HIPCC] + codegen.HIPCC_FLAGS + ['-o', tmp, src]
-    if verbose:
-        print(' '.join(cmd))
+    asm = tmp + '.s'
+    flags = list(codegen.HIPCC_FLAGS)
+    to_asm = ['--cuda-device-only', '-S'] + [x for x in flags if x != '--genco']
+    _hipcc([HIPCC] + flags + ['-o', tmp, src], src, verbose)
     try:
-        subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    except FileNotFoundError:
-        raise NativeError('hipcc not found at {}: cannot compile the model kernel'.format(HIPCC))
-    except subprocess.CalledProcessError as e:
-        raise NativeError('hipcc failed on the generated model {}:\n{}'.format(
-            src, e.stdout.decode(errors='replace')))
-    os.replace(tmp, out)
+        with open(tmp, 'rb') as f:
+            may_spill = codegen.code_object_may_spill(f.read())
+        if may_spill:
+            log = []
+            for cap in (None,) + WAVES_CAPS:
+                extra = [] if cap is None else ['-DSDP_WAVES_CAP={}'.format(cap)]
+                _hipcc([HIPCC] + to_asm + extra + ['-o', asm, src], src, verbose)
+                with open(asm) as f:
+                    hazards = codegen.spill_hazards(f.read())
+                log.append('waves cap {}: {}'.format(cap, '; '.join(
+                    '{} {}: {} before the mask restore'.format(k, b, ', '.join(ins)) for k, b, _, ins in hazards) or 'clean'))
+                if not hazards:
+                    break
+            else:
+                raise NativeError('the compiler places spill code before the execution mask is restored in {} at every '
+                                  'register budget tried:\n{}'.format(src, '\n'.join(log)))
+            if cap is not None:
+                _hipcc([HIPCC] + flags + extra + ['-o', tmp, src], src, verbose)
+            if len(log) > 1:
+                with open(os.path.join(KCACHE, key + '.build.txt'), 'w') as f:
+                    f.write('\n'.join(log) + '\n')
+        os.replace(tmp, out)
+    finally:
+        for leftover in (tmp, asm):
+            if os.path.exists(leftover):
+                os.remove(leftover)
     return out
 
 

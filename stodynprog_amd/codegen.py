@@ -9,6 +9,7 @@ so that every operator is one IEEE operation, as in numpy on the host
 (reference stodynprog.py:674-677 evaluates the same expressions with numpy).
 """
 import hashlib
+import re
 import math
 import os
 
@@ -457,8 +458,11 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
         lines.append('#define SDP_COL_WRES {}         // resident-chunk form: perturbation points the table holds at a time'.format(int(wres)))
     if filtered and int(col_cfg[0]) <= 256 and not _dbg(debug, 'SDP_COL_MIN_WAVES'):
         if wres:
-            lines.append('#define SDP_COL_MIN_WAVES {}    // as many waves per SIMD as the LDS image admits workgroups per CU'.format(
-                max(1, min(8, (COLUMN_LDS_MAX // int(col_cfg[1])) * int(col_cfg[0]) // 256))))
+            # (at most 4: 128 registers per lane.  Round 4 asked for up to 8 for small tables -- 64 registers, which these
+            # kernels do not fit in: 90 - 200 spilled registers in the suite's small models, and spill code the compiler
+            # got wrong, see spill_hazards)
+            lines.append('#define SDP_COL_MIN_WAVES {}    // as many waves per SIMD as the LDS image admits workgroups per CU, at most 4'.format(
+                max(1, min(4, (COLUMN_LDS_MAX // int(col_cfg[1])) * int(col_cfg[0]) // 256))))
         else:
             lines.append('#define SDP_COL_MIN_WAVES 1    // small workgroups of the filtered kernel: no register cap')
     if filtered:
@@ -1014,10 +1018,80 @@ def compiler_identity():
     return _compiler_id
 
 
+BUILD_RULES = 'spill fence 1'       # what _native.compile_model does beyond one hipcc call (below): part of the key
+
+
 def source_key(source):
     """Cache key of a code object: generated text + kernel headers + flags + the compiler's identity."""
     h = _headers_digest()
     h.update(source.encode())
     h.update(' '.join(HIPCC_FLAGS[:-1]).encode())
     h.update(compiler_identity().encode())
+    h.update(BUILD_RULES.encode())
     return h.hexdigest()[:24]
+
+
+# ---------------------------------------------------------------------------
+# Spill code and the execution mask.  Round 5 found a kernel of the test suite (resident chunks, long first pass,
+# 128 threads under a budget of 64 vector registers) that never ended: the compiler (ROCm 7.2's clang 20) had put the
+# store of a spilled vector register -- threadIdx.x -- at the top of a block where divergent paths JOIN, before the
+# instruction that restores the execution mask (`s_or_b64 exec, exec, s[..]`).  A store to scratch memory writes the
+# active lanes only: a wavefront that had skipped the branch altogether stored nothing, reloaded whatever its scratch
+# memory held, took itself for wave 0 and never claimed the workgroup's next unit.  Which kernels are hit depends on
+# the register allocation alone -- three unrelated one-line changes each made it come and go -- so the build LOOKS:
+# a code object whose kernels use scratch memory or accumulation registers (the two places spilled vector registers
+# go) is compiled to assembly once more and scanned for exactly this pattern; a kernel that shows it is rebuilt with
+# fewer waves per SIMD asked of the register allocator (more registers, less spill code) until it is clean, or refused.
+# ---------------------------------------------------------------------------
+_ASM_FUNC = re.compile(r'^([A-Za-z_]\w*):\s*; @')
+_ASM_BLOCK = re.compile(r'^(\.LBB\d+_\d+):|^; %bb\.(\d+):')
+_ASM_SPILL = re.compile(r'^\s+(?:scratch_(?:store|load)\w*|buffer_(?:store|load)\w*|v_accvgpr_(?:write|read)\w*)\b.*;.*\b(?:Spill|Reload)\b')
+_ASM_END_CF = re.compile(r'^\s+s_or_b64\s+exec,\s*exec,')
+_ASM_EXEC_WRITE = re.compile(r'^\s+s_\w+\s+exec(?:_lo|_hi)?\b|^\s+s_\w*saveexec\w*\b|^\s+v_cmpx')
+
+
+def spill_hazards(asm):
+    """[(kernel, block, line number of the mask restore, [spill instructions before it]), ...] of an assembly listing
+    (hipcc -S): spill stores / reloads of vector registers between the top of a basic block and the `s_or_b64 exec,
+    exec, ..` that re-activates the lanes joining there.  Those instructions run for the lanes of ONE incoming path."""
+    out, func, block, pending, at_top = [], None, None, [], False
+    for n, line in enumerate(asm.splitlines(), 1):
+        m = _ASM_FUNC.match(line)
+        if m:
+            func, block, pending, at_top = m.group(1), 'entry', [], False     # (the entry block: every launched lane is active)
+            continue
+        m = _ASM_BLOCK.match(line)
+        if m:
+            block, pending, at_top = m.group(1) or '%bb.' + m.group(2), [], True
+            continue
+        if not at_top:
+            continue
+        if _ASM_SPILL.match(line):
+            pending.append(line.strip())
+        elif _ASM_END_CF.match(line):
+            if pending:
+                out.append((func, block, n, pending))
+            at_top = False
+        elif _ASM_EXEC_WRITE.match(line):
+            at_top = False
+    return out
+
+
+def _msgpack_ints_after(blob, key):
+    out, i = [], blob.find(key)
+    while i >= 0:
+        j = i + len(key)
+        b = blob[j] if j < len(blob) else 0
+        out.append(b if b <= 0x7f else int.from_bytes(blob[j + 1:j + 1 + {0xcc: 1, 0xcd: 2, 0xce: 4}.get(b, 0)], 'big') if b in (0xcc, 0xcd, 0xce) else -1)
+        i = blob.find(key, j)
+    return out
+
+
+def code_object_may_spill(blob):
+    """True when a kernel of the code object (its bytes) uses scratch memory or accumulation registers, by its own
+    metadata (the msgpack note: .private_segment_fixed_size, .agpr_count), or when the metadata cannot be read."""
+    scratch = _msgpack_ints_after(blob, b'.private_segment_fixed_size')
+    agprs = _msgpack_ints_after(blob, b'.agpr_count')
+    if not scratch or len(agprs) != len(scratch):
+        return True
+    return any(v != 0 for v in scratch) or any(v != 0 for v in agprs)

@@ -100,6 +100,11 @@
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
 #endif
+#if defined(SDP_WAVES_CAP) && SDP_COL_MIN_WAVES > SDP_WAVES_CAP
+// (a rebuild with more registers: the first build's spill code was unsafe -- codegen.spill_hazards, _native.compile_model)
+#undef SDP_COL_MIN_WAVES
+#define SDP_COL_MIN_WAVES SDP_WAVES_CAP
+#endif
 #ifndef SDP_COL_WPAIR
 #define SDP_COL_WPAIR 0          // 1 (4-byte reals): the table interleaves perturbation points 2k and
 #endif                           //    2k+1, T2[k][r] = (inner_2k(r), inner_2k+1(r)); one 8-byte LDS read

@@ -108,7 +108,12 @@ SDP_DEV int sdp_stg_locate(const SdpGrid<sdp_real, SDP_D> &g, int k, sdp_real s,
     return q;
 }
 
-extern "C" __global__ void __launch_bounds__(SDP_STG_THREADS, SDP_STG_THREADS / 128) sdp_sweep_lds(SdpSweepArgs a)
+#if defined(SDP_WAVES_CAP)      // (a rebuild with more registers: codegen.spill_hazards, _native.compile_model)
+#define SDP_STG_MIN_WAVES ((SDP_STG_THREADS / 128) < SDP_WAVES_CAP ? (SDP_STG_THREADS / 128) : SDP_WAVES_CAP)
+#else
+#define SDP_STG_MIN_WAVES (SDP_STG_THREADS / 128)
+#endif
+extern "C" __global__ void __launch_bounds__(SDP_STG_THREADS, SDP_STG_MIN_WAVES) sdp_sweep_lds(SdpSweepArgs a)
 {
     __shared__ sdp_real sdp_box[SDP_STG_CAP];
     __shared__ SdpStgShared sh;

@@ -585,3 +585,21 @@ def test_the_short_wide_first_pass_when_lanes_share_a_node(gpu):
     short = _sweep(make, True, V, np.float32)
     assert '#define SDP_COL_WIDE2 1' in short[3]._kernel_plan()['source']
     _same(short, off)
+
+
+def test_a_budget_of_64_registers_gives_the_same_bits(gpu, debug_defines):
+    """Round 5: with 8 waves per SIMD asked of the register allocator (64 registers; what the planner chose for small
+    tables until then) the compiler stored a spilled threadIdx.x before it restored the execution mask, and the kernel
+    of this very configuration never ended.  The build now scans for that pattern and rebuilds with more registers
+    (codegen.spill_hazards, _native.compile_model; tests/test_trace_codegen.py checks the build log): forced back to
+    that budget, the kernel ends and gives the bits of the kernel without the filter."""
+    make = lambda: _shaped('no_u_cost')
+    V = np.random.default_rng(11).standard_normal(make()[1]._state_grid_shape)
+    off = _sweep(make, False, V)
+    debug_defines.set(SDP_COL_MIN_WAVES='8', SDP_COL_LEAN2='0')
+    try:
+        forced = _wres(debug_defines, make, V, 4)
+        assert '#define SDP_COL_MIN_WAVES 8' in forced[3].wres_source
+    finally:
+        debug_defines.unset('SDP_COL_MIN_WAVES', 'SDP_COL_LEAN2')
+    _same(forced, off)

@@ -646,3 +646,86 @@ def test_the_short_first_pass_is_planned_where_the_model_has_its_shape():
         assert fr is None or m.additive_control_split(fr) is None
     m = trace_model(lambda x, y, u, w: ((x + 0.5 * u) - 0.1 * w, 0.5 * y + w), lambda x, y, u, w: x + u * u, 2, 1, 1)
     assert m.additive_control_split(m.control_uniform_frontier(m.lead_split()[0])) is None
+
+
+# ---------------------------------------------------------------------------
+# Spill code before the execution mask is restored (codegen.spill_hazards, _native.compile_model)
+# ---------------------------------------------------------------------------
+_ASM_JOIN = """
+\t.text
+sdp_sweep_col:                          ; @sdp_sweep_col
+; %bb.0:
+\tscratch_store_dword off, v1, off offset:4 ; 4-byte Folded Spill
+\ts_and_saveexec_b64 s[2:3], vcc
+\ts_cbranch_execz .LBB3_2
+; %bb.1:
+\tscratch_store_dword off, v2, off offset:8 ; 4-byte Folded Spill
+\tv_mov_b32_e32 v2, 0
+\tscratch_load_dword v2, off, off offset:8 ; 4-byte Folded Reload
+.LBB3_2:
+\tv_writelane_b32 v62, s30, 55
+{before}
+\ts_or_b64 exec, exec, s[2:3]
+{after}
+\ts_endpgm
+"""
+
+
+def test_spill_code_before_the_mask_restore_is_found():
+    """the pattern of round 5's endless kernel: a vector register stored (or reloaded) at the top of a block where
+    paths join, before `s_or_b64 exec, exec, ..`; spill code anywhere else -- the entry block, inside the branch,
+    after the restore -- is none of the scan's business, and SGPR spills (v_writelane) ignore the mask"""
+    from stodynprog_amd import codegen
+    store = '\tscratch_store_dwordx2 off, v[24:25], off offset:144 ; 8-byte Folded Spill'
+    load = '\tscratch_load_dword v7, off, off offset:4 ; 4-byte Folded Reload'
+    acc = '\tv_accvgpr_write_b32 a3, v9 ; Reload Reuse'
+    plain = '\tscratch_load_dword v7, off, off offset:4'          # (the kernel's own scratch traffic: not spill code)
+    assert codegen.spill_hazards(_ASM_JOIN.format(before='', after=store)) == []
+    assert codegen.spill_hazards(_ASM_JOIN.format(before=plain, after='')) == []
+    for ins in (store, load, acc):
+        hz = codegen.spill_hazards(_ASM_JOIN.format(before=ins, after=''))
+        assert len(hz) == 1 and hz[0][:2] == ('sdp_sweep_col', '.LBB3_2') and hz[0][3] == [ins.strip()], hz
+    # another write of the mask first: not the top of a join any more
+    assert codegen.spill_hazards(_ASM_JOIN.format(before='\ts_mov_b64 exec, s[4:5]\n' + store, after='')) == []
+
+
+def test_code_objects_that_may_spill_are_told_from_their_metadata():
+    from stodynprog_amd import codegen
+    note = lambda scratch, agprs: (b'\x82\xa5.name\xa9sdp_sweep\xbb.private_segment_fixed_size' + scratch +
+                                   b'\xab.agpr_count' + agprs)
+    assert not codegen.code_object_may_spill(note(b'\x00', b'\x00') + note(b'\x00', b'\x00'))
+    assert codegen.code_object_may_spill(note(b'\x00', b'\x00') + note(b'\xcd\x01\x28', b'\x00'))      # 296 bytes of scratch
+    assert codegen.code_object_may_spill(note(b'\x00', b'\x08'))
+    assert codegen.code_object_may_spill(b'no metadata at all')
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs hipcc')
+def test_a_kernel_with_unsafe_spill_code_is_rebuilt_with_more_registers(monkeypatch):
+    """the kernel that never ended in round 5 (resident chunks, long first pass, 2 waves, a budget of 64 registers:
+    the budget is forced here, the planner no longer asks for it): the first build shows the pattern, the build with
+    4 waves per SIMD asked of the allocator is clean, and <key>.build.txt says so"""
+    from stodynprog_amd import codegen, _native as nat, SysDescription, DPSolver
+    from stodynprog_amd.models import NormalLaw
+    sysd = SysDescription((2, 1, 1), name='stock, no_u_cost')
+    sysd.dyn = lambda x, y, u, w: (0.7 * u + x, 0.8 * y + w)
+    sysd.cost = lambda x, y, u, w: 0.05 * x + y * y
+    sysd.control_box = lambda x, y: ((-1.0, 1.0),)
+    sysd.perturb_laws = [NormalLaw(0, 0.2)]
+    s = DPSolver(sysd)
+    s.discretize_state(0, 3, 96, -1, 1, 9)
+    s.discretize_perturb(-0.5, 0.5, 7)
+    s.control_steps = (0.0625,)
+    monkeypatch.setattr(DPSolver, 'debug_defines', {'SDP_COL_WRES': '4', 'SDP_COL_LEAN2': '0'})
+    assert '#define SDP_COL_MIN_WAVES 4' in s._kernel_plan()['source']          # (what the planner asks for)
+    monkeypatch.setattr(DPSolver, 'debug_defines', {'SDP_COL_WRES': '4', 'SDP_COL_LEAN2': '0', 'SDP_COL_MIN_WAVES': '8'})
+    source = s._kernel_plan()['source']
+    assert '#define SDP_COL_MIN_WAVES 8' in source and '#define SDP_COL_WRES 4' in source
+    base = os.path.join(nat.KCACHE, codegen.source_key(source))
+    for ext in ('.hsaco', '.build.txt'):
+        if os.path.exists(base + ext):
+            os.unlink(base + ext)
+    out = nat.compile_model(source)
+    assert out == base + '.hsaco' and os.path.getsize(out) > 10000
+    log = open(base + '.build.txt').read().splitlines()
+    assert log[0].startswith('waves cap None: sdp_sweep_col') and 'before the mask restore' in log[0], log
+    assert log[-1].endswith(': clean') and len(log) >= 2, log
