@@ -73,6 +73,9 @@ WORKLOADS = {
     # runs on the shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)
     'noisy256': ('synthetic3d', dict(N=256, stock_noise=0.07), 'float64', None,
                  'synthetic3d {n}^3 x 64 controls x 32 perturbations, perturbation also in the stock'),
+    # the same sum in another nesting, x0' = x0 + (b u - 0.07 w): regrouped by the tracer (TracedModel.lead_split), no control table
+    'noisy256_nested': ('synthetic3d', dict(N=256, stock_noise=0.07, nested=True), 'float64', None,
+                        'synthetic3d {n}^3 x 64 controls x 32 perturbations, perturbation also in the stock: x0 + (b u - 0.07 w)'),
     # not a BASELINE config: two controlled stocks (a cascade of reservoirs) next to an exogenous inflow,
     # 128 x 128 x 64 nodes x 16 x 16 controls x 16 perturbation points -- the node-order sweep with the
     # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h)
@@ -877,7 +880,7 @@ def finish_single(args, env, out):
                                     'time by HIP events; outside the timed region of `value`')
     if not args.no_cpu_baseline and world == 1:
         try:
-            if model_name == 'synthetic3d' and args.config != 'noisy256':     # (the C oracle's model has no noise in the stock)
+            if model_name == 'synthetic3d' and not args.config.startswith('noisy256'):     # (the C oracle's model has no noise in the stock)
                 out['cpu_baseline'] = cpu_baseline_synth(ref_solver, np.asarray(V0, dtype=np.float64),
                                                          models, U_max)
             else:

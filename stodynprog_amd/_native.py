@@ -6,6 +6,7 @@ cannot be loaded, or no GPU is visible, every compute entry point raises.
 """
 import ctypes as C
 import os
+import re
 import subprocess
 import threading
 
@@ -257,7 +258,8 @@ def compile_model(source, verbose=False):
             may_spill = codegen.code_object_may_spill(f.read())
         if may_spill:
             log = []
-            for cap in (None,) + WAVES_CAPS:
+            asked = re.search(r'^#define SDP_COL_MIN_WAVES (\d+)', source, re.M)       # (a cap at or above what the unit asks for changes nothing)
+            for cap in (None,) + tuple(c for c in WAVES_CAPS if asked is None or c < int(asked.group(1))):
                 extra = [] if cap is None else ['-DSDP_WAVES_CAP={}'.format(cap)]
                 _hipcc([HIPCC] + to_asm + extra + ['-o', asm, src], src, verbose)
                 with open(asm) as f:

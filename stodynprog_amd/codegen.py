@@ -249,6 +249,17 @@ def separable_functions_source(model):
         names = _emit_body(model, model.slice_nodes([a_node]), lines)
         lines += ['    return {};'.format(names[a_node.id]), '}']
         out.append('\n'.join(lines))
+        chain = model.lead_split_chain()
+        if chain is not None:
+            # a chain of sums in another nesting, regrouped (TracedModel.lead_split): a is the sum of the chain's w-free
+            # leaves, no value of the reference's; the sum of their magnitudes bounds what the regrouping costs
+            # (SDP_COL_SHIFT_CHAIN of csrc/sdp_column_kernel.h)
+            leaves = [n for n, _ in chain[0]]
+            lines = ['SDP_DEV sdp_real sdp_model_lead_aabs(const sdp_real *x, const sdp_real *u, sdp_real t)',
+                     '{', '    (void)x; (void)u; (void)t;']
+            names = _emit_body(model, model.slice_nodes(leaves), lines)
+            lines += ['    return {};'.format(' + '.join('fabs({})'.format(names[n.id]) for n in leaves)), '}']
+            out.append('\n'.join(lines))
         lines = ['SDP_DEV void sdp_model_lead_b(const sdp_real *x, sdp_real w, sdp_real t, sdp_real &b, sdp_real &babs)',
                  '{', '    (void)x; (void)w; (void)t;']
         names = _emit_body(model, model.slice_nodes([b for b, _ in terms]), lines)
@@ -337,7 +348,7 @@ def control_table_plan(model, dtype, per_node, max_controls, debug=None):
     lead = None
     if model.lead_depends_on_w:
         split = model.lead_split()
-        if split is None:
+        if split is None or model.lead_split_chain() is not None:     # (a regrouped chain: the first pass bounds the sum of its leaves per control)
             return None
         lead = split[0]
     fr = model.control_uniform_frontier(lead)
@@ -470,6 +481,8 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
         if shifted:
             lines += ['#define SDP_COL_SHIFT 1        // x0\' = a(x, u) +- b_1(x_1.., w) +- ..: first pass on the shifted lattice',
                       '#define SDP_COL_SHIFT_TERMS {}'.format(len(model.lead_split()[1])),
+                      '#define SDP_COL_SHIFT_CHAIN {}        // additions of a chain of sums that was regrouped (0: the final-sum form)'.format(
+                          model.lead_split_chain()[1] if model.lead_split_chain() is not None else 0),
                       '#define SDP_COL_SHIFT_ROWS {}'.format(int(col_cfg[2]))]
         if _dbg(debug, 'SDP_COL_FILTER_SCALE'):
             lines.append('#define SDP_COL_FILTER_SCALE {}'.format(float(_dbg(debug, 'SDP_COL_FILTER_SCALE'))))

@@ -187,6 +187,11 @@
 // the table reduced over w on a lattice SHIFTED by the perturbation points -- see sdp_col_shift_reduce.
 #define SDP_COL_SHIFT 0
 #endif
+#ifndef SDP_COL_SHIFT_CHAIN
+// m > 0: the sums are a chain in another nesting, x + (w - u), with m <= 3 additions, regrouped by the tracer: a is the
+// sum of the chain's w-free leaves (sdp_model_lead_aabs: the sum of their magnitudes) -- see sdp_col_lean_eval
+#define SDP_COL_SHIFT_CHAIN 0
+#endif
 #ifndef SDP_COL_SHIFT_ROWS
 #define SDP_COL_SHIFT_ROWS (2 * SDP_COL_N0)     // rows of the shifted lattice held in LDS
 #endif
@@ -1836,6 +1841,15 @@ SDP_DEV void sdp_col_lean_eval(const sdp_real *A, const SdpColFilter &f, const S
 {
 #if SDP_COL_SHIFT
     const sdp_real xn0 = sdp_model_lead_a(x, u, t);
+#if SDP_COL_SHIFT_CHAIN
+    // A chain of sums that was regrouped (x + (w - u): a = x - u is not a value the reference computes).  With SA, SB the
+    // sums of the magnitudes of the chain's w-free and other leaves and m <= 3 its additions, the reference's sum and
+    // this pass's a + B each lie within gamma_m (SA + SB) of the real sum: 2 m u (1 + eps) (PA + PB) rows, PA = SA c,
+    // instead of the k u (|pa| + PB + |smin| c) .. of the final-sum form.  With the 6.2 |pa| + 5.2 PB of the position's own
+    // roundings and |pa| <= PA + |smin| c that is below 14 u (PA + PB + |smin| c) -- the bound of sdp_col_shift_col's
+    // comment with PA in the place of |pa| --, and PA enters where |pa| does: through L.
+    lmax = sdp_vmax_abs(lmax, sdp_model_lead_aabs(x, u, t) * (fabs(l.nm1 * l.rspan) * (sdp_real)1.002));
+#endif
 #else
     const sdp_real xn0 = sdp_model_lead(x, u, (sdp_real)0, t);
 #endif

@@ -282,9 +282,10 @@ SYNTH_PAR = [SYNTH[k] for k in ('b', 'm1', 'a11', 'a12', 'm2', 'a21', 'a22', 'c'
                                 'k1', 'k0', 'eps', 'kx')]
 
 
-def synthetic3d(api=None, N=256, n_w=32, stock_noise=0.0):
+def synthetic3d(api=None, N=256, n_w=32, stock_noise=0.0, nested=False):
     """(`stock_noise` != 0: the perturbation also reaches the stock, x0' = (x0 + b u) - stock_noise w --
-    the shape of the reference's inventory example, doc/example_inventory.py:31-33, at benchmark size)"""
+    the shape of the reference's inventory example, doc/example_inventory.py:31-33, at benchmark size;
+    `nested`: the same sum in another nesting, x0' = x0 + (b u - stock_noise w))"""
     SysDescription, DPSolver = _classes(api)
     p = SYNTH
     b, a11, a12, a21, a22, c = p['b'], p['a11'], p['a12'], p['a21'], p['a22'], p['c']
@@ -294,7 +295,7 @@ def synthetic3d(api=None, N=256, n_w=32, stock_noise=0.0):
     def synth_dyn(x0, x1, x2, u, w):
         x0n = x0 + b * u
         if stock_noise:
-            x0n = x0n - stock_noise * w
+            x0n = x0 + (b * u - stock_noise * w) if nested else x0n - stock_noise * w
         x1n = m1 + a11 * x1 + a12 * x2 + w
         x2n = m2 + a21 * x1 + a22 * x2 + c * w
         return (x0n, x1n, x2n)

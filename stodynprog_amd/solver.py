@@ -948,6 +948,9 @@ class DPSolver(object):
                          filter_form=(None if not plan.get('filtered') else
                                       ('shifted lattice' if '#define SDP_COL_SHIFT 1' in plan['source'] else
                                        ('reduced array' if plan.get('lead_axes') else 'reduced table'))),
+                         # x0' = a chain of sums in another nesting than ((a +- b) +- ..), x + (w - u): regrouped for the first pass
+                         regrouped_sums=bool(plan.get('filtered') and '#define SDP_COL_SHIFT 1' in plan['source']
+                                             and '#define SDP_COL_SHIFT_CHAIN 0' not in plan['source']),
                          arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),

@@ -768,7 +768,28 @@ class TracedModel(object):
         the axis-0 position of every control of a column by the same amounts, so the expectation over
         w can still be taken on the table before the controls are looked at
         (csrc/sdp_column_kernel.h, SDP_COL_SHIFT).  `a` is one sub-expression, evaluated as the
-        reference evaluates it: the first pass then starts from the reference's own value of it."""
+        reference evaluates it: the first pass then starts from the reference's own value of it.
+
+        Round 5: a chain of sums in ANY nesting, `x + (w - u)`, `(x - 0.1 * y) - (u - w)`, is taken too
+        (`lead_split_chain`): its leaves are regrouped into a sum of the w-free ones, a*, and a sum of the others --
+        a* is then NOT a value the reference computes; what the regrouping costs is part of the error radius."""
+        cached = getattr(self, '_lead_split_cache', None)
+        if cached is None:
+            res, chain = self._lead_split_final(), None
+            if res is None:
+                got = self._lead_split_any_nesting()
+                if got is not None:
+                    res, chain = got
+            cached = self._lead_split_cache = (res, chain)
+        return cached[0]
+
+    def lead_split_chain(self):
+        """None when `lead_split` found the final-sum form (or nothing); else the regrouped chain's
+        (w-free leaves [(node, sign), ..], number of additions / subtractions of the whole chain)."""
+        self.lead_split()
+        return self._lead_split_cache[1]
+
+    def _lead_split_final(self):
         top = self.x_next[0]
         if not (top.deps & DEP_W):
             return None
@@ -794,6 +815,45 @@ class TracedModel(object):
         if not any(b.deps & DEP_W for b, _ in terms):
             return None
         return node, terms
+
+    LEAD_CHAIN_MAX_LEAVES = 4       # (three additions: the radius' constant 14 of the positions covers 2 x 3 + 6.2 roundings)
+
+    def _lead_split_any_nesting(self):
+        """x0' = a tree of real + / - whose leaves are either free of w (they may see x, u) or free of x0 and u (they
+        may see x_1.., w), at most LEAD_CHAIN_MAX_LEAVES of them.  The leaves keep the reference's operations; the
+        tree is regrouped as a* = the signed sum of the w-free leaves (new nodes of the graph, left to right) and
+        the signed sum of the others.  Returns ((a*, [(b, sign), ..]), (w-free leaves, additions)) or None."""
+        top = self.x_next[0]
+        if not (top.deps & DEP_W) or top.kind != 'r':
+            return None
+        leaves = []
+
+        def walk(n, sign):
+            if not (n.deps & DEP_W):
+                leaves.append((n, sign, 'a'))
+                return True
+            if (n.deps & (DEP_X | DEP_U)) == 0:
+                leaves.append((n, sign, 'b'))
+                return True
+            if n.op not in ('add', 'sub') or n.kind != 'r':
+                return False
+            l, r = n.args
+            return walk(l, sign) and walk(r, sign if n.op == 'add' else -sign)
+        if not walk(top, 1) or len(leaves) > self.LEAD_CHAIN_MAX_LEAVES:
+            return None
+        a_leaves = [(n, sg) for n, sg, what in leaves if what == 'a']
+        b_leaves = [(n, sg) for n, sg, what in leaves if what == 'b']
+        if not a_leaves or not b_leaves or not any(n.deps & (DEP_X | DEP_U) for n, _ in a_leaves):
+            return None
+        if len(b_leaves) > self.LEAD_SPLIT_MAX_TERMS:
+            return None
+        a_leaves.sort(key=lambda item: item[1] < 0)          # (a positive leaf first, if there is one: no negation needed)
+        g = self.graph
+        first, sg = a_leaves[0]
+        a_star = first if sg > 0 else g.op('neg', first)
+        for n, sg in a_leaves[1:]:
+            a_star = g.op('add' if sg > 0 else 'sub', a_star, n)
+        return (a_star, b_leaves), (a_leaves, len(leaves) - 1)
 
 
 def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationnary=True,

@@ -659,9 +659,12 @@ def test_the_wide_pass_radius_covers_the_difference_exactly(regime):
 # arithmetic -- G is tabulated at whole positions and interpolated -- and the radius is cu S_node + max B'[q0]:
 # both parts are checked together, exactly.  Grid [0, 1] (axis mode 2), one term b.
 # ---------------------------------------------------------------------------
-def shifted_check(T, p, X, a, g, b, order):
+def shifted_check(T, p, X, a, g, b, order, chain=None, leaf_sum=True):
     """a, g: per control; b: per perturbation point (x0' = (X + a_u) - b_w); order: the order in which the partial
-    sums of the perturbation points reach the lattice (LDS atomics: any order is possible)"""
+    sums of the perturbation points reach the lattice (LDS atomics: any order is possible).
+    chain: the REFERENCE adds the same three leaves in another nesting -- 'x+(w-u)': X + ((-b_w) - (-a_u)),
+    '(x-w)+u': (X - b_w) + a_u -- and the pass regroups them (TracedModel.lead_split, SDP_COL_SHIFT_CHAIN):
+    its a is still fl(X + a_u), and the sum of the magnitudes of the w-free leaves enters the bound through L."""
     W, N0 = T.shape
     nm1 = float(N0 - 1)
     fc = filter_constants(p)
@@ -702,6 +705,8 @@ def shifted_check(T, p, X, a, g, b, order):
         q0 = max(min(int(pk), rows - 2), 0)
         lam0 = pk - float(q0)
         lmax = max(lmax, abs(lam0))
+        if chain and leaf_sum:
+            lmax = max(lmax, (abs(X) + abs(a[u])) * (abs(nm1 * 1.0) * 1.002))      # sdp_model_lead_aabs x the rows per unit (span 1)
         bmax = max(bmax, Bp[q0])
         f = fma(g[u], fc['psum'], fma(lam0, Ap[q0 + 1] - Ap[q0], Ap[q0]))
         fsum = fsum + abs(f)
@@ -709,7 +714,12 @@ def shifted_check(T, p, X, a, g, b, order):
         # the reference: its own position per perturbation point (pyx:75-81), stodynprog.py:677-681
         acc = 0.0
         for w in range(W):
-            s = (xa - b[w]) * nm1
+            if chain == 'x+(w-u)':
+                s = (X + ((-b[w]) - (-a[u]))) * nm1
+            elif chain == '(x-w)+u':
+                s = ((X - b[w]) + a[u]) * nm1
+            else:
+                s = (xa - b[w]) * nm1
             qr = max(min(int(s), N0 - 2), 0)
             lr = s - float(qr)
             val = (1.0 - lr) * T[w][qr] + lr * T[w][qr + 1]
@@ -722,8 +732,9 @@ def shifted_check(T, p, X, a, g, b, order):
     return float(worst / Fraction(radius)), float(Fraction(bmax) / Fraction(radius))
 
 
+@pytest.mark.parametrize('chain', [None, 'x+(w-u)', '(x-w)+u'])
 @pytest.mark.parametrize('regime', ['smooth', 'rough', 'cancel', 'weights', 'large'])
-def test_the_shifted_lattice_radius_covers_the_difference_exactly(regime):
+def test_the_shifted_lattice_radius_covers_the_difference_exactly(regime, chain):
     rng = np.random.default_rng(400 + ['smooth', 'rough', 'cancel', 'weights', 'large'].index(regime))
     worst, model_part = 0.0, 0.0
     for trial in range(200):
@@ -754,12 +765,44 @@ def test_the_shifted_lattice_radius_covers_the_difference_exactly(regime):
         if trial % 4 == 0:
             b[0] = float(rng.integers(-3, 4)) / (N0 - 1)      # a shift of a whole number of rows
         order = list(rng.permutation(W))
-        ratio, share = shifted_check(T, p, X, a, g, b, order)
-        assert ratio <= 1.0, (regime, trial, ratio)
+        if chain and trial % 3 == 0:                          # leaves that nearly cancel: the sum of their magnitudes is what counts
+            X = float(rng.uniform(0.5, 1))
+            a = [-X + float(v) for v in rng.uniform(-spread, spread, size=n) * 1e-3]
+        ratio, share = shifted_check(T, p, X, a, g, b, order, chain)
+        assert ratio <= 1.0, (regime, trial, ratio, chain)
         worst, model_part = max(worst, ratio), max(model_part, share)
     assert worst > 0.05, worst                               # the chord bound B' is close to what the lerp leaves out ...
     if regime in ('smooth', 'rough'):
         assert model_part > 0.9, model_part                  # ... and it is what the radius is made of there
+
+
+@pytest.mark.parametrize('chain', ['x+(w-u)', '(x-w)+u'])
+def test_a_regrouped_chain_needs_the_sum_of_its_leaves_in_the_bound(chain):
+    """leaves that cancel far outside the grid (x = 1e3 .. 1e6, u = x - 1 .. x + 1 on a grid [0, 1]) and tables that are
+    straight lines: no chord error, the roundings decide.  The reference's nesting and the regrouped sum then differ by
+    roundings of the LEAVES' magnitude, not of the position's: the bound holds with the sum of the leaves' magnitudes in
+    L (SDP_COL_SHIFT_CHAIN) and fails by an order of magnitude without it."""
+    rng = np.random.default_rng(77)
+    worst, worst_without = 0.0, 0.0
+    for trial in range(300):
+        W, N0 = int(rng.integers(1, 8)), int(rng.integers(4, 16))
+        T = np.stack([np.linspace(rng.uniform(-1, 1), rng.uniform(-1, 1), N0) for _ in range(W)])
+        if trial % 3 == 0:
+            T = T * 10.0 ** rng.uniform(100, 250)
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        n = int(rng.integers(1, 12))
+        X = float(rng.uniform(0.5, 1) * 10.0 ** rng.uniform(3, 6))
+        a = [-X + float(v) for v in rng.uniform(-1, 1, size=n)]
+        g = [float(v) * float(np.abs(T).max()) for v in rng.standard_normal(n)]
+        b = [float(v) for v in rng.uniform(-1, 1, size=W) * 0.1]
+        order = list(rng.permutation(W))
+        ratio, _ = shifted_check(T, p, X, a, g, b, order, chain)
+        assert ratio <= 1.0, (trial, ratio)
+        worst = max(worst, ratio)
+        worst_without = max(worst_without, shifted_check(T, p, X, a, g, b, order, chain, leaf_sum=False)[0])
+    assert 0.0 < worst <= 1.0, worst                         # (loose by the size of the leaves: the price of not knowing how they cancel)
+    assert worst_without > 5.0, worst_without
 
 
 # ---------------------------------------------------------------------------

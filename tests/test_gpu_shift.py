@@ -183,6 +183,59 @@ def test_a_chain_of_sums(gpu):
         _same(on, _sweep(make, True, V, kernel='generic', sweeps=2))
 
 
+NESTINGS = {
+    'x+(w-u)': lambda x, y, u, w: (x + ((0.5 * w + 0.1 * y) - u), 0.8 * y + w),
+    '(x-w)+u': lambda x, y, u, w: ((x - (0.5 * w + 0.1 * y)) + u, 0.8 * y + w),
+    '(x-0.1y)-(u-w)': lambda x, y, u, w: ((x - 0.1 * y) - (u - 0.5 * w), 0.8 * y + w),
+    'w-(u-x)': lambda x, y, u, w: (0.5 * w - (u - x), 0.8 * y + w),
+    'four leaves': lambda x, y, u, w: ((x + 0.5 * w) + (0.3 * u - (0.1 * y + 0.2 * u)), 0.8 * y + w),
+}
+
+
+def _nested(nesting, x_range=(-1., 1.), dtype=np.float64):
+    def make():
+        sysd = SysDescription((2, 1, 1), name='reservoir, ' + nesting)
+        sysd.dyn = NESTINGS[nesting]
+        sysd.cost = lambda x, y, u, w: (x - 0.3) * (x - 0.3) + 0.1 * u * u
+        sysd.control_box = lambda x, y: ((-1., 1.),)
+        sysd.perturb_laws = [NormalLaw(0, 0.2)]
+        s = DPSolver(sysd)
+        s.discretize_state(x_range[0], x_range[1], 65, -1, 1, 17)
+        s.discretize_perturb(-0.5, 0.5, 7)
+        s.control_steps = (0.05,)
+        s.dtype = np.dtype(dtype)
+        return sysd, s
+    return make
+
+
+@pytest.mark.parametrize('nesting', sorted(NESTINGS))
+def test_sums_in_another_nesting_are_regrouped_and_keep_the_bits(gpu, nesting):
+    """x + (w - u) and its relatives (round 5; VERDICT r04 "shape cliffs"): the chain's leaves regrouped into a sum of
+    the w-free ones and a sum of the others (TracedModel.lead_split, SDP_COL_SHIFT_CHAIN), the first pass on the
+    shifted lattice with the sum of the leaves' magnitudes in its bound -- same bits as every control the long way, as
+    the generic kernel and as the numpy oracle; smooth and rough cost-to-go, a grid far from the origin (leaves of
+    magnitude 1e3 whose sum is the position)."""
+    from oracle import vi_numpy
+    make = _nested(nesting)
+    plan = make()[1]._kernel_plan()
+    assert '#define SDP_COL_SHIFT 1' in plan['source'] and plan['filtered']
+    if nesting != 'w-(u-x)':                                             # (one w-free leaf there: an exact negation, nothing regrouped)
+        assert '#define SDP_COL_SHIFT_CHAIN 0' not in plan['source'] and 'sdp_model_lead_aabs' in plan['source']
+    for V in (np.random.default_rng(23).standard_normal((65, 17)),
+              np.add.outer(np.linspace(-1, 1, 65) ** 2, np.cos(np.linspace(-1, 1, 17)))):
+        on, off = _sweep(make, True, V, sweeps=2), _sweep(make, False, V, sweeps=2)
+        assert on[3].backend_info['filter_form'] == 'shifted lattice'
+        _same(on, off)
+        _same(on, _sweep(make, True, V, kernel='generic', sweeps=2))
+    s = make()[1]
+    Jo, uo, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(s), V)
+    J, u = s.value_iteration(V, report_time=False)
+    assert np.array_equal(J, Jo) and np.array_equal(s.last_policy_index, io)
+    far = _nested(nesting, x_range=(1000., 1002.))
+    Vf = np.random.default_rng(24).standard_normal((65, 17))
+    _same(_sweep(far, True, Vf), _sweep(far, False, Vf))
+
+
 def test_a_cost_that_sees_the_perturbation_too(gpu):
     make = lambda: _shop(cost_w=True)
     V = _smooth(make()[1])

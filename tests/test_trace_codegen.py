@@ -428,7 +428,7 @@ def test_shifted_lattice_planning_without_a_gpu():
     m3 = tr(lambda x, y, u, w: ((y + w) + (x + 0.7 * u), 0.5 * y + w))        # the w-part first
     assert m3.lead_split()[1][0][1] == 1 and m3.lead_split()[0].deps & DEP_U
     for bad in (lambda x, y, u, w: ((x + u) * (1.0 + 0.1 * w), 0.5 * y + w),  # not a sum
-                lambda x, y, u, w: (x + (w - u), 0.5 * y + w),                # the control inside the w-part
+                lambda x, y, u, w: (x + (w * u - u), 0.5 * y + w),            # the control inside a w-term (x + (w - u) is regrouped since round 5: next test)
                 lambda x, y, u, w: (x + u - 0.1 * y, 0.5 * y + w),            # no perturbation in x0' at all
                 lambda x, y, u, w: (x + u - w - w - w - w - w, 0.5 * y + w)): # more terms than the bound covers
         assert tr(bad).lead_split() is None
@@ -450,6 +450,47 @@ def test_shifted_lattice_planning_without_a_gpu():
     assert plan['column'] and not plan['filtered'] and 'SDP_COL_SHIFT' not in plan['source']
     _, s = models.synthetic3d(N=256, stock_noise=0.07)
     assert '#define SDP_COL_SHIFT 1' in s._kernel_plan()['source']
+
+
+def test_sums_in_another_nesting_are_regrouped_by_the_tracer():
+    """TracedModel.lead_split: the final-sum form is returned as the reference adds it (nothing regrouped); a chain of
+    sums in another nesting is flattened into at most 4 leaves and regrouped -- a* is a new node of the graph, the
+    w-free leaves and the number of additions go to the kernel's bound; products and longer chains are refused"""
+    from stodynprog_amd.trace import trace_model
+    cost = lambda x, y, u, w: x * x + u * u
+    def split(dyn):
+        m = trace_model(dyn, cost, 2, 1, 1)
+        return m, m.lead_split(), m.lead_split_chain()
+    m, sp, chain = split(lambda x, y, u, w: (x + u - w, 0.8 * y + w))
+    assert sp is not None and chain is None and sp[0].op == 'add' and [sg for _, sg in sp[1]] == [-1]
+    m, sp, chain = split(lambda x, y, u, w: (x + (w - u), 0.8 * y + w))
+    assert sp[0].op == 'sub' and [a.op for a in sp[0].args] == ['var', 'var'] and [sg for _, sg in sp[1]] == [1]
+    assert [sg for _, sg in chain[0]] == [1, -1] and chain[1] == 2
+    assert m.lead_split() is sp                                          # (cached: the graph grows once)
+    m, sp, chain = split(lambda x, y, u, w: ((x - 0.1 * y) - (u - 0.5 * w), 0.8 * y + w))
+    assert [n.op for n, _ in chain[0]] == ['sub', 'var'] and chain[1] == 2 and sp[1][0][1] == 1
+    m, sp, chain = split(lambda x, y, u, w: (w - (u - x), y))             # one w-free leaf, negated: nothing to regroup but the sign
+    assert sp[0].op == 'neg' and chain[1] == 1
+    m, sp, chain = split(lambda x, y, u, w: (-u + (w - x), y))            # no positive w-free leaf
+    assert sp[0].op == 'sub' and sp[0].args[0].op == 'neg'
+    assert split(lambda x, y, u, w: ((x + u) * (1 + 0.1 * w), y))[1] is None
+    assert split(lambda x, y, u, w: (x + (w - u) + (0.1 * y - 0.2 * u) + 0.3, y))[1] is None      # five leaves
+    assert split(lambda x, y, u, w: (x + (w * u - u), y))[1] is None      # a leaf that sees the control and the perturbation
+    # the plan: the shifted lattice without the control table, the sum of the leaves' magnitudes generated
+    sysd = SysDescription((2, 1, 1))
+    sysd.dyn = lambda x, y, u, w: (x + ((0.5 * w + 0.1 * y) - u), 0.8 * y + w)
+    sysd.cost = lambda x, y, u, w: (x - 0.3) * (x - 0.3) + 0.1 * u * u
+    sysd.control_box = lambda x, y: ((-1., 1.),)
+    sysd.perturb_laws = [models.NormalLaw(0, 0.2)]
+    s = DPSolver(sysd)
+    s.discretize_state(-1, 1, 65, -1, 1, 17)
+    s.discretize_perturb(-0.5, 0.5, 7)
+    s.control_steps = (0.05,)
+    src = s._kernel_plan()['source']
+    assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_SHIFT_CHAIN 2' in src and '#define SDP_COL_UTAB' not in src
+    assert 'return fabs(x[0]) + fabs(u[0]);' in src
+    s.dtype = np.dtype(np.float32)                                        # (8-byte reals only, like the final-sum form)
+    assert '#define SDP_COL_SHIFT 1' not in s._kernel_plan()['source']
 
 
 def test_controlled_axes_and_the_reduced_array_plan_without_a_gpu():
