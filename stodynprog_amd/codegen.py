@@ -348,7 +348,7 @@ def control_table_plan(model, dtype, per_node, max_controls, debug=None):
     lead = None
     if model.lead_depends_on_w:
         split = model.lead_split()
-        if split is None or model.lead_split_chain() is not None:     # (a regrouped chain: the first pass bounds the sum of its leaves per control)
+        if split is None:
             return None
         lead = split[0]
     fr = model.control_uniform_frontier(lead)
@@ -379,6 +379,14 @@ def control_table_source(model, frontier):
                  '{', '    (void)x; (void)tab; (void)t;']
         names = _emit_body(model, model.slice_nodes_until([node], set(slot)), lines, pre)
         lines += ['    return {};'.format(names[node.id]), '}']
+        out.append('\n'.join(lines))
+    chain = model.lead_split_chain() if split else None
+    if chain is not None:              # (a regrouped chain of sums: the sum of the w-free leaves' magnitudes, from the table too)
+        leaves = [n for n, _ in chain[0]]
+        lines = ['SDP_DEV sdp_real sdp_model_lead_aabs_tab(const sdp_real *x, const sdp_real *tab, sdp_real t)',
+                 '{', '    (void)x; (void)tab; (void)t;']
+        names = _emit_body(model, model.slice_nodes_until(leaves, set(slot)), lines, pre)
+        lines += ['    return {};'.format(' + '.join('fabs({})'.format(names[n.id]) for n in leaves)), '}']
         out.append('\n'.join(lines))
     return '\n\n'.join(out)
 

@@ -1875,6 +1875,9 @@ SDP_DEV void sdp_col_lean_eval_tab(const sdp_real *A, const sdp_real *utab, cons
     for (int k = 0; k < SDP_COL_UTAB; ++k) tab[k] = utab[ci * SDP_COL_UTAB + k];
     const sdp_real xn0 = sdp_model_lead_tab(x, tab, t);
     const sdp_real g = sdp_model_cost_tab(x, tab, t);
+#if SDP_COL_SHIFT && SDP_COL_SHIFT_CHAIN
+    lmax = sdp_vmax_abs(lmax, sdp_model_lead_aabs_tab(x, tab, t) * (fabs(l.nm1 * l.rspan) * (sdp_real)1.002));      // (see sdp_col_lean_eval)
+#endif
     sdp_col_lean_core<AXIS>(A, f, l, xn0, g, F, lmax, bmax);
 }
 // the table of one column (its coordinates in x[1..]; x[0] is not read): threads `first` ..

@@ -487,8 +487,9 @@ def test_sums_in_another_nesting_are_regrouped_by_the_tracer():
     s.discretize_perturb(-0.5, 0.5, 7)
     s.control_steps = (0.05,)
     src = s._kernel_plan()['source']
-    assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_SHIFT_CHAIN 2' in src and '#define SDP_COL_UTAB' not in src
-    assert 'return fabs(x[0]) + fabs(u[0]);' in src
+    assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_SHIFT_CHAIN 2' in src
+    assert 'return fabs(x[0]) + fabs(u[0]);' in src                       # sdp_model_lead_aabs
+    assert '#define SDP_COL_UTAB 2' in src and 'return fabs(x[0]) + fabs(tab[0]);' in src          # .. and from the control table
     s.dtype = np.dtype(np.float32)                                        # (8-byte reals only, like the final-sum form)
     assert '#define SDP_COL_SHIFT 1' not in s._kernel_plan()['source']
 
