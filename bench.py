@@ -81,6 +81,8 @@ WORKLOADS = {
     # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h)
     'reservoirs': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float64', None,
                    'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations (two controlled state variables)'),
+    'reservoirs_f32': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float32', None,
+                       'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations, fp32 (the wide form of the reduced-array filter)'),
     'coupled256': ('synthetic3d_coupled', dict(N=256), 'float64', None,
                    'synthetic3d {n}^3 x 64 controls x 32 perturbations, control-coupled x1 (non-separable)'),
 }
@@ -927,7 +929,7 @@ def main():
     ap.add_argument('--grid', type=int, default=0,
                     help='synthetic workloads: points per state axis (default: the config\'s)')
     ap.add_argument('--dtype', default=None, choices=['float64', 'float32'])
-    ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged'],
+    ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged', 'lead'],
                     help='kernel family (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-filter-check', action='store_true',

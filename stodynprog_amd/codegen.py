@@ -307,25 +307,27 @@ def lead_functions_source(model, m, order=None):
     return '\n\n'.join(out)
 
 
-def lead_filter_applies(model, dtype, min_axes=2, debug=None):
+def lead_filter_applies(model, dtype, min_axes=2, debug=None, wide=False):
     """Several controlled state variables next to an exogenous process (TracedModel.controlled_axes
     >= 2; one stock is the column kernel's case), a perturbation that does not reach them (the cost may see
-    it), 8-byte reals: the node-order sweep with the certified filter on an array reduced over w
+    it), 8-byte reals -- `wide`: 4-byte reals too (round 5, the wide form: correct, but on the benchmark's lattice of
+    256 controls its radius of ~1e-5 of the values keeps so many controls that the sweep is 3 x SLOWER than every
+    control the long way, 8.9 against 2.6 ms; only `kernel = 'lead'` asks for it) --: the node-order sweep with the certified filter on an array reduced over w
     (csrc/sdp_lead_kernel.h).  Returns the number of controlled axes, or 0.  (`debug`: SDP_LEAD_FILTER = 0
     switches it off, A/B runs.)"""
     if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0':
         return 0
-    if model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
+    if model.n_perturb != 1 or (np.dtype(dtype).itemsize != 8 and not wide):
         return 0
     m = model.controlled_axes()
     return int(m) if m is not None and m >= min_axes else 0
 
 
-def lead_order(model, dtype, debug=None):
+def lead_order(model, dtype, debug=None, wide=False):
     """(m, order) for the reduced-array sweep of a model whose stocks are NOT listed first (the order of the
     state variables is the user's: reference stodynprog.py:119-131), or None: TracedModel.controlled_order
-    with at least one exogenous variable, 8-byte reals, one perturbation."""
-    if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0' or model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
+    with at least one exogenous variable, 8-byte reals (`wide`: see lead_filter_applies), one perturbation."""
+    if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0' or model.n_perturb != 1 or (np.dtype(dtype).itemsize != 8 and not wide):
         return None
     co = model.controlled_order()
     if co is None or co[1] == tuple(range(model.n_state)) or co[0] >= model.n_state:

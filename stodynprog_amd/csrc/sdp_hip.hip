@@ -1050,7 +1050,7 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         e = hipModuleGetFunction(&p->f_lead_reduce, p->mod, "sdp_lead_reduce");
         if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_lead_reduce kernel: %s", desc->module_path, hipGetErrorString(e));
         if (p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
-        int rc = p->lead_a.alloc((size_t)p->S * rs);
+        int rc = p->lead_a.alloc((size_t)p->S * 8);                                     // (the reduced array: 8-byte sums whatever the reals are, sdp_lead_kernel.h)
         if (!rc) rc = p->lead_v.alloc((size_t)p->S * rs);
         if (!rc) rc = p->lead_e.alloc((size_t)lead_trailing_nodes(p) * rs);            // (a value per trailing index)
         if (!rc) rc = p->lead_vmax.alloc(8);

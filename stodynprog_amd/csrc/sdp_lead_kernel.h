@@ -36,14 +36,26 @@
 // sticks in sum |F|; an infinity makes Dabs or sum |F| infinite; |p_k| >= 2^31 (x86 truncation of the
 // reference, sdp_trunc_i32) makes Lp >= 2^30: all of them mark the node, which then evaluates every
 // control the long way.  Dabs carries 2 tiny / cu so that the radius never drops below the smallest
-// normal number.  8-byte reals only (in 4-byte reals the radius, ~1e-5 relative, leaves too many survivors
-// for a pass 2 that costs 2^d loads per perturbation point).
+// normal number.
+// 4-BYTE REALS (round 5): the wide form of sdp_col_wide_core.  The positions, the cells and g are the reference's
+// own 4-byte values (inputs of E); the reduced array accumulates the reference's 4-byte inner_w in 8-BYTE reals and F
+// is evaluated in 8-byte arithmetic, so |F - R| is what the inner_w carry, 3 (d - m) u per term, u = 2^-24, and the
+// radius has to cover |E - R| <= (W + 3d + 2) u S on top.  Two things change, both to keep a radius of ~1e-5 of the
+// values useful: S(u) = |g| Pcap + prod_k<m (|oml_k| + |lam_k|) Dabs with the reference's own oml_k = fl(1 - lam_k)
+// -- the weights of ITS nest (1 inside the grid), not the 1 + 2 |lam| of a fused lerp, which F no longer rounds in
+// 4-byte arithmetic -- and S_node takes the LARGEST |F| of the node, not the sum over its controls:
+//     S_node = ratio (max |F| (1 + 1e-6) + Lp Dabs) + Lp Dabs,   Lp = 1.001 max_u prod_k<m (|oml_k| + |lam_k|),
+//     radius = cu S_node,   cu = 4 (W + 3d + 4) 2^-24
+// (|h| <= prod (|1 - lam_k| + |lam_k|) max |A| (1 + tiny) in 8-byte arithmetic, and fl(1 - lam) is within u of 1 - lam:
+// the 1.001).  A node whose S_node reaches 2^100 takes the long way (the reference's own 4-byte intermediates are
+// bounded by a small multiple of S: none of them overflows below that).
 #pragma once
 
 #if SDP_LEAD_AXES < 1 || SDP_LEAD_AXES > SDP_D || !SDP_HAS_W || SDP_LANES != 1
 #error "sdp_lead_kernel.h: 1 <= SDP_LEAD_AXES <= SDP_D, a perturbation, one lane per node"
 #endif
-static_assert(sizeof(sdp_real) == 8, "the global-memory filter is built for 8-byte reals");
+typedef double sdp_lacc;             // the reduced array, F and the bound: 8-byte reals whatever sdp_real is
+constexpr bool SDP_LEAD_WIDE = sizeof(sdp_real) == 4;
 #ifndef SDP_LEAD_COST_HAS_W
 #define SDP_LEAD_COST_HAS_W 0        // 1: the cost depends on the perturbation (see sdp_lead_first)
 #endif
@@ -174,7 +186,7 @@ SDP_DEV void sdp_lead_trail_grid(const SdpSweepArgs &a, const SdpLeadGeom &geo, 
 extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a)
 {
     const sdp_real *__restrict__ V = (const sdp_real *)a.V;
-    sdp_real *__restrict__ A = (sdp_real *)a.aux_a;
+    sdp_lacc *__restrict__ A = (sdp_lacc *)a.aux_a;
     sdp_real *__restrict__ Vt = (sdp_real *)a.aux_v;
     sdp_real *__restrict__ E = (sdp_real *)a.aux_e;
     const sdp_real *__restrict__ wgrid = (const sdp_real *)a.wgrid;
@@ -195,7 +207,8 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
         sdp_node_coords(a, node, x);
         int64_t lead, trail;
         sdp_lead_split(geo, node, lead, trail);
-        sdp_real acc = (sdp_real)0, emax = (sdp_real)0;
+        sdp_lacc acc = (sdp_lacc)0;
+        sdp_real emax = (sdp_real)0;
         for (int wi = 0; wi < a.W; ++wi) {
 #if SDP_LEAD_AXES < SDP_D
             sdp_real xt[SDP_LT];
@@ -213,39 +226,39 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
             const sdp_real inner = V[node];
             emax = (sdp_real)1;
 #endif
-            acc = fma(proba[wi], inner, acc);
+            acc = fma((sdp_lacc)proba[wi], (sdp_lacc)inner, acc);
         }
         const sdp_real vn = V[node];
         A[trail * geo.ls + lead] = acc;                   // plane-major: [trailing index][lead index]
         Vt[trail * geo.ls + lead] = vn;
         if (lead == a.aux_begin) E[trail] = emax;
-        vmax = sdp_lead_vmax_abs(vmax, vn);
+        vmax = (sdp_real)sdp_lead_vmax_abs((double)vmax, (double)vn);
     }
-    vmax = __ockl_wfred_max_f64(vmax);
+    const double vmax_w = __ockl_wfred_max_f64((double)vmax);
     if ((threadIdx.x & 63) == 0)
-        atomicMax(a.aux_vmax, (unsigned long long)__double_as_longlong(vmax));   // (>= 0: ordered as integers)
+        atomicMax(a.aux_vmax, (unsigned long long)__double_as_longlong(vmax_w)); // (>= 0: ordered as integers)
 }
 
 // ---- the sweep ---------------------------------------------------------------------------------
 // multilinear interpolation of A over the lead axes, last lead axis innermost, fused (a filter value)
 template <int K>
 struct SdpLeadLerp {
-    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int *off, const int *lm,
+    static SDP_DEV sdp_lacc eval(const sdp_lacc *__restrict__ A, const int *off, const int *lm,
                                  const sdp_real *lam, int base)
     {
-        const sdp_real lo = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K]);
-        const sdp_real hi = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K] + lm[K]);
-        return fma(lam[K], hi - lo, lo);
+        const sdp_lacc lo = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K]);
+        const sdp_lacc hi = SdpLeadLerp<K + 1>::eval(A, off, lm, lam, base + off[K] + lm[K]);
+        return fma((sdp_lacc)lam[K], hi - lo, lo);
     }
 };
 template <>
 struct SdpLeadLerp<SDP_LM> {
-    static SDP_DEV sdp_real eval(const sdp_real *__restrict__ A, const int *, const int *,
+    static SDP_DEV sdp_lacc eval(const sdp_lacc *__restrict__ A, const int *, const int *,
                                  const sdp_real *, int base) { return A[base]; }
 };
 
 struct SdpLeadConst {
-    sdp_real psum, pcap, ratio, cu, floor;
+    sdp_lacc psum, pcap, ratio, cu, floor;
     const sdp_cst_real *p, *wg;    // weights and points (scalar loads)
     int W;
     bool ok;
@@ -253,20 +266,20 @@ struct SdpLeadConst {
 SDP_DEV void sdp_lead_const(const SdpSweepArgs &a, SdpLeadConst &f)
 {
     const sdp_cst_real *p = (const sdp_cst_real *)a.proba;
-    sdp_real ps = (sdp_real)0, pa = (sdp_real)0;
+    sdp_lacc ps = (sdp_lacc)0, pa = (sdp_lacc)0;
     for (int w = 0; w < a.W; ++w) {
-        ps = ps + p[w];
-        pa = pa + fabs(p[w]);
+        ps = ps + (sdp_lacc)p[w];
+        pa = pa + fabs((sdp_lacc)p[w]);
     }
     f.psum = ps;
     f.p = p;
     f.wg = (const sdp_cst_real *)a.wgrid;
     f.W = a.W;
-    f.pcap = pa > (sdp_real)1 ? pa : (sdp_real)1;
+    f.pcap = pa > (sdp_lacc)1 ? pa : (sdp_lacc)1;
     f.ratio = f.pcap / fabs(ps);                   // (psum = 0: infinite -> every node takes the long way)
-    f.cu = (sdp_real)SDP_LEAD_FILTER_SCALE * (sdp_real)(4 * (a.W + 3 * SDP_D + 4)) * (sdp_real)0x1p-53;
-    f.floor = (sdp_real)2 * (sdp_real)2.2250738585072014e-308 / f.cu;
-    f.ok = pa <= (sdp_real)1024;                   // (false for a NaN)
+    f.cu = (sdp_lacc)SDP_LEAD_FILTER_SCALE * (sdp_lacc)(4 * (a.W + 3 * SDP_D + 4)) * (SDP_LEAD_WIDE ? (sdp_lacc)0x1p-24 : (sdp_lacc)0x1p-53);
+    f.floor = (sdp_lacc)2 * (SDP_LEAD_WIDE ? (sdp_lacc)1.17549435e-38 : (sdp_lacc)2.2250738585072014e-308) / f.cu;
+    f.ok = pa <= (sdp_lacc)1024;                   // (false for a NaN)
 }
 
 // the control lattice in C order (control 0 slowest) without a division per point: the flat index i of the
@@ -305,14 +318,14 @@ SDP_DEV void sdp_lead_walk_next(const SdpBox &b, SdpLeadWalk &w)
 // gmax collects Gabs = max(sum_w |p_w g_w|, max_w |g_w|), which stands where |g| Pcap stood in the bound
 // (the raw magnitude too: a tiny weight must not hide a g_w that overflows g_w + val on the reference's path).
 // [lmin, lmax]: lead indices (positions inside a plane) the node's controls have read so far
-SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeom &geo, const SdpLeadConst &f,
-                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_real &lp, sdp_real &gmax,
+SDP_DEV sdp_lacc sdp_lead_first(const sdp_lacc *__restrict__ A, const SdpLeadGeom &geo, const SdpLeadConst &f,
+                                const sdp_real *x, const sdp_real *u, sdp_real t, sdp_lacc &lp, sdp_lacc &gmax,
                                 int &lmin, int &lmax)
 {
     sdp_real xl[SDP_LM], lam[SDP_LM];
     int off[SDP_LM];
     sdp_model_leads(x, u, t, xl);
-    sdp_real prod = (sdp_real)1;
+    sdp_lacc prod = (sdp_lacc)1;
 #pragma unroll
     for (int k = 0; k < SDP_LM; ++k) {
         const sdp_real sn = sdp_div_span<sdp_real>(xl[k] - geo.smin[k], geo.span[k], geo.rspan[k], (geo.pow2 >> k) & 1);
@@ -320,7 +333,9 @@ SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeo
         const int q = max(min((int)p, geo.ordm2[k]), 0);       // (saturating conversion; NaN -> 0)
         lam[k] = p - (sdp_real)q;
         off[k] = q * geo.pm[k];
-        prod = prod * fma((sdp_real)2, fabs(lam[k]), (sdp_real)1);
+        // (8-byte reals: the fused lerp of F rounds too, 1 + 2 |lam|; 4-byte reals: the weights of the reference's nest)
+        prod = prod * (SDP_LEAD_WIDE ? (sdp_lacc)fabs((sdp_real)1 - lam[k]) + (sdp_lacc)fabs(lam[k])
+                                     : fma((sdp_lacc)2, (sdp_lacc)fabs(lam[k]), (sdp_lacc)1));
     }
     lp = sdp_lead_vmax(lp, prod);
     {
@@ -330,12 +345,12 @@ SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeo
         lmin = min(lmin, lo);
         lmax = max(lmax, lo + span);
     }
-    const sdp_real h = SdpLeadLerp<0>::eval(A, off, geo.pm, lam, 0);
+    const sdp_lacc h = SdpLeadLerp<0>::eval(A, off, geo.pm, lam, 0);
 #if SDP_LEAD_COST_HAS_W
-    sdp_real G = (sdp_real)0, gabs = (sdp_real)0, graw = (sdp_real)0;
+    sdp_lacc G = (sdp_lacc)0, gabs = (sdp_lacc)0, graw = (sdp_lacc)0;
     for (int w = 0; w < f.W; ++w) {
-        const sdp_real pw = f.p[w];
-        const sdp_real gw = sdp_model_cost(x, u, f.wg[w], t);
+        const sdp_lacc pw = (sdp_lacc)f.p[w];
+        const sdp_lacc gw = (sdp_lacc)sdp_model_cost(x, u, f.wg[w], t);
         G = fma(pw, gw, G);
         gabs = fma(fabs(pw), fabs(gw), gabs);
         graw = sdp_lead_vmax_abs(graw, gw);
@@ -344,13 +359,13 @@ SDP_DEV sdp_real sdp_lead_first(const sdp_real *__restrict__ A, const SdpLeadGeo
     return G + h;
 #else
     (void)gmax;
-    return fma(sdp_model_cost(x, u, (sdp_real)0, t), f.psum, h);
+    return fma((sdp_lacc)sdp_model_cost(x, u, (sdp_real)0, t), f.psum, h);
 #endif
 }
 
 extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
 {
-    const sdp_real *__restrict__ Aall = (const sdp_real *)a.aux_a;
+    const sdp_lacc *__restrict__ Aall = (const sdp_lacc *)a.aux_a;
     const sdp_real *__restrict__ Vt = (const sdp_real *)a.aux_v;
     const sdp_real *__restrict__ E = (const sdp_real *)a.aux_e;
     SdpLeadGeom geo;
@@ -369,7 +384,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
     sdp_lead_const(a, fc);
     const sdp_real t = (sdp_real)a.t_k;
     sdp_trap_unless(a.aux_a != nullptr && a.aux_e != nullptr && a.aux_v != nullptr);
-    const sdp_real vmax = (sdp_real)__longlong_as_double((long long)*a.aux_vmax);
+    const sdp_lacc vmax = __longlong_as_double((long long)*a.aux_vmax);
 
     // the second pass of a node whose controls reach beyond the reduced part of the grid (sharded backups: the
     // host's guess of the reach was too small) reads V itself, in node order
@@ -398,34 +413,36 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         SdpBox box;
         sdp_node_coords(a, node, x);
         sdp_load_box(a, node, box);
-        const sdp_real *__restrict__ A = Aall + trail * geo.ls;
-        const sdp_real dabs = fc.pcap * (E[trail] * vmax) + fc.floor;
+        const sdp_lacc *__restrict__ A = Aall + trail * geo.ls;
+        const sdp_lacc dabs = fc.pcap * ((sdp_lacc)E[trail] * vmax) + fc.floor;
         // pass 1
-        sdp_real f1 = INFINITY, f2 = INFINITY, fsum = (sdp_real)0, lp = (sdp_real)0, gmax = (sdp_real)0;
+        sdp_lacc f1 = INFINITY, f2 = INFINITY, fsum = (sdp_lacc)0, fbig = (sdp_lacc)0, lp = (sdp_lacc)0, gmax = (sdp_lacc)0;
         int i1 = INT_MAX, lmin = INT_MAX, lmax = INT_MIN;
         SdpLeadWalk walk;
         sdp_lead_walk_begin(box, walk);
 #pragma unroll SDP_LEAD_UNROLL
         for (int ci = 0; ci < box.total; ++ci) {
-            const sdp_real F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp, gmax, lmin, lmax);
-            fsum = fsum + fabs(F);
+            const sdp_lacc F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp, gmax, lmin, lmax);
+            fsum = fsum + fabs(F);                         // (a NaN sticks; 4-byte reals: only that is read of it)
+            if (SDP_LEAD_WIDE) fbig = sdp_lead_vmax_abs(fbig, F);
             f2 = sdp_lead_vmin(f2, sdp_lead_vmax(f1, F));
             i1 = F < f1 ? ci : i1;
             f1 = sdp_lead_vmin(f1, F);
             sdp_lead_walk_next(box, walk);
         }
-        const sdp_real h_cap = lp * dabs;
+        const sdp_lacc h_cap = (SDP_LEAD_WIDE ? lp * (sdp_lacc)1.001 : lp) * dabs;
 #if SDP_LEAD_COST_HAS_W
-        const sdp_real s_node = fsum == fsum ? gmax + h_cap : (sdp_real)NAN;     // (a NaN of any F sticks in the sum)
+        const sdp_lacc s_node = fsum == fsum ? gmax + h_cap : (sdp_lacc)NAN;     // (a NaN of any F sticks in the sum)
 #else
-        const sdp_real s_node = fma(fc.ratio, fsum + h_cap, h_cap);
+        const sdp_lacc s_node = !SDP_LEAD_WIDE ? fma(fc.ratio, fsum + h_cap, h_cap)
+                                : (fsum == fsum ? fma(fc.ratio, fma(fbig, (sdp_lacc)1.000001, h_cap), h_cap) : (sdp_lacc)NAN);
 #endif
         // the reduced array and the plane-major copy of V hold this rank's part of the grid: a control that reads
         // outside it saw stale values -- the node then takes every control the long way on V itself
         const bool outside = (int64_t)lmin < a.aux_begin || (int64_t)lmax >= a.aux_end;
-        const bool bad = outside || !fc.ok || !(s_node < (sdp_real)0x1p1000) || !(lp < (sdp_real)1073741824.0);
-        const sdp_real radius = fc.cu * s_node;
-        const sdp_real m_hi = f1 + radius;                 // >= the minimum of E over the node
+        const bool bad = outside || !fc.ok || !(s_node < (SDP_LEAD_WIDE ? (sdp_lacc)0x1p100 : (sdp_lacc)0x1p1000)) || !(lp < (sdp_lacc)1073741824.0);
+        const sdp_lacc radius = fc.cu * s_node;
+        const sdp_lacc m_hi = f1 + radius;                 // >= the minimum of E over the node
         const bool single = !bad && i1 != INT_MAX && f2 - radius > m_hi;
         // pass 2: the reference's operations on the survivors, in lattice order
         sdp_real best = INFINITY;
@@ -436,7 +453,7 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         for (int ci = first; ci < last; ++ci) {
             bool cand = single || bad;
             if (!cand) {
-                sdp_real lq = (sdp_real)0, gq = (sdp_real)0;
+                sdp_lacc lq = (sdp_lacc)0, gq = (sdp_lacc)0;
                 int l0 = 0, l1 = 0;
                 cand = !(sdp_lead_first(A, geo, fc, x, walk.u, t, lq, gq, l0, l1) - radius > m_hi);
             }

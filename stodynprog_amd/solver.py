@@ -671,7 +671,7 @@ class DPSolver(object):
             # (one stock whose table does not fit LDS too: measured 5.9 ms against 12.7 ms of the row-window
             # column kernel at 1024 x 128 x 128 x 64 x 32, tools/window_vs_lead.py)
             lead_axes = codegen.lead_filter_applies(
-                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2, debug)
+                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2, debug, wide=self.kernel == 'lead')
         # the stocks need not be listed first (the order of the state variables is the user's, reference
         # stodynprog.py:119-131): the filter then works on a permuted view of the axes, the second pass keeps the
         # reference's own axis order
@@ -679,12 +679,12 @@ class DPSolver(object):
         if (not column and not lead_axes and self.kernel in ('auto', 'lead') and W > 0 and not self._cache.get('no_lead')
                 and (self.comm is None or self.comm.is_device)
                 and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
-            co = codegen.lead_order(model, dt, debug)
+            co = codegen.lead_order(model, dt, debug, wide=self.kernel == 'lead')
             if co is not None:
                 lead_axes, lead_perm = co
         if self.kernel == 'lead' and not lead_axes:
             raise ValueError("kernel = 'lead' needs controlled state variables next to an exogenous process, "
-                             'a perturbation that reaches only that process, 8-byte reals, the certified '
+                             'a perturbation that reaches only that process, the certified '
                              'filter and exact arithmetic (several GPUs: a device communicator)')
         if lead_axes:
             lanes = 1                                     # one lane per node, the control loop in-lane
