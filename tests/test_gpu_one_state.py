@@ -146,3 +146,15 @@ def test_where_the_lifted_problem_is_not_used(gpu):
     s2.embed_1d = False
     x2, u2, g2 = s2.simulate(pol, np.array([[1.0], [3.0]]), np.random.default_rng(5).uniform(0, 4, size=(20, 2)))
     assert np.array_equal(x, x2) and np.array_equal(u, u2) and np.array_equal(g, g2)
+
+
+def test_4_byte_reals(gpu):
+    """the storage shape in 4-byte reals takes the wide pass of the column kernel through the lifted problem; the inventory
+    shape has no 4-byte filter and runs as written"""
+    V = np.random.default_rng(43).standard_normal(512).astype(np.float32)
+    emb, plain = _both(_storage, V, dtype=np.dtype(np.float32))
+    assert emb[0].dtype == np.float32 and emb[3].backend_info.get('embedded_1d') and emb[3].backend_info['kernel'] == 'column'
+    _same(emb, plain)
+    s = _inventory()
+    s.dtype = np.dtype(np.float32)
+    assert s._lifted_1d(None) is None
