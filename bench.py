@@ -812,7 +812,7 @@ def finish_single(args, env, out):
         others = {}
         for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
             solver._cache.pop(k_).close()
-        for name in ('ar1', 'searev', 'synth512f32', 'noisy256', 'reservoirs'):
+        for name in ('ar1', 'searev', 'synth512f32', 'noisy256', 'noisy256_nested', 'reservoirs'):
             try:
                 a2 = copy.copy(args)
                 a2.config, a2.grid, a2.dtype = name, 0, None
