@@ -70,7 +70,7 @@ WORKLOADS = {
     # (x1' += 0.1 u) -- not storage-separable, runs the LDS-staged tile kernel
     # not a BASELINE config: the benchmark problem with the perturbation also reaching the stock,
     # x0' = (x0 + b u) - 0.07 w (the shape of the reference's inventory example): the certified filter
-    # runs on the shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)
+    # runs on the shifted lattice (csrc/sdp_colfilter_kernel.h, SDP_COL_SHIFT)
     'noisy256': ('synthetic3d', dict(N=256, stock_noise=0.07), 'float64', None,
                  'synthetic3d {n}^3 x 64 controls x 32 perturbations, perturbation also in the stock'),
     # the same sum in another nesting, x0' = x0 + (b u - 0.07 w): regrouped by the tracer (TracedModel.lead_split), no control table

@@ -242,7 +242,7 @@ def separable_functions_source(model):
     if split is not None:
         # x0' = a(x, u) +- b_1(x_1.., w) +- b_2 ..: a, the sum B of the signed b_i in the reference's order, and
         # the sum of the |b_i| (for the error bound), each b_i with the reference's own operations
-        # (SDP_COL_SHIFT of csrc/sdp_column_kernel.h)
+        # (SDP_COL_SHIFT of csrc/sdp_colfilter_kernel.h)
         a_node, terms = split
         lines = ['SDP_DEV sdp_real sdp_model_lead_a(const sdp_real *x, const sdp_real *u, sdp_real t)',
                  '{', '    (void)x; (void)u; (void)t;']
@@ -253,7 +253,7 @@ def separable_functions_source(model):
         if chain is not None:
             # a chain of sums in another nesting, regrouped (TracedModel.lead_split): a is the sum of the chain's w-free
             # leaves, no value of the reference's; the sum of their magnitudes bounds what the regrouping costs
-            # (SDP_COL_SHIFT_CHAIN of csrc/sdp_column_kernel.h)
+            # (SDP_COL_SHIFT_CHAIN of csrc/sdp_colfilter_kernel.h)
             leaves = [n for n, _ in chain[0]]
             lines = ['SDP_DEV sdp_real sdp_model_lead_aabs(const sdp_real *x, const sdp_real *u, sdp_real t)',
                      '{', '    (void)x; (void)u; (void)t;']
@@ -341,7 +341,7 @@ UTAB_MAX_BYTES = 4096        # per parity buffer of the table in LDS
 
 def control_table_plan(model, dtype, per_node, max_controls, debug=None):
     """Can the column-uniform sub-expressions of x0' and of the cost be tabulated once per
-    (column, control) (SDP_COL_UTAB of csrc/sdp_column_kernel.h)?  Needs a control lattice that
+    (column, control) (SDP_COL_UTAB of csrc/sdp_colfilter_kernel.h)?  Needs a control lattice that
     is the same at every node (constant box) and small enough for LDS.  Returns the frontier
     nodes (TracedModel.control_uniform_frontier) or None.  (`debug`: SDP_COL_UTAB = 0 switches it
     off, A/B runs.)"""
@@ -556,7 +556,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
     per_control: None, or the tuple of `column_percontrol_config` (column kernel
     that rebuilds its table for every control).
     filtered: column kernel with the certified expectation-first filter (SDP_COL_FILTER of
-    csrc/sdp_column_kernel.h; see `column_filter_applies`).
+    csrc/sdp_colfilter_kernel.h; see `column_filter_applies`).
     utab: None, or (frontier nodes, capacity of the control table in controls) of `control_table_plan`
     (filtered kernel only): the first pass reads the column-uniform sub-expressions from a table.
     debug: None (the product), or a dict of diagnostic switches (see DEBUG_NAMES)."""
@@ -734,7 +734,7 @@ def use_wpair(model, dtype, debug=None):
 def column_shift_applies(model, dtype, table=None, debug=None):
     """The certified filter with a perturbation that reaches x0' additively (`x + u - w`): the first
     pass then reads a table reduced over w on a lattice that the perturbation points have SHIFTED
-    (SDP_COL_SHIFT of csrc/sdp_column_kernel.h).  8-byte reals only: in 4-byte reals the rounding of
+    (SDP_COL_SHIFT of csrc/sdp_colfilter_kernel.h).  8-byte reals only: in 4-byte reals the rounding of
     the positions alone would put most controls inside the radius.  (`debug`: SDP_COL_SHIFT = 0 switches
     it off, A/B runs.)"""
     if _dbg(debug, 'SDP_COL_SHIFT', '1') == '0':
@@ -750,7 +750,7 @@ def column_shift_applies(model, dtype, table=None, debug=None):
 
 def column_filter_applies(model, fused=False, window=None, per_control=None, dtype=None, table=None, debug=None):
     """Can phase B of the column kernel run the certified expectation-first filter
-    (SDP_COL_FILTER of csrc/sdp_column_kernel.h)?  It needs a perturbation that reaches
+    (SDP_COL_FILTER of csrc/sdp_colfilter_kernel.h)?  It needs a perturbation that reaches
     neither x0' nor the cost -- then the expectation commutes with the lerp along axis 0 and
     all but the surviving controls of a node are decided on a table reduced over w -- and the
     plain full-column table with the reference's arithmetic.  Same bits as without it
@@ -998,7 +998,7 @@ HIPCC_FLAGS = ['--genco', '--offload-arch=gfx950', '-O3', '-ffp-contract=off',
                '-fno-fast-math', '-std=c++17', '-I', CSRC]
 
 
-_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_colres_kernel.h',
+_HEADERS = ('sdp_kernel_args.h', 'sdp_device.h', 'sdp_sweep_kernel.h', 'sdp_column_kernel.h', 'sdp_colfilter_kernel.h', 'sdp_colres_kernel.h',
             'sdp_colfull_kernel.h', 'sdp_colu_kernel.h',
             'sdp_lead_kernel.h', 'sdp_staged_kernel.h')
 _digest_cache = {}

@@ -96,7 +96,7 @@ def inventory_markov(api=None, n_x=128, n_d=32, n_w=9, h=0.5, p=3., c=1., x_max=
     """The shop inventory next to an exogenous demand level (two state variables): the stock follows
     `x + u - demand` as in the reference's example (doc/example_inventory.py:31-33, cost :59-65), the
     demand of a period is a mean-reverting level plus noise.  The perturbation reaches the stock, not
-    the cost: the column kernel filters it on the shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT)."""
+    the cost: the column kernel filters it on the shifted lattice (csrc/sdp_colfilter_kernel.h, SDP_COL_SHIFT)."""
     SysDescription, DPSolver = _classes(api)
     shop = SysDescription((2, 1, 1), name='Shop inventory, Markov demand')
     mean, corr, sigma = 2.0, 0.7, 0.6

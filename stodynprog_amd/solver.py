@@ -341,7 +341,7 @@ class DPSolver(object):
         # column kernel, 'exact' arithmetic: decide all but the near-minimal controls of a node on
         # a table reduced over the perturbation (rigorous error radius) and evaluate only the
         # survivors with the reference's operations -- same bits, ~W times less work per control
-        # (csrc/sdp_column_kernel.h, SdpColFilter).  False: every control the long way.
+        # (csrc/sdp_colfilter_kernel.h, SdpColFilter).  False: every control the long way.
         self.certified_filter = True
         self._cache = {}
         self._idx_cache = None             # see last_policy_index

@@ -560,7 +560,7 @@ class TracedModel(object):
         x0 (or are x0' / the cost themselves).  With a control lattice shared by the nodes of a
         column they can be evaluated once per (column, control) instead of once per (node,
         control): the same operations on the same operands, hence the same bits
-        (csrc/sdp_column_kernel.h, SDP_COL_UTAB).  Returns the nodes in recording order, or None
+        (csrc/sdp_colfilter_kernel.h, SDP_COL_UTAB).  Returns the nodes in recording order, or None
         when there is none or a boolean is among them."""
         outs = [lead if lead is not None else self.x_next[0], self.cost]
         nodes = self.slice_nodes(outs)
@@ -767,7 +767,7 @@ class TracedModel(object):
         in the order the reference adds them, sign = +1 / -1, or None.  The perturbation then moves
         the axis-0 position of every control of a column by the same amounts, so the expectation over
         w can still be taken on the table before the controls are looked at
-        (csrc/sdp_column_kernel.h, SDP_COL_SHIFT).  `a` is one sub-expression, evaluated as the
+        (csrc/sdp_colfilter_kernel.h, SDP_COL_SHIFT).  `a` is one sub-expression, evaluated as the
         reference evaluates it: the first pass then starts from the reference's own value of it.
 
         Round 5: a chain of sums in ANY nesting, `x + (w - u)`, `(x - 0.1 * y) - (u - w)`, is taken too

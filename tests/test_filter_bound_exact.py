@@ -247,7 +247,7 @@ BNB_DELTA = 2.0 ** -20
 
 
 def block_bound_check(T, p, X, K, a, h, chunked, sign, block, lead='add'):
-    """The branch and bound of the short first pass (sdp_short_bnb of csrc/sdp_column_kernel.h, round 5), as the kernels
+    """The branch and bound of the short first pass (sdp_short_bnb of csrc/sdp_colfilter_kernel.h, round 5), as the kernels
     evaluate it.  The control table's wave keeps per block of `block` controls where it STARTS -- the smallest
     pa = +-a k of its controls, k = (N0 - 1) / span, moved down by DELTA -- and the smallest fl(+-h psum); the last
     block's end is its largest pa + DELTA (sdp_col_phase_u).  A node adds pX = +-(X -+ smin) k, evaluates the
@@ -354,7 +354,7 @@ def test_the_packed_index_comes_back_and_the_order_survives():
 
 
 # ---------------------------------------------------------------------------
-# The short WIDE first pass (4-byte reals, SDP_COL_WIDE2 of csrc/sdp_column_kernel.h): the reference runs in 4-byte
+# The short WIDE first pass (4-byte reals, SDP_COL_WIDE2 of csrc/sdp_colfilter_kernel.h): the reference runs in 4-byte
 # arithmetic, F' in 8-byte arithmetic on A[r] accumulated in 8-byte reals, one bound per node:
 #     S = (Gc + Pcap) [ |K| + max |h| + (1 + 2 L) max |T| ],   radius = 1.001 2^-24 (S + floor) + 2^(bits-51) S
 # ---------------------------------------------------------------------------
@@ -578,7 +578,7 @@ def test_the_short_wide_pass_radius_covers_the_difference_exactly(regime):
 #     F = fma(g, P, fma(oml0, A[q0], lam0 A[q0+1]))   in 8-byte arithmetic, q0 / lam0 / oml0 / g the reference's 4-byte values
 #     bound(u) = Gc |g| + |oml0| B[q0] + |lam0| B[q0+1],   B[r] = sum_w n_w |p_w| |T[w][r]|,   n_w = W - w + 4 (W + 3 for w = 0)
 #     radius = 1.001 2^-24 (max_u bound(u) + floor)
-# (sdp_col_wide_core, sdp_col_filter_reduce, sdp_col_filter_nodes of csrc/sdp_column_kernel.h)
+# (sdp_col_wide_core, sdp_col_filter_reduce, sdp_col_filter_nodes of csrc/sdp_colfilter_kernel.h)
 # ---------------------------------------------------------------------------
 def wide_check(T, p, controls):
     """controls: (position p as the reference computes it in 4-byte reals, cost g) per control"""
@@ -655,7 +655,7 @@ def test_the_wide_pass_radius_covers_the_difference_exactly(regime):
 # ---------------------------------------------------------------------------
 # The filter on the SHIFTED LATTICE (8-byte reals; a perturbation that reaches the stock through a final sum:
 # x0' = (X + a_u) - b_w; sdp_col_phase_shift / sdp_col_shift_col / sdp_col_shift_reduce /
-# sdp_col_lean_core of csrc/sdp_column_kernel.h).  Here the filter value differs from the reference's even in exact
+# sdp_col_lean_core of csrc/sdp_colfilter_kernel.h).  Here the filter value differs from the reference's even in exact
 # arithmetic -- G is tabulated at whole positions and interpolated -- and the radius is cu S_node + max B'[q0]:
 # both parts are checked together, exactly.  Grid [0, 1] (axis mode 2), one term b.
 # ---------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""Certified expectation-first filter of the column kernel (csrc/sdp_column_kernel.h,
+"""Certified expectation-first filter of the column kernel (csrc/sdp_colfilter_kernel.h,
 SdpColFilter).  When the perturbation reaches neither x0' nor the cost, the first pass
 decides all but the near-minimal controls of a node on a table reduced over w, with a
 rigorous error radius, and only the survivors are evaluated with the reference's

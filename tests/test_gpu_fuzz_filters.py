@@ -1,7 +1,7 @@
 """Randomised models for the two filter forms added in round 3 (tracer + code generator + kernels against the
 kernels that do no filtering): random expressions built from correctly rounded operators, so every family must
 give the same bits.
-* shifted lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT): x0' = a(x, y, u) +- b_1(y, w) [+- b_2(y, w)];
+* shifted lattice (csrc/sdp_colfilter_kernel.h, SDP_COL_SHIFT): x0' = a(x, y, u) +- b_1(y, w) [+- b_2(y, w)];
 * reduced array (csrc/sdp_lead_kernel.h): two controlled stocks, one exogenous variable, two controls."""
 import numpy as np
 import pytest

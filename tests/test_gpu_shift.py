@@ -1,4 +1,4 @@
-"""Certified filter on the SHIFTED lattice (csrc/sdp_column_kernel.h, SDP_COL_SHIFT): a perturbation
+"""Certified filter on the SHIFTED lattice (csrc/sdp_colfilter_kernel.h, SDP_COL_SHIFT): a perturbation
 that reaches the stock through a final sum, x0' = a(x, u) +- b(x_1.., w) -- the reference's inventory
 example `x + u - w` (doc/example_inventory.py:31-33) next to an exogenous axis.  The first pass reads
 G(s) = sum_w p_w T_w(s + shift_w), tabulated at the whole positions of a lattice moved by the

@@ -376,7 +376,7 @@ def test_percontrol_and_window_shapes():
 
 def test_certified_filter_planning_without_a_gpu():
     """where the column kernel gets the certified expectation-first filter (SDP_COL_FILTER of
-    csrc/sdp_column_kernel.h) and the workgroup shape that goes with it: one lane per node"""
+    csrc/sdp_colfilter_kernel.h) and the workgroup shape that goes with it: one lane per node"""
     from stodynprog_amd import codegen
     _, s = models.synthetic3d(N=256)
     plan = s._kernel_plan()

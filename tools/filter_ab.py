@@ -1,5 +1,5 @@
 """A/B of the certified expectation-first filter of the column kernel (SdpColFilter in
-csrc/sdp_column_kernel.h): same problem with DPSolver.certified_filter on / off -- J, policy
+csrc/sdp_colfilter_kernel.h): same problem with DPSolver.certified_filter on / off -- J, policy
 index bit for bit, and kernel time per sweep.  Usage: python tools/filter_ab.py [N] [dtype]
 (SDP_STOCK_NOISE=c in the environment: the perturbation also reaches the stock, x0' = (x0 + b u) - c w)"""
 import os
