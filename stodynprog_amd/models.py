@@ -91,6 +91,32 @@ def inventory(api=None, h=0.5, p=3, c=1):
     return shop, solver
 
 
+def inventory_fine(api=None, n_x=600, n_u=257, n_w=16, h=0.5, p=3., c=1.):
+    """The shop inventory (ONE state variable, `x + u - w`: reference doc/example_inventory.py:31-33, cost :59-65) on a
+    finer grid with a continuous demand: the size where a 1-D problem is worth a kernel (DPSolver.embed_1d)."""
+    SysDescription, DPSolver = _classes(api)
+    shop = SysDescription((1, 1, 1), name='Shop inventory, fine grid')
+
+    def stock_dyn(x, u, w):
+        return (x + u - w,)
+    shop.dyn = stock_dyn
+    shop.perturb_laws = [NormalLaw(2.0, 0.8)]
+
+    def order_box(x):
+        return ((0., 8.),)
+    shop.control_box = order_box
+
+    def shop_cost(x, u, w):
+        return np.where(x > 0, x * h, -x * p) + u * c
+    shop.cost = shop_cost
+
+    solver = DPSolver(shop)
+    solver.discretize_state(-8., 24., n_x)
+    solver.discretize_perturb(0., 4., n_w)
+    solver.control_steps = (8. / (n_u - 1),)
+    return shop, solver
+
+
 def inventory_markov(api=None, n_x=128, n_d=32, n_w=9, h=0.5, p=3., c=1., x_max=24., order_max=10.,
                      order_step=0.25):
     """The shop inventory next to an exogenous demand level (two state variables): the stock follows
