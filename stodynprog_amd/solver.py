@@ -471,26 +471,8 @@ class DPSolver(object):
             return self.sys.control_box(*(lead + x), **params)
 
         def vectorised():
-            # open (sparse) grids: axis k has shape (1,..,N_k,..,1), so a box that
-            # ignores the state, or depends on one axis only, stays small
             d = len(shape)
-            open_grid = [np.asarray(g, dtype=float).reshape((1,) * k + (-1,) + (1,) * (d - k - 1))
-                         for k, g in enumerate(self.state_grid)]
-            with np.errstate(all='ignore'):
-                box = self.sys.control_box(*(lead + tuple(open_grid)), **params)
-            if len(box) != nu:
-                raise ValueError
-            ends = [(np.asarray(a, dtype=float), np.asarray(b, dtype=float)) for a, b in box]
-            constant = all(a.size == 1 and b.size == 1 for a, b in ends)
-            cols = 1 if constant else S
-            lo_v = np.empty((nu, cols))
-            hi_v = np.empty((nu, cols))
-            for c, (a, b) in enumerate(ends):
-                if constant:
-                    lo_v[c, 0], hi_v[c, 0] = a.reshape(()), b.reshape(())
-                else:
-                    lo_v[c] = np.broadcast_to(a, shape).ravel()
-                    hi_v[c] = np.broadcast_to(b, shape).ravel()
+            lo_v, hi_v, constant = self._box_whole_grid(t_k)
             # accepted only if it reproduces the scalar calls the reference makes: at EVERY
             # node of a small grid; on a large one along every grid line through the
             # corners and the centre (every distinct row / column of the open grid shows
@@ -515,6 +497,7 @@ class DPSolver(object):
             return lo_v, hi_v
 
         lo = hi = None
+        self._box_mode = None           # how the table was made: 'plain' / 'patched' whole-grid evaluation, or None (node by node)
         # 1) the callback as it is, on whole-grid arrays; 2) the same with
         # np.max / np.min of a TUPLE of operands read as an elementwise
         # maximum / minimum -- the idiom of every control_box of the reference's
@@ -532,6 +515,7 @@ class DPSolver(object):
                 got = None
             if got is not None:
                 lo, hi = got
+                self._box_mode = 'patched' if patch else 'plain'
                 break
         if lo is None:
             lo = np.empty((nu, S))
@@ -541,6 +525,11 @@ class DPSolver(object):
                 for c, (a, b) in enumerate(box):
                     lo[c, flat] = a
                     hi[c, flat] = b
+        return self._box_lattice(lo, hi)
+
+    def _box_lattice(self, lo, hi):
+        """(lo, hi, n) of the control lattice from the ends of the boxes, with control_grids' operators (sdp.py:446-453)"""
+        nu = len(self.sys.control)
         n = np.empty(lo.shape, dtype=np.int32)
         with np.errstate(all='ignore'):
             for c in range(nu):
@@ -553,6 +542,35 @@ class DPSolver(object):
                 lo[c] = np.where(single, mid, lo[c])
                 hi[c] = np.where(single, mid, hi[c])
         return lo, hi, n
+
+    def _box_whole_grid(self, t_k=None):
+        """the box callback on whole-grid arrays, as it is: (lo, hi, constant) with lo, hi of shape (nu, S) -- (nu, 1)
+        when the box ignores the state.  Open (sparse) grids: axis k has shape (1,..,N_k,..,1), so a box that ignores
+        the state, or depends on one axis only, stays small.  (The caller decides whether np.max / np.min of tuples are
+        patched, and whether the result can be trusted: _box_table.)"""
+        shape = self._shape()
+        S = int(np.prod(shape))
+        nu = len(self.sys.control)
+        d = len(shape)
+        lead = () if t_k is None else (t_k,)
+        open_grid = [np.asarray(g, dtype=float).reshape((1,) * k + (-1,) + (1,) * (d - k - 1))
+                     for k, g in enumerate(self.state_grid)]
+        with np.errstate(all='ignore'):
+            box = self.sys.control_box(*(lead + tuple(open_grid)), **self.sys.params)
+        if len(box) != nu:
+            raise ValueError
+        ends = [(np.asarray(a, dtype=float), np.asarray(b, dtype=float)) for a, b in box]
+        constant = all(a.size == 1 and b.size == 1 for a, b in ends)
+        cols = 1 if constant else S
+        lo_v = np.empty((nu, cols))
+        hi_v = np.empty((nu, cols))
+        for c, (a, b) in enumerate(ends):
+            if constant:
+                lo_v[c, 0], hi_v[c, 0] = a.reshape(()), b.reshape(())
+            else:
+                lo_v[c] = np.broadcast_to(a, shape).ravel()
+                hi_v[c] = np.broadcast_to(b, shape).ravel()
+        return lo_v, hi_v, constant
 
     def _fingerprint(self, t_k):
         s = self.sys
@@ -650,7 +668,7 @@ class DPSolver(object):
             lo, hi, n = (np.ascontiguousarray(a) for a in (lo, hi, n))
             digest = hash((lo.tobytes(), hi.tobytes(), n.tobytes()))
             bp = dict(lo=lo, hi=hi, n=n, per_node=per_node, max_u=max_u,
-                      lanes=codegen.lanes_for(max_u), digest=digest)
+                      lanes=codegen.lanes_for(max_u), digest=digest, mode=getattr(self, '_box_mode', None))
             if box_t is not None:           # one table per time step: keep only the latest
                 for k in [k for k in self._cache if k[0] == 'box']:
                     del self._cache[k]
@@ -666,12 +684,37 @@ class DPSolver(object):
         cached table; any difference rebuilds it."""
         shape = self._shape()
         S = int(np.prod(shape))
-        self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
-        rng = np.random.default_rng(self._box_probe_round)
-        probe = set(rng.integers(0, S, size=min(S, n_probe)).tolist())
-        probe.update([0, S - 1, S // 2])
-        lead = () if box_t is None else (box_t,)
         lo, hi, n = bp['lo'], bp['hi'], bp['n']
+        if bp.get('mode') and S <= 20000:
+            # A table made by ONE whole-grid call that reproduced the scalar calls at every node of this (small) grid:
+            # the same call again, compared at EVERY node -- a few tens of microseconds where 67 scalar calls took a
+            # millisecond, more than the kernels of the reference's own problem sizes -- and three scalar calls (the
+            # corners, the centre) as the reference would make them.
+            try:
+                if bp['mode'] == 'patched':
+                    with _TupleMinMax():
+                        lo_v, hi_v, constant = self._box_whole_grid(box_t)
+                else:
+                    lo_v, hi_v, constant = self._box_whole_grid(box_t)
+                lo_v, hi_v, n_v = self._box_lattice(lo_v, hi_v)
+            except Exception:
+                return False
+            if not bp['per_node']:
+                if not (np.all(lo_v == lo_v[:, :1]) and np.all(hi_v == hi_v[:, :1]) and np.all(n_v == n_v[:, :1])):
+                    return False
+                lo_v, hi_v, n_v = lo_v[:, :1], hi_v[:, :1], n_v[:, :1]
+            if lo_v.shape != lo.shape:
+                return False
+            same = lambda a, b: bool(np.all((a == b) | ((a != a) & (b != b))))
+            if not (same(lo_v, lo) and same(hi_v, hi) and np.array_equal(n_v, n)):
+                return False
+            probe = {0, S - 1, S // 2}
+        else:
+            self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
+            rng = np.random.default_rng(self._box_probe_round)
+            probe = set(rng.integers(0, S, size=min(S, n_probe)).tolist())
+            probe.update([0, S - 1, S // 2])
+        lead = () if box_t is None else (box_t,)
         try:
             for flat in probe:
                 ind = np.unravel_index(flat, shape)
@@ -708,6 +751,24 @@ class DPSolver(object):
         lanes = bp['lanes']
         debug = codegen.check_debug(self.debug_defines)
         W = len(self.perturb_grid[0]) if self.perturb_grid else 0
+        # The callables are traced afresh on every call (_trace_now), but a trace with the structure and the constants
+        # of the last one plans -- and generates -- the same unit: the plan is kept (the source text of a call was a
+        # fifth of a millisecond, as much as the kernels of the reference's own problem sizes).
+        memo = ('plan', self._fingerprint(None), bp['digest'], None if box_t is None else float(box_t),
+                model.structure_key(), np.asarray(model.param_values(), dtype=float).tobytes(),
+                model.param_index is not None, model.t_value, bool(self._cache.get('no_lead')))
+        kept = self._cache.get(memo)
+        if kept is not None:
+            return dict(kept, model=model)
+        plan = self._kernel_plan_now(box_t, model, bp, lanes, debug, W)
+        for k in [k for k in self._cache if k[0] == 'plan' and k[1:4] != memo[1:4]]:
+            del self._cache[k]                  # (another discretisation / box table: its plans are never asked for again)
+        self._cache[memo] = plan
+        return plan
+
+    def _kernel_plan_now(self, box_t, model, bp, lanes, debug, W):
+        shape = self._shape()
+        dt = self.dtype
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         if self.kernel not in ('auto', 'generic', 'column', 'staged', 'lead'):

@@ -485,6 +485,9 @@ class TracedModel(object):
         """Text identifying the live DAG up to the values of its real
         constants (two models with equal keys generate the same source once
         their constants are lifted)."""
+        kept = getattr(self, '_structure_key', None)
+        if kept is not None and kept[0] == (len(self.graph.nodes), self.param_index is not None):
+            return kept[1]
         live = self.live_nodes()
         pos = {n.id: i for i, n in enumerate(live)}
         parts = []
@@ -500,7 +503,9 @@ class TracedModel(object):
             else:
                 parts.append('{}({})'.format(n.op, ','.join(str(pos[a.id]) for a in n.args)))
         outs = [pos[n.id] for n in self.x_next] + [pos[self.cost.id]]
-        return ';'.join(parts) + '|' + ','.join(map(str, outs))
+        key = ';'.join(parts) + '|' + ','.join(map(str, outs))
+        self._structure_key = ((len(self.graph.nodes), self.param_index is not None), key)     # (the live DAG of a trace does not change)
+        return key
 
     def live_nodes(self):
         """Nodes reachable from the outputs, in topological (creation) order."""

@@ -325,3 +325,37 @@ def test_interpolator_loader_refuses_anything_but_data(tmp_path):
     path.write_bytes(pickle.dumps(Evil(), protocol=2))
     with pytest.raises(pickle.UnpicklingError):
         load_interpolator(str(path))
+
+
+@pytest.mark.parametrize('grid', [(41, 61), (200, 200)])
+def test_a_cached_control_box_table_notices_data_the_callback_reads(grid):
+    """The reference calls control_box at every node of every sweep (stodynprog.py:440); here the table is cached and
+    re-checked on every call: on a small grid by ONE whole-grid call compared at every node (plus three scalar calls), on a
+    large one by 67 scalar calls at the corners, the centre and a fresh random sample.  Module-level data the callback
+    reads may change between calls: the table follows."""
+    from stodynprog_amd import SysDescription, DPSolver
+    rated = {'P': 1.0}
+    sysd = SysDescription((2, 1, 1), name='storage')
+    sysd.dyn = lambda E, P, u, w: (E + u, 0.8 * P + w)
+    sysd.cost = lambda E, P, u, w: (P - u) * (P - u)
+    sysd.control_box = lambda E, P: ((np.max((-E, -rated['P'])), np.min((10. - E, rated['P']))),)
+    sysd.perturb_laws = [__import__('stodynprog_amd').models.NormalLaw(0, 0.5)]
+    s = DPSolver(sysd)
+    s.discretize_state(0, 10, grid[0], -2, 2, grid[1])
+    s.discretize_perturb(-1, 1, 5)
+    s.control_steps = (0.1,)
+    bp = s._box_plan()
+    small = grid[0] * grid[1] <= 20000
+    assert bp['mode'] == 'patched' and bp['per_node']
+    calls = []
+    inner = sysd.control_box
+    sysd._control_box = lambda E, P: (calls.append(1), inner(E, P))[1]
+    s._cache.clear()
+    bp = s._box_plan()
+    del calls[:]
+    assert s._box_plan() is bp                                   # unchanged data: the cached table, re-checked
+    assert len(calls) == (4 if small else 67) or (not small and 60 <= len(calls) <= 67)
+    rated['P'] = 0.5                                             # the data changes: the table is rebuilt
+    bp2 = s._box_plan()
+    assert bp2 is not bp and bp2['hi'].max() == 0.5 and bp['hi'].max() == 1.0
+    assert s._box_plan() is bp2
