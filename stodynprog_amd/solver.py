@@ -685,11 +685,12 @@ class DPSolver(object):
         shape = self._shape()
         S = int(np.prod(shape))
         lo, hi, n = bp['lo'], bp['hi'], bp['n']
-        if bp.get('mode') and S <= 20000:
-            # A table made by ONE whole-grid call that reproduced the scalar calls at every node of this (small) grid:
-            # the same call again, compared at EVERY node -- a few tens of microseconds where 67 scalar calls took a
-            # millisecond, more than the kernels of the reference's own problem sizes -- and three scalar calls (the
-            # corners, the centre) as the reference would make them.
+        if bp.get('mode') and (S <= 20000 or (S <= 200000 and not bp['per_node'])):     # (a box per node on a larger grid: the scalar calls below are cheaper -- measured)
+            # A table made by ONE whole-grid call that reproduced the scalar calls (at every node of a grid of up to
+            # 20 000 nodes, along the grid lines through corners and centre plus a sample beyond): the same call again,
+            # compared at EVERY node -- tens of microseconds where 67 scalar calls took a millisecond, more than the
+            # kernels of the reference's own problem sizes -- and a few scalar calls as the reference would make them
+            # (the corners and the centre; eight more nodes, a different sample every time, on the larger grids).
             try:
                 if bp['mode'] == 'patched':
                     with _TupleMinMax():
@@ -709,6 +710,9 @@ class DPSolver(object):
             if not (same(lo_v, lo) and same(hi_v, hi) and np.array_equal(n_v, n)):
                 return False
             probe = {0, S - 1, S // 2}
+            if S > 20000:
+                self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
+                probe.update(np.random.default_rng(self._box_probe_round).integers(0, S, size=8).tolist())
         else:
             self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
             rng = np.random.default_rng(self._box_probe_round)

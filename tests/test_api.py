@@ -327,11 +327,12 @@ def test_interpolator_loader_refuses_anything_but_data(tmp_path):
         load_interpolator(str(path))
 
 
-@pytest.mark.parametrize('grid', [(41, 61), (200, 200)])
+@pytest.mark.parametrize('grid', [(41, 61), (200, 200), (500, 500)])
 def test_a_cached_control_box_table_notices_data_the_callback_reads(grid):
     """The reference calls control_box at every node of every sweep (stodynprog.py:440); here the table is cached and
-    re-checked on every call: on a small grid by ONE whole-grid call compared at every node (plus three scalar calls), on a
-    large one by 67 scalar calls at the corners, the centre and a fresh random sample.  Module-level data the callback
+    re-checked on every call: on grids of up to 20 000 nodes (200 000 when the box ignores the state) by ONE whole-grid call
+    compared at every node (plus 3 .. 11 scalar calls), beyond that by 67 scalar calls at the corners, the centre and a fresh
+    random sample.  Module-level data the callback
     reads may change between calls: the table follows."""
     from stodynprog_amd import SysDescription, DPSolver
     rated = {'P': 1.0}
@@ -345,7 +346,7 @@ def test_a_cached_control_box_table_notices_data_the_callback_reads(grid):
     s.discretize_perturb(-1, 1, 5)
     s.control_steps = (0.1,)
     bp = s._box_plan()
-    small = grid[0] * grid[1] <= 20000
+    S = grid[0] * grid[1]
     assert bp['mode'] == 'patched' and bp['per_node']
     calls = []
     inner = sysd.control_box
@@ -354,7 +355,8 @@ def test_a_cached_control_box_table_notices_data_the_callback_reads(grid):
     bp = s._box_plan()
     del calls[:]
     assert s._box_plan() is bp                                   # unchanged data: the cached table, re-checked
-    assert len(calls) == (4 if small else 67) or (not small and 60 <= len(calls) <= 67)
+    # (+ the whole-grid call where there is one)
+    assert len(calls) == 4 if S <= 20000 else 60 <= len(calls) <= 67          # (a box per node: whole-grid calls on small grids only)
     rated['P'] = 0.5                                             # the data changes: the table is rebuilt
     bp2 = s._box_plan()
     assert bp2 is not bp and bp2['hi'].max() == 0.5 and bp['hi'].max() == 1.0
