@@ -675,13 +675,14 @@ class DPSolver(object):
             self._cache[key] = bp
         return bp
 
-    def _box_still_valid(self, bp, box_t, n_probe=64):
+    def _box_still_valid(self, bp, box_t, n_probe=21):
         """The reference calls control_box at every node of every sweep
         (stodynprog.py:440); here the table is cached, so module-level data the
         callback reads (a rated power, a capacity) could change unnoticed.  Each
         call re-evaluates the callback at `n_probe` nodes (the corners, the
         centre and a different random sample every time) and compares with the
-        cached table; any difference rebuilds it."""
+        cached table; any difference rebuilds it.  (24 nodes a call since round 5, 67 before: each scalar call of the
+        reference's own box callbacks takes ~13 microseconds, 67 of them more than the Searev kernel of the reference's size.)"""
         shape = self._shape()
         S = int(np.prod(shape))
         lo, hi, n = bp['lo'], bp['hi'], bp['n']
