@@ -477,8 +477,15 @@ class DPSolver(object):
             # node of a small grid; on a large one along every grid line through the
             # corners and the centre (every distinct row / column of the open grid shows
             # up there) plus a random sample
-            if S <= 20000:
+            if S <= 20000 and not trusted:
                 probe = range(S)
+            elif S <= 20000:
+                # (this callback's whole-grid form has reproduced the scalar calls at every node of this grid at another
+                # time index: a time step of a finite horizon checks the corners, the centre and a fresh sample -- at every
+                # node, the table of every step cost more than the step's kernel)
+                self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
+                probe = set(np.random.default_rng(self._box_probe_round).integers(0, S, size=min(S, 8)).tolist())
+                probe.update([0, S - 1, S // 2])
             else:
                 rng = np.random.default_rng(12345)
                 probe = set(rng.integers(0, S, size=256).tolist())
@@ -498,13 +505,15 @@ class DPSolver(object):
 
         lo = hi = None
         self._box_mode = None           # how the table was made: 'plain' / 'patched' whole-grid evaluation, or None (node by node)
+        seen_key = ('box whole-grid', self.sys.control_box, tuple(np.asarray(g, dtype=float).tobytes() for g in self.state_grid))
+        trusted = t_k is not None and self._cache.get(seen_key) is not None
         # 1) the callback as it is, on whole-grid arrays; 2) the same with
         # np.max / np.min of a TUPLE of operands read as an elementwise
         # maximum / minimum -- the idiom of every control_box of the reference's
         # examples (`np.max((-E/dt, -P_rated))`, AR1 notebook cell 15,
         # searev/storage_control.py:76-78), which is scalar-only as written;
         # 3) node by node, like the reference.
-        for patch in (False, True):
+        for patch in (((self._cache[seen_key] == 'patched'),) if trusted else (False, True)):     # (trusted: the form that was checked)
             try:
                 if patch:
                     with _TupleMinMax():
@@ -516,6 +525,8 @@ class DPSolver(object):
             if got is not None:
                 lo, hi = got
                 self._box_mode = 'patched' if patch else 'plain'
+                if t_k is not None and not trusted:
+                    self._cache[seen_key] = self._box_mode
                 break
         if lo is None:
             lo = np.empty((nu, S))
@@ -941,6 +952,11 @@ class DPSolver(object):
                 or not getattr(self, 'certified_filter', True) or self.arithmetic != 'exact'
                 or getattr(self, '_state_grid_shape', None) is None or self._state_grid_shape[0] < 3):
             return None
+        if not self.sys.perturb or not self.perturb_grid or len(self.perturb_grid[0]) < 1:
+            return None                     # (nothing random: the filter has nothing to save)
+        no_key = ('not lifted', self._fingerprint(None))
+        if self._cache.get(no_key):
+            return None                     # (planned before with these callables and grids: not the column family's)
         outer = self.sys
         key = ('lifted', outer.dyn, outer.cost, outer.control_box, _params_key(outer.params))
         inner = self._cache.get(key)
@@ -977,12 +993,17 @@ class DPSolver(object):
         inner.debug_defines, inner.host_overlap = self.debug_defines, self.host_overlap
         model = inner._trace_now(t_k)
         if isinstance(model, TraceError):
+            self._cache[no_key] = True
             return None
         try:
             plan = inner._kernel_plan(None if self.sys.stationnary else t_k, model)
         except Exception:
+            self._cache[no_key] = True
             return None
-        return inner if (plan['column'] and plan['filtered']) else None
+        if plan['column'] and plan['filtered']:
+            return inner
+        self._cache[no_key] = True
+        return None
 
     def _problem(self, t_k=None, model=None, embed=True):
         """Device problem for the current discretisation and callables.  The
