@@ -83,8 +83,8 @@ WORKLOADS = {
                    'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations (two controlled state variables)'),
     'reservoirs_f32': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float32', None,
                        'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations, fp32 (the wide form of the reduced-array filter)'),
-    # not a BASELINE config: ONE state variable (the reference's tutorial shape at a size worth a kernel): run as the same
-    # problem with an inert second state variable on the filtered column kernel (DPSolver.embed_1d)
+    # not a BASELINE config: ONE state variable (the reference's tutorial shape at a size worth a kernel): the direct kernel
+    # (grids of at most DPSolver.STAGED_MIN_NODES nodes and 1-D problems: round 5; the staged tiles took 0.95 ms here)
     'inventory1d': ('inventory_fine', dict(n_x=600, n_u=257, n_w=16), 'float64', None,
                     'shop inventory, one state variable: 600 nodes x 257 controls x 16 perturbations'),
     'coupled256': ('synthetic3d_coupled', dict(N=256), 'float64', None,
@@ -838,8 +838,6 @@ def finish_single(args, env, out):
                                 'kernel_family': s2.backend_info.get('kernel'),
                                 'certified_filter': bool(s2.backend_info.get('certified_filter')),
                                 'filter_form': s2.backend_info.get('filter_form')}
-                if s2.backend_info.get('embedded_1d'):
-                    others[name]['run_as'] = 'the same problem with an inert second state variable (DPSolver.embed_1d)'
                 for k_ in [k_ for k_ in s2._cache if k_[0] == 'problem']:
                     s2._cache.pop(k_).close()
             except Exception as e:

@@ -93,7 +93,7 @@ def inventory(api=None, h=0.5, p=3, c=1):
 
 def inventory_fine(api=None, n_x=600, n_u=257, n_w=16, h=0.5, p=3., c=1.):
     """The shop inventory (ONE state variable, `x + u - w`: reference doc/example_inventory.py:31-33, cost :59-65) on a
-    finer grid with a continuous demand: the size where a 1-D problem is worth a kernel (DPSolver.embed_1d)."""
+    finer grid with a continuous demand: a size where a 1-D problem is worth a kernel."""
     SysDescription, DPSolver = _classes(api)
     shop = SysDescription((1, 1, 1), name='Shop inventory, fine grid')
 

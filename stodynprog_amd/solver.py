@@ -29,7 +29,6 @@ import numpy as np
 from . import _native as nat
 from . import codegen
 from .interp import MlinInterpolator
-from .sysdesc import SysDescription
 from .trace import TraceError, trace_model
 
 __all__ = ['DPSolver']
@@ -212,75 +211,6 @@ class _DeviceProblem(object):
         return loop.value, kern.value
 
 
-class _Embedded1D(object):
-    """A problem with ONE state variable run as the same problem with a second, inert state variable (two grid points,
-    z' = z): what `DPSolver._problem` hands out when the column family takes the lifted problem (DPSolver._lifted_1d).
-    Arrays cross this object in the 1-D problem's shapes; the device problem behind it is the lifted solver's.
-    The cost-to-go of the second column is ZERO: the interpolation along z then computes 1 x V[r] + 0 x 0 -- V[r] itself
-    (also an infinite or NaN one) --, and what follows is the reference's 1-D arithmetic operation for operation."""
-
-    def __init__(self, prob):
-        self.p = prob
-        self.n0, self.nu, self.dtype = prob.shape[0], prob.nu, prob.dtype
-        self.shape, self.S = (self.n0,), self.n0
-        self.dev_shape = self.shape
-        self.info = dict(prob.info, embedded_1d=True)
-
-    h = property(lambda self: self.p.h)
-
-    def ref_flat(self, ref_ind):
-        return 2 * int(ref_ind[0])
-
-    def _lift(self, A, extra=()):
-        A = np.asarray(A, dtype=self.dtype).reshape((self.n0,) + extra)
-        out = np.zeros((self.n0, 2) + extra, dtype=self.dtype)
-        out[:, 0] = A
-        return out
-
-    def set_value(self, V):
-        self.p.set_value(self._lift(V))
-
-    def set_policy(self, pol):
-        L = self._lift(pol, (self.nu,))
-        L[:, 1] = L[:, 0]                                   # (any admissible control: the column is not read)
-        self.p.set_policy(L)
-
-    def set_params(self, values):
-        self.p.set_params(values)
-
-    def sweep(self, *a):
-        return self.p.sweep(*a)
-
-    def eval_policy(self, *a):
-        return self.p.eval_policy(*a)
-
-    def backup_host(self, V, t_k=0.0, rel_dp=False, ref_index=0, overlap=True):
-        J, pol, ref = self.p.backup_host(self._lift(V), t_k, rel_dp, ref_index, overlap)
-        return np.ascontiguousarray(J[:, 0]), np.ascontiguousarray(pol[:, 0]), ref
-
-    def get_index(self):
-        return np.ascontiguousarray(self.p.get_index()[:, 0])
-
-    def swap(self):
-        self.p.swap()
-
-    def complete(self):
-        self.p.complete()
-
-    def get_value(self):
-        return np.ascontiguousarray(self.p.get_value()[:, 0])
-
-    def get_policy(self):
-        pol, idx = self.p.get_policy()
-        return np.ascontiguousarray(pol[:, 0]), np.ascontiguousarray(idx[:, 0])
-
-    def last_kernel_ms(self):
-        return self.p.last_kernel_ms()
-
-    def bench_sweeps(self, *a):
-        return self.p.bench_sweeps(*a)
-
-
 class DPSolver(object):
     # Diagnostic / A-B switches of the generated kernels (codegen.DEBUG_NAMES): None in the product.
     # Tests and tools/ set a dict here (on an instance, or on the class for a block of solvers);
@@ -292,11 +222,7 @@ class DPSolver(object):
     # and then the downloads.  Same arrays either way.
     host_overlap = True
     _debug_after_create = None
-    # One state variable (the reference's tutorial and `det/` examples): the column family needs an exogenous axis next
-    # to the stock, so the problem is run as the same problem with a second, inert state variable where that gets
-    # the filtered column kernel (_lifted_1d, _Embedded1D): same J, policy and index, 9 - 20 x less time at 600 - 2000 nodes.
-    # False: the LDS-staged tile kernel, as before round 5.
-    embed_1d = True
+    STAGED_MIN_NODES = 65536          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now)
 
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
@@ -872,7 +798,13 @@ class DPSolver(object):
         if self.arithmetic not in ('exact', 'fused'):
             raise ValueError("arithmetic must be 'exact' or 'fused'")
         staged = None
-        if not column and not lead_axes and self.kernel in ('auto', 'staged'):
+        # The staged kernel gives a node to a thread, the direct one to `lanes` of them: below ~1e5 nodes the staged tiles
+        # do not fill the chip and the value array sits in the caches anyway.  Measured in round 5 (staged / direct):
+        # 1-D inventory 600 nodes x 257 controls x 16 w 0.95 / 0.023 ms, 4096 x 1025 x 32 6.9 / 0.23 ms, 65 536 x 1025 x 16
+        # 7.8 / 3.3 ms, 262 144 x 257 x 16 5.0 / 4.2 ms; control-coupled 3-D 16^3 0.85 / 0.037 ms, 32^3 0.87 / 0.25 ms,
+        # 64^3 1.42 / 2.05 ms.  So: one state variable, or at most STAGED_MIN_NODES nodes -> the direct kernel.
+        small = len(shape) == 1 or int(np.prod(shape)) <= self.STAGED_MIN_NODES
+        if not column and not lead_axes and (self.kernel == 'staged' or (self.kernel == 'auto' and not small)):
             key = ('staged', model.structure_key(), bp['digest'], str(dt), shape, W, _dbg_key(debug))
             staged = self._cache.get(key)
             if staged is None:
@@ -944,68 +876,7 @@ class DPSolver(object):
             return int(np.ceil(np.abs(rows - idx[0][None, :]).max())) + 1
         return int(np.ceil((rows.max(axis=0) - rows.min(axis=0)).max())) + 1
 
-    def _lifted_1d(self, t_k):
-        """The solver of the same problem with a second, inert state variable -- when this problem has one state
-        variable, runs on one GPU with the planner's choice of kernel, and the lifted problem gets the filtered column
-        kernel -- or None.  The lifted system's callables wrap THESE callables (a new lifted solver when they change)."""
-        if (len(self.sys.state) != 1 or not self.embed_1d or self.comm is not None or self.kernel != 'auto'
-                or not getattr(self, 'certified_filter', True) or self.arithmetic != 'exact'
-                or getattr(self, '_state_grid_shape', None) is None or self._state_grid_shape[0] < 3):
-            return None
-        if not self.sys.perturb or not self.perturb_grid or len(self.perturb_grid[0]) < 1:
-            return None                     # (nothing random: the filter has nothing to save)
-        no_key = ('not lifted', self._fingerprint(None))
-        if self._cache.get(no_key):
-            return None                     # (planned before with these callables and grids: not the column family's)
-        outer = self.sys
-        key = ('lifted', outer.dyn, outer.cost, outer.control_box, _params_key(outer.params))
-        inner = self._cache.get(key)
-        if inner is None:
-            dyn, cost, box, first = outer.dyn, outer.cost, outer.control_box, 0 if outer.stationnary else 1
-
-            def lifted_dyn(*a, **kw):
-                out = dyn(*(a[:first + 1] + a[first + 2:]), **kw)
-                x1 = out[0] if isinstance(out, (tuple, list)) else out
-                return (x1, a[first + 1])
-
-            def lifted_cost(*a, **kw):
-                return cost(*(a[:first + 1] + a[first + 2:]), **kw)
-
-            def lifted_box(*a, **kw):
-                return box(*a[:first + 1], **kw)
-            lifted = SysDescription((2, len(outer.control), len(outer.perturb)), stationnary=outer.stationnary,
-                                    name=(outer.name or '') + ' [1-D, lifted]', params=outer.params)
-            lifted.state = [outer.state[0], '_inert']
-            lifted.control, lifted.perturb = list(outer.control), list(outer.perturb)
-            lifted._dyn_args = ([] if outer.stationnary else ['time_k']) + lifted.state + lifted.control + lifted.perturb
-            lifted._dyn, lifted._cost, lifted._control_box = lifted_dyn, lifted_cost, lifted_box
-            lifted._perturb_laws, lifted.perturb_types = outer._perturb_laws, getattr(outer, 'perturb_types', None)
-            inner = DPSolver(lifted, self.dtype)
-            inner.embed_1d = False
-            self._cache[key] = inner
-        inner.sys.params = outer.params
-        inner.state_grid = [np.asarray(self.state_grid[0]), np.array([0., 1.])]
-        inner._state_grid_shape = (self._state_grid_shape[0], 2)
-        inner._state_ref_ind = (self._state_ref_ind[0], 0)
-        inner._state_ref = (self._state_ref[0], 0.)
-        inner.perturb_grid, inner.perturb_proba = self.perturb_grid, self.perturb_proba
-        inner.control_steps, inner.dtype = self.control_steps, self.dtype
-        inner.debug_defines, inner.host_overlap = self.debug_defines, self.host_overlap
-        model = inner._trace_now(t_k)
-        if isinstance(model, TraceError):
-            self._cache[no_key] = True
-            return None
-        try:
-            plan = inner._kernel_plan(None if self.sys.stationnary else t_k, model)
-        except Exception:
-            self._cache[no_key] = True
-            return None
-        if plan['column'] and plan['filtered']:
-            return inner
-        self._cache[no_key] = True
-        return None
-
-    def _problem(self, t_k=None, model=None, embed=True):
+    def _problem(self, t_k=None, model=None):
         """Device problem for the current discretisation and callables.  The
         handle is reused from call to call (and from time step to time step)
         as long as the generated source and the control-box table are the
@@ -1016,12 +887,6 @@ class DPSolver(object):
             model = self._trace_now(t_k)
         if isinstance(model, TraceError):
             raise model
-        if embed:
-            inner = self._lifted_1d(t_k)
-            if inner is not None:
-                prob = _Embedded1D(inner._problem(t_k))
-                self.backend_info = dict(inner.backend_info, embedded_1d=True)
-                return prob
         plan = self._kernel_plan(box_t, model)
         fp = ('problem', self._fingerprint(None), plan['box_digest'],
               codegen.source_key(plan['source']))
@@ -1238,8 +1103,6 @@ class DPSolver(object):
 
     def _ref_flat(self, prob=None):
         """flat C-order index of the relative-DP reference node (sdp.py:384)"""
-        if isinstance(prob, _Embedded1D):
-            return prob.ref_flat(self._state_ref_ind)
         return int(np.ravel_multi_index(self._state_ref_ind, self._shape()))
 
     # ------------------------------------------------------------ value iteration
@@ -1695,7 +1558,7 @@ class DPSolver(object):
         if isinstance(model, TraceError) or (model.t_value is not None):
             x, u, g = self._simulate_host(pol, x0, w, T, t0)
         else:
-            prob = self._problem(t_trace, model, embed=False)     # (trajectories of the problem as written)
+            prob = self._problem(t_trace, model)
             dt = self.dtype
             pol_d = np.ascontiguousarray(np.moveaxis(pol, -1, 0), dtype=dt)        # [nu][S]
             x0_d = np.ascontiguousarray(x0.T, dtype=dt)                             # [d][B]

@@ -38,11 +38,14 @@ CASES = [('synthetic3d', dict(N=20), 'column'),
          ('nas_demo', dict(), None),
          ('inventory', dict(), None),
          ('synthetic3d_coupled', dict(N=20), 'column'),              # table per control
-         ('synthetic3d_coupled', dict(N=18, cross=0.2), 'staged')]   # LDS-staged tiles
+         ('synthetic3d_coupled', dict(N=18, cross=0.2), 'generic'),  # a small grid: the direct kernel (round 5)
+         ('synthetic3d_coupled', dict(N=18, cross=0.2), 'staged')]   # LDS-staged tiles (asked for: the planner keeps them for grids beyond 65 536 nodes)
 for name, kw, kernel in CASES:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
     two.comm = comm
+    if kernel == 'staged':
+        one.kernel = two.kernel = 'staged'
     shape = one._state_grid_shape
     V0 = rng.standard_normal(shape)
     J1, p1 = one.value_iteration(V0, report_time=False)

@@ -336,19 +336,28 @@ def test_kernel_family_planning_without_a_gpu():
     plan = c._kernel_plan()
     assert plan['column'] and plan['per_control'] and '#define SDP_TRAIL_HAS_U 1' in plan['source']
     assert '#define SDP_COL_WCHUNK' in plan['source'] and plan['col_seg_nodes'] in (64, 128, 256, 512)
-    # x1 also depends on x0: nothing to share along a column -> LDS-staged tiles
+    # x1 also depends on x0: nothing to share along a column -> LDS-staged tiles on a grid of more than
+    # DPSolver.STAGED_MIN_NODES nodes, the direct kernel (`lanes` threads per node) on a smaller one (round 5: a thread per
+    # node does not fill the chip there -- 32^3: 0.87 ms staged, 0.25 ms direct)
     _, f = models.synthetic3d_coupled(N=32, cross=0.3)
     assert not f._traced().column_shareable
+    plan = f._kernel_plan()
+    assert not plan['column'] and plan['staged'] is None and not plan['lead_axes']
+    _, f = models.synthetic3d_coupled(N=48, cross=0.3)
     plan = f._kernel_plan()
     st = plan['staged']
     assert not plan['column'] and st['threads'] == int(np.prod(st['tile'])) == 512
     assert 1 <= st['cu'] <= 8 and 1 <= st['cw'] <= 32 and st['cap'] * 8 <= codegen.STAGED_LDS_BYTES
     for macro in ('SDP_STG_THREADS 512', 'SDP_STG_T0 8', 'SDP_STG_CU', 'SDP_STG_CW', 'SDP_STG_CAP'):
         assert '#define ' + macro in plan['source']
-    # 1-D problems (no column): staged
+    # 1-D problems (no column): the direct kernel whatever the size of the grid; the staged tiles when asked for
     _, inv = models.inventory()
     plan = inv._kernel_plan()
-    assert not plan['column'] and plan['staged']['tile'] == (512,)
+    assert not plan['column'] and plan['staged'] is None
+    _, fine = models.inventory_fine(n_x=200000)
+    assert fine._kernel_plan()['staged'] is None
+    inv.kernel = 'staged'
+    assert inv._kernel_plan()['staged']['tile'] == (512,)
     # forcing a family
     c.kernel = 'staged'
     assert c._kernel_plan()['staged'] is not None

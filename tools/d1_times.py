@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """One state variable (the reference's tutorial and `det/` examples are 1-D; VERDICT r04: "d = 1 problems never enter
 the column family ... a cliff for a fine 1-D grid with thousands of controls per node"): what such problems cost on the
-kernel they get -- since round 5 the filtered column kernel on the problem lifted by an inert second state variable where
-its table fits the LDS (DPSolver._lifted_1d), the LDS-staged tile kernel otherwise and with `embed_1d = False` --, fine grids
-and thousands of controls included.  Kernel time per sweep by
+kernel they get -- since round 5 the direct kernel (`lanes` threads per node), before that the LDS-staged tile kernel (a
+thread per node: 30 - 60 x slower at these sizes) --, fine grids and thousands of controls included.  Kernel time per sweep by
 HIP events, lattice cells (node x control x perturbation point) per second beside it."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -55,11 +54,10 @@ for name, make, cells in (
         ('inventory 4096 nodes x 1025 controls x 32 w', lambda: inventory(4096, 1025, 32), 4096 * 1025 * 32),
         ('inventory 65536 nodes x 4097 controls x 16 w', lambda: inventory(65536, 4097, 16), 65536 * 4097 * 16),
         ('storage 65536 nodes x 4097 controls x 8 w', lambda: storage(65536, 4097), 65536 * 4097 * 8)):
-    for embed in (True, False):
+    for kernel in ('auto', 'staged'):
         s = make()
-        s.embed_1d = embed                 # (True: the default -- the lifted problem where the column family takes it)
+        s.kernel = kernel                  # ('auto': the direct kernel for one state variable since round 5; 'staged': what ran before)
         V = np.zeros(s._state_grid_shape)
         ms, info = sweep_ms(s, V)
-        print('{:50s} {:9s} sweep {:9.3f} ms  ({:.3g} lattice cells, {:.3g} cells/s, kernel {}, filter {})'.format(
-            name, 'default' if embed else 'as written', ms, float(cells), cells / ms * 1e3, info['kernel'] + (' (lifted)' if info.get('embedded_1d') else ''),
-            info['certified_filter']))
+        print('{:50s} {:7s} sweep {:9.3f} ms  ({:.3g} lattice cells, {:.3g} cells/s, kernel {})'.format(
+            name, kernel, ms, float(cells), cells / ms * 1e3, info['kernel']))
