@@ -223,6 +223,7 @@ class DPSolver(object):
     host_overlap = True
     _debug_after_create = None
     STAGED_MIN_NODES = 65536          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now)
+    PERCONTROL_MIN_NODES = 32768      # 'auto': .. and grids of fewer nodes than this the direct kernel rather than a table per control
 
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
@@ -769,8 +770,11 @@ class DPSolver(object):
         # trailing next states that depend on the control but not on x0: the nodes of a
         # column still share a table, control by control, provided they share their control
         # values (box independent of x0) -- csrc/sdp_column_kernel.h, SDP_TRAIL_HAS_U
+        # (on a grid of fewer than PERCONTROL_MIN_NODES nodes the direct kernel is faster than a table per control: 16^3
+        # 0.160 / 0.036 ms, 24^3 0.224 / 0.101 ms, 32^3 0.242 / 0.251 ms, 48^3 0.46 / 0.95 ms -- round 5)
         per_control = (not column and not lead_axes and self.kernel in ('auto', 'column') and model.column_shareable
                        and model.trail_depends_on_u and self.arithmetic == 'exact'
+                       and (self.kernel == 'column' or int(np.prod(shape)) >= self.PERCONTROL_MIN_NODES)
                        and self._box_constant_along_axis0(bp, shape))
         per_control_cfg = None
         if per_control:

@@ -44,8 +44,8 @@ for name, kw, kernel in CASES:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)
     two.comm = comm
-    if kernel == 'staged':
-        one.kernel = two.kernel = 'staged'
+    if kernel == 'staged' or name == 'synthetic3d_coupled' and kernel == 'column':
+        one.kernel = two.kernel = kernel              # (small grids: the planner itself picks the direct kernel)
     shape = one._state_grid_shape
     V0 = rng.standard_normal(shape)
     J1, p1 = one.value_iteration(V0, report_time=False)

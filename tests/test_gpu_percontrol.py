@@ -46,7 +46,7 @@ def _check_same(a, b):
 
 def test_control_coupled_benchmark_runs_the_per_control_table(gpu):
     make = lambda: models.synthetic3d_coupled(N=24)
-    auto = _run(make, 'auto')
+    auto = _run(make, 'column')
     assert auto[3].backend_info['kernel'] == 'column' and auto[3].backend_info['table_per_control']
     _check_same(auto, _run(make, 'generic'))
     _check_same(auto, _run(make, 'staged'))
@@ -54,7 +54,7 @@ def test_control_coupled_benchmark_runs_the_per_control_table(gpu):
 
 def test_against_the_numpy_oracle(gpu):
     from oracle import vi_numpy
-    J, pol, idx, s, V = _run(lambda: models.synthetic3d_coupled(N=20), 'auto',
+    J, pol, idx, s, V = _run(lambda: models.synthetic3d_coupled(N=20), 'column',
                              V=models.synthetic3d_V0(models.synthetic3d_coupled(N=20)[1].state_grid))
     assert s.backend_info['table_per_control']
     nodes = np.arange(0, V.size, 11)
@@ -65,14 +65,14 @@ def test_against_the_numpy_oracle(gpu):
 
 def test_more_nodes_per_column_than_threads_two_controls(gpu):
     """600 nodes along axis 0 > 512 threads: the column is split over workgroups"""
-    auto = _run(_price_maker, 'auto')
+    auto = _run(_price_maker, 'column')
     assert auto[3].backend_info['table_per_control'], auto[3].backend_info
     _check_same(auto, _run(_price_maker, 'generic'))
 
 
 def test_box_may_depend_on_the_trailing_state_but_not_on_the_stock(gpu):
     make = lambda: _price_maker(n_E=40, box_on_price=True)
-    auto = _run(make, 'auto')
+    auto = _run(make, 'column')
     assert auto[3].backend_info['table_per_control'] and auto[3].backend_info['box_per_node']
     _check_same(auto, _run(make, 'generic'))
     # a box that depends on the stock: the nodes of a column no longer share their controls
@@ -87,7 +87,7 @@ def test_box_may_depend_on_the_trailing_state_but_not_on_the_stock(gpu):
 def test_eval_policy_and_relative_dp(gpu):
     make = lambda: _price_maker(n_E=48)
     Ja, pa, ia, one, V = _run(make, 'generic')
-    Jb, pb, ib, two, _ = _run(make, 'auto')
+    Jb, pb, ib, two, _ = _run(make, 'column')
     assert two.backend_info['table_per_control']
     Ea, fa = one.eval_policy(pa, 4, rel_dp=True, report_time=False, J_ref_full=True)
     Eb, fb = two.eval_policy(pb, 4, rel_dp=True, report_time=False, J_ref_full=True)
@@ -109,7 +109,7 @@ def test_deterministic_and_float32_per_control_tables(gpu):
         s.discretize_state(0, 10, 70, -2, 2, 9)
         s.control_steps = (0.125,)
         return sysd, s
-    auto = _run(make_det, 'auto')
+    auto = _run(make_det, 'column')
     assert auto[3].backend_info['table_per_control']
     _check_same(auto, _run(make_det, 'generic'))
 
@@ -118,6 +118,6 @@ def test_deterministic_and_float32_per_control_tables(gpu):
         s.dtype = np.dtype(np.float32)
         return sysd, s
     V = models.synthetic3d_V0(make32()[1].state_grid, np.float32)
-    auto = _run(make32, 'auto', V=V)
+    auto = _run(make32, 'column', V=V)
     assert auto[3].backend_info['table_per_control'] and auto[0].dtype == np.float32
     _check_same(auto, _run(make32, 'generic', V=V))
