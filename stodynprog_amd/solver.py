@@ -222,7 +222,8 @@ class DPSolver(object):
     # and then the downloads.  Same arrays either way.
     host_overlap = True
     _debug_after_create = None
-    STAGED_MIN_NODES = 65536          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now)
+    STAGED_MIN_NODES = 32768          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now);
+    STAGED_MIN_WORK = 1024            #         up to 4 x as many where a node has this many control x perturbation points or more
     PERCONTROL_MIN_NODES = 32768      # 'auto': .. and grids of fewer nodes than this the direct kernel rather than a table per control
 
     def __init__(self, sys, dtype=np.float64, comm=None):
@@ -806,8 +807,13 @@ class DPSolver(object):
         # do not fill the chip and the value array sits in the caches anyway.  Measured in round 5 (staged / direct):
         # 1-D inventory 600 nodes x 257 controls x 16 w 0.95 / 0.023 ms, 4096 x 1025 x 32 6.9 / 0.23 ms, 65 536 x 1025 x 16
         # 7.8 / 3.3 ms, 262 144 x 257 x 16 5.0 / 4.2 ms; control-coupled 3-D 16^3 0.85 / 0.037 ms, 32^3 0.87 / 0.25 ms,
-        # 64^3 1.42 / 2.05 ms.  So: one state variable, or at most STAGED_MIN_NODES nodes -> the direct kernel.
-        small = len(shape) == 1 or int(np.prod(shape)) <= self.STAGED_MIN_NODES
+        # 40^3 0.88 / 0.46 ms, 48^3 0.92 / 0.88 ms, 64^3 1.42 / 2.05 ms; coupled 2-D, 65 controls x 9 w: 128^2 0.196 / 0.069 ms,
+        # 256^2 0.218 / 0.288 ms, 512^2 0.34 / 1.26 ms; the same with 1025 controls: 256^2 3.04 / 1.46 ms, 512^2 4.5 / 5.9 ms.
+        # So the direct kernel for one state variable, for grids of at most STAGED_MIN_NODES nodes, and up to four times
+        # that where a node has STAGED_MIN_WORK control x perturbation points or more (few threads with long loops).
+        S_nodes = int(np.prod(shape))
+        small = (len(shape) == 1 or S_nodes <= self.STAGED_MIN_NODES
+                 or (S_nodes <= 4 * self.STAGED_MIN_NODES and bp['max_u'] * max(W, 1) >= self.STAGED_MIN_WORK))
         if not column and not lead_axes and (self.kernel == 'staged' or (self.kernel == 'auto' and not small)):
             key = ('staged', model.structure_key(), bp['digest'], str(dt), shape, W, _dbg_key(debug))
             staged = self._cache.get(key)

@@ -39,7 +39,7 @@ CASES = [('synthetic3d', dict(N=20), 'column'),
          ('inventory', dict(), None),
          ('synthetic3d_coupled', dict(N=20), 'column'),              # table per control
          ('synthetic3d_coupled', dict(N=18, cross=0.2), 'generic'),  # a small grid: the direct kernel (round 5)
-         ('synthetic3d_coupled', dict(N=18, cross=0.2), 'staged')]   # LDS-staged tiles (asked for: the planner keeps them for grids beyond 65 536 nodes)
+         ('synthetic3d_coupled', dict(N=18, cross=0.2), 'staged')]   # LDS-staged tiles (asked for: the planner keeps them for large grids)
 for name, kw, kernel in CASES:
     _, one = getattr(models, name)(**kw)
     _, two = getattr(models, name)(**kw)

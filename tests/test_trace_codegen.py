@@ -341,14 +341,15 @@ def test_kernel_family_planning_without_a_gpu():
     plan = c._kernel_plan()
     assert plan['column'] and plan['per_control'] and '#define SDP_TRAIL_HAS_U 1' in plan['source']
     assert '#define SDP_COL_WCHUNK' in plan['source'] and plan['col_seg_nodes'] in (64, 128, 256, 512)
-    # x1 also depends on x0: nothing to share along a column -> LDS-staged tiles on a grid of more than
-    # DPSolver.STAGED_MIN_NODES nodes, the direct kernel (`lanes` threads per node) on a smaller one (round 5: a thread per
-    # node does not fill the chip there -- 32^3: 0.87 ms staged, 0.25 ms direct)
+    # x1 also depends on x0: nothing to share along a column -> LDS-staged tiles on a large grid, the direct kernel
+    # (`lanes` threads per node) on a small one (round 5: a thread per node does not fill the chip there -- 32^3: 0.87 ms
+    # staged, 0.25 ms direct; 48^3, 64 x 32 lattice points per node: 0.92 / 0.88 ms; DPSolver.STAGED_MIN_NODES, STAGED_MIN_WORK)
     _, f = models.synthetic3d_coupled(N=32, cross=0.3)
     assert not f._traced().column_shareable
     plan = f._kernel_plan()
     assert not plan['column'] and plan['staged'] is None and not plan['lead_axes']
-    _, f = models.synthetic3d_coupled(N=48, cross=0.3)
+    assert models.synthetic3d_coupled(N=48, cross=0.3)[1]._kernel_plan()['staged'] is None       # 110 592 nodes x 2048 points
+    _, f = models.synthetic3d_coupled(N=56, cross=0.3)
     plan = f._kernel_plan()
     st = plan['staged']
     assert not plan['column'] and st['threads'] == int(np.prod(st['tile'])) == 512
