@@ -34,7 +34,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 DEBUG_INT_MACROS = ('SDP_COL_SHARE_X2', 'SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'SDP_COL_WMODE', 'SDP_COL_UNROLL_U', 'SDP_COL_UNROLL_W',
                     'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO',
                     'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE',
-                    'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP', 'SDP_COL_LDS_PAD', 'SDP_COL_HOIST')
+                    'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP', 'SDP_COL_LDS_PAD', 'SDP_COL_HOIST',
+                    'SDP_COL_TAIL_KEEP', 'SDP_COL_KEEP_BATCH', 'SDP_COL_KEEP_LOADS')
 # (SDP_COL_LEAN2 = 0 keeps the resident-chunk kernel on the first pass of section 3.1c: an A/B switch of short_pass_source)
 # (SDP_COL_WRES is a planning switch: it sizes the LDS image -- column_config)
 # every name a `debug` dict may carry (a typo must not pass silently)

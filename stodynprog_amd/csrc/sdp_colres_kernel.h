@@ -36,6 +36,22 @@ static_assert(!SDP_COL_TOP2 || SDP_COL_SHIFT, "resident chunks: two carried surv
 static_assert(SDP_COL_WRES >= 1 && 2 * SDP_COL_WRES >= SDP_COL_W, "resident chunks: at least half of the points resident");
 constexpr int SDP_COLRES_K = SDP_COL_TOP2 ? 2 : 1;        // survivors a lane can carry through the rebuild of the tail
 
+// SDP_COL_TAIL_KEEP (round 6): the tail is built ONCE.  Its first build also stores the entries to a block of global memory
+// private to the workgroup (SdpSweepArgs.tail: (W - C) x N0 reals, rewritten every column, so it lives in L2 / the Infinity
+// Cache), and the second pass reads the survivor's T[w][q0], T[w][q0+1], w = C .. W-1, back from there: 2 (W - C) coalesced
+// 8-byte loads per node (neighbouring lanes: neighbouring rows) in place of (W - C) N0 / threads rebuilt entries per thread
+// (4 strip loads and 9 operations each) and the two barriers around them.  The entries are the reference's values either
+// way -- the same SdpColNest on the same operands -- so nothing changes in J, policy or index.  A workgroup's waves run on
+// one CU and share its vector L1 (write-through), and every build is followed by a workgroup barrier before anything reads:
+// the block needs no fence beyond __syncthreads().
+#ifndef SDP_COL_TAIL_KEEP
+#define SDP_COL_TAIL_KEEP 0
+#endif
+#if SDP_COL_TAIL_KEEP && (SDP_COL_SHIFT || !SDP_COL_A_WIDE_LOADS || SDP_COL_A_ORDER != 2 || SDP_COL_WPAIR)
+#error "SDP_COL_TAIL_KEEP: the plain resident-chunk kernel with 16-byte build loads"
+#endif
+#define SDP_COLRES_TAIL_BYTES (SDP_COL_TAIL_KEEP ? (SDP_COL_W - SDP_COL_WRES) * SDP_COL_ROWS * (int)sizeof(sdp_real) : 0)
+
 // cell of x0' along axis 0 of one control for the perturbation point value `wv`, as sdp_col_expected_cost computes it (pyx:75-81)
 SDP_DEV void sdp_colres_cell(const SdpLeadAxis &l, const sdp_real *x, const sdp_real *u, sdp_real wv, sdp_real t,
                              int &q0, sdp_real &lam0, sdp_real &oml0)
@@ -101,6 +117,50 @@ SDP_DEV void sdp_colres_partial(const sdp_real *T, const SdpColWeights &k, const
             }
     }
 }
+
+#if SDP_COL_TAIL_KEEP
+// sdp_colres_partial<1> for the points [w_lo, w_hi) with the table rows read from the workgroup's block of global
+// memory (row w - w_lo of `G`): the loads of SDP_COL_KEEP_BATCH points are in flight together.
+#ifndef SDP_COL_KEEP_BATCH
+#define SDP_COL_KEEP_BATCH 8
+#endif
+#ifndef SDP_COL_KEEP_LOADS
+#define SDP_COL_KEEP_LOADS 0
+#endif
+SDP_DEV void sdp_colres_partial_kept(const sdp_real *__restrict__ G, const SdpColWeights &k, const int w_lo, const int w_hi,
+                                     SdpColresCand &c)
+{
+    constexpr int N0 = SDP_COL_ROWS;
+    constexpr int B = SDP_COL_KEEP_BATCH;
+    const sdp_real *__restrict__ g0 = G + c.q0[0];
+#pragma unroll
+    for (int w0 = w_lo; w0 < w_hi; w0 += B) {
+        sdp_real lo[B], hi[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (w0 + b < w_hi) {
+#if SDP_COL_KEEP_LOADS == 1          // plain loads
+                lo[b] = g0[(w0 + b - w_lo) * N0];
+                hi[b] = g0[(w0 + b - w_lo) * N0 + 1];
+#elif SDP_COL_KEEP_LOADS == 2        // past the vector L1 (sc1)
+                lo[b] = __hip_atomic_load(g0 + (w0 + b - w_lo) * N0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[b] = __hip_atomic_load(g0 + (w0 + b - w_lo) * N0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                lo[b] = __builtin_nontemporal_load(g0 + (w0 + b - w_lo) * N0);
+                hi[b] = __builtin_nontemporal_load(g0 + (w0 + b - w_lo) * N0 + 1);
+#endif
+            }
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+            if (w0 + b < w_hi) {
+                const sdp_real pw = SDP_COL_PW(k, w0 + b);
+                const sdp_real val = c.oml0[0] * lo[b] + c.lam0[0] * hi[b];            // pyx:88-300
+                const sdp_real jc = c.g[0] + val;                                      // stodynprog.py:677
+                c.acc[0] = c.acc[0] + jc * pw;                                         // stodynprog.py:681, w order
+            }
+    }
+}
+#endif
 
 #if SDP_COL_LEAN2
 // ---------------------------------------------------------------------------
@@ -212,6 +272,11 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     sdp_col_load_weights(a, wts, sdp_lds.pw, sdp_lds.gw);
     SdpColFilter filt;
     sdp_col_filter_setup(a, filt);
+#if SDP_COL_TAIL_KEEP
+    sdp_real *__restrict__ kept = (sdp_real *)((char *)a.tail + (size_t)blockIdx.x * (size_t)SDP_COLRES_TAIL_BYTES);
+#else
+    sdp_real *kept = nullptr;
+#endif
     const int axis_mode = __builtin_amdgcn_readfirstlane(sdp_col_axis_mode(lead));
     const sdp_cst_real *pw = (const sdp_cst_real *)a.proba;
     // (what is the same in every lane for the whole kernel lives in scalar registers: sdp_uniform)
@@ -300,7 +365,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_shift_col(sdp_lds, lead, upar, shc);
         sdp_col_shift_zero(sdp_lds, shc);
 #endif
-        sdp_col_phase_a<false>(a, tg, s, C, R);
+        sdp_col_phase_a<false>(a, tg, s, C, R, kept);
         __syncthreads();
 #if SDP_COL_SHIFT
         sdp_col_shift_reduce(a, sdp_lds, filt, shc, parity, upar, C, R);         // (adds into the cleared lattice)
@@ -514,6 +579,14 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         const bool two = SDP_COLRES_K > 1 && __any(cd.n == 2);
         if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
         else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
+#if SDP_COL_TAIL_KEEP
+        // ---- second pass over the tail, from the copy its first build left in global memory (no barrier: the table
+        // is not touched again before the top of the next unit)
+        if (cd.n) sdp_colres_partial_kept(kept, wts, C, Wn, cd);
+#ifdef SDP_DIAG_KEEP_BARRIER
+        __syncthreads();
+#endif
+#else
         __syncthreads();                                   // the head has been read
         // ---- the tail again, second pass over it
         __builtin_amdgcn_s_setprio(0);
@@ -522,6 +595,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
         if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
         else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
+#endif
         if (live) {
             // the carried survivors in lattice order, compared like the reference compares
 #pragma unroll

@@ -493,10 +493,12 @@ SDP_DEV double sdp_wave_sum(double v) { return __ockl_wfred_add_f64(v); }
 SDP_DEV float sdp_wave_sum(float v) { return __ockl_wfred_add_f32(v); }
 
 // (w_begin, w_count: the perturbation points to tabulate, into table rows 0 .. w_count-1 -- all of them by
-// default; the resident-chunk kernel builds the table a part at a time)
+// default; the resident-chunk kernel builds the table a part at a time; `keep`: a copy of the entries in global
+// memory, same layout -- SDP_COL_TAIL_KEEP of sdp_colres_kernel.h, 16-byte build loads only)
 template <bool SHIFT = false>
 SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg,
-                             const SdpColShared &s, const int w_begin = 0, const int w_count = SDP_COL_W)
+                             const SdpColShared &s, const int w_begin = 0, const int w_count = SDP_COL_W,
+                             sdp_real *__restrict__ keep = nullptr)
 {
     constexpr int N0 = SDP_COL_ROWS;        // rows held by the table (the whole axis without a window)
     const int Wn = w_begin + w_count;       // one past the last point
@@ -570,6 +572,7 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                         for (int c = 0; c < RPL; ++c) s.T[((tw >> 1) * N0 + r + c) * 2 + (tw & 1)] = e[c];
 #else
                         *(sdp_rows *)(s.T + tw * N0 + r) = e;
+                        if (keep) *(sdp_rows *)(keep + tw * N0 + r) = e;
 #endif
                     }
                 }
@@ -1342,7 +1345,13 @@ __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
 #endif
         ((SDP_COL_FILTER || SDP_TRAIL_HAS_U) ? SDP_META_F_CLAIMS : 0) | SDP_META_F_PEER_STORES,
     SDP_COL_FILTER ? SDP_COL_UTAB : 0, SDP_COL_FILTER ? SDP_COL_UTAB_N : 0, SDP_COL_THREADS, SDP_COL_ROWS,
-    0, 0, 0};
+    0, 0,
+#ifdef SDP_COLRES_TAIL_BYTES
+    SDP_COLRES_TAIL_BYTES
+#else
+    0
+#endif
+    };
 }
 
 #else   // SDP_D < 2: no column kernels; the unit is a node-order one after all

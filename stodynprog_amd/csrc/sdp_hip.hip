@@ -784,7 +784,7 @@ struct sdp_problem {
     int64_t S = 0, node_begin = 0, node_end = 0;
     int32_t orders[SDP_MAXD] = {0, 0, 0, 0};
     int32_t axis_off[SDP_MAXD] = {0, 0, 0, 0};
-    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps, claim;
+    DevBuf axes, wgrid, proba, box_lo, box_hi, box_n, V, J, pol, idx, pol_in, refs, scratch, stamps, claim, tail;
     DevBuf gstage;                         // gather buffer of phases with uneven parts (gather_phase_of)
     size_t gstage_bytes = 0;
     DevBuf stage[3];                       // layout-conversion buffers of the fused host call (J, pol, idx)
@@ -1045,6 +1045,15 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         int rc = p->claim.alloc(4 * (8 * 32 + 32));
         if (rc) return rc;
         HIP_TRY(hipMemset(p->claim.p, 0, 4 * (8 * 32 + 32)));
+        // the tail of every workgroup's table (SdpSweepArgs.tail): such kernels claim their units, so their grid is
+        // what the chip holds at once (column_grid)
+        if (p->meta[SDP_META_TAIL_BYTES] > 0) {
+            if (!(p->meta[SDP_META_FLAGS] & SDP_META_F_CLAIMS))
+                return fail(SDP_EMODULE, "code object %s keeps the tail of its table in global memory but does not claim its units", desc->module_path);
+            const size_t blocks = (((size_t)p->cus * (size_t)p->col_occupancy + 7) / 8) * 8;
+            rc = p->tail.alloc(blocks * (size_t)p->meta[SDP_META_TAIL_BYTES]);
+            if (rc) return rc;
+        }
     }
     if (p->layout != SDP_LAYOUT_COLUMNS && p->variant != SDP_VARIANT_STAGED && (p->meta[SDP_META_FLAGS] & SDP_META_F_LEAD)) {
         e = hipModuleGetFunction(&p->f_lead_reduce, p->mod, "sdp_lead_reduce");
@@ -1183,6 +1192,7 @@ static void fill_args(const sdp_problem *p, SdpSweepArgs &a, double t_k, int64_t
     a.shift_index = -1; a.ref_out = nullptr;
     a.stamps = (unsigned long long *)p->stamps.p;
     a.claim = (unsigned int *)p->claim.p;
+    a.tail = p->tail.p;
     a.aux_a = p->lead_a.p; a.aux_v = p->lead_v.p; a.aux_e = p->lead_e.p; a.aux_vmax = (unsigned long long *)p->lead_vmax.p;
     a.aux_begin = p->red_begin; a.aux_end = p->red_end;
     if (p->direct && p->comm && p->comm->nranks > 1 && p->peer_exchange) {

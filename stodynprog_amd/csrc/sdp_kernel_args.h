@@ -23,7 +23,8 @@ enum {
     SDP_META_THREADS,       // workgroup size of the sweep kernel (column / staged units)
     SDP_META_COL_ROWS,      // rows of axis 0 the table holds (< COL_N0: row window)
     SDP_META_LEAD_AXES,     // SDP_META_F_LEAD units: controlled state variables (the plane-major arrays' "lead" axes)
-    SDP_META_LEAD_PERM      // ... and which state variable logical axis j is (nibble j; stocks first)
+    SDP_META_LEAD_PERM,     // ... and which state variable logical axis j is (nibble j; stocks first)
+    SDP_META_TAIL_BYTES     // resident-chunk column kernel that keeps its tail in global memory (SdpSweepArgs.tail): bytes per workgroup
 };
 enum {
     SDP_META_F_FILTER = 1, SDP_META_F_WINDOW = 2, SDP_META_F_TRAIL_HAS_U = 4, SDP_META_F_STAGED = 8,
@@ -91,6 +92,9 @@ struct SdpSweepArgs {
     const unsigned char *peer_mask;     // column layout: [columns] bit q set = rank q reads the column; null: every peer gets every node
     int32_t n_peer;                     // 0: single GPU or another exchange -- no peer stores at all
     int32_t pad_;
+    // ---- resident-chunk column kernel (sdp_colres_kernel.h, SDP_COL_TAIL_KEEP): the tail of a workgroup's table, written by
+    // its first build and read back by the second pass instead of building it again ----
+    void *tail;                         // [gridDim.x][sdp_meta[SDP_META_TAIL_BYTES]] bytes; private to a workgroup, no initial contents
 };
 
 // Batched closed-loop simulation (the user loop of the reference's examples, e.g.

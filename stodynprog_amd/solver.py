@@ -29,7 +29,7 @@ import numpy as np
 from . import _native as nat
 from . import codegen
 from .interp import MlinInterpolator
-from .trace import TraceError, trace_model
+from .trace import TraceError, trace_model, trace_box
 
 __all__ = ['DPSolver']
 
@@ -221,6 +221,9 @@ class DPSolver(object):
     # rows of a phase to the host under the next phase's kernel (grids of 8 MiB and more), False runs one launch
     # and then the downloads.  Same arrays either way.
     host_overlap = True
+    # a control_box callback that cannot be traced (its table is made by scalar calls at every node, like the reference's):
+    # 'sample' re-checks the cached table at 24 nodes per call, 'every node' rebuilds it on every call (stodynprog.py:440)
+    box_recheck = 'sample'
     _debug_after_create = None
     STAGED_MIN_NODES = 32768          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now);
     STAGED_MIN_WORK = 1024            #         up to 4 x as many where a node has this many control x perturbation points or more
@@ -381,82 +384,84 @@ class DPSolver(object):
     def _shape(self):
         return tuple(len(g) for g in self.state_grid)
 
-    def _box_table(self, t_k=None):
-        """control_grids() for every node at once: (lo, hi, n) arrays of shape
-        (nu, S), with the same numpy operators as control_grids.  The box
-        callback is first tried on whole-grid arrays and checked against
-        scalar calls on sample nodes; callbacks that only work on scalars
-        (np.max((a, b)) style) are evaluated node by node."""
+    def _trace_box_now(self, t_k=None):
+        """The control_box callback traced for ONE call (trace.trace_box): a TracedBox whose whole-grid evaluation is,
+        node for node, what the reference's scalar calls return (stodynprog.py:438-440) -- or a TraceError, and the
+        table is then made by those scalar calls themselves.  Traced afresh on every call, like dyn and cost: data the
+        callback reads (a rated power in a closure, a module-level capacity) are constants of the DAG, so data that
+        changed show up as a changed signature.  A time index (t_k not None) is traced as a symbol, or failing that as
+        the concrete step (`data[k]`)."""
+        sd = self.sys
+        nx, nu = len(sd.state), len(sd.control)
+        try:
+            tb = trace_box(sd.control_box, nx, nu, sd.params, stationnary=t_k is None)
+        except TraceError as e:
+            if t_k is None:
+                return e
+            try:
+                tb = trace_box(sd.control_box, nx, nu, sd.params, stationnary=False, t_value=t_k)
+            except TraceError:
+                return e
+        bad = tb.inexact_ops()
+        if bad:
+            return TraceError('control_box uses operations whose whole-grid evaluation need not repeat the scalar call '
+                              'bit for bit: {}'.format(', '.join(bad)))
+        return tb
+
+    def _box_from_trace(self, tb, t_k=None):
+        """(lo, hi) of shape (nu, S) -- (nu, 1) when the box ignores the state -- from a traced box, on the open grid"""
+        shape = self._shape()
+        d = len(shape)
+        S = int(np.prod(shape))
+        nu = len(self.sys.control)
+        open_grid = [np.asarray(g, dtype=float).reshape((1,) * k + (-1,) + (1,) * (d - k - 1))
+                     for k, g in enumerate(self.state_grid)]
+        ends = tb.evaluate(open_grid, t_k)
+        constant = all(np.ndim(a) == 0 and np.ndim(b) == 0 for a, b in ends)
+        cols = 1 if constant else S
+        lo_v = np.empty((nu, cols))
+        hi_v = np.empty((nu, cols))
+        for c, (a, b) in enumerate(ends):
+            if constant:
+                lo_v[c, 0], hi_v[c, 0] = a, b
+            else:
+                lo_v[c] = np.broadcast_to(a, shape).ravel()
+                hi_v[c] = np.broadcast_to(b, shape).ravel()
+        return lo_v, hi_v
+
+    def _box_table(self, t_k=None, traced=None):
+        """control_grids() for every node at once: (lo, hi, n) arrays of shape (nu, S) -- (nu, 1) when the box ignores
+        the state -- with the same numpy operators as control_grids (sdp.py:432-463).
+
+        The ends of the boxes come from the callback's TRACE evaluated on the whole grid (`_trace_box_now`): per node
+        the same IEEE operations as the reference's scalar call, so the table is exact at every node by construction
+        -- no sampling.  (As a check of the tracer itself the corners and the centre of the grid are compared with
+        scalar calls whenever a table is built.)  A callback that cannot be traced is called node by node, as the
+        reference does."""
         shape = self._shape()
         S = int(np.prod(shape))
         nu = len(self.sys.control)
         params = self.sys.params
         lead = () if t_k is None else (t_k,)
-
-        def scalar_box(flat):
-            ind = np.unravel_index(flat, shape)
-            x = tuple(g[i] for g, i in zip(self.state_grid, ind))
-            return self.sys.control_box(*(lead + x), **params)
-
-        def vectorised():
-            d = len(shape)
-            lo_v, hi_v, constant = self._box_whole_grid(t_k)
-            # accepted only if it reproduces the scalar calls the reference makes: at EVERY
-            # node of a small grid; on a large one along every grid line through the
-            # corners and the centre (every distinct row / column of the open grid shows
-            # up there) plus a random sample
-            if S <= 20000 and not trusted:
-                probe = range(S)
-            elif S <= 20000:
-                # (this callback's whole-grid form has reproduced the scalar calls at every node of this grid at another
-                # time index: a time step of a finite horizon checks the corners, the centre and a fresh sample -- at every
-                # node, the table of every step cost more than the step's kernel)
-                self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
-                probe = set(np.random.default_rng(self._box_probe_round).integers(0, S, size=min(S, 8)).tolist())
-                probe.update([0, S - 1, S // 2])
-            else:
-                rng = np.random.default_rng(12345)
-                probe = set(rng.integers(0, S, size=256).tolist())
-                anchors = list(itertools.product(*[(0, n // 2, n - 1) for n in shape]))
-                for k in range(d):
-                    for anc in anchors:
-                        ind = [np.full(shape[k], a) for a in anc]
-                        ind[k] = np.arange(shape[k])
-                        probe.update(np.ravel_multi_index(tuple(ind), shape).tolist())
-            for flat in probe:
-                sb = scalar_box(flat)
-                col = 0 if constant else flat
-                for c, (a, b) in enumerate(sb):
-                    if not (_same(lo_v[c, col], a) and _same(hi_v[c, col], b)):
-                        return None
-            return lo_v, hi_v
-
+        tb = self._trace_box_now(t_k) if traced is None else traced
+        self._box_mode = None           # how the table was made: 'traced', or None (node by node)
+        self._box_sig = None
         lo = hi = None
-        self._box_mode = None           # how the table was made: 'plain' / 'patched' whole-grid evaluation, or None (node by node)
-        seen_key = ('box whole-grid', self.sys.control_box, tuple(np.asarray(g, dtype=float).tobytes() for g in self.state_grid))
-        trusted = t_k is not None and self._cache.get(seen_key) is not None
-        # 1) the callback as it is, on whole-grid arrays; 2) the same with
-        # np.max / np.min of a TUPLE of operands read as an elementwise
-        # maximum / minimum -- the idiom of every control_box of the reference's
-        # examples (`np.max((-E/dt, -P_rated))`, AR1 notebook cell 15,
-        # searev/storage_control.py:76-78), which is scalar-only as written;
-        # 3) node by node, like the reference.
-        for patch in (((self._cache[seen_key] == 'patched'),) if trusted else (False, True)):     # (trusted: the form that was checked)
-            try:
-                if patch:
-                    with _TupleMinMax():
-                        got = vectorised()
-                else:
-                    got = vectorised()
-            except Exception:
-                got = None
-            if got is not None:
-                lo, hi = got
-                self._box_mode = 'patched' if patch else 'plain'
-                if t_k is not None and not trusted:
-                    self._cache[seen_key] = self._box_mode
-                break
-        if lo is None:
+        if not isinstance(tb, TraceError):
+            lo, hi = self._box_from_trace(tb, t_k)
+            anchors = sorted({int(np.ravel_multi_index(ind, shape))
+                              for ind in itertools.product(*[(0, n - 1) for n in shape])} | {S // 2})
+            for flat in anchors:
+                ind = np.unravel_index(flat, shape)
+                x = tuple(g[i] for g, i in zip(self.state_grid, ind))
+                col = flat if lo.shape[1] > 1 else 0
+                for c, (a, b) in enumerate(self.sys.control_box(*(lead + x), **params)):
+                    if not (_same(lo[c, col], a) and _same(hi[c, col], b)):
+                        raise AssertionError('the traced control_box differs from the callback at node {}: the callback is '
+                                             'not a pure function of its arguments, or the tracer is wrong'.format(ind))
+            self._box_mode = 'traced'
+            self._box_sig = tb.signature()
+        else:
             lo = np.empty((nu, S))
             hi = np.empty((nu, S))
             for flat, x in enumerate(itertools.product(*self.state_grid)):
@@ -481,35 +486,6 @@ class DPSolver(object):
                 lo[c] = np.where(single, mid, lo[c])
                 hi[c] = np.where(single, mid, hi[c])
         return lo, hi, n
-
-    def _box_whole_grid(self, t_k=None):
-        """the box callback on whole-grid arrays, as it is: (lo, hi, constant) with lo, hi of shape (nu, S) -- (nu, 1)
-        when the box ignores the state.  Open (sparse) grids: axis k has shape (1,..,N_k,..,1), so a box that ignores
-        the state, or depends on one axis only, stays small.  (The caller decides whether np.max / np.min of tuples are
-        patched, and whether the result can be trusted: _box_table.)"""
-        shape = self._shape()
-        S = int(np.prod(shape))
-        nu = len(self.sys.control)
-        d = len(shape)
-        lead = () if t_k is None else (t_k,)
-        open_grid = [np.asarray(g, dtype=float).reshape((1,) * k + (-1,) + (1,) * (d - k - 1))
-                     for k, g in enumerate(self.state_grid)]
-        with np.errstate(all='ignore'):
-            box = self.sys.control_box(*(lead + tuple(open_grid)), **self.sys.params)
-        if len(box) != nu:
-            raise ValueError
-        ends = [(np.asarray(a, dtype=float), np.asarray(b, dtype=float)) for a, b in box]
-        constant = all(a.size == 1 and b.size == 1 for a, b in ends)
-        cols = 1 if constant else S
-        lo_v = np.empty((nu, cols))
-        hi_v = np.empty((nu, cols))
-        for c, (a, b) in enumerate(ends):
-            if constant:
-                lo_v[c, 0], hi_v[c, 0] = a.reshape(()), b.reshape(())
-            else:
-                lo_v[c] = np.broadcast_to(a, shape).ravel()
-                hi_v[c] = np.broadcast_to(b, shape).ravel()
-        return lo_v, hi_v, constant
 
     def _fingerprint(self, t_k):
         s = self.sys
@@ -589,14 +565,27 @@ class DPSolver(object):
             raise Exception("Can't interpolate in dimension strictly greater than 5")
 
     def _box_plan(self, box_t=None):
-        """Control-box table of the current discretisation (cached: the scalar
-        fallback of _box_table is a Python loop over the nodes)."""
+        """Control-box table of the current discretisation, cached.
+
+        The reference calls control_box at every node of every sweep (stodynprog.py:440), so data the callback reads (a
+        rated power in a closure, a module-level capacity) may change between two calls.  The callback is therefore
+        TRACED AGAIN on every call -- as dyn and cost are --: what it reads are constants of its DAG, and the cached
+        table stays exactly as long as the new trace has the structure and the constants of the one the table was made
+        from (`TracedBox.signature`): a proof for every node, not a probe of some.  Only a callback that cannot be traced
+        (its table was made by scalar calls at every node) is re-checked by scalar calls at `n_probe` nodes -- the
+        corners, the centre and a different sample every time -- which is all a cached table of an opaque callable can
+        offer; `DPSolver.box_recheck = 'every node'` rebuilds such a table on every call instead, as the reference does."""
         key = ('box', self._fingerprint(box_t))
         bp = self._cache.get(key)
-        if bp is not None and not self._box_still_valid(bp, box_t):
-            bp = None                       # the callback reads data that changed: rebuild
+        tb = self._trace_box_now(box_t)
+        if bp is not None:
+            if not isinstance(tb, TraceError):
+                if bp.get('sig') != tb.signature():
+                    bp = None                   # the callback reads data that changed (or is no longer what it was): rebuild
+            elif bp.get('sig') is not None or self.box_recheck == 'every node' or not self._box_still_valid(bp, box_t):
+                bp = None
         if bp is None:
-            lo, hi, n = self._box_table(box_t)
+            lo, hi, n = self._box_table(box_t, traced=tb)
             per_node = not (np.all(lo == lo[:, :1]) and np.all(hi == hi[:, :1])
                             and np.all(n == n[:, :1]))
             max_u = int(np.prod(n.astype(np.int64), axis=0).max())
@@ -607,7 +596,8 @@ class DPSolver(object):
             lo, hi, n = (np.ascontiguousarray(a) for a in (lo, hi, n))
             digest = hash((lo.tobytes(), hi.tobytes(), n.tobytes()))
             bp = dict(lo=lo, hi=hi, n=n, per_node=per_node, max_u=max_u,
-                      lanes=codegen.lanes_for(max_u), digest=digest, mode=getattr(self, '_box_mode', None))
+                      lanes=codegen.lanes_for(max_u), digest=digest, mode=getattr(self, '_box_mode', None),
+                      sig=getattr(self, '_box_sig', None))
             if box_t is not None:           # one table per time step: keep only the latest
                 for k in [k for k in self._cache if k[0] == 'box']:
                     del self._cache[k]
@@ -615,49 +605,15 @@ class DPSolver(object):
         return bp
 
     def _box_still_valid(self, bp, box_t, n_probe=21):
-        """The reference calls control_box at every node of every sweep
-        (stodynprog.py:440); here the table is cached, so module-level data the
-        callback reads (a rated power, a capacity) could change unnoticed.  Each
-        call re-evaluates the callback at `n_probe` nodes (the corners, the
-        centre and a different random sample every time) and compares with the
-        cached table; any difference rebuilds it.  (24 nodes a call since round 5, 67 before: each scalar call of the
-        reference's own box callbacks takes ~13 microseconds, 67 of them more than the Searev kernel of the reference's size.)"""
+        """A table made by scalar calls at every node (the callback could not be traced): the callback again at
+        `n_probe` nodes plus the corners and the centre, compared with the table; any difference rebuilds it."""
         shape = self._shape()
         S = int(np.prod(shape))
         lo, hi, n = bp['lo'], bp['hi'], bp['n']
-        if bp.get('mode') and (S <= 20000 or (S <= 200000 and not bp['per_node'])):     # (a box per node on a larger grid: the scalar calls below are cheaper -- measured)
-            # A table made by ONE whole-grid call that reproduced the scalar calls (at every node of a grid of up to
-            # 20 000 nodes, along the grid lines through corners and centre plus a sample beyond): the same call again,
-            # compared at EVERY node -- tens of microseconds where 67 scalar calls took a millisecond, more than the
-            # kernels of the reference's own problem sizes -- and a few scalar calls as the reference would make them
-            # (the corners and the centre; eight more nodes, a different sample every time, on the larger grids).
-            try:
-                if bp['mode'] == 'patched':
-                    with _TupleMinMax():
-                        lo_v, hi_v, constant = self._box_whole_grid(box_t)
-                else:
-                    lo_v, hi_v, constant = self._box_whole_grid(box_t)
-                lo_v, hi_v, n_v = self._box_lattice(lo_v, hi_v)
-            except Exception:
-                return False
-            if not bp['per_node']:
-                if not (np.all(lo_v == lo_v[:, :1]) and np.all(hi_v == hi_v[:, :1]) and np.all(n_v == n_v[:, :1])):
-                    return False
-                lo_v, hi_v, n_v = lo_v[:, :1], hi_v[:, :1], n_v[:, :1]
-            if lo_v.shape != lo.shape:
-                return False
-            same = lambda a, b: bool(np.all((a == b) | ((a != a) & (b != b))))
-            if not (same(lo_v, lo) and same(hi_v, hi) and np.array_equal(n_v, n)):
-                return False
-            probe = {0, S - 1, S // 2}
-            if S > 20000:
-                self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
-                probe.update(np.random.default_rng(self._box_probe_round).integers(0, S, size=8).tolist())
-        else:
-            self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
-            rng = np.random.default_rng(self._box_probe_round)
-            probe = set(rng.integers(0, S, size=min(S, n_probe)).tolist())
-            probe.update([0, S - 1, S // 2])
+        self._box_probe_round = getattr(self, '_box_probe_round', 0) + 1
+        rng = np.random.default_rng(self._box_probe_round)
+        probe = set(rng.integers(0, S, size=min(S, n_probe)).tolist())
+        probe.update([0, S - 1, S // 2])
         lead = () if box_t is None else (box_t,)
         try:
             for flat in probe:
@@ -839,7 +795,7 @@ class DPSolver(object):
                     window=window, per_control=per_control,
                     col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
-                    max_u=bp['max_u'], W=W, box_digest=bp['digest'])
+                    max_u=bp['max_u'], W=W, box_digest=bp['digest'], box_mode=bp.get('mode'))
 
     @staticmethod
     def _box_constant_along_axis0(bp, shape):
@@ -920,7 +876,10 @@ class DPSolver(object):
         if model.param_index is not None:
             prob.set_params(model.param_values())
         self.backend_info = dict(prob.info, time_specialized=model.t_value is not None,
-                                 lifted_constants=len(model.param_index or ()))
+                                 lifted_constants=len(model.param_index or ()),
+                                 # how the table of admissible boxes was made: 'traced' (the callback's DAG on the whole grid: exact
+                                 # at every node by construction) or 'node by node' (scalar calls, like the reference)
+                                 box_mode=plan.get('box_mode') or 'node by node')
         return prob
 
     def _create_problem(self, fp, plan):
@@ -1649,42 +1608,6 @@ class DPSolver(object):
             print('  control combinations:'
                   ' [{:,d} to {:,d}] possible values ({:,.1f} on average)'.format(
                       tot.min(), tot.max(), tot.mean()))
-
-
-class _TupleMinMax(object):
-    """While active, np.max / np.min / np.amax / np.amin called on a tuple or
-    list of SEVERAL operands, at least one of them an array, return their
-    elementwise maximum / minimum (NaN-propagating, like the reduction they
-    stand for when the operands are scalars).  Used only inside the
-    whole-grid evaluation of control_box, whose result is then checked against
-    unpatched scalar calls."""
-    NAMES = (('max', np.maximum), ('amax', np.maximum), ('min', np.minimum), ('amin', np.minimum))
-
-    def __enter__(self):
-        self.saved = {}
-        for name, ufunc in self.NAMES:
-            if not hasattr(np, name):
-                continue
-            orig = getattr(np, name)
-            self.saved[name] = orig
-            setattr(np, name, self._wrap(orig, ufunc))
-        return self
-
-    @staticmethod
-    def _wrap(orig, ufunc):
-        def reduce_operands(a, *args, **kw):
-            if (isinstance(a, (tuple, list)) and len(a) >= 2 and not args and not kw
-                    and any(np.ndim(v) > 0 for v in a)):
-                out = a[0]
-                for v in a[1:]:
-                    out = ufunc(out, v)
-                return out
-            return orig(a, *args, **kw)
-        return reduce_operands
-
-    def __exit__(self, *exc):
-        for name, orig in self.saved.items():
-            setattr(np, name, orig)
 
 
 def _params_key(params):

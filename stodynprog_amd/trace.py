@@ -19,7 +19,7 @@ import numbers
 
 import numpy as np
 
-__all__ = ['TraceError', 'Graph', 'Sym', 'trace_model']
+__all__ = ['TraceError', 'Graph', 'Sym', 'trace_model', 'trace_box', 'TracedBox']
 
 
 class TraceError(Exception):
@@ -79,6 +79,7 @@ class Graph(object):
         self.unique_consts = unique_consts
         self.tables = []          # lookup tables of np.interp nodes: (xp, fp, left, right)
         self.scalar_pow = set()   # ids of nodes standing for a numpy SCALAR power (see _power)
+        self.fork = None          # trace_box: the decisions of the path being traced (_Fork)
 
     def _intern(self, key, op, args, value, kind, deps):
         n = self._memo.get(key)
@@ -223,6 +224,10 @@ class Sym(object):
 
     # ---- things that need a concrete value -------------------------------------------
     def __bool__(self):
+        fork = getattr(self.g, 'fork', None)
+        if fork is not None:
+            # trace_box: the callable is run once per PATH through its data-dependent branches (see _Fork)
+            return fork.decide(self)
         raise TraceError('the truth value of a symbolic expression is needed '
                          '(Python `if`/`max`/`min` on state, control or perturbation)')
     __nonzero__ = __bool__
@@ -918,6 +923,239 @@ def trace_model(dyn, cost, n_state, n_control, n_perturb, params=None, stationna
                         (not stationnary) and t_value is None)
     model.t_value = t_value
     return model
+
+
+# ---------------------------------------------------------------------------
+# The admissible box of the controls (reference stodynprog.py:432-463: `control_box(*state_k, **params)` is called at
+# every node of every sweep).  DPSolver keeps a table of it, so the table has to be what those calls return AT EVERY
+# NODE: the callback is traced like dyn and cost, and a trace IS that proof -- the DAG, evaluated with numpy on the
+# whole grid, performs per node exactly the IEEE operations the scalar call performs (EXACT_OPS only; anything else
+# sends the solver back to calling the callback node by node, like the reference).
+#   * `np.max((a, b))` / `np.min(..)` / `np.amax` / `np.amin` of a tuple or list of operands -- the idiom of every box of the
+#     reference's examples (AR1 notebook cell 15, searev/storage_control.py:76-78) -- is scalar-only as written.  The
+#     callback is run on a copy of itself whose GLOBALS name a stand-in for the numpy module (every global bound to
+#     numpy itself: `np`, `numpy`, ..): the stand-in forwards everything to numpy except these four, which fold the
+#     operands with the `max` / `min` of the DAG (np.maximum / np.minimum: what the reduction over a short float array
+#     computes, NaN included).  Nothing outside that one function object sees the stand-in -- no rebinding of numpy's
+#     own attributes (round 5 patched np.max / np.min process-wide while the callback ran).
+#   * Python control flow on the state (`if E > 5:`, the builtins `max(a, b)` / `min(a, b)`) asks a symbolic
+#     condition for its truth value.  The callback is then traced once per PATH: every such question is answered
+#     from a script of decisions (first run: always True), and after the run the last undecided True is flipped
+#     and the callback runs again, until every path has been taken (at most _FORK_MAX_PATHS); the paths' results
+#     are merged with `select` nodes on the recorded conditions.  Per node the merged DAG picks what the scalar
+#     call would have returned -- the callback is assumed to be a pure function of its arguments, as the whole
+#     tracer assumes.
+# ---------------------------------------------------------------------------
+_FORK_MAX_PATHS = 64
+
+
+class _Fork(object):
+    """decisions of one path: `script` is the prefix to replay, `taken` what this run met: (condition node, decision)"""
+
+    def __init__(self, script):
+        self.script = list(script)
+        self.taken = []
+
+    def decide(self, sym):
+        n = sym.n
+        if n.kind != 'b':
+            n = sym.g.op('ne', n, sym.g.const(0.0))          # truthiness of a real
+        if n.op == 'bconst':
+            return bool(n.value)
+        for cond, d in self.taken:                            # the same question again on this path: the same answer
+            if cond is n:
+                return d
+        k = len(self.taken)
+        d = self.script[k] if k < len(self.script) else True
+        self.taken.append((n, d))
+        return d
+
+
+class _NumpyStandIn(object):
+    """what the traced copy of a box callback sees under the names that are bound to the numpy module in its globals"""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def _fold(op, a, args, kw):
+        real = getattr(np, op)
+        if args or kw or not isinstance(a, (tuple, list)) or not any(isinstance(v, Sym) for v in a):
+            return real(a, *args, **kw)
+        sym = _any_sym(*a)
+        out = a[0]
+        for v in a[1:]:
+            if not (isinstance(v, Sym) or _is_plain_number(v)):
+                raise TraceError('np.{} of nested operands is not traceable'.format(op))
+            out = sym._bin('max' if op in ('max', 'amax') else 'min', out, v)      # maximum.reduce / minimum.reduce, left to right
+        return out if isinstance(out, Sym) else Sym(sym.g, sym._lift(out))
+
+    def max(self, a, *args, **kw): return self._fold('max', a, args, kw)
+    def amax(self, a, *args, **kw): return self._fold('amax', a, args, kw)
+    def min(self, a, *args, **kw): return self._fold('min', a, args, kw)
+    def amin(self, a, *args, **kw): return self._fold('amin', a, args, kw)
+
+
+_NP_STAND_IN = _NumpyStandIn()
+
+
+def _with_numpy_stand_in(fn):
+    """a copy of the Python function `fn` (plain function, bound method or functools.partial of one) whose globals
+    name _NP_STAND_IN wherever fn's name the numpy module; anything else is returned as it is"""
+    import functools
+    import types
+    if isinstance(fn, functools.partial):
+        inner = _with_numpy_stand_in(fn.func)
+        return fn if inner is fn.func else functools.partial(inner, *fn.args, **(fn.keywords or {}))
+    if isinstance(fn, types.MethodType):
+        inner = _with_numpy_stand_in(fn.__func__)
+        return fn if inner is fn.__func__ else types.MethodType(inner, fn.__self__)
+    if not isinstance(fn, types.FunctionType):
+        return fn
+    glob = fn.__globals__
+    names = [k for k in fn.__code__.co_names if glob.get(k) is np]
+    if not names:
+        return fn
+    g2 = dict(glob)
+    for k in names:
+        g2[k] = _NP_STAND_IN
+    copy = types.FunctionType(fn.__code__, g2, fn.__name__, fn.__defaults__, fn.__closure__)
+    copy.__kwdefaults__ = fn.__kwdefaults__
+    return copy
+
+
+class TracedBox(object):
+    """Result of tracing a `control_box` callback: per control the nodes of its lower and upper end."""
+
+    def __init__(self, graph, ends, n_state, time_dep, t_value, paths):
+        self.graph, self.ends, self.n_state = graph, ends, n_state
+        self.time_dep, self.t_value, self.paths = time_dep, t_value, paths
+
+    def live_nodes(self):
+        seen, order = set(), []
+        stack = [n for pair in self.ends for n in pair]
+        # (ids increase from operands to results: the live nodes in id order are a valid evaluation order)
+        while stack:
+            n = stack.pop()
+            if n.id in seen:
+                continue
+            seen.add(n.id)
+            stack.extend(n.args)
+        for n in self.graph.nodes:
+            if n.id in seen:
+                order.append(n)
+        return order
+
+    def inexact_ops(self):
+        """operations of the live DAG whose whole-grid numpy evaluation is not guaranteed to repeat the scalar call bit
+        for bit (transcendentals; a numpy SCALAR power, see _power): a box with any of them is not taken from its trace"""
+        bad = sorted({n.op for n in self.live_nodes() if n.op not in EXACT_OPS})
+        if any(n.id in self.graph.scalar_pow for n in self.live_nodes()):
+            bad.append('scalar_pow')
+        return bad
+
+    def signature(self):
+        """structure AND constants of the live DAG (tables included): two traces with the same signature give the same
+        box at every node -- what DPSolver compares from call to call instead of probing nodes"""
+        sig = []
+        for n in self.live_nodes():
+            if n.op == 'const':
+                sig.append(('c', np.float64(n.value).tobytes()))
+            elif n.op in ('var', 'bconst'):
+                sig.append((n.op, n.value))
+            elif n.op == 'interp1':
+                sig.append((n.op, n.args[0].id, self.graph.tables[n.value][4]))
+            else:
+                sig.append((n.op,) + tuple(a.id for a in n.args))
+        sig.append(tuple((lo.id, hi.id) for lo, hi in self.ends))
+        return tuple(sig)
+
+    def evaluate(self, x, t=None):
+        """the box on numpy arrays (any mutually broadcastable shapes, e.g. an open grid): [(lo, hi)] per control"""
+        vals = {'x%d' % i: v for i, v in enumerate(x)}
+        vals['t'] = t
+        env = {}
+        with np.errstate(all='ignore'):
+            for n in self.live_nodes():
+                if n.op == 'var':
+                    env[n.id] = np.asarray(vals[n.value], dtype=float)
+                elif n.op == 'const':
+                    env[n.id] = np.float64(n.value)
+                elif n.op == 'bconst':
+                    env[n.id] = np.bool_(n.value)
+                elif n.op == 'interp1':
+                    xp, fp, left, right = self.graph.tables[n.value][:4]
+                    env[n.id] = np.interp(env[n.args[0].id], xp, fp, left, right)
+                else:
+                    env[n.id] = _NP_EVAL[n.op](*[env[a.id] for a in n.args])
+        return [(env[lo.id], env[hi.id]) for lo, hi in self.ends]
+
+
+def trace_box(control_box, n_state, n_control, params=None, stationnary=True, t_value=None):
+    """Trace `control_box(*state, **params)` (reference stodynprog.py:438-440; the time index first for a time-dependent
+    system: symbolic, or the concrete `t_value`).  Returns a TracedBox or raises TraceError."""
+    params = params or {}
+    g = Graph()
+    xs = [Sym(g, g.var('x%d' % i, DEP_X if i == 0 else DEP_XR)) for i in range(n_state)]
+    args = list(xs)
+    if not stationnary:
+        args = [Sym(g, g.var('t', DEP_T)) if t_value is None else t_value] + args
+    some = xs[0] if xs else Sym(g, g.const(0.0))
+    fn = _with_numpy_stand_in(control_box)
+
+    def run(script):
+        g.fork = _Fork(script)
+        try:
+            out = fn(*args, **params)
+            out = tuple(out)
+            if len(out) != n_control:
+                raise TraceError('control_box returned {} intervals for {} controls'.format(len(out), n_control))
+            ends = []
+            for iv in out:
+                lo, hi = iv
+                pair = []
+                for v in (lo, hi):
+                    n = v.n if isinstance(v, Sym) else some._lift(v)
+                    pair.append(some._real(n))
+                ends.append(tuple(pair))
+            return ends, g.fork.taken
+        except TraceError:
+            raise
+        except Exception as e:
+            raise TraceError('control_box not traceable: {}: {}'.format(type(e).__name__, e))
+        finally:
+            g.fork = None
+
+    # depth-first over the decision tree: a leaf is a path with its result; merged bottom-up with selects
+    leaves = []                                   # (decisions, conds, ends)
+    script = []
+    while True:
+        ends, taken = run(script)
+        leaves.append(([d for _, d in taken], [c for c, _ in taken], ends))
+        if len(leaves) > _FORK_MAX_PATHS:
+            raise TraceError('control_box branches on the state along more than {} paths'.format(_FORK_MAX_PATHS))
+        dec = [d for _, d in taken]
+        while dec and dec[-1] is False:
+            dec.pop()
+        if not dec:
+            break
+        dec[-1] = False
+        script = dec
+
+    def merge(group, depth):
+        # every leaf of `group` shares its first `depth` decisions
+        if len(group) == 1 and len(group[0][0]) == depth:
+            return group[0][2]
+        cond = group[0][1][depth]
+        yes = [l for l in group if l[0][depth]]
+        no = [l for l in group if not l[0][depth]]
+        if not yes or not no or any(l[1][depth] is not cond for l in group):
+            raise TraceError('control_box is not a pure function of its arguments (its branches changed between two runs)')
+        a, b = merge(yes, depth + 1), merge(no, depth + 1)
+        return [tuple(g.op('select', cond, u, v) if u is not v else u for u, v in zip(pa, pb)) for pa, pb in zip(a, b)]
+
+    ends = merge(leaves, 0)
+    return TracedBox(g, ends, n_state, (not stationnary) and t_value is None, t_value, len(leaves))
 
 
 def evaluate(model, x, u, w, t=None):

@@ -279,10 +279,9 @@ def test_load_the_reference_searev_policy_pickle():
 def test_control_box_table_vectorises_the_tuple_min_max_idiom():
     """the reference's control_box callbacks use np.max((a, b)) on scalars
     (AR1 notebook cell 15, searev/storage_control.py:76-78): scalar-only as
-    written.  The table builder evaluates them on whole-grid arrays with
-    np.max / np.min of a tuple read elementwise, accepts the result only if it
-    reproduces scalar calls, and must give the node-by-node table bit for bit;
-    numpy itself is left untouched afterwards."""
+    written.  The table builder TRACES them (np.max / np.min of a tuple become
+    the DAG's max / min) and evaluates the DAG on the whole grid: the
+    node-by-node table bit for bit; numpy itself is never touched."""
     import itertools
     from stodynprog_amd import models, solver as solver_mod
     for name, kw, t in (('searev', dict(n_E=12, n_S=7, n_A=5), None), ('storage_ar1', {}, None),
@@ -329,35 +328,164 @@ def test_interpolator_loader_refuses_anything_but_data(tmp_path):
 
 @pytest.mark.parametrize('grid', [(41, 61), (200, 200), (500, 500)])
 def test_a_cached_control_box_table_notices_data_the_callback_reads(grid):
-    """The reference calls control_box at every node of every sweep (stodynprog.py:440); here the table is cached and
-    re-checked on every call: on grids of up to 20 000 nodes (200 000 when the box ignores the state) by ONE whole-grid call
-    compared at every node (plus 3 .. 11 scalar calls), beyond that by 24 scalar calls at the corners, the centre and a fresh
-    random sample.  Module-level data the callback
-    reads may change between calls: the table follows."""
+    """The reference calls control_box at every node of every sweep (stodynprog.py:440); here the table is cached, and the
+    callback is TRACED again on every call: data it reads are constants of its DAG, the table stays while the DAG is the
+    same (a proof for every node: no scalar call, no sample) and is rebuilt when module-level data changed."""
     from stodynprog_amd import SysDescription, DPSolver
     rated = {'P': 1.0}
     sysd = SysDescription((2, 1, 1), name='storage')
     sysd.dyn = lambda E, P, u, w: (E + u, 0.8 * P + w)
     sysd.cost = lambda E, P, u, w: (P - u) * (P - u)
-    sysd.control_box = lambda E, P: ((np.max((-E, -rated['P'])), np.min((10. - E, rated['P']))),)
+    calls = []
+
+    def box(E, P):
+        calls.append(type(E).__name__)
+        return ((np.max((-E, -rated['P'])), np.min((10. - E, rated['P']))),)
+    sysd.control_box = box
     sysd.perturb_laws = [__import__('stodynprog_amd').models.NormalLaw(0, 0.5)]
     s = DPSolver(sysd)
     s.discretize_state(0, 10, grid[0], -2, 2, grid[1])
     s.discretize_perturb(-1, 1, 5)
     s.control_steps = (0.1,)
     bp = s._box_plan()
-    S = grid[0] * grid[1]
-    assert bp['mode'] == 'patched' and bp['per_node']
-    calls = []
-    inner = sysd.control_box
-    sysd._control_box = lambda E, P: (calls.append(1), inner(E, P))[1]
-    s._cache.clear()
-    bp = s._box_plan()
+    assert bp['mode'] == 'traced' and bp['per_node']
+    # building the table: one symbolic call, plus the tracer's self-check at the corners and the centre
+    assert calls.count('Sym') == 1 and len(calls) == 1 + 5
     del calls[:]
-    assert s._box_plan() is bp                                   # unchanged data: the cached table, re-checked
-    # (+ the whole-grid call where there is one)
-    assert len(calls) == 4 if S <= 20000 else 20 <= len(calls) <= 24          # (a box per node: whole-grid calls on small grids only)
+    assert s._box_plan() is bp                                   # unchanged data: the cached table
+    assert calls == ['Sym']                                      # .. for the price of one trace, whatever the grid's size
     rated['P'] = 0.5                                             # the data changes: the table is rebuilt
     bp2 = s._box_plan()
     assert bp2 is not bp and bp2['hi'].max() == 0.5 and bp['hi'].max() == 1.0
     assert s._box_plan() is bp2
+
+
+def _box_by_scalar_calls(s, t=None):
+    """the reference's control_grids at every node (stodynprog.py:432-463)"""
+    import itertools
+    lead = () if t is None else (t,)
+    shape = tuple(len(g) for g in s.state_grid)
+    nu = len(s.sys.control)
+    lo = np.empty((nu,) + shape)
+    hi = np.empty((nu,) + shape)
+    n = np.empty((nu,) + shape, dtype=np.int32)
+    for ind in itertools.product(*[range(k) for k in shape]):
+        x = tuple(g[i] for g, i in zip(s.state_grid, ind))
+        for c, (a, b) in enumerate(s.sys.control_box(*(lead + x), **s.sys.params)):
+            n_interv = (b - a) / s.control_steps[c]
+            if n_interv < 0.1:
+                lo[(c,) + ind] = hi[(c,) + ind] = (a + b) / 2
+                n[(c,) + ind] = 1
+            else:
+                lo[(c,) + ind], hi[(c,) + ind], n[(c,) + ind] = a, b, int(np.ceil(n_interv) + 1)
+    return lo.reshape(nu, -1), hi.reshape(nu, -1), n.reshape(nu, -1)
+
+
+def test_a_box_with_a_branch_in_one_small_region_is_exact_at_every_node():
+    """a whole-grid evaluation validated on a SAMPLE accepts a box whose data-dependent branch
+    bites in a small interior region.  The trace follows every path of the callback (`if`, the builtins max / min) and
+    merges them with selects on the recorded conditions: the table is the scalar calls' at EVERY node, the odd one too."""
+    from stodynprog_amd import SysDescription, DPSolver
+    sysd = SysDescription((3, 1, 0), name='one odd node')
+    sysd.dyn = lambda a, b, c, u: (a + u, b, c)
+    sysd.cost = lambda a, b, c, u: u * u
+
+    def box(a, b, c):
+        hi = min(1.0, 2.0 - a)                                   # builtin min: a branch on the state
+        if 0.49 < a < 0.51 and 0.29 < b < 0.31 and abs(c - 0.7) < 0.01:      # one node of the 21^3 grid
+            hi = 0.25
+        return ((max(-a, -1.0), hi),)
+    sysd.control_box = box
+    s = DPSolver(sysd)
+    s.discretize_state(0, 1, 21, 0, 1, 21, 0, 1, 21)
+    s.control_steps = (0.05,)
+    lo, hi, n = s._box_table()
+    assert s._box_mode == 'traced'
+    lo_r, hi_r, n_r = _box_by_scalar_calls(s)
+    assert np.array_equal(lo, lo_r) and np.array_equal(hi, hi_r) and np.array_equal(n, n_r)
+    assert (hi == 0.25).sum() == 1                               # the odd node is there, once
+    # the naive whole-grid call of the same callback does not even run (Python `if` on an array), and what round 5
+    # accepted instead -- the branch-free part, validated on a sample -- misses the node:
+    naive_hi = np.minimum(1.0, 2.0 - s.state_grid[0])
+    assert (np.broadcast_to(naive_hi[:, None, None], (21, 21, 21)).ravel() != hi[0]).sum() == 1
+
+
+def test_closure_data_that_changes_for_one_node_rebuilds_the_table():
+    from stodynprog_amd import SysDescription, DPSolver
+    odd = {'at': (0.5, 0.3), 'hi': 0.25}
+    sysd = SysDescription((2, 1, 0), name='closure')
+    sysd.dyn = lambda a, b, u: (a + u, b)
+    sysd.cost = lambda a, b, u: u * u
+
+    def box(a, b):
+        hi = np.min((1.0, 2.0 - a))
+        hi = np.where((a == odd['at'][0]) & (b == odd['at'][1]), odd['hi'], hi)
+        return ((np.max((-a, -1.0)), hi),)
+    sysd.control_box = box
+    s = DPSolver(sysd)
+    s.discretize_state(0, 1, 201, 0, 1, 101)                   # 20 301 nodes: round 5 re-checked such a grid at 24 of them
+    s.control_steps = (0.05,)
+    bp = s._box_plan()
+    assert bp['mode'] == 'traced' and (bp['hi'] == 0.25).sum() == 1
+    assert s._box_plan() is bp
+    odd['hi'] = 0.125                                            # one node's box changes between two calls
+    bp2 = s._box_plan()
+    assert bp2 is not bp and (bp2['hi'] == 0.125).sum() == 1 and (bp2['hi'] == 0.25).sum() == 0
+    lo_r, hi_r, n_r = _box_by_scalar_calls(s)
+    assert np.array_equal(bp2['lo'], lo_r) and np.array_equal(bp2['hi'], hi_r) and np.array_equal(bp2['n'], n_r)
+    odd['at'] = (0.25, 0.5)                                      # .. and moves to another node
+    bp3 = s._box_plan()
+    lo_r, hi_r, n_r = _box_by_scalar_calls(s)
+    assert bp3 is not bp2 and np.array_equal(bp3['hi'], hi_r) and np.array_equal(bp3['n'], n_r)
+
+
+def test_tracing_a_box_leaves_numpy_alone():
+    """np.max / np.min of a tuple are read elementwise by a stand-in for the numpy module in the GLOBALS OF A COPY of the
+    callback; numpy's own attributes are never rebound (round 5 patched them process-wide while the callback ran)."""
+    import numpy
+    from stodynprog_amd import models
+    from stodynprog_amd import trace
+    seen = []
+    _, s = models.storage_ar1()
+    inner = s.sys.control_box
+    orig = (numpy.max, numpy.min, numpy.amax, numpy.amin)
+
+    def spy(E, P):
+        import numpy as real                                     # (what any other module, or thread, sees meanwhile)
+        seen.append((real.max, real.min, real.amax, real.amin) == orig and real.max((1.0, 3.0)) == 3.0)
+        return inner(E, P)
+    s.sys._control_box = spy
+    bp = s._box_plan()
+    assert bp['mode'] == 'traced' and seen and all(seen)
+    assert (numpy.max, numpy.min, numpy.amax, numpy.amin) == orig
+    assert not hasattr(__import__('stodynprog_amd').solver, '_TupleMinMax')
+    # the callback itself is untouched too: the stand-in lives in the globals of a copy
+    assert inner.__globals__['np'] is numpy
+    tb = trace.trace_box(inner, 2, 2)
+    assert tb.paths == 1 and not tb.inexact_ops()
+
+
+def test_a_box_that_cannot_be_traced_is_called_node_by_node():
+    from stodynprog_amd import SysDescription, DPSolver
+    table = np.linspace(1.0, 2.0, 11)
+    sysd = SysDescription((1, 1, 0))
+    sysd.dyn = lambda x, u: (x + u,)
+    sysd.control_box = lambda x: ((0.0, float(table[int(round(x * 10))])),)       # an index from the state: no trace
+    s = DPSolver(sysd)
+    s.discretize_state(0, 1, 11)
+    s.control_steps = (0.5,)
+    bp = s._box_plan()
+    assert bp['mode'] is None and bp['sig'] is None
+    assert np.array_equal(bp['hi'][0], table)
+    assert s._box_plan() is bp                                   # re-checked at a sample of nodes
+    table[5] = 5.0                                               # (11 nodes: the sample is the whole grid)
+    assert s._box_plan()['hi'][0, 5] == 5.0
+    s.box_recheck = 'every node'
+    bp = s._box_plan()
+    assert s._box_plan() is not bp                               # rebuilt on every call, as the reference does
+    # transcendental functions in a box: traceable, but numpy's whole-grid loops need not repeat the scalar call's bits
+    sysd.control_box = lambda x: ((0.0, 1.0 + np.exp(-x)),)
+    s2 = DPSolver(sysd)
+    s2.discretize_state(0, 1, 11)
+    s2.control_steps = (0.5,)
+    assert s2._box_plan()['mode'] is None

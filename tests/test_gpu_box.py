@@ -1,0 +1,135 @@
+"""control_box on the device path: the table of admissible boxes comes from the callback's TRACE (exact at every node
+by construction, stodynprog.py:432-463 calls the callback at every node of every sweep), checked here end to end --
+J, policy and index of a sweep against oracle/vi_numpy.py, which calls the callback node by node as the reference does.
+VERDICT r05 "what's weak" 1(b): a localised discrepancy on a large grid; closure data that changes for one node."""
+import numpy as np
+import pytest
+
+from stodynprog_amd import SysDescription, DPSolver, models
+from oracle import vi_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+def _storage(N, box, perturb=True):
+    """a stock a, an exogenous pair (b, c): the column family takes it"""
+    sysd = SysDescription((3, 1, 1), name='box test')
+    sysd.dyn = lambda a, b, c, u, w: (a + 0.125 * u, 0.9 * b + 0.1 * c + w, 0.8 * c - 0.1 * b + 0.5 * w)
+    sysd.cost = lambda a, b, c, u, w: (b - u) * (b - u) + 0.1 * u * u + 0.25 * a
+    sysd.control_box = box
+    sysd.perturb_laws = [models.NormalLaw(0, 0.05)]
+    s = DPSolver(sysd)
+    s.discretize_state(0, 1, N, 0, 1, N, 0, 1, N)
+    s.discretize_perturb(-0.1, 0.1, 5)
+    s.control_steps = (0.125,)
+    return s
+
+
+def _V0(s):
+    a, b, c = np.meshgrid(*s.state_grid, indexing='ij')
+    return np.sin(3 * a) + np.cos(2 * b + c) + (a - 0.5) ** 2
+
+
+def _check_against_the_oracle(s, V, nodes):
+    J, pol = s.value_iteration(V, report_time=False)
+    idx = s.last_policy_index
+    Jo, po, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(s), V, nodes=nodes)
+    assert np.array_equal(J.ravel()[nodes], Jo)
+    assert np.array_equal(idx.ravel()[nodes], io)
+    assert np.array_equal(pol.reshape(-1, 1)[nodes], po)
+    return J, pol, idx
+
+
+def test_a_box_that_differs_from_its_vectorisation_at_one_interior_node_of_a_128_cubed_grid(gpu):
+    N = 128
+    grid = np.linspace(0, 1, N)
+    odd = (41, 77, 103)
+    at = tuple(float(grid[i]) for i in odd)
+
+    def box(a, b, c):
+        lo, hi = np.max((-a * 8, -1.0)), np.min(((1 - a) * 8, 1.0))
+        if a == at[0] and b == at[1] and c == at[2]:          # ONE interior node of 2 097 152: every sample misses it
+            hi = 0.0
+        return ((lo, hi),)
+    s = _storage(N, box)
+    V = _V0(s)
+    flat_odd = int(np.ravel_multi_index(odd, (N, N, N)))
+    rng = np.random.default_rng(6)
+    nodes = np.unique(np.concatenate([[flat_odd, flat_odd - 1, flat_odd + 1, flat_odd - N, flat_odd + N * N, 0, N ** 3 - 1],
+                                      rng.integers(0, N ** 3, size=300)]))
+    J, pol, idx = _check_against_the_oracle(s, V, nodes)
+    assert s.backend_info['box_mode'] == 'traced' and s.backend_info['box_per_node']
+    # the odd node's lattice ends at 0: 9 points on [-1, 0] where its neighbours have 17 on [-1, 1]
+    bp = s._box_plan()
+    assert bp['n'][0, flat_odd] == 9 and bp['n'][0, flat_odd + 1] == 17 and (bp['hi'][0] == 0.0).sum() == 1
+    assert pol.ravel()[flat_odd] <= 0.0
+    # .. and it matters: without the branch the node's optimum lies at a positive control
+    s2 = _storage(N, lambda a, b, c: ((np.max((-a * 8, -1.0)), np.min(((1 - a) * 8, 1.0))),))
+    J2, pol2 = s2.value_iteration(V, report_time=False)
+    assert pol2.ravel()[flat_odd] > 0.0 and J2.ravel()[flat_odd] < J.ravel()[flat_odd]
+    same = np.ones(N ** 3, dtype=bool)
+    same[flat_odd] = False
+    assert np.array_equal(J2.ravel()[same], J.ravel()[same])
+
+
+def test_closure_data_that_changes_for_one_node_between_two_calls(gpu):
+    N = 48
+    grid = np.linspace(0, 1, N)
+    special = {'node': (10, 20, 30), 'hi': 0.25}
+
+    def box(a, b, c):
+        i, j, k = special['node']
+        hi = np.min(((1 - a) * 8, 1.0))
+        hi = np.where((a == grid[i]) & (b == grid[j]) & (c == grid[k]), special['hi'], hi)
+        return ((np.max((-a * 8, -1.0)), hi),)
+    s = _storage(N, box)
+    V = _V0(s)
+    rng = np.random.default_rng(7)
+
+    def nodes_around(ind):
+        f = int(np.ravel_multi_index(ind, (N, N, N)))
+        return f, np.unique(np.concatenate([[f, f - 1, f + 1, f + N, f - N * N], rng.integers(0, N ** 3, size=200)]))
+    f1, nodes = nodes_around(special['node'])
+    J1, pol1, _ = _check_against_the_oracle(s, V, nodes)
+    assert s.backend_info['box_mode'] == 'traced'
+    assert pol1.ravel()[f1] <= 0.25
+    special['hi'] = -0.5                                       # the same node, another box: nothing else changes
+    J2, pol2, _ = _check_against_the_oracle(s, V, nodes)
+    assert pol2.ravel()[f1] <= -0.5 and J2.ravel()[f1] != J1.ravel()[f1]
+    rest = np.ones(N ** 3, dtype=bool)
+    rest[f1] = False
+    assert np.array_equal(J1.ravel()[rest], J2.ravel()[rest])
+    special['node'] = (30, 5, 17)                              # the odd box moves to another node
+    f3, nodes3 = nodes_around(special['node'])
+    J3, pol3, _ = _check_against_the_oracle(s, V, np.unique(np.concatenate([nodes, nodes3])))
+    assert pol3.ravel()[f3] <= -0.5 and pol3.ravel()[f1] == pol_without(s, V, f1)
+
+
+def pol_without(s, V, flat):
+    """the policy at one node when no node is special (the oracle, node by node)"""
+    spec = vi_numpy.Spec.from_solver(s)
+    _, po, _, _ = vi_numpy.value_iteration(spec, V, nodes=[flat])
+    return po[0, 0]
+
+
+def test_branches_on_the_state_in_every_kernel_family(gpu):
+    """a box with Python control flow (builtins max / min, `if`) used to send the table to scalar calls at every node;
+    traced along every path it is a table like any other -- for the column kernel, the staged tiles and the direct kernel"""
+    def box(a, b, c):
+        lo = max(-a * 8, -1.0)
+        if a > 0.75:
+            hi = min((1 - a) * 8, 0.5)
+        else:
+            hi = 1.0
+        return ((lo, hi),)
+    ref = None
+    for kernel in ('auto', 'staged', 'generic'):
+        s = _storage(20, box)
+        s.kernel = kernel
+        V = _V0(s)
+        J, pol = s.value_iteration(V, report_time=False)
+        assert s.backend_info['box_mode'] == 'traced'
+        if ref is None:
+            Jo, po, io, _ = vi_numpy.value_iteration(vi_numpy.Spec.from_solver(s), V)
+            ref = (Jo, po, io)
+        assert np.array_equal(J, ref[0]) and np.array_equal(pol, ref[1]) and np.array_equal(s.last_policy_index, ref[2])

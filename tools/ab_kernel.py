@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Same-box A/B of kernel variants of one bench configuration: every variant is a set of K=V switches of the generated
+kernels (codegen.DEBUG_NAMES); the variants are timed in interleaved rounds in ONE process (devices differ by a few per
+cent, and a chip warms up), and every variant's J and policy index after the chain of sweeps are compared with the
+first variant's over all nodes.
+usage: python tools/ab_kernel.py [--config synth256|synth512f32|noisy256] [--rounds R] [--sweeps K] -- [K=V ..] -- [K=V ..] ...
+       (an empty group is the default kernel)                                          (through gpurun)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from stodynprog_amd import models
+
+
+def build(config, defs):
+    if config == 'synth256':
+        _, s = models.synthetic3d(N=256)
+        V0 = models.synthetic3d_V0(s.state_grid)
+    elif config == 'noisy256':
+        _, s = models.synthetic3d(N=256, stock_noise=0.07)
+        V0 = models.synthetic3d_V0(s.state_grid)
+    elif config == 'synth512f32':
+        _, s = models.synthetic3d(N=512)
+        s.dtype = np.dtype('float32')
+        V0 = models.synthetic3d_V0(s.state_grid, np.float32)
+    else:
+        raise SystemExit('unknown config ' + config)
+    s.debug_defines = dict(defs) or None
+    prob = s._problem()
+    prob.set_value(V0)
+    return s, prob
+
+
+def main():
+    argv = sys.argv[1:]
+    head = argv[:argv.index('--')] if '--' in argv else argv
+    rest = argv[len(head):]
+    config, rounds, sweeps, warm = 'synth256', 5, 10, 3
+    it = iter(head)
+    for a in it:
+        if a == '--config': config = next(it)
+        elif a == '--rounds': rounds = int(next(it))
+        elif a == '--sweeps': sweeps = int(next(it))
+        elif a == '--warm': warm = int(next(it))
+    groups, cur = [], None
+    for a in rest:
+        if a == '--':
+            if cur is not None: groups.append(cur)
+            cur = []
+        else:
+            cur.append(tuple(a.split('=', 1)))
+    if cur is not None: groups.append(cur)
+    if not groups: groups = [[]]
+    probs = []
+    for g in groups:
+        s, p = build(config, g)
+        p.bench_sweeps(max(warm, 1))
+        probs.append((g, s, p))
+    times = [[] for _ in probs]
+    for r in range(rounds if warm > 0 else 0):
+        for k, (g, s, p) in enumerate(probs):
+            p.swap()                                   # (go on from the last J: a call starts on the buffers it finds)
+            _, kern = p.bench_sweeps(sweeps)
+            times[k].append(kern / sweeps)
+    ref = None
+    for k, (g, s, p) in enumerate(probs):
+        # every problem has run the same number of sweeps from the same V0 (bench_sweeps ping-pongs V and J)
+        J = p.get_value()
+        _, idx = p.get_policy()
+        if ref is None:
+            ref = (J, idx)
+            same = 'reference'
+        else:
+            same = 'J identical: {}  index identical: {}'.format(np.array_equal(J, ref[0]), np.array_equal(idx, ref[1]))
+            if not np.array_equal(J, ref[0]):
+                bad = J != ref[0]
+                where = np.argwhere(bad)
+                same += '  ({} entries differ, largest {:.3e}; first at {}, last at {})'.format(
+                    int(bad.sum()), float(np.abs(J - ref[0])[bad].max()), where[0].tolist(), where[-1].tolist())
+        t = np.array(times[k])
+        print('{:60s} kernel min {:.4f}  median {:.4f}  max {:.4f} ms   {}'.format(
+            ' '.join('='.join(kv) for kv in g) or '(default)', t.min(), np.median(t), t.max(), same), flush=True)
+
+
+if __name__ == '__main__':
+    main()
