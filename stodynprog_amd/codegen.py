@@ -35,14 +35,15 @@ DEBUG_INT_MACROS = ('SDP_COL_SHARE_X2', 'SDP_COL_MIN_WAVES', 'SDP_COL_BATCH', 'S
                     'SDP_COL_A_GROUP', 'SDP_COL_A_ORDER', 'SDP_COL_FILTER_UNROLL', 'SDP_COL_B_PRIO',
                     'SDP_COL_FILTER_TOP2', 'SDP_COL_TILE', 'SDP_COL_FILTER_RUNROLL', 'SDP_COL_LEAN', 'SDP_COL_WIDE',
                     'SDP_COL_A_WIDE_LOADS', 'SDP_COLU_WIDE_LOADS', 'SDP_COLU_A_GROUP', 'SDP_COL_LDS_PAD', 'SDP_COL_HOIST',
-                    'SDP_COL_TAIL_KEEP', 'SDP_COL_KEEP_BATCH', 'SDP_COL_KEEP_LOADS')
+                    'SDP_COL_TAIL_KEEP', 'SDP_COL_KEEP_BATCH', 'SDP_COL_KEEP_LOADS', 'SDP_COL_TAIL_HOLD', 'SDP_SHORT_GROUP', 'SDP_BNB_CHUNK')
 # (SDP_COL_LEAN2 = 0 keeps the resident-chunk kernel on the first pass of section 3.1c: an A/B switch of short_pass_source)
 # (SDP_COL_WRES is a planning switch: it sizes the LDS image -- column_config)
 # every name a `debug` dict may carry (a typo must not pass silently)
 DEBUG_NAMES = frozenset(DEBUG_INT_MACROS + (
     'SDP_STAMP', 'SDP_NO_POW2', 'SDP_EXTRA_DEFINES', 'SDP_COL_FILTER_SCALE', 'SDP_LEAD_FILTER_SCALE',
     'SDP_LEAD_UNROLL', 'SDP_COL_A_LW', 'SDP_COL_FILTER', 'SDP_COL_SHIFT', 'SDP_COL_UTAB', 'SDP_LEAD_FILTER',
-    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES', 'SDP_COL_LEAN2', 'SDP_COL_BNB'))
+    'SDP_COL_THREADS', 'SDP_COL_WCHUNK', 'SDP_STG_CU', 'SDP_COL_WPAIR', 'SDP_COL_WRES', 'SDP_COL_LEAN2', 'SDP_COL_BNB',
+    'SDP_LINE_FILTER', 'SDP_LINE_FILTER_SCALE', 'SDP_LINE_TOP2'))
 
 
 def check_debug(debug):
@@ -503,10 +504,20 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
         order = column_build_order(int(col_cfg[0]), column[1], int(window[2]) if window is not None else column[0],
                                    (16 // rs) if wide else 1)
         if order[0] == 2:
+            lw = int(_dbg(debug, 'SDP_COL_A_LW') or order[1])
             lines += ['#define SDP_COL_A_ORDER 2',
-                      '#define SDP_COL_A_LW {}'.format(int(_dbg(debug, 'SDP_COL_A_LW') or order[1]))]
+                      '#define SDP_COL_A_LW {}'.format(lw)]
             if wide and not _dbg(debug, 'SDP_COL_A_WIDE_LOADS'):
                 lines.append('#define SDP_COL_A_WIDE_LOADS 1')
+                # resident chunks: the tail is built once, its entries wait in the registers of the threads that made
+                # them (SDP_COL_TAIL_HOLD of csrc/sdp_colres_kernel.h; round 6: 1.235 -> 1.048 ms on the benchmark, same
+                # bits) -- where they are whole rounds of points and rows and at most 32 registers per thread
+                if (wres and rs == 8 and not shifted and not wpair and window is None and _dbg(debug, 'SDP_COL_TAIL_HOLD') is None
+                        and not _dbg(debug, 'SDP_COL_TAIL_KEEP')):
+                    tail, groups = int(column[1]) - int(wres), int(col_cfg[0]) // lw
+                    if (tail > 0 and tail % groups == 0 and int(column[0]) % (2 * lw) == 0
+                            and (tail // groups) * (int(column[0]) // (2 * lw)) * 4 <= 32):
+                        lines.append('#define SDP_COL_TAIL_HOLD 1    // the tail of the table is built once and held in registers')
     if window is not None:
         lines.append('#define SDP_COL_ROWS {}'.format(int(window[2])))
     if per_control is not None:
@@ -542,9 +553,60 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
     return lines
 
 
+def line_filter_applies(model, dtype, W, debug=None):
+    """ONE state variable whose perturbation enters x' through final sums (`x + u - w`, the shop inventory of the
+    reference's tutorial, doc/example_inventory.py:31-33), a cost that does not see the perturbation, 8-byte reals:
+    the certified filter on the shifted lattice with the value array itself as the table (csrc/sdp_line_kernel.h).
+    (`debug`: SDP_LINE_FILTER = 0 switches it off, A/B runs.)"""
+    if _dbg(debug, 'SDP_LINE_FILTER', '1') == '0':
+        return False
+    return bool(model.n_state == 1 and model.n_perturb == 1 and 1 <= int(W) <= 1024 and np.dtype(dtype).itemsize == 8
+                and not model.time_dep and model.lead_depends_on_w and not model.cost_depends_on_w
+                and model.lead_split() is not None)
+
+
+def line_functions_source(model):
+    """C++ text of the slices csrc/sdp_line_kernel.h uses: a, the signed sum B of the b_i with the sum of their
+    magnitudes, the cost -- each with the reference's own operations (as separable_functions_source emits them
+    for the column kernel's shifted lattice)"""
+    a_node, terms = model.lead_split()
+    out = []
+    lines = ['SDP_DEV sdp_real sdp_model_lead_a(const sdp_real *x, const sdp_real *u, sdp_real t)',
+             '{', '    (void)x; (void)u; (void)t;']
+    names = _emit_body(model, model.slice_nodes([a_node]), lines)
+    lines += ['    return {};'.format(names[a_node.id]), '}']
+    out.append('\n'.join(lines))
+    chain = model.lead_split_chain()
+    if chain is not None:
+        leaves = [n for n, _ in chain[0]]
+        lines = ['SDP_DEV sdp_real sdp_model_lead_aabs(const sdp_real *x, const sdp_real *u, sdp_real t)',
+                 '{', '    (void)x; (void)u; (void)t;']
+        names = _emit_body(model, model.slice_nodes(leaves), lines)
+        lines += ['    return {};'.format(' + '.join('fabs({})'.format(names[n.id]) for n in leaves)), '}']
+        out.append('\n'.join(lines))
+    lines = ['SDP_DEV void sdp_model_lead_b(const sdp_real *x, sdp_real w, sdp_real t, sdp_real &b, sdp_real &babs)',
+             '{', '    (void)x; (void)w; (void)t;']
+    names = _emit_body(model, model.slice_nodes([b for b, _ in terms]), lines)
+    b0, s0 = terms[0]
+    lines.append('    b = {}{};'.format('-' if s0 < 0 else '', names[b0.id]))
+    lines.append('    babs = fabs({});'.format(names[b0.id]))
+    for bn, sg in terms[1:]:
+        lines.append('    b = b {} {};'.format('+' if sg > 0 else '-', names[bn.id]))
+        lines.append('    babs = babs + fabs({});'.format(names[bn.id]))
+    lines.append('}')
+    out.append('\n'.join(lines))
+    lines = ['SDP_DEV sdp_real sdp_model_cost(const sdp_real *x, const sdp_real *u, sdp_real w,',
+             '                                sdp_real t)',
+             '{', '    (void)x; (void)u; (void)w; (void)t;']
+    names = _emit_body(model, model.slice_nodes([model.cost]), lines)
+    lines += ['    return {};'.format(names[model.cost.id]), '}']
+    out.append('\n'.join(lines))
+    return '\n\n'.join(out)
+
+
 def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
                      per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None, wres=0,
-                     lead_perm=None):
+                     lead_perm=None, line=0):
     """column: None for the generic node-order kernels, or (N0, W[, controls, columns]) to also
     build the column kernels of csrc/sdp_column_kernel.h for a storage-separable
     model on a grid with N0 points along axis 0 and W perturbation points.
@@ -591,6 +653,19 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
             '#define SDP_STG_CAP {}'.format(int(staged['cap'])),
             '#include "sdp_staged_kernel.h"    // also brings in sdp_sweep_kernel.h',
             '']
+    elif line:
+        # one state variable with noise in its sums: the filter on the shifted lattice, the value array as its table
+        chain = model.lead_split_chain()
+        head += ['#define SDP_LINE 1',
+                 '#define SDP_LINE_W {}'.format(int(line)),
+                 '#define SDP_LINE_CHAIN {}        // additions of a chain of sums that was regrouped (0: the final-sum form)'.format(
+                     chain[1] if chain is not None else 0)]
+        if _dbg(debug, 'SDP_LINE_FILTER_SCALE'):
+            head.append('#define SDP_LINE_FILTER_SCALE {}'.format(float(_dbg(debug, 'SDP_LINE_FILTER_SCALE'))))
+        if _dbg(debug, 'SDP_LINE_TOP2') is not None:
+            head.append('#define SDP_LINE_TOP2 {}'.format(int(_dbg(debug, 'SDP_LINE_TOP2'))))
+        head += [line_functions_source(model), '',
+                 '#include "sdp_sweep_kernel.h"    // brings in sdp_line_kernel.h', '']
     elif lead_axes:
         # several controlled state variables: node-order sweep with the filter on an array reduced over w
         head += ['#define SDP_LEAD_AXES {}'.format(int(lead_axes)),

@@ -50,6 +50,86 @@ constexpr int SDP_COLRES_K = SDP_COL_TOP2 ? 2 : 1;        // survivors a lane ca
 #if SDP_COL_TAIL_KEEP && (SDP_COL_SHIFT || !SDP_COL_A_WIDE_LOADS || SDP_COL_A_ORDER != 2 || SDP_COL_WPAIR)
 #error "SDP_COL_TAIL_KEEP: the plain resident-chunk kernel with 16-byte build loads"
 #endif
+// SDP_COL_TAIL_HOLD (round 6): the tail is built ONCE and its entries stay IN REGISTERS.  The thread that computes
+// T[w][r .. r+1], w >= C, in the first build of the tail keeps them -- (W - C) N0 / threads entries, 32 registers at
+// 16 x 256 / 256 -- through the first pass and the second pass over the head, and writes them back into the table where
+// the rebuild of the tail used to be: no strip loads (a third of the kernel's vector-memory instructions), no
+// interpolation (9 operations per entry), the same values by construction.  The registers are what it costs: the
+// kernel no longer fits the 128 of four waves per SIMD, so such a build asks for three (168 registers; the LDS image
+// still admits four workgroups per CU, the register file three).
+#ifndef SDP_COL_TAIL_HOLD
+#define SDP_COL_TAIL_HOLD 0
+#endif
+#if SDP_COL_TAIL_HOLD && (SDP_COL_SHIFT || !SDP_COL_A_WIDE_LOADS || SDP_COL_A_ORDER != 2 || SDP_COL_WPAIR || SDP_COL_TAIL_KEEP || \
+                          (SDP_COL_W - SDP_COL_WRES) % (SDP_COL_THREADS / SDP_COL_A_LW) != 0 || SDP_COL_ROWS % (2 * SDP_COL_A_LW) != 0)
+#error "SDP_COL_TAIL_HOLD: the plain resident-chunk kernel with 16-byte build loads, whole rounds of points and rows"
+#endif
+#if SDP_COL_TAIL_HOLD
+// the tail's build with the entries kept (BUILD) / the kept entries back into the table (!BUILD): the loops of
+// sdp_col_phase_a's 16-byte form with compile-time trip counts, so that `held` lives in registers
+typedef sdp_real sdp_held_rows __attribute__((ext_vector_type(2)));
+constexpr int SDP_HOLD_WP = SDP_COL_THREADS / SDP_COL_A_LW;                    // perturbation points side by side
+constexpr int SDP_HOLD_NW = (SDP_COL_W - SDP_COL_WRES) / SDP_HOLD_WP;            // points per thread
+constexpr int SDP_HOLD_NJ = SDP_COL_ROWS / (2 * SDP_COL_A_LW);                   // row pairs per thread and point
+template <bool BUILD>
+SDP_DEV void sdp_colres_tail(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_DT> &tg, const SdpColShared &s,
+                             sdp_held_rows (&held)[SDP_HOLD_NW][SDP_HOLD_NJ])
+{
+    constexpr int N0 = SDP_COL_ROWS, C = SDP_COL_WRES, LW = SDP_COL_A_LW, NV = 1 << SDP_DT;
+    const sdp_real *__restrict__ V = (const sdp_real *)a.V + s.r0;
+    const int rl = threadIdx.x % LW, wg = threadIdx.x / LW;
+#pragma unroll
+    for (int wi = 0; wi < SDP_HOLD_NW; ++wi) {
+        const int tw = wg + wi * SDP_HOLD_WP, w = C + tw;
+        if (BUILD) {
+            int off[SDP_DT];
+            sdp_real lam[SDP_DT], oml[SDP_DT];
+#pragma unroll
+            for (int k = 0; k < SDP_DT; ++k) {
+                off[k] = s.w_off[w * SDP_DT + k];
+                lam[k] = s.w_lam[w * SDP_DT + k];
+                oml[k] = s.w_oml[w * SDP_DT + k];
+            }
+            int voff[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                int o = 0;
+#pragma unroll
+                for (int k = 0; k < SDP_DT; ++k) o += off[k] + (((q >> (SDP_DT - 1 - k)) & 1) ? tg.M[k] : 0);
+                voff[q] = o;
+            }
+            sdp_held_rows vals2[SDP_HOLD_NJ][NV];
+#pragma unroll
+            for (int j = 0; j < SDP_HOLD_NJ; ++j) {
+                const int r = (j * LW + rl) * 2;
+#pragma unroll
+                for (int q = 0; q < NV; ++q) vals2[j][q] = *(const sdp_held_rows *)(V + r + voff[q]);
+            }
+#pragma unroll
+            for (int j = 0; j < SDP_HOLD_NJ; ++j) {
+                sdp_held_rows e;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    sdp_real one[NV];
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) one[q] = vals2[j][q][c];
+                    e[c] = SdpColNest<0, false>::run(one, lam, oml, tg.shift);
+                }
+                held[wi][j] = e;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SDP_HOLD_NJ; ++j) *(sdp_held_rows *)(s.T + tw * N0 + (j * LW + rl) * 2) = held[wi][j];
+    }
+}
+#endif
+
+// diagnostic builds only (results wrong): bit mask of the parts of a unit to leave out -- 1 first build of the tail and
+// its reduction, 2 build of the head and its reduction, 4 first pass, 8 second pass over the head, 16 rebuild of the
+// tail, 32 second pass over the tail, 64 the next unit's column-level tables, 128 the stores
+#ifndef SDP_DIAG_SKIP
+#define SDP_DIAG_SKIP 0
+#endif
 #define SDP_COLRES_TAIL_BYTES (SDP_COL_TAIL_KEEP ? (SDP_COL_W - SDP_COL_WRES) * SDP_COL_ROWS * (int)sizeof(sdp_real) : 0)
 
 // cell of x0' along axis 0 of one control for the perturbation point value `wv`, as sdp_col_expected_cost computes it (pyx:75-81)
@@ -365,13 +445,18 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         sdp_col_shift_col(sdp_lds, lead, upar, shc);
         sdp_col_shift_zero(sdp_lds, shc);
 #endif
-        sdp_col_phase_a<false>(a, tg, s, C, R, kept);
+#if SDP_COL_TAIL_HOLD
+        sdp_held_rows held[SDP_HOLD_NW][SDP_HOLD_NJ];
+        sdp_colres_tail<true>(a, tg, s, held);
+#else
+        if (!(SDP_DIAG_SKIP & 1)) sdp_col_phase_a<false>(a, tg, s, C, R, kept);
+#endif
         __syncthreads();
 #if SDP_COL_SHIFT
         sdp_col_shift_reduce(a, sdp_lds, filt, shc, parity, upar, C, R);         // (adds into the cleared lattice)
 #else
         sdp_real acc_t = (sdp_real)0, big = (sdp_real)0;
-        if (r < N0) {
+        if (r < N0 && !(SDP_DIAG_SKIP & 1)) {
 #pragma unroll SDP_COL_FILTER_RUNROLL
             for (int w = 0; w < R; ++w) {
                 const sdp_real v = sdp_lds.T[w * N0 + r];
@@ -382,7 +467,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
         __syncthreads();                                   // the tail has been read
         // ---- head of the table, the reduced table
-        sdp_col_phase_a<false>(a, tg, s, 0, C);
+        if (!(SDP_DIAG_SKIP & 2)) sdp_col_phase_a<false>(a, tg, s, 0, C);
         if (wave == waves - 1 && lane == 0) sdp_lds.next_unit = nx;
         __syncthreads();
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
@@ -394,7 +479,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             if (r < N0) {
                 sdp_real acc = (sdp_real)0;
 #pragma unroll SDP_COL_FILTER_RUNROLL
-                for (int w = 0; w < C; ++w) {
+                for (int w = 0; w < ((SDP_DIAG_SKIP & 2) ? 0 : C); ++w) {
                     const sdp_real v = sdp_lds.T[w * N0 + r];
                     acc = acc + pw[w] * v;
                     big = sdp_vmax_abs(big, v);
@@ -444,6 +529,13 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #pragma unroll
             for (int c = 0; c < SDP_NU; ++c) cd.u[j][c] = (sdp_real)0;
         }
+        if (live && (SDP_DIAG_SKIP & 4)) {
+            x[0] = axis0[i];
+            cd.n = 1; cd.idx[0] = 3; ibest = 3;
+            sdp_controls_at(box, 3, cd.u[0]);
+            cd.g[0] = sdp_model_cost(x, cd.u[0], (sdp_real)0, t);
+            sdp_colres_cell(lead, x, cd.u[0], (sdp_real)0, t, cd.q0[0], cd.lam0[0], cd.oml0[0]);
+        } else
         if (live) {
             x[0] = axis0[i];
 #if SDP_COL_LEAN2
@@ -577,7 +669,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #endif
         // (the lanes of a wave run the same code: two chains where any lane carries two survivors)
         const bool two = SDP_COLRES_K > 1 && __any(cd.n == 2);
-        if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
+        if (SDP_DIAG_SKIP & 8) {}
+        else if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
         else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, 0, C, 0, cd);
 #if SDP_COL_TAIL_KEEP
         // ---- second pass over the tail, from the copy its first build left in global memory (no barrier: the table
@@ -590,10 +683,15 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         __syncthreads();                                   // the head has been read
         // ---- the tail again, second pass over it
         __builtin_amdgcn_s_setprio(0);
-        sdp_col_phase_a<false>(a, tg, s, C, R);
+#if SDP_COL_TAIL_HOLD
+        sdp_colres_tail<false>(a, tg, s, held);
+#else
+        if (!(SDP_DIAG_SKIP & 16)) sdp_col_phase_a<false>(a, tg, s, C, R);
+#endif
         __syncthreads();
         __builtin_amdgcn_s_setprio(SDP_COL_B_PRIO);
-        if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
+        if (SDP_DIAG_SKIP & 32) {}
+        else if (SDP_COLRES_K > 1 && two) sdp_colres_partial<SDP_COLRES_K>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
         else if (cd.n) sdp_colres_partial<1>(sdp_lds.T, wts, lead, x, t, C, Wn, C, cd);
 #endif
         if (live) {
@@ -606,7 +704,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
 #ifdef SDP_DIAG_BNB_COUNT
             best = diag_cnt;
 #endif
-            sdp_col_store(a, node, box, best, ibest);
+            if (!(SDP_DIAG_SKIP & 128)) sdp_col_store(a, node, box, best, ibest);
             if (ibest != INT_MAX) guess = ibest;
         }
         {
@@ -614,7 +712,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             // the stores, a wave holds next to nothing in registers: between the two halves of the second pass these tables
             // cost the branch-and-bound build five reloads of spilled registers per unit, each a memory round trip)
             const int nxu = __builtin_amdgcn_readfirstlane(sdp_lds.next_unit);
-            if (u_base + nxu < u_end) {
+            if (u_base + nxu < u_end && !(SDP_DIAG_SKIP & 64)) {
                 sdp_real xn[SDP_D];
                 sdp_col_coords(a, sdp_col_of_unit(a, u_base + nxu), xn);
                 sdp_col_phase_w(a, tg, s, xn, nullptr, t, (waves - 1) * 64, 64, w_mine);

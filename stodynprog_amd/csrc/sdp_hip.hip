@@ -1058,9 +1058,14 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
     if (p->layout != SDP_LAYOUT_COLUMNS && p->variant != SDP_VARIANT_STAGED && (p->meta[SDP_META_FLAGS] & SDP_META_F_LEAD)) {
         e = hipModuleGetFunction(&p->f_lead_reduce, p->mod, "sdp_lead_reduce");
         if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_lead_reduce kernel: %s", desc->module_path, hipGetErrorString(e));
-        if (p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
-        int rc = p->lead_a.alloc((size_t)p->S * 8);                                     // (the reduced array: 8-byte sums whatever the reals are, sdp_lead_kernel.h)
-        if (!rc) rc = p->lead_v.alloc((size_t)p->S * rs);
+        // (one state variable, sdp_line_kernel.h: the filter on the shifted lattice -- several lanes per node, and aux_a holds
+        // (A', B') pairs for the positions of a lattice of 2 S + 64 rows at most; no copy of V)
+        const bool line = p->d == 1 && (p->meta[SDP_META_FLAGS] & SDP_META_F_SHIFT);
+        if (line && p->meta[SDP_META_COL_W] != p->W)
+            return fail(SDP_EMODULE, "code object %s was built for %d perturbation points, the problem has %d", desc->module_path, p->meta[SDP_META_COL_W], p->W);
+        if (!line && p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
+        int rc = p->lead_a.alloc(line ? (size_t)(2 * p->S + 64) * 16 : (size_t)p->S * 8);   // (the reduced array: 8-byte sums whatever the reals are, sdp_lead_kernel.h)
+        if (!rc) rc = p->lead_v.alloc(line ? 8 : (size_t)p->S * rs);
         if (!rc) rc = p->lead_e.alloc((size_t)lead_trailing_nodes(p) * rs);            // (a value per trailing index)
         if (!rc) rc = p->lead_vmax.alloc(8);
         if (rc) return rc;
@@ -1260,7 +1265,9 @@ static unsigned sweep_blocks(const sdp_problem *p, int64_t nodes)
 {
     // (with a communicator the bounded grid is kept: the generic kernel leaves
     // most of the LDS and half of the wave slots free for the RCCL kernels)
-    const int64_t tile = (64 / p->lanes) * 4;
+    // (the line kernel, one state variable on the shifted lattice: a workgroup's four waves share a tile of 64 / lanes nodes)
+    const bool line = p->d == 1 && (p->meta[SDP_META_FLAGS] & SDP_META_F_LEAD) && (p->meta[SDP_META_FLAGS] & SDP_META_F_SHIFT);
+    const int64_t tile = (64 / p->lanes) * (line ? 1 : 4);
     int64_t tiles = (nodes + tile - 1) / tile;
     int64_t blocks = (int64_t)p->cus * 8;
     if (blocks > tiles) blocks = tiles;

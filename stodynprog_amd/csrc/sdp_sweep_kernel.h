@@ -151,7 +151,9 @@ SDP_DEV sdp_real sdp_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real
 #endif
 }
 
-#if defined(SDP_LEAD_AXES)
+#if defined(SDP_LINE)
+#include "sdp_line_kernel.h"    // sdp_sweep (+ sdp_lead_reduce) for ONE state variable with noise in its sums: the filter on the shifted lattice
+#elif defined(SDP_LEAD_AXES)
 #include "sdp_lead_kernel.h"    // sdp_sweep (+ sdp_lead_reduce) for several controlled state variables
 #else
 extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
@@ -290,8 +292,16 @@ extern "C" __global__ void __launch_bounds__(64) sdp_simulate(SdpSimArgs a)
 #if !defined(SDP_COL_N0)
 extern "C" {
 __constant__ int32_t sdp_meta[SDP_META_WORDS] = {
-    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0, 1,
-#if defined(SDP_STG_THREADS)
+    SDP_META_MAGIC, (int32_t)sizeof(sdp_real), SDP_D, SDP_NU, SDP_HAS_W, 0, 0,
+#if defined(SDP_LINE)
+    SDP_LINE_W,
+#else
+    1,
+#endif
+#if defined(SDP_LINE)
+    // (one state variable, the filter on the shifted lattice: sdp_lead_reduce fills aux_a with 2 S + 64 (A', B') pairs at most)
+    SDP_META_F_LEAD | SDP_META_F_FILTER | SDP_META_F_SHIFT | SDP_META_F_PEER_STORES, 0, 0, 256, 0, 1, 0,
+#elif defined(SDP_STG_THREADS)
     SDP_META_F_STAGED | SDP_META_F_PEER_STORES, 0, 0, SDP_STG_THREADS, 0, 0, 0,
 #elif defined(SDP_LEAD_AXES)
     SDP_META_F_LEAD | SDP_META_F_FILTER | SDP_META_F_PEER_STORES, 0, 0, 256, 0, SDP_LEAD_AXES,

@@ -228,6 +228,7 @@ class DPSolver(object):
     STAGED_MIN_NODES = 32768          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now);
     STAGED_MIN_WORK = 1024            #         up to 4 x as many where a node has this many control x perturbation points or more
     PERCONTROL_MIN_NODES = 32768      # 'auto': .. and grids of fewer nodes than this the direct kernel rather than a table per control
+    LINE_MIN_CELLS = 1 << 20          # 'auto': one state variable, x' = a(x, u) +- b(w): the filtered line kernel from this many lattice cells per sweep
 
     def __init__(self, sys, dtype=np.float64, comm=None):
         """Dynamic Programming solver for stochastic dynamic control of `sys`
@@ -671,8 +672,8 @@ class DPSolver(object):
         dt = self.dtype
         # storage-separable models on a grid whose (W x N0) table fits the LDS of
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
-        if self.kernel not in ('auto', 'generic', 'column', 'staged', 'lead'):
-            raise ValueError("kernel must be 'auto', 'column', 'lead', 'staged' or 'generic'")
+        if self.kernel not in ('auto', 'generic', 'column', 'staged', 'lead', 'line'):
+            raise ValueError("kernel must be 'auto', 'column', 'lead', 'line', 'staged' or 'generic'")
         may_filter = (getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'
                       and codegen.column_filter_applies(model, dtype=dt, table=(shape[0], W, len(shape)), debug=debug))
         # The shape of the full-table column kernel is planned ONCE, with everything that sizes its LDS image
@@ -777,6 +778,27 @@ class DPSolver(object):
                 staged = codegen.staged_config(model, self.state_grid, self.perturb_grid, bp, dt,
                                                0.0 if box_t is None else float(box_t), debug=debug)
                 self._cache[key] = staged
+        # ONE state variable with the perturbation in its sums (`x + u - w`): the certified filter on the shifted lattice with
+        # the value array itself as the table (csrc/sdp_line_kernel.h; one GPU).  Two launches per sweep, so only where
+        # there is work to save: LINE_MIN_CELLS lattice cells per sweep (below that the direct kernel takes microseconds).
+        line = 0
+        if (len(shape) == 1 and self.kernel in ('auto', 'line') and self.comm is None and W > 0 and staged is None
+                and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact' and box_t is None
+                and model.t_value is None and model.param_index is None
+                and (self.kernel == 'line' or S_nodes * int(bp['max_u']) * W >= self.LINE_MIN_CELLS)
+                and codegen.line_filter_applies(model, dt, W, debug)):
+            line = W
+            # lanes = slices of the control lattice per wave (csrc/sdp_line_kernel.h: a workgroup's four waves share a tile of
+            # 64 / lanes consecutive nodes): enough of them to fill the chip (8192 waves), at least 8 controls per slice,
+            # and a tile's (node, perturbation point) items within the kernel's LDS table of terms (2048)
+            pow2 = lambda v: 1 << max(int(np.ceil(np.log2(max(v, 1)))), 0)
+            need = pow2(W * 64 / 2048.)
+            want = min(pow2(131072. / S_nodes), max(1 << int(np.floor(np.log2(max(bp['max_u'] / 32., 1)))), 1))
+            lanes = int(min(64, max(need, want)))
+        if self.kernel == 'line' and not line:
+            raise ValueError("kernel = 'line' needs one state variable whose perturbation enters x' through final sums "
+                             "(x + u - w), a cost that does not see it, 8-byte reals, a stationary system, the certified "
+                             'filter and exact arithmetic, one GPU')
         filtered = bool(column and getattr(self, 'certified_filter', True) and codegen.column_filter_applies(
             model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None, dtype=dt,
             table=(shape[0], W, len(shape)), debug=debug))
@@ -788,10 +810,10 @@ class DPSolver(object):
                                           window=window, per_control=per_control_cfg if per_control else None,
                                           filtered=filtered, utab=utab, lead_axes=lead_axes,
                                           col_cfg=col_cfg, debug=debug, wres=wres if filtered else 0,
-                                          lead_perm=lead_perm)
-        filtered = filtered or bool(lead_axes)
+                                          lead_perm=lead_perm, line=line)
+        filtered = filtered or bool(lead_axes) or bool(line)
         return dict(model=model, source=source, column=column, lanes=lanes, staged=staged, filtered=filtered,
-                    lead_axes=lead_axes, lead_perm=lead_perm,
+                    lead_axes=lead_axes, lead_perm=lead_perm, line=bool(line),
                     window=window, per_control=per_control,
                     col_seg_nodes=(window[3] if window else (per_control_cfg[0] if per_control else 0)),
                     per_node=bp['per_node'], lo=bp['lo'], hi=bp['hi'], n=bp['n'],
@@ -988,7 +1010,7 @@ class DPSolver(object):
             nat.check(nat.lib().sdp_problem_set_lead_halo(prob.h, self._lead_reach_rows(model, plan, None, around=True) + 1))
         prob.info = dict(mode='traced', exchange=exchange,
                          kernel='column' if column else ('staged' if plan['staged'] else
-                                                         ('lead' if plan.get('lead_axes') else 'generic')),
+                                                         ('lead' if plan.get('lead_axes') else ('line' if plan.get('line') else 'generic'))),
                          controlled_axes=int(plan.get('lead_axes') or (1 if column else 0)),
                          # state variables in the order the filter sees them (stocks first) when they are not listed first
                          controlled_order=(list(plan['lead_perm']) if plan.get('lead_perm') else None),
@@ -999,7 +1021,7 @@ class DPSolver(object):
                          certified_filter=bool(plan.get('filtered')),
                          # 'shifted lattice': the perturbation reaches x0' through a final sum (SDP_COL_SHIFT)
                          filter_form=(None if not plan.get('filtered') else
-                                      ('shifted lattice' if '#define SDP_COL_SHIFT 1' in plan['source'] else
+                                      ('shifted lattice' if ('#define SDP_COL_SHIFT 1' in plan['source'] or plan.get('line')) else
                                        ('reduced array' if plan.get('lead_axes') else 'reduced table'))),
                          # x0' = a chain of sums in another nesting than ((a +- b) +- ..), x + (w - u): regrouped for the first pass
                          regrouped_sums=bool(plan.get('filtered') and '#define SDP_COL_SHIFT 1' in plan['source']
