@@ -1123,6 +1123,10 @@ BUILD_RULES = 'spill fence 1'       # what _native.compile_model does beyond one
 def source_key(source):
     """Cache key of a code object: generated text + kernel headers + flags + the compiler's identity."""
     h = _headers_digest()
+    # (headers only some units include enter the key of those units alone: an edit there leaves the other code objects valid)
+    if '#define SDP_LINE ' in source:
+        with open(os.path.join(CSRC, 'sdp_line_kernel.h'), 'rb') as f:
+            h.update(f.read())
     h.update(source.encode())
     h.update(' '.join(HIPCC_FLAGS[:-1]).encode())
     h.update(compiler_identity().encode())

@@ -1059,15 +1059,15 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         e = hipModuleGetFunction(&p->f_lead_reduce, p->mod, "sdp_lead_reduce");
         if (e != hipSuccess) return fail(SDP_EMODULE, "code object %s has no sdp_lead_reduce kernel: %s", desc->module_path, hipGetErrorString(e));
         // (one state variable, sdp_line_kernel.h: the filter on the shifted lattice -- several lanes per node, and aux_a holds
-        // (A', B') pairs for the positions of a lattice of 2 S + 64 rows at most; no copy of V)
+        // (A', B', C') triplets for the positions of a lattice of 2 S + 64 rows at most; no copy of V)
         const bool line = p->d == 1 && (p->meta[SDP_META_FLAGS] & SDP_META_F_SHIFT);
         if (line && p->meta[SDP_META_COL_W] != p->W)
             return fail(SDP_EMODULE, "code object %s was built for %d perturbation points, the problem has %d", desc->module_path, p->meta[SDP_META_COL_W], p->W);
         if (!line && p->lanes != 1) return fail(SDP_EINVAL, "the reduced-array sweep takes one lane per node (lanes = %d)", p->lanes);
-        int rc = p->lead_a.alloc(line ? (size_t)(2 * p->S + 64) * 16 : (size_t)p->S * 8);   // (the reduced array: 8-byte sums whatever the reals are, sdp_lead_kernel.h)
+        int rc = p->lead_a.alloc(line ? (size_t)(2 * p->S + 64) * 24 : (size_t)p->S * 8);   // (the reduced array: 8-byte sums whatever the reals are, sdp_lead_kernel.h)
         if (!rc) rc = p->lead_v.alloc(line ? 8 : (size_t)p->S * rs);
         if (!rc) rc = p->lead_e.alloc((size_t)lead_trailing_nodes(p) * rs);            // (a value per trailing index)
-        if (!rc) rc = p->lead_vmax.alloc(8);
+        if (!rc) rc = p->lead_vmax.alloc(16);        // (the line kernel keeps two maxima)
         if (rc) return rc;
     }
     if (p->variant == SDP_VARIANT_STAGED) {
@@ -1337,7 +1337,7 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
         int64_t lb, le;
         lead_reduce_range(p, nb, ne, lb, le);
         if (!(p->red_V == p->V.p && p->red_gen == p->V_gen && p->red_t == t_k && p->red_begin <= lb && le <= p->red_end)) {
-            HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 8, p->stream));
+            HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 16, p->stream));
             const int64_t ts = lead_trailing_nodes(p);
             SdpSweepArgs r = a;
             r.n_peer = 0;

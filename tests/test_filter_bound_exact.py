@@ -1001,3 +1001,173 @@ def test_the_reduced_array_radius_covers_the_difference_exactly_in_4_byte_reals(
             assert ratio <= 1.0, (regime, trial, ratio)
             worst = max(worst, ratio)
     assert 0.005 < worst < 0.6, worst
+
+
+# ---------------------------------------------------------------------------
+# The LINE kernel (csrc/sdp_line_kernel.h, round 6): ONE state variable, x' = (X + a_u) - b_w, the shifted lattice with the
+# value array itself as the table.  Its bounds are PER CONTROL and local: e = B'[q0] + cu (ratio (|F| + lf Cq) + lf Cq +
+# (Lc + |lam0| + PA) Dv) for the first level (chord of the reduced table), e2 = 2 cu (the same without B') for the second
+# (G itself in fused arithmetic).  Both are checked against the reference's value exactly, on axes whose span is and is not
+# a power of two and that do not start at zero.
+# ---------------------------------------------------------------------------
+def line_check(V, p, X, a, g, b, smin, span, chain=None):
+    N0 = len(V)
+    nm1 = float(N0 - 1)
+    fc = filter_constants(p)
+    W = len(p)
+    m, e_ = np.frexp(span)
+    pow2 = m == 0.5
+    rspan = 1.0 / span
+    div = (lambda v: v * rspan) if pow2 else (lambda v: v / span)
+    # sdp_line_setup: the shifts
+    q_w, f_w, c_w, pbabs = [], [], [], 0
+    for w in range(W):
+        pb = div(-b[w]) * nm1
+        pa_ = abs(div(abs(b[w])) * nm1)
+        fl = float(np.floor(pb))
+        q_w.append(int(fl))
+        f_w.append(pb - fl)
+        c_w.append(abs(p[w]) * (f_w[-1] * (1.0 - f_w[-1])))
+        pbabs = max(pbabs, int(pa_) + 1)
+    flmax, nflmin = max(q_w), max(-q for q in q_w)
+    kmin, rows = -(flmax + 1), N0 + flmax + nflmin + 1
+    pbmax = float(max(abs(flmax), abs(nflmin), pbabs) + 1)
+    p0 = abs(smin) * (nm1 / abs(span))
+    lc = float(rows) + float(abs(kmin)) + pbmax + p0 * 1.001 + float(N0 + 1)
+    # sdp_lead_reduce
+    Ap, Bp, Cp, dvcol = np.zeros(rows), np.zeros(rows), np.zeros(rows), 0.0
+    for ki in range(rows):
+        k = kmin + ki
+        acc = bnd = big = dv = 0.0
+        lmax = 1.0
+        for w in range(W):
+            j = k + q_w[w]
+            q = max(min(j, N0 - 2), 0)
+            lam = float(j - q) + f_w[w]
+            t0, t1 = V[q], V[q + 1]
+            t2 = V[q + 2] if q + 2 < N0 else V[q + 1]
+            acc = fma(p[w], fma(lam, t1 - t0, t0), acc)
+            d2 = (t2 - t1) - (t1 - t0)
+            bnd = fma(c_w[w], abs(d2) if 0 <= j <= N0 - 3 else 0.0, bnd)
+            big = max(big, abs(t0), abs(t1), abs(t2), abs(V[q - 1] if q > 0 else V[q]))
+            dv = max(dv, abs(t1 - t0), abs(t2 - t1))
+            lmax = max(lmax, abs(lam))
+        Ap[ki], Bp[ki] = acc, bnd
+        Cp[ki] = (3.0 + 2.0 * (lmax + 1.0)) * (fc['pcap'] * big + fc['floor'])
+        dvcol = max(dvcol, fc['pcap'] * (dv * 1.01) + fc['floor'])
+    worst1 = worst2 = share = Fraction(0)
+    for u in range(len(a)):
+        xa = X + a[u]                                        # sdp_model_lead_a
+        pa_abs = (abs(X) + abs(a[u])) * (abs(nm1 * rspan) * 1.002) if chain else 0.0
+        pp = div(xa - smin) * nm1
+        pk = pp - float(kmin)
+        q0 = max(min(int(pk), rows - 2), 0)
+        lam0 = pk - float(q0)
+        F = fma(g[u], fc['psum'], fma(lam0, Ap[q0 + 1] - Ap[q0], Ap[q0]))
+        lc_q = fma(3.0, abs(lam0), 2.0) * max(Cp[q0], Cp[q0 + 1])
+        rnd = fma(fc['ratio'], abs(F) + lc_q, lc_q) + ((lc + abs(lam0)) + pa_abs) * dvcol
+        e1 = fma(fc['cu'], rnd, Bp[q0])
+        # second level: sdp_line_value2
+        pf = float(np.floor(pp))
+        fr = pp - pf
+        k = int(pf)
+        acc = 0.0
+        for w in range(W):
+            fs = fr + f_w[w]
+            carry = 1 if fs >= 1.0 else 0
+            jw = k + q_w[w] + carry
+            q = max(min(jw, N0 - 2), 0)
+            lam = float(jw - q) + (fs - float(carry))
+            acc = fma(p[w], fma(lam, V[q + 1] - V[q], V[q]), acc)
+        F2 = fma(g[u], fc['psum'], acc)
+        e2 = (2.0 * fc['cu']) * (rnd + fc['ratio'] * abs(F2 - F))
+        # the reference: its own position per perturbation point (pyx:75-81), stodynprog.py:677-681
+        E = 0.0
+        for w in range(W):
+            if chain == 'x+(w-u)':
+                xn = X + ((-b[w]) - (-a[u]))
+            elif chain == '(x-w)+u':
+                xn = (X - b[w]) + a[u]
+            else:
+                xn = xa - b[w]
+            sref = div(xn - smin) * nm1
+            qr = max(min(int(sref), N0 - 2), 0)
+            lr = sref - float(qr)
+            val = (1.0 - lr) * V[qr] + lr * V[qr + 1]
+            E = E + (g[u] + val) * p[w]
+        d1, d2_ = abs(Fraction(E) - Fraction(F)), abs(Fraction(E) - Fraction(F2))
+        worst1 = max(worst1, d1 / Fraction(e1))
+        worst2 = max(worst2, d2_ / Fraction(e2))
+        share = max(share, Fraction(Bp[q0]) / Fraction(e1))
+    return float(worst1), float(worst2), float(share)
+
+
+LINE_AXES = [(0.0, 1.0), (-8.0, 32.0), (1000.0, 2.0), (0.0, 10.0), (-3.0, 9.0), (0.25, 0.7)]
+
+
+@pytest.mark.parametrize('chain', [None, 'x+(w-u)', '(x-w)+u'])
+@pytest.mark.parametrize('regime', ['smooth', 'rough', 'cancel', 'weights', 'large', 'fine'])
+def test_the_line_kernels_bounds_cover_the_difference_exactly(regime, chain):
+    rng = np.random.default_rng(900 + ['smooth', 'rough', 'cancel', 'weights', 'large', 'fine'].index(regime))
+    worst1 = worst2 = share = 0.0
+    for trial in range(150):
+        W = int(rng.integers(1, 8))
+        N0 = int(rng.integers(4, 16)) if regime != 'fine' else int(rng.integers(40, 90))
+        smin, span = LINE_AXES[trial % len(LINE_AXES)]
+        r = np.arange(N0) / (N0 - 1.0)
+        if regime in ('smooth', 'fine'):                     # a cost-to-go with curvature: the chord bound decides
+            V = (r - rng.uniform(0, 1)) ** 2 * rng.uniform(0.5, 3) + rng.uniform(-1, 1) * r + rng.uniform(-2, 2)
+        elif regime == 'cancel':
+            V = 1e6 + 1e-6 * rng.standard_normal(N0)
+        else:
+            V = rng.standard_normal(N0)
+            if regime == 'large':
+                V = V * 10.0 ** rng.uniform(100, 250)
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        if regime == 'weights':
+            p = rng.standard_normal(W) * 2.1
+            if abs(p.sum()) < 0.2:
+                p[0] += 1.0
+        scale = float(np.abs(V).max())
+        n = int(rng.integers(1, 12))
+        X = smin + span * float(rng.uniform(0, 1))
+        reach = span * float(10.0 ** rng.uniform(-2, 0.5))   # controls inside the grid ... far outside it
+        a = [float(v) for v in rng.uniform(-reach, reach, size=n)]
+        g = [float(v) * scale * 10.0 ** rng.uniform(-3, 2) for v in rng.standard_normal(n)]
+        b = [span * float(v) for v in rng.uniform(-1, 1, size=W) * 10.0 ** rng.uniform(-2.5, 0.3)]
+        if trial % 4 == 0:
+            b[0] = span * float(rng.integers(-3, 4)) / (N0 - 1)      # a shift of a whole number of rows
+        if trial % 5 == 0:
+            a[0] = span * float(rng.integers(0, N0)) / (N0 - 1) - (X - smin)       # a control that lands on a node (up to roundings)
+        if chain and trial % 3 == 0:                          # leaves that nearly cancel
+            a = [-X + smin + span * float(v) for v in rng.uniform(0, 1, size=n)]
+        w1, w2, sh = line_check(V, p, X, a, g, b, smin, span, chain)
+        assert w1 <= 1.0, (regime, chain, trial, 'first level', w1)
+        assert w2 <= 1.0, (regime, chain, trial, 'second level', w2)
+        worst1, worst2, share = max(worst1, w1), max(worst2, w2), max(share, sh)
+    assert worst1 > 0.05, worst1                              # the chord bound is close to what the lerp leaves out ...
+    if regime in ('smooth', 'rough', 'fine'):
+        assert share > 0.9, share                             # ... and it is what the first level's interval is made of there
+    assert 0.0 < worst2 < 0.6, worst2                         # the second level: roundings only, the documented factor 2 to spare
+
+
+def test_the_line_kernels_position_term_is_needed_on_a_long_axis():
+    """a value array that is a steep straight line (no chord error) on an axis whose positions are large: what separates
+    the reference's value from the filter's is the rounding of the POSITIONS times the slope -- the (Lc + |lam0|) Dv term;
+    without it the local bound (magnitudes around the control's cell) is exceeded"""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for trial in range(60):
+        N0, W = 200, 3
+        V = np.linspace(0.0, 1.0, N0) * 1e6 + 1e-9 * rng.standard_normal(N0)
+        V -= V[N0 // 2]                                       # small values around the controls' cells, a steep slope
+        p = np.array([0.3, 0.4, 0.3])
+        X = 1000.0 + 1.0
+        a = [float(v) for v in rng.uniform(-0.01, 0.01, size=6)]
+        g = [0.0] * 6
+        b = [float(v) for v in rng.uniform(-0.004, 0.004, size=W)]
+        w1, w2, _ = line_check(V, p, X, a, g, b, 1000.0, 2.0)
+        assert w1 <= 1.0 and w2 <= 1.0
+        worst = max(worst, w2)
+    assert worst > 1e-3, worst

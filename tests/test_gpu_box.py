@@ -61,7 +61,8 @@ def test_a_box_that_differs_from_its_vectorisation_at_one_interior_node_of_a_128
     assert s.backend_info['box_mode'] == 'traced' and s.backend_info['box_per_node']
     # the odd node's lattice ends at 0: 9 points on [-1, 0] where its neighbours have 17 on [-1, 1]
     bp = s._box_plan()
-    assert bp['n'][0, flat_odd] == 9 and bp['n'][0, flat_odd + 1] == 17 and (bp['hi'][0] == 0.0).sum() == 1
+    assert bp['n'][0, flat_odd] == 9 and bp['n'][0, flat_odd + 1] == 17
+    assert (bp['hi'][0].reshape(N, N, N)[:-1] == 0.0).sum() == 1          # (the plane a = 1 has hi = 0 everywhere)
     assert pol.ravel()[flat_odd] <= 0.0
     # .. and it matters: without the branch the node's optimum lies at a positive control
     s2 = _storage(N, lambda a, b, c: ((np.max((-a * 8, -1.0)), np.min(((1 - a) * 8, 1.0))),))
