@@ -335,7 +335,11 @@ def run_sharded(args, env):
     import threading
     solver, dev_comm, V0, rank, nat = (env[k] for k in ('solver', 'dev_comm', 'V0', 'rank', 'nat'))
     sync_all, timed_region = env['sync_all'], env['timed_region']
-    exchanges = [e for e in os.environ.get('SDP_COMM_EXCHANGES', 'rccl,direct,sparse,peer').split(',') if e]
+    # Default: the exchanges that rest on the collective library alone -- the all-gather and the grouped sends / receives of
+    # what each rank reads.  The exchanges over buffers mapped through HIP IPC ('direct', 'sparse', 'peer') have never
+    # crossed a real xGMI link: they are opt-in (--exchanges rccl,sendrecv,direct,..) until a multi-GPU run has
+    # reproduced the single-GPU J with them (advisor, round 4).
+    exchanges = [e for e in (args.exchanges or os.environ.get('SDP_COMM_EXCHANGES', '') or 'rccl,sendrecv').split(',') if e]
     if 'rccl' not in exchanges:
         exchanges.insert(0, 'rccl')
     # phases per backup: each phase's exchange runs under the next phase's kernel.  Few phases leave
@@ -344,6 +348,7 @@ def run_sharded(args, env):
     # 'direct': the kernel stores J into the ranks that read it (sparse need lists where the model has them):
     # nothing to hide behind a second phase, so one launch per sweep comes first.
     PLANS = {'rccl': ((4, False), (2, False), (1, False), (8, False), (16, False), (4, True), (8, True)),
+             'sendrecv': ((1, False), (2, False), (4, False)),
              'direct': ((1, False), (2, False)),
              'peer': ((2, False), (1, False), (4, False), (8, False)),
              'sparse': ((1, False), (2, False), (4, False))}
@@ -367,7 +372,7 @@ def run_sharded(args, env):
 
     def configure(exch, ph, taper):
         solver.comm_phases, solver.comm_taper = ph, taper
-        solver.comm_exchange = 'peer' if exch == 'sparse' else exch
+        solver.comm_exchange = 'peer' if exch == 'sparse' else exch          # ('sendrecv': sparse by construction)
         solver.comm_sparse = exch in ('sparse', 'direct')
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -412,7 +417,7 @@ def run_sharded(args, env):
                 trial = configure(exch, ph, taper)
                 _trace('plan', key_of(exch, ph, taper), 'configured')
                 got = solver.backend_info.get('exchange') or 'rccl'        # (None with one rank)
-                if got not in {'sparse': ('peer-sparse',), 'direct': ('direct-sparse', 'direct')}.get(exch, (exch,)):
+                if got not in {'sparse': ('peer-sparse',), 'direct': ('direct-sparse', 'direct'), 'sendrecv': ('sendrecv',)}.get(exch, (exch,)):
                     local_error = ('not available on this node: {}'.format(getattr(trial, 'peer_failure', 'buffers not mappable'))
                                    if got == 'rccl' else 'does not apply to this kernel family')
                 else:
@@ -479,12 +484,12 @@ def run_sharded(args, env):
         box = {'out': best_out}
 
         def bail(exch=exch, box=box):
-            # Every rank leaves with status 0 (the launcher turns any other status of any worker into a failed
-            # run, and the RCCL result is valid): the hang is reported IN the line, as its own field.
-            # Every rank says so on stderr before it leaves (advisor, round 4: ranks other than 0 left no record).
+            # A rank that never answers is a hung GPU process: rank 0 prints the valid RCCL line (with the hang in it, as
+            # its own field), every rank says so on stderr, and every rank leaves with status 3 -- a hang must not
+            # look like a successful run (rounds 3-5 left with 0).  Nothing is restarted.
             try:
                 os.write(2, '[bench rank {}] watchdog: the optional {} exchange did not answer within {:.0f} s; leaving with '
-                            'the RCCL result (exit status 0: the timed RCCL run is valid)\n'.format(rank, exch, budget).encode())
+                            'the RCCL result printed, exit status 3\n'.format(rank, exch, budget).encode())
             except OSError:
                 pass
             try:
@@ -498,7 +503,7 @@ def run_sharded(args, env):
                     # (file descriptor 1 is fenced off while run() executes: write to the real one)
                     os.write(_REAL_STDOUT[0] if _REAL_STDOUT else 1, (json.dumps(o) + '\n').encode())
             finally:
-                os._exit(0)
+                os._exit(3)
         dog = threading.Timer(budget, bail)
         dog.daemon = True
         dog.start()
@@ -526,7 +531,7 @@ def run_sharded(args, env):
         def bail2(box=box):
             try:
                 os.write(2, '[bench rank {}] watchdog: the long-way chain did not answer within {:.0f} s; leaving with the '
-                            'headline result (exit status 0)\n'.format(rank, budget).encode())
+                            'headline result printed, exit status 3\n'.format(rank, budget).encode())
             except OSError:
                 pass
             try:
@@ -538,7 +543,7 @@ def run_sharded(args, env):
                     o['config']['optional_exchange_hang'] = 'long-way chain'
                     os.write(_REAL_STDOUT[0] if _REAL_STDOUT else 1, (json.dumps(o) + '\n').encode())
             finally:
-                os._exit(0)
+                os._exit(3)
         dog = threading.Timer(budget, bail2)
         dog.daemon = True
         dog.start()
@@ -936,6 +941,9 @@ def main():
     ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged', 'lead'],
                     help='kernel family (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--exchanges', default=None, metavar='LIST',
+                    help="N > 1: the exchanges of J to time, comma-separated (default rccl,sendrecv: the collective library "
+                         "alone; direct / sparse / peer write into buffers mapped through HIP IPC: opt-in)")
     ap.add_argument('--no-filter-check', action='store_true',
                     help='skip the untimed re-run of the chain with every control the long way and its comparison')
     ap.add_argument('--no-filter', action='store_true',

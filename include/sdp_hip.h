@@ -331,6 +331,16 @@ int sdp_problem_complete_value(sdp_problem *p);
  */
 int sdp_problem_set_direct_exchange(sdp_problem *p, int on);
 /*
+ * Send / receive exchange (an alternative to sdp_problem_enable_peer_exchange; call it BEFORE sdp_problem_set_peer_needs):
+ * the sparse exchange through the collective library alone.  After each phase's kernel a rank ncclSends every other
+ * rank the bounding range of the rows of that phase the other rank reads, and ncclRecvs its own -- one grouped
+ * send / receive per pair of ranks and phase, no buffer of another process mapped, no store into one.  A rank's J is
+ * complete where it reads; sdp_problem_complete_value / sdp_problem_get_value run the all-gather of every phase.
+ * Without need lists it is the RCCL all-gather.  (The reference's counterpart: none; its loop over the nodes is
+ * serial, stodynprog.py:511-515.)
+ */
+int sdp_problem_set_sendrecv_exchange(sdp_problem *p, int on);
+/*
  * Reduced-array sweep (several controlled state variables, csrc/sdp_lead_kernel.h) on a sharded
  * problem: rows of the FIRST state axis the controls of a node reach on either side.  A rank then
  * reduces its own rows plus that many instead of the whole grid.  A guess is enough: a node whose

@@ -122,6 +122,7 @@ def _declare(lib):
         'sdp_problem_enable_peer_exchange': (C.c_int, [vp]),
         'sdp_problem_disable_peer_exchange': (C.c_int, [vp]),
         'sdp_problem_set_direct_exchange': (C.c_int, [vp, C.c_int]),
+        'sdp_problem_set_sendrecv_exchange': (C.c_int, [vp, C.c_int]),
         'sdp_problem_set_lead_halo': (C.c_int, [vp, i64]),
         'sdp_comm_allreduce_max': (C.c_int, [vp, P(dbl)]),
         'sdp_comm_barrier': (C.c_int, [vp]),

@@ -60,7 +60,7 @@ constexpr int SDP_COLRES_K = SDP_COL_TOP2 ? 2 : 1;        // survivors a lane ca
 #ifndef SDP_COL_TAIL_HOLD
 #define SDP_COL_TAIL_HOLD 0
 #endif
-#if SDP_COL_TAIL_HOLD && (SDP_COL_SHIFT || !SDP_COL_A_WIDE_LOADS || SDP_COL_A_ORDER != 2 || SDP_COL_WPAIR || SDP_COL_TAIL_KEEP || \
+#if SDP_COL_TAIL_HOLD && (!SDP_COL_A_WIDE_LOADS || SDP_COL_A_ORDER != 2 || SDP_COL_WPAIR || SDP_COL_TAIL_KEEP || \
                           (SDP_COL_W - SDP_COL_WRES) % (SDP_COL_THREADS / SDP_COL_A_LW) != 0 || SDP_COL_ROWS % (2 * SDP_COL_A_LW) != 0)
 #error "SDP_COL_TAIL_HOLD: the plain resident-chunk kernel with 16-byte build loads, whole rounds of points and rows"
 #endif

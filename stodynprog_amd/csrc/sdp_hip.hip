@@ -655,6 +655,11 @@ struct RcclApi {
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    // point-to-point, grouped: the sparse exchange that needs nothing but the collective library (sendrecv_phase)
+    int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)(void) = nullptr;
+    int (*GroupEnd)(void) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -698,6 +703,10 @@ static int rccl_load()
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllGather, "ncclAllGather");
     SYM(AllReduce, "ncclAllReduce");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.h = h;
@@ -829,6 +838,7 @@ struct sdp_problem {
     // direct exchange (sdp_problem_set_direct_exchange): the backup kernels themselves store J into the
     // peers' mapped buffers (SdpSweepArgs.peer_J); sparse: per column the ranks that read it
     bool direct = false, mask_valid = false, send_everything = false;
+    bool sendrecv = false;                 // sparse exchange by grouped ncclSend / ncclRecv (no mapped buffers): sdp_problem_set_sendrecv_exchange
     DevBuf peer_mask;
     // reduced-array sweep (csrc/sdp_lead_kernel.h), sharded: rows of the first stock the controls of a node
     // reach on either side (a guess of the host: too small costs time, not correctness); < 0: reduce everything
@@ -1522,6 +1532,70 @@ static int build_peer_mask(sdp_problem *p)
     return SDP_OK;
 }
 
+// Sparse exchange of one phase of J through the collective library alone (the path to a sparse
+// exchange that rests on RCCL, not on stores into HIP-IPC mappings).  A rank reads the cost-to-go array only where the
+// trailing next states of its columns fall (need lists: sdp_problem_set_peer_needs); rank q therefore gets, of this
+// rank's rows of the phase, the BOUNDING range of what it reads there -- one ncclSend / ncclRecv per pair of ranks
+// and phase inside one group (the need lists of a contracting exogenous process are runs of whole rows of the second
+// axis: the bounding range is little more than their union; for anything else it is at worst the dense exchange).
+// Both sides work the range out from the same lists and partition, so the counts match by construction.  Two-sided:
+// nothing lands in a rank's J before that rank has posted its receive, which it does behind the phase's own kernel
+// on the communicator stream -- no rendezvous beside the sends and receives themselves.
+static void bounding_need(const std::vector<std::pair<int64_t, int64_t>> &iv, int64_t lo, int64_t hi, int64_t &s0, int64_t &s1)
+{
+    s0 = s1 = 0;
+    if (hi <= lo) return;
+    auto it = std::lower_bound(iv.begin(), iv.end(), lo,
+                               [](const std::pair<int64_t, int64_t> &r, int64_t v) { return r.second <= v; });
+    if (it == iv.end() || it->first >= hi) return;
+    s0 = it->first > lo ? it->first : lo;
+    auto last = std::lower_bound(iv.begin(), iv.end(), hi,
+                                 [](const std::pair<int64_t, int64_t> &r, int64_t v) { return r.first < v; });
+    --last;                                                // the last range that starts below hi
+    s1 = last->second < hi ? last->second : hi;
+}
+// (slab partitions -- dist.slab_partition: nranks x G phases in node order, phase r G + g owned by rank r alone -- are
+// exchanged G times a backup, not nranks x G times: when this rank's g-th phase is done it sends its rows of that phase
+// and receives every peer's rows of THEIR g-th phase in one group; the phases it does not own pass)
+static bool slab_phases(const sdp_problem *p, int &per_rank)
+{
+    const int n = p->comm->nranks;
+    per_rank = 0;
+    if (p->n_phases % n) return false;
+    const int g = p->n_phases / n;
+    for (int ph = 0; ph < p->n_phases; ++ph) {
+        const int64_t *b = p->parts.data() + (size_t)ph * (n + 1);
+        for (int r = 0; r < n; ++r)
+            if (b[r + 1] > b[r] && r != ph / g) return false;
+    }
+    per_rank = g;
+    return true;
+}
+static int sendrecv_phase(sdp_problem *p, int phase)
+{
+    const int n = p->comm->nranks, me = p->comm->rank;
+    int per = 0;
+    const bool slab = slab_phases(p, per);
+    if (slab && phase / per != me) return SDP_OK;
+    const int g = slab ? phase % per : 0;
+    const int64_t *b = p->parts.data() + (size_t)phase * (n + 1);
+    const size_t rs = real_size(p->dtype);
+    hipStream_t cs = p->comm->stream;
+    char *J = (char *)p->J.p;
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int k = 1; k < n; ++k) {
+        const int to = (me + k) % n, from = (me - k + n) % n;
+        const int64_t *bf = slab ? p->parts.data() + (size_t)(from * per + g) * (n + 1) : b;
+        int64_t s0, s1;
+        bounding_need(p->need[(size_t)to], b[me], b[me + 1], s0, s1);
+        if (s1 > s0) NCCL_TRY(g_rccl.Send(J + (size_t)s0 * rs, (size_t)(s1 - s0) * rs, NCCL_INT8, to, p->comm->comm, cs));
+        bounding_need(p->need[(size_t)me], bf[from], bf[from + 1], s0, s1);
+        if (s1 > s0) NCCL_TRY(g_rccl.Recv(J + (size_t)s0 * rs, (size_t)(s1 - s0) * rs, NCCL_INT8, from, p->comm->comm, cs));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return SDP_OK;
+}
+
 static int gather_phase(sdp_problem *p, int phase)
 {
     return gather_phase_of(p, phase, p->J.p, real_size(p->dtype));
@@ -1557,6 +1631,9 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
                 // (the kernel has stored its rows into the peers that read them: nothing to copy)
             } else if (p->peer_exchange) {
                 if ((rc = push_phase(p, ph, p->ev_phase[ph], everything))) return rc;
+            } else if (p->sendrecv && p->sparse && !everything) {
+                HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
+                if ((rc = sendrecv_phase(p, ph))) return rc;
             } else {
                 HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_phase[ph], 0));
                 if ((rc = gather_phase(p, ph))) return rc;
@@ -1567,7 +1644,7 @@ static int run_backup(sdp_problem *p, bool evalpol, double t_k, int64_t shift_in
         if (p->peer_exchange && (rc = finish_pushes(p, p->n_phases ? p->ev_phase[p->n_phases - 1] : nullptr))) return rc;
         HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
         p->comm_pending = true;
-        p->J_partial = p->peer_exchange && p->sparse && !everything;
+        p->J_partial = (p->peer_exchange || p->sendrecv) && p->sparse && !everything;
     }
     return SDP_OK;
 }
@@ -1586,9 +1663,20 @@ static int join_comm(sdp_problem *p)
 // it computed to every peer.  Collective, like the backups.
 static int complete_J(sdp_problem *p)
 {
-    if (!p->comm || p->comm->nranks == 1 || !p->peer_exchange || !p->J_partial) return SDP_OK;
+    if (!p->comm || p->comm->nranks == 1 || !(p->peer_exchange || p->sendrecv) || !p->J_partial) return SDP_OK;
     int rc;
     if ((rc = join_comm(p))) return rc;
+    if (p->sendrecv) {                                     // every rank's rows to every rank: the all-gather of each phase
+        HIP_TRY(hipEventRecord(p->ev_enter, p->stream));
+        HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_enter, 0));
+        for (int ph = 0; ph < p->n_phases; ++ph)
+            if ((rc = gather_phase(p, ph))) return rc;
+        HIP_TRY(hipEventRecord(p->ev_comm, p->comm->stream));
+        p->comm_pending = true;
+        if ((rc = join_comm(p))) return rc;
+        p->J_partial = false;
+        return SDP_OK;
+    }
     p->peer_fence = true;                                  // nobody may still be reading its J
     if ((rc = open_pushes(p))) return rc;
     HIP_TRY(hipEventRecord(p->ev_enter, p->stream));
@@ -2201,7 +2289,7 @@ extern "C" int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_of
 {
     if (!p) return fail(SDP_EINVAL, "NULL problem");
     if (!need_off || !ranges) { p->sparse = false; p->need.clear(); p->mask_valid = false; return SDP_OK; }
-    if (!p->comm || !p->peer_exchange) return fail(SDP_EINVAL, "sparse exchange needs the peer exchange (sdp_problem_enable_peer_exchange)");
+    if (!p->comm || !(p->peer_exchange || p->sendrecv)) return fail(SDP_EINVAL, "sparse exchange needs the peer exchange (sdp_problem_enable_peer_exchange) or the send / receive one (sdp_problem_set_sendrecv_exchange)");
     if (p->J_partial || p->V_partial) return fail(SDP_EINVAL, "the value arrays are incomplete: fetch or set them first");
     const int n = p->comm->nranks;
     const int64_t unit = p->layout == SDP_LAYOUT_COLUMNS ? p->orders[0] : 1;
@@ -2220,6 +2308,16 @@ extern "C" int sdp_problem_set_peer_needs(sdp_problem *p, const int64_t *need_of
     p->need.swap(need);
     p->sparse = true;
     p->mask_valid = false;
+    return SDP_OK;
+}
+
+extern "C" int sdp_problem_set_sendrecv_exchange(sdp_problem *p, int on)
+{
+    if (!p) return fail(SDP_EINVAL, "NULL problem");
+    if (!on) { p->sendrecv = false; return SDP_OK; }
+    if (!p->comm) return fail(SDP_EINVAL, "no communicator attached");
+    if (p->peer_exchange) return fail(SDP_EINVAL, "the send / receive exchange is an alternative to the peer exchange, not an addition");
+    p->sendrecv = true;
     return SDP_OK;
 }
 

@@ -29,7 +29,7 @@ import numpy as np
 from . import _native as nat
 from . import codegen
 from .interp import MlinInterpolator
-from .trace import TraceError, trace_model, trace_box
+from .trace import TraceError, trace_model, trace_box, callable_fingerprint
 
 __all__ = ['DPSolver']
 
@@ -224,6 +224,10 @@ class DPSolver(object):
     # a control_box callback that cannot be traced (its table is made by scalar calls at every node, like the reference's):
     # 'sample' re-checks the cached table at 24 nodes per call, 'every node' rebuilds it on every call (stodynprog.py:440)
     box_recheck = 'sample'
+    # dyn, cost and control_box are traced again on a call only when their fingerprint changed (trace.callable_fingerprint:
+    # code, defaults, closure cells and the globals they name, by value; callables that have none are traced on every call);
+    # False: trace on every call, as rounds 1-5 did
+    trace_cache = True
     _debug_after_create = None
     STAGED_MIN_NODES = 32768          # 'auto': grids of at most this many nodes run the direct kernel, not the staged tiles (see _kernel_plan_now);
     STAGED_MIN_WORK = 1024            #         up to 4 x as many where a node has this many control x perturbation points or more
@@ -528,6 +532,21 @@ class DPSolver(object):
         parameters (trace.TracedModel.lift_constants), so the steps of a
         horizon share one code object.  Returns a TracedModel or a TraceError."""
         s = self.sys
+        # (round 6: a callable whose FINGERPRINT -- code, defaults, closure cells and the globals it names, by value -- is
+        # what it was at the last call traces to the same graph: the trace is kept.  No fingerprint (an object, a large
+        # array, a module of the user's in sight): traced afresh, as before.  trace.callable_fingerprint)
+        fp = callable_fingerprint(s.dyn, s.cost, s.params) if self.trace_cache else None
+        if fp is not None:
+            kept = self._cache.get(('trace now', s.stationnary, None if s.stationnary else t_k))
+            if kept is not None and kept[0] == fp:
+                return kept[1]
+        model = self._trace_now_uncached(t_k)
+        if fp is not None and (s.stationnary or getattr(model, 't_value', None) is None):
+            self._cache[('trace now', s.stationnary, None if s.stationnary else t_k)] = (fp, model)
+        return model
+
+    def _trace_now_uncached(self, t_k=None):
+        s = self.sys
         try:
             model = trace_model(s.dyn, s.cost, len(s.state), len(s.control), len(s.perturb),
                                 s.params, s.stationnary)
@@ -578,11 +597,17 @@ class DPSolver(object):
         offer; `DPSolver.box_recheck = 'every node'` rebuilds such a table on every call instead, as the reference does."""
         key = ('box', self._fingerprint(box_t))
         bp = self._cache.get(key)
+        # (a callback whose fingerprint is what it was when the table was made would trace to the same graph: no trace)
+        fp = callable_fingerprint(self.sys.control_box, self.sys.params) if self.trace_cache else None
+        if bp is not None and fp is not None and bp.get('fp') == fp and bp.get('sig') is not None:
+            return bp
         tb = self._trace_box_now(box_t)
         if bp is not None:
             if not isinstance(tb, TraceError):
                 if bp.get('sig') != tb.signature():
                     bp = None                   # the callback reads data that changed (or is no longer what it was): rebuild
+                else:
+                    bp['fp'] = fp               # (the same graph under another fingerprint: data it does not depend on)
             elif bp.get('sig') is not None or self.box_recheck == 'every node' or not self._box_still_valid(bp, box_t):
                 bp = None
         if bp is None:
@@ -598,7 +623,7 @@ class DPSolver(object):
             digest = hash((lo.tobytes(), hi.tobytes(), n.tobytes()))
             bp = dict(lo=lo, hi=hi, n=n, per_node=per_node, max_u=max_u,
                       lanes=codegen.lanes_for(max_u), digest=digest, mode=getattr(self, '_box_mode', None),
-                      sig=getattr(self, '_box_sig', None))
+                      sig=getattr(self, '_box_sig', None), fp=fp)
             if box_t is not None:           # one table per time step: keep only the latest
                 for k in [k for k in self._cache if k[0] == 'box']:
                     del self._cache[k]
@@ -655,9 +680,16 @@ class DPSolver(object):
         # The callables are traced afresh on every call (_trace_now), but a trace with the structure and the constants
         # of the last one plans -- and generates -- the same unit: the plan is kept (the source text of a call was a
         # fifth of a millisecond, as much as the kernels of the reference's own problem sizes).
+        # (a trace that was kept -- trace_cache -- keeps what it contributes to the key, too)
+        mk = getattr(model, '_plan_key', None)
+        if mk is None or mk[0] != (model.param_index is not None):
+            mk = (model.param_index is not None, model.structure_key(), np.asarray(model.param_values(), dtype=float).tobytes())
+            try:
+                model._plan_key = mk
+            except AttributeError:
+                pass
         memo = ('plan', self._fingerprint(None), bp['digest'], None if box_t is None else float(box_t),
-                model.structure_key(), np.asarray(model.param_values(), dtype=float).tobytes(),
-                model.param_index is not None, model.t_value, bool(self._cache.get('no_lead')))
+                mk[1], mk[2], model.param_index is not None, model.t_value, bool(self._cache.get('no_lead')))
         kept = self._cache.get(memo)
         if kept is not None:
             return dict(kept, model=model)
@@ -930,7 +962,8 @@ class DPSolver(object):
             unit = shape[0] if column else 1
             bounds = phase_partition(S // unit, unit, self.comm.nranks, self.comm_phases,
                                      self.comm_taper)
-            sparse = (getattr(self, 'comm_sparse', False) and self.comm_exchange in ('peer', 'direct')
+            sparse = ((getattr(self, 'comm_sparse', False) or self.comm_exchange == 'sendrecv')
+                      and self.comm_exchange in ('peer', 'direct', 'sendrecv')
                       and self.comm.nranks > 1 and column and not plan['per_control']
                       and not plan['window'] and model.storage_separable and self.sys.stationnary
                       and len(shape) >= 2)
@@ -1002,8 +1035,18 @@ class DPSolver(object):
                     else:
                         import warnings
                         warnings.warn('the direct exchange serves the (at most 8) GPUs of one node: peer copies instead')
+            elif self.comm_exchange == 'sendrecv':
+                # the sparse exchange through the collective library alone: grouped ncclSend / ncclRecv of the bounding
+                # range of what each rank reads (csrc/sdp_hip.hip, sendrecv_phase); where the model gives no need lists
+                # it is the RCCL all-gather
+                if sparse:
+                    nat.check(nat.lib().sdp_problem_set_sendrecv_exchange(prob.h, 1))
+                    off, ranges = self._peer_needs(model, prob.parts, shape)
+                    nat.check(nat.lib().sdp_problem_set_peer_needs(prob.h, nat.ptr(off), nat.ptr(ranges)))
+                    exchange = 'sendrecv'
+                    prob.need_fraction = float((ranges[:, 1] - ranges[:, 0]).sum()) / S / self.comm.nranks
             elif self.comm_exchange != 'rccl':
-                raise ValueError("comm_exchange must be 'rccl', 'peer' or 'direct'")
+                raise ValueError("comm_exchange must be 'rccl', 'sendrecv', 'peer' or 'direct'")
         if plan.get('lead_axes') and self.comm is not None and self.comm.is_device and self.comm.nranks > 1:
             # rows of the first stock a node's controls reach (sampled: the kernel notices a node that
             # reaches further and evaluates it from the value array itself)

@@ -19,7 +19,7 @@ import numbers
 
 import numpy as np
 
-__all__ = ['TraceError', 'Graph', 'Sym', 'trace_model', 'trace_box', 'TracedBox']
+__all__ = ['TraceError', 'Graph', 'Sym', 'trace_model', 'trace_box', 'TracedBox', 'callable_fingerprint']
 
 
 class TraceError(Exception):
@@ -1156,6 +1156,118 @@ def trace_box(control_box, n_state, n_control, params=None, stationnary=True, t_
 
     ends = merge(leaves, 0)
     return TracedBox(g, ends, n_state, (not stationnary) and t_value is None, t_value, len(leaves))
+
+
+# ---------------------------------------------------------------------------
+# Is a callable still what it was when it was traced?  The reference evaluates dyn, cost and control_box at call time
+# (stodynprog.py:440, 674-676), so data they read may change between two calls; DPSolver therefore traced them afresh
+# on every call (~0.1 ms each: as much as the kernels of the reference's own problem sizes).  A FINGERPRINT of a
+# callable is everything a pure Python function's result can depend on besides its arguments, by VALUE: its code object,
+# its defaults, the contents of its closure cells and of the globals its code names -- numbers, strings, small arrays
+# (bytes), tuples / lists / dicts of those, other Python functions (recursively), library modules and builtins by
+# identity.  Anything else -- an object with attributes, a module that is not a library, an array beyond 64 KiB,
+# deep nesting -- has NO fingerprint (None) and the callable is traced on every call as before: the cache can only
+# ever return the trace of a callable that would trace to the same graph.
+# ---------------------------------------------------------------------------
+_FP_LIBRARIES = ('numpy', 'math', 'cmath', 'scipy', 'operator', 'functools', 'itertools', 'builtins')
+_FP_MAX_ARRAY_BYTES = 1 << 16
+_FP_MAX_ITEMS = 512
+
+
+class _NoFingerprint(Exception):
+    pass
+
+
+def _fp_value(v, depth, budget):
+    import types
+    budget[0] -= 1
+    if budget[0] < 0 or depth > 4:
+        raise _NoFingerprint
+    if v is None or isinstance(v, (bool, int, float, complex, str, bytes)):
+        return (type(v).__name__, v if v == v else 'nan')
+    if isinstance(v, np.generic):
+        return ('g', v.dtype.str, v.tobytes())
+    if isinstance(v, np.ndarray):
+        if v.nbytes > _FP_MAX_ARRAY_BYTES or v.dtype.kind == 'O':
+            raise _NoFingerprint
+        return ('a', v.dtype.str, v.shape, v.tobytes())
+    if isinstance(v, (tuple, list)):
+        return (type(v).__name__,) + tuple(_fp_value(x, depth + 1, budget) for x in v)
+    if isinstance(v, dict):
+        try:
+            keys = sorted(v)
+        except TypeError:
+            raise _NoFingerprint
+        return ('d',) + tuple((_fp_value(k, depth + 1, budget), _fp_value(v[k], depth + 1, budget)) for k in keys)
+    if isinstance(v, types.ModuleType):
+        if v.__name__.split('.')[0] in _FP_LIBRARIES:
+            return ('m', v.__name__)
+        raise _NoFingerprint
+    if isinstance(v, (types.BuiltinFunctionType, np.ufunc)) or (isinstance(v, type) and v.__module__ in ('builtins', 'numpy')):
+        return ('b', getattr(v, '__module__', None), getattr(v, '__qualname__', getattr(v, '__name__', None)), id(v))
+    if isinstance(v, (types.FunctionType, types.MethodType)) or type(v).__name__ == 'partial':
+        return _fp_callable(v, depth + 1, budget)
+    raise _NoFingerprint
+
+
+def _fp_callable(fn, depth, budget):
+    import functools
+    import types
+    if isinstance(fn, functools.partial):
+        return ('partial', _fp_callable(fn.func, depth, budget), _fp_value(tuple(fn.args), depth, budget),
+                _fp_value(dict(fn.keywords or {}), depth, budget))
+    if isinstance(fn, types.MethodType):
+        raise _NoFingerprint                               # (the instance's attributes are out of sight)
+    if not isinstance(fn, types.FunctionType):
+        raise _NoFingerprint
+    code = fn.__code__
+    if getattr(fn.__module__, 'split', None) and (fn.__module__ or '').split('.')[0] in _FP_LIBRARIES:
+        return ('lib', fn.__module__, fn.__qualname__, id(code))
+    parts = ['f', id(code), code.co_code, _fp_value(code.co_consts if not any(isinstance(c, types.CodeType) for c in code.co_consts)
+                                                   else tuple(c for c in code.co_consts if not isinstance(c, types.CodeType)), depth, budget)]
+    for c in code.co_consts:
+        if isinstance(c, types.CodeType):                    # a nested def / lambda / comprehension: its names count too
+            parts.append(('inner', c.co_code, tuple(c.co_names)))
+    parts.append(_fp_value(fn.__defaults__, depth, budget))
+    parts.append(_fp_value(fn.__kwdefaults__, depth, budget))
+    for cell in fn.__closure__ or ():
+        try:
+            parts.append(_fp_value(cell.cell_contents, depth, budget))
+        except ValueError:                                  # an empty cell
+            parts.append(('empty',))
+    glob = fn.__globals__
+    names = set(code.co_names)
+    for c in code.co_consts:
+        if isinstance(c, types.CodeType):
+            names.update(c.co_names)
+    for name in sorted(names):
+        if name in glob:
+            v = glob[name]
+            if v is fn:
+                continue
+            parts.append((name, _fp_value(v, depth, budget)))
+        # (a name that is neither a global nor a builtin is an attribute name: it belongs to a value seen elsewhere)
+    return tuple(parts)
+
+
+def callable_fingerprint(*callables_and_data):
+    """hashable image of everything the results of these callables (pure Python functions) and data (params dicts,
+    numbers) can depend on besides their arguments, or None when that cannot be established (see above)"""
+    import types
+    import functools
+    budget = [_FP_MAX_ITEMS]
+    try:
+        out = []
+        for c in callables_and_data:
+            if isinstance(c, (types.FunctionType, types.MethodType, functools.partial)):
+                out.append(_fp_callable(c, 0, budget))
+            else:
+                out.append(_fp_value(c, 0, budget))
+        fp = tuple(out)
+        hash(fp)
+        return fp
+    except (_NoFingerprint, TypeError, RecursionError):
+        return None
 
 
 def evaluate(model, x, u, w, t=None):

@@ -1,6 +1,6 @@
 // tests/mock_rccl.cpp -- TEST INFRASTRUCTURE.  A stand-in for librccl.so with
 // the nccl* entry points libsdp_hip.so binds (ncclGetUniqueId, CommInitRank,
-// CommDestroy, AllGather, Broadcast, AllReduce, GroupStart/End, GetErrorString),
+// CommDestroy, AllGather, Broadcast, AllReduce, Send, Recv, GroupStart/End, GetErrorString),
 // implemented over a POSIX shared-memory segment and blocking host-staged
 // copies, so that SEVERAL RANKS CAN SHARE ONE GPU: RCCL itself refuses two
 // ranks on one device, and the test box has one.  Loaded through
@@ -63,6 +63,10 @@ void barrier(Comm *c)
     }
 }
 char *slot(Comm *c, int r) { return c->slots + (size_t)r * SLOT; }
+// the communicator and stream of this thread's last call: a group that records nothing (a rank with nothing to send or
+// receive in a phase) still has to meet the others at ncclGroupEnd
+thread_local Comm *g_last_comm = nullptr;
+thread_local hipStream_t g_last_stream = nullptr;
 }  // namespace
 
 extern "C" {
@@ -143,6 +147,7 @@ void reduce_cb(void *p)
 int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *h, hipStream_t stream)
 {
     Comm *c = (Comm *)h;
+    g_last_comm = c; g_last_stream = stream;
     const size_t bytes = count * dtype_size[dtype];
     if (bytes > SLOT) return 4;
     TRY(hipMemcpyAsync(slot(c, c->rank), send, bytes, hipMemcpyDeviceToHost, stream));
@@ -187,6 +192,7 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
 int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *h, hipStream_t stream)
 {
     Comm *c = (Comm *)h;
+    g_last_comm = c; g_last_stream = stream;
     const size_t bytes = count * dtype_size[dtype];
     if (bytes > SLOT) return 4;
     if (hipStreamSynchronize(stream) != hipSuccess) return 1;
@@ -247,8 +253,57 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
 
 #endif  // SDP_MOCK_ASYNC
 
-int ncclGroupStart(void) { return 0; }
-int ncclGroupEnd(void) { return 0; }
+// ---- grouped point-to-point (both builds): ncclSend / ncclRecv between ncclGroupStart and ncclGroupEnd are recorded
+// and carried out at ncclGroupEnd -- every rank stages what it sends to rank q in sub-slot q of its own slot, the
+// ranks meet, every rank fetches sub-slot `me` of each sender's slot, the ranks meet again.  EVERY rank must close
+// the same number of groups (the library does: one per phase, with or without transfers); one send and one receive
+// per pair of ranks and group, each below SLOT / nranks bytes.
+namespace {
+struct P2P { bool send; void *buf; size_t bytes; int peer; Comm *c; hipStream_t stream; };
+thread_local P2P g_ops[4 * MAXR];
+thread_local int g_nops = 0, g_depth = 0;
+}  // namespace
+int ncclGroupStart(void) { if (g_depth++ == 0) g_nops = 0; return 0; }
+int ncclSend(const void *buf, size_t count, int dtype, int peer, void *h, hipStream_t stream)
+{
+    if (g_depth == 0 || g_nops >= 4 * MAXR) return 4;
+    g_ops[g_nops++] = P2P{true, (void *)buf, count * dtype_size[dtype], peer, (Comm *)h, stream};
+    return 0;
+}
+int ncclRecv(void *buf, size_t count, int dtype, int peer, void *h, hipStream_t stream)
+{
+    if (g_depth == 0 || g_nops >= 4 * MAXR) return 4;
+    g_ops[g_nops++] = P2P{false, buf, count * dtype_size[dtype], peer, (Comm *)h, stream};
+    return 0;
+}
+int ncclGroupEnd(void)
+{
+    if (--g_depth > 0) return 0;
+    Comm *c = g_nops ? g_ops[0].c : g_last_comm;
+    hipStream_t stream = g_nops ? g_ops[0].stream : g_last_stream;
+    if (!c) return 4;
+    g_last_comm = c; g_last_stream = stream;
+    const size_t sub = SLOT / (size_t)c->n;
+    for (int k = 0; k < g_nops; ++k) if (g_ops[k].bytes > sub || g_ops[k].c != c) return 4;
+#ifdef SDP_MOCK_ASYNC
+    for (int k = 0; k < g_nops; ++k)
+        if (g_ops[k].send && hipMemcpyAsync(slot(c, c->rank) + (size_t)g_ops[k].peer * sub, g_ops[k].buf, g_ops[k].bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
+    if (hipLaunchHostFunc(stream, barrier_cb, c) != hipSuccess) return 1;
+    for (int k = 0; k < g_nops; ++k)
+        if (!g_ops[k].send && hipMemcpyAsync(g_ops[k].buf, slot(c, g_ops[k].peer) + (size_t)c->rank * sub, g_ops[k].bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+    if (hipLaunchHostFunc(stream, barrier_cb, c) != hipSuccess) return 1;
+#else
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+    for (int k = 0; k < g_nops; ++k)
+        if (g_ops[k].send && hipMemcpy(slot(c, c->rank) + (size_t)g_ops[k].peer * sub, g_ops[k].buf, g_ops[k].bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    barrier(c);
+    for (int k = 0; k < g_nops; ++k)
+        if (!g_ops[k].send && hipMemcpy(g_ops[k].buf, slot(c, g_ops[k].peer) + (size_t)c->rank * sub, g_ops[k].bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    barrier(c);
+#endif
+    g_nops = 0;
+    return 0;
+}
 const char *ncclGetErrorString(int r)
 {
     switch (r) {

@@ -353,7 +353,11 @@ def test_a_cached_control_box_table_notices_data_the_callback_reads(grid):
     assert calls.count('Sym') == 1 and len(calls) == 1 + 5
     del calls[:]
     assert s._box_plan() is bp                                   # unchanged data: the cached table
-    assert calls == ['Sym']                                      # .. for the price of one trace, whatever the grid's size
+    assert calls == []                                           # .. the callback's fingerprint (code, closure cells, globals) is what it was: not even a trace
+    s.trace_cache = False
+    assert s._box_plan() is bp and calls == ['Sym']              # (without fingerprints: one trace per call, whatever the grid's size)
+    s.trace_cache = True
+    del calls[:]
     rated['P'] = 0.5                                             # the data changes: the table is rebuilt
     bp2 = s._box_plan()
     assert bp2 is not bp and bp2['hi'].max() == 0.5 and bp['hi'].max() == 1.0
@@ -489,3 +493,46 @@ def test_a_box_that_cannot_be_traced_is_called_node_by_node():
     s2.discretize_state(0, 1, 11)
     s2.control_steps = (0.5,)
     assert s2._box_plan()['mode'] is None
+
+
+def test_a_trace_is_kept_while_the_callables_fingerprint_stands():
+    """dyn and cost are traced again on a call only when something their result can depend on has changed: their code,
+    their defaults, the contents of their closure cells and of the globals they name (by VALUE).  What cannot be
+    fingerprinted -- an object with attributes, an array beyond 64 KiB -- is traced on every call, as before."""
+    from stodynprog_amd import SysDescription, DPSolver
+    from stodynprog_amd.trace import callable_fingerprint
+    par = {'gain': 0.5, 'table': np.linspace(0., 1., 8)}
+    sysd = SysDescription((1, 1, 1))
+    sysd.dyn = lambda x, u, w: (x + par['gain'] * u - w,)
+    sysd.cost = lambda x, u, w: u * u + np.interp(x, np.linspace(0., 1., 8), par['table'])
+    sysd.control_box = lambda x: ((0., 1.),)
+    s = DPSolver(sysd)
+    s.discretize_state(0, 1, 9)
+    m1 = s._trace_now()
+    assert s._trace_now() is m1                                  # same fingerprint: the same trace object
+    par['gain'] = 0.25                                           # a mutated closure value invalidates
+    m2 = s._trace_now()
+    assert m2 is not m1 and m2.param_values() != m1.param_values()
+    assert s._trace_now() is m2
+    par['table'][3] = 7.0                                        # .. an array mutated in place too (hashed by content)
+    m3 = s._trace_now()
+    assert m3 is not m2
+    s.trace_cache = False
+    assert s._trace_now() is not s._trace_now()
+    s.trace_cache = True
+
+    class Holder(object):
+        gain = 0.5
+    h = Holder()
+    sysd.dyn = lambda x, u, w: (x + h.gain * u - w,)              # an object's attribute: out of the fingerprint's sight
+    assert callable_fingerprint(sysd.dyn) is None
+    a = s._trace_now()
+    assert s._trace_now() is not a                               # traced on every call
+    h.gain = 0.125
+    assert s._trace_now().param_values() != a.param_values()
+    big = np.zeros(20000)
+    sysd.dyn = lambda x, u, w: (x + big[0] * u - w,)
+    assert callable_fingerprint(sysd.dyn) is None                # 160 kB: not hashed on every call
+    import math
+    sysd.dyn = lambda x, u, w: (x + math.sqrt(2.0) * u - w,)      # a library module and a builtin are fine
+    assert callable_fingerprint(sysd.dyn) is not None
