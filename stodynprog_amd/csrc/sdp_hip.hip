@@ -1667,6 +1667,7 @@ static int complete_J(sdp_problem *p)
     int rc;
     if ((rc = join_comm(p))) return rc;
     if (p->sendrecv) {                                     // every rank's rows to every rank: the all-gather of each phase
+        if (!p->ev_enter) HIP_TRY(hipEventCreateWithFlags(&p->ev_enter, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(p->ev_enter, p->stream));
         HIP_TRY(hipStreamWaitEvent(p->comm->stream, p->ev_enter, 0));
         for (int ph = 0; ph < p->n_phases; ++ph)
