@@ -847,6 +847,7 @@ struct sdp_problem {
     // (bumped whenever the contents of V change), and the lead indices covered
     const void *red_V = nullptr;
     uint64_t red_gen = 0, V_gen = 1;
+    int red_parity = 0;                    // line kernel: which of the two slots of lead_vmax the last reduction used
     int64_t red_begin = 0, red_end = 0;
     double red_t = 0;
     int cus = 256;
@@ -1077,7 +1078,8 @@ extern "C" int sdp_problem_create(const sdp_problem_desc *desc, sdp_problem **ou
         int rc = p->lead_a.alloc(line ? (size_t)(2 * p->S + 64) * 24 : (size_t)p->S * 8);   // (the reduced array: 8-byte sums whatever the reals are, sdp_lead_kernel.h)
         if (!rc) rc = p->lead_v.alloc(line ? 8 : (size_t)p->S * rs);
         if (!rc) rc = p->lead_e.alloc((size_t)lead_trailing_nodes(p) * rs);            // (a value per trailing index)
-        if (!rc) rc = p->lead_vmax.alloc(16);        // (the line kernel keeps two maxima)
+        if (!rc) rc = p->lead_vmax.alloc(32);        // (the line kernel: two slots of two words, used in turn)
+        if (!rc) HIP_TRY(hipMemset(p->lead_vmax.p, 0, 32));
         if (rc) return rc;
     }
     if (p->variant == SDP_VARIANT_STAGED) {
@@ -1347,9 +1349,17 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
         int64_t lb, le;
         lead_reduce_range(p, nb, ne, lb, le);
         if (!(p->red_V == p->V.p && p->red_gen == p->V_gen && p->red_t == t_k && p->red_begin <= lb && le <= p->red_end)) {
-            HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 16, p->stream));
+            const bool line = p->d == 1 && (p->meta[SDP_META_FLAGS] & SDP_META_F_SHIFT);
+            // (the line kernel keeps its maximum in one of two slots and clears the other for the next reduction itself:
+            // no fill launch between the kernels of a sweep that takes tens of microseconds)
+            if (line) p->red_parity ^= 1;
+            else HIP_TRY(hipMemsetAsync(p->lead_vmax.p, 0, 16, p->stream));
             const int64_t ts = lead_trailing_nodes(p);
             SdpSweepArgs r = a;
+            if (line) {
+                r.aux_vmax = (unsigned long long *)p->lead_vmax.p + 2 * p->red_parity;
+                r.aux_e = (unsigned long long *)p->lead_vmax.p + 2 * (p->red_parity ^ 1);
+            }
             r.n_peer = 0;
             r.node_begin = lb * ts; r.node_end = le * ts;
             r.aux_begin = lb; r.aux_end = le;
@@ -1358,6 +1368,7 @@ static int launch_sweep(sdp_problem *p, double t_k, int64_t nb, int64_t ne)
             p->red_V = p->V.p; p->red_gen = p->V_gen; p->red_t = t_k; p->red_begin = lb; p->red_end = le;
         }
         a.aux_begin = p->red_begin; a.aux_end = p->red_end;
+        if (p->d == 1 && (p->meta[SDP_META_FLAGS] & SDP_META_F_SHIFT)) a.aux_vmax = (unsigned long long *)p->lead_vmax.p + 2 * p->red_parity;
     }
     return launch_module(p->f_sweep, a, sweep_blocks(p, ne - nb), 256, p->stream);
 }

@@ -168,6 +168,8 @@ extern "C" __global__ void __launch_bounds__(256) sdp_lead_reduce(SdpSweepArgs a
     SdpLineFilter f;
     SdpLineCol c;
     sdp_line_setup(a, m, l, f, c);
+    // (the slot the NEXT reduction will use -- SdpSweepArgs.aux_e here -- is cleared now: the sweep that read it is over)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.aux_e) *(unsigned long long *)a.aux_e = 0ull;
     if (!c.ok) return;
     const double *__restrict__ V = (const double *)a.V;
     double *__restrict__ ad = (double *)a.aux_a;

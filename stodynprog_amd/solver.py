@@ -694,6 +694,7 @@ class DPSolver(object):
         if kept is not None:
             return dict(kept, model=model)
         plan = self._kernel_plan_now(box_t, model, bp, lanes, debug, W)
+        plan['_memo'] = memo
         for k in [k for k in self._cache if k[0] == 'plan' and k[1:4] != memo[1:4]]:
             del self._cache[k]                  # (another discretisation / box table: its plans are never asked for again)
         self._cache[memo] = plan
@@ -908,8 +909,14 @@ class DPSolver(object):
         if isinstance(model, TraceError):
             raise model
         plan = self._kernel_plan(box_t, model)
-        fp = ('problem', self._fingerprint(None), plan['box_digest'],
-              codegen.source_key(plan['source']))
+        # (the key of the unit's source: a hash of the text and of the kernel headers -- once per plan, not per call)
+        skey = plan.get('_source_key')
+        if skey is None:
+            skey = codegen.source_key(plan['source'])
+            kept_plan = self._cache.get(plan.get('_memo'))
+            if kept_plan is not None:
+                kept_plan['_source_key'] = skey
+        fp = ('problem', self._fingerprint(None), plan['box_digest'], skey)
         prob = self._cache.get(fp)
         if prob is None:
             try:
