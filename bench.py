@@ -83,10 +83,13 @@ WORKLOADS = {
                    'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations (two controlled state variables)'),
     'reservoirs_f32': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float32', None,
                        'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations, fp32 (the wide form of the reduced-array filter)'),
-    # not a BASELINE config: ONE state variable (the reference's tutorial shape at a size worth a kernel): the direct kernel
-    # (grids of at most DPSolver.STAGED_MIN_NODES nodes and 1-D problems: round 5; the staged tiles took 0.95 ms here)
+    # not a BASELINE config: ONE state variable (the reference's tutorial shape, x + u - w, at sizes worth a kernel): since
+    # round 6 the filtered line kernel (csrc/sdp_line_kernel.h: the shifted lattice with the value array as its table);
+    # round 5 ran the direct kernel (0.023 ms here, 6.6 ms on the fine grid below), rounds 2-4 the staged tiles (0.95 ms)
     'inventory1d': ('inventory_fine', dict(n_x=600, n_u=257, n_w=16), 'float64', None,
                     'shop inventory, one state variable: 600 nodes x 257 controls x 16 perturbations'),
+    'inventory1d_fine': ('inventory_fine', dict(n_x=65536, n_u=4097, n_w=16), 'float64', None,
+                         'shop inventory, one state variable: 65 536 nodes x 4097 controls x 16 perturbations'),
     'coupled256': ('synthetic3d_coupled', dict(N=256), 'float64', None,
                    'synthetic3d {n}^3 x 64 controls x 32 perturbations, control-coupled x1 (non-separable)'),
 }
@@ -821,7 +824,7 @@ def finish_single(args, env, out):
         others = {}
         for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
             solver._cache.pop(k_).close()
-        for name in ('ar1', 'searev', 'synth512f32', 'noisy256', 'noisy256_nested', 'reservoirs', 'inventory1d'):
+        for name in ('ar1', 'searev', 'synth512f32', 'noisy256', 'noisy256_nested', 'reservoirs', 'inventory1d', 'inventory1d_fine'):
             try:
                 a2 = copy.copy(args)
                 a2.config, a2.grid, a2.dtype = name, 0, None

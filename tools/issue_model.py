@@ -78,7 +78,8 @@ def main():
             found[kind] = dict(per_item=per_item, body=body, items=items, trips_per_wave_unit=trips_total / float(items))
 
     tail = W - wres
-    entries_per_unit = (W + tail) * N0                       # table entries built per unit (the tail twice)
+    hold = '#define SDP_COL_TAIL_HOLD 1' in src                # round 6: the tail is built once (unrolled: no loop) and held in registers
+    entries_per_unit = (wres if hold else W + tail) * N0     # table entries built per unit BY THE LOOP (without the hold: the tail twice)
     for body in bodies:
         if len(body) > 400:
             continue                                         # an outer loop
