@@ -671,7 +671,7 @@ def report(args, env):
                         'spec: 256 CU x 4 SIMD x 2.4 GHz / {} clk per wave64 {} VALU instruction '
                         '(MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s, fp64 half of it)'.format(
                             4 if rb == 8 else 2, 'fp64' if rb == 8 else 'fp32')),
-        'why_not_hbm': 'certified expectation-first filter (DESIGN.md section 3): the expectation over w commutes '
+        'why_not_hbm': 'certified expectation-first filter (docs/NOTEBOOK.md section 3): the expectation over w commutes '
                        'with the lerp along axis 0, so one lerp on a w-reduced table plus a proven error radius '
                        'decides every control but the near-minimal ones; only those run the reference\'s W x 6 '
                        'operations, and J / policy / index keep the same bits.  What is left is VALU issue (cell '
@@ -682,7 +682,7 @@ def report(args, env):
                        'gather per lattice cell never reaches L2/HBM; HBM is a few % utilised (hbm block) '
                        'and the 6 separately rounded operations per cell that bit-exactness forbids to '
                        'fuse bind the kernel' if kernel_family == 'column' else
-                       'per-cell gathers: bound by vector-memory/LDS gather issue, see DESIGN.md section 4',
+                       'per-cell gathers: bound by vector-memory/LDS gather issue, see docs/NOTEBOOK.md section 4',
     }
     if filtered and valu_all is not None:
         roof['frac_uniform_4clk'] = 4.0 * valu_all * share / k_s / issue_peak
@@ -773,7 +773,7 @@ def finish_single(args, env, out):
             and not solver.backend_info.get('table_per_control'):
         # secondary figure (never the headline `value`): the opt-in fused-arithmetic
         # variant of the same kernel (weight-scaled LDS table + FMAs; J within
-        # ~1e-15 relative of the exact kernel)
+        # ~1e-15 relative of the exact kernel, see docs/NOTEBOOK.md 3.1)
         try:
             fs = clone_solver(DPSolver, sysd, solver, dtype, arithmetic='fused')
             for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
@@ -941,7 +941,7 @@ def main():
     ap.add_argument('--grid', type=int, default=0,
                     help='synthetic workloads: points per state axis (default: the config\'s)')
     ap.add_argument('--dtype', default=None, choices=['float64', 'float32'])
-    ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged', 'lead'],
+    ap.add_argument('--kernel', default=None, choices=['auto', 'generic', 'column', 'staged', 'lead', 'line'],
                     help='kernel family (default: auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--exchanges', default=None, metavar='LIST',

@@ -3,7 +3,7 @@
 // column's bound (sdp_col_filter_reduce), the shifted lattice for a perturbation that reaches the stock (SDP_COL_SHIFT),
 // the lean / tabulated / wide first passes, the short first passes of the additive shape and their certified branch and
 // bound (SDP_COL_BNB), and phase B with the filter for the whole-table forms (sdp_col_filter_nodes).  The three forms of
-// sdp_sweep_col (sdp_colfull_kernel.h, sdp_colres_kernel.h, sdp_colu_kernel.h) call into it.  DESIGN.md 3.1b - 3.1f.
+// sdp_sweep_col (sdp_colfull_kernel.h, sdp_colres_kernel.h, sdp_colu_kernel.h) call into it.  docs/NOTEBOOK.md 3.1b - 3.1f.
 #pragma once
 
 // ---------------------------------------------------------------------------

@@ -246,7 +246,7 @@ SDP_DEV void sdp_colres_partial_kept(const sdp_real *__restrict__ G, const SdpCo
 // ---------------------------------------------------------------------------
 // The short first pass (generated where x0' = X(x) +- a and cost = K(x) +- h, a and h entries of the column's control
 // table: codegen.short_pass_source).  Vector issue binds this kernel and the first pass is half of its instructions
-// (DESIGN.md section 3.1e), so it sheds what need not be per control:
+// (docs/NOTEBOOK.md section 3.1e), so it sheds what need not be per control:
 //   * K does not change the argmin over the controls of a node: the pass orders  F' = fma(+-h, psum, lerp)  -- an
 //     approximation of E - K P*, P* the exact sum of the weights -- instead of F (one addition less);
 //   * |g| <= (|K| + max |h|)(1 + u), max |h| of the column from sdp_col_phase_u, replaces the running sum of the |F|

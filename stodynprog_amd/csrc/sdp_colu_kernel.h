@@ -1,5 +1,5 @@
 // sdp_colu_kernel.h -- the column kernels with a TABLE PER CONTROL (SDP_TRAIL_HAS_U: the trailing next states depend on
-// the control but not on x0).  Included by sdp_column_kernel.h, which defines the building blocks.
+// the control but not on x0; docs/NOTEBOOK.md section 3.3b).  Included by sdp_column_kernel.h, which defines the building blocks.
 #pragma once
 // ---------------------------------------------------------------------------
 // Trailing next states that depend on the control (but not on x0), e.g. a stock

@@ -2,7 +2,7 @@
 //     x' = fl(.. fl(fl(a(x, u) +- b_1(w)) +- b_2(w)) ..)          (the shop inventory `x + u - w`,
 // reference doc/example_inventory.py:31-33; the stocks of examples/01 Deterministic storage control), with a cost that
 // does not see the perturbation: the CERTIFIED FILTER ON THE SHIFTED LATTICE of sdp_colfilter_kernel.h (SDP_COL_SHIFT;
-// DESIGN.md section 3.1d) for d = 1, where the "table" T[w][r] of the column kernel IS the value array -- no trailing
+// docs/NOTEBOOK.md section 3.1d) for d = 1, where the "table" T[w][r] of the column kernel IS the value array -- no trailing
 // axes, nothing to interpolate before axis 0 -- so nothing has to sit in LDS at all.
 // Included by sdp_sweep_kernel.h in place of its own sdp_sweep when the generated unit defines SDP_LINE; the unit brings
 //     sdp_model_lead_a(x, u, t)              a, with the reference's own operations

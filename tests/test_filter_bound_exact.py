@@ -1,13 +1,13 @@
 """The error radii of the certified filters, checked in EXACT arithmetic (no GPU): the lean first pass of 8-byte reals
 (section 3.1c), the short first passes of round 4 (8-byte, and the wide one of 4-byte reals), the wide first pass of
-4-byte reals, the shifted lattice (3.1d) and the reduced array (3.3c) -- every form whose radius DESIGN.md derives to
+4-byte reals, the shifted lattice (3.1d) and the reduced array (3.3c) -- every form whose radius docs/NOTEBOOK.md derives to
 first order with a factor to spare.  The first block below explains the method on the lean pass.
 
 
 The filter of csrc/sdp_column_kernel.h skips a control when its short value F -- two fused operations on a table
 reduced over the perturbation -- lies further than a radius above the smallest F of the node; that is sound if
 |E - F| <= radius for every control, E being the reference's value (W x 6 separately rounded operations,
-stodynprog.py:677-681 on multilinear_cython.pyx:88).  DESIGN.md section 3.1c derives the radius to first order in
+stodynprog.py:677-681 on multilinear_cython.pyx:88).  docs/NOTEBOOK.md section 3.1c derives the radius to first order in
 the unit roundoff with a factor 2 to spare; the GPU tests back it empirically (same bits at the proven radius and at
 half of it).  Here both values are computed with Python floats, operation by operation as the kernels round
 (`fma` = one rounding of the exact a*b + c through fractions.Fraction), their difference is taken EXACTLY, and
@@ -654,7 +654,7 @@ def test_the_wide_pass_radius_covers_the_difference_exactly(regime):
 
 # ---------------------------------------------------------------------------
 # The filter on the SHIFTED LATTICE (8-byte reals; a perturbation that reaches the stock through a final sum:
-# x0' = (X + a_u) - b_w; sdp_col_phase_shift / sdp_col_shift_col / sdp_col_shift_reduce /
+# x0' = (X + a_u) - b_w; docs/NOTEBOOK.md section 3.1d; sdp_col_phase_shift / sdp_col_shift_col / sdp_col_shift_reduce /
 # sdp_col_lean_core of csrc/sdp_colfilter_kernel.h).  Here the filter value differs from the reference's even in exact
 # arithmetic -- G is tabulated at whole positions and interpolated -- and the radius is cu S_node + max B'[q0]:
 # both parts are checked together, exactly.  Grid [0, 1] (axis mode 2), one term b.
@@ -806,7 +806,7 @@ def test_a_regrouped_chain_needs_the_sum_of_its_leaves_in_the_bound(chain):
 
 
 # ---------------------------------------------------------------------------
-# The filter on the REDUCED ARRAY (csrc/sdp_lead_kernel.h): two controlled stocks next to one
+# The filter on the REDUCED ARRAY (csrc/sdp_lead_kernel.h; docs/NOTEBOOK.md section 3.3c): two controlled stocks next to one
 # exogenous axis (d = 3, m = 2), grids [0, 1].  sdp_lead_reduce: A[i0, i1] = sum_w p_w inner_w(i0, i1) with the reference's
 # lerp along the trailing axis; first pass F = fma(g, psum, bilerp(A)) with fused lerps; bound per node
 #     S = ratio (sum |F| + Lp Dabs) + Lp Dabs,   Lp = max_u prod_k (1 + 2 |lam_k|),   Dabs = Pcap (max_w E_w) max |V| + floor,

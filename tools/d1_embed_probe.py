@@ -5,7 +5,7 @@ fits the LDS -- J and indices of the first column equal the 1-D problem's -- and
 Round 5 measured 0.93 -> 0.105 ms (600 nodes x 257 controls x 16 w, inventory shape), 1.33 -> 0.064 ms (2048 x 1025 x 8,
 storage shape), 5.3 -> 4.4 ms (65536 x 4097 x 8) -- against the STAGED kernel.  The direct kernel, which `kernel = 'auto'` picks
 for such problems since the same round, is 3 - 4 x faster still (0.023 and 0.027 ms): the lifting was built into DPSolver, measured
-against it and taken out again."""
+against it and taken out again (docs/NOTEBOOK.md section 8)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 6: the end-of-round evidence of tools/final_profiles.sh plus the profiles the verdict of round 5 asked for --
+# the shifted lattice under its current key, the direct kernel on a fine 1-D grid and the line kernel that replaces it.
+#     bash tools/final_profiles_r06.sh            (through gpurun, from the repo root)
+set -u
+bash tools/final_profiles.sh r06
+OUT=$PWD/gpurun_out/final_r06
+PROF_STEPS=6 bash tools/profile_bench.sh r06_noisy noisy256_f64_column_filter --config noisy256 > "$OUT/profile_noisy.log" 2>&1
+PROF_STEPS=6 bash tools/profile_bench.sh r06_line1d inventory1d_fine_f64_line_filter --config inventory1d_fine > "$OUT/profile_line1d.log" 2>&1
+PROF_STEPS=4 bash tools/profile_bench.sh r06_direct1d inventory1d_fine_f64_generic --config inventory1d_fine --kernel generic > "$OUT/profile_direct1d.log" 2>&1
+for t in r06_noisy r06_line1d r06_direct1d; do
+  cp gpurun_out/prof_$t/summary.txt "$OUT/${t}_summary.txt"
+  cp gpurun_out/prof_$t/kernel_stats.csv "$OUT/${t}_kernel_stats.csv"
+  cp gpurun_out/prof_$t/pmc_*.json "$OUT/" 2>/dev/null
+done
+ls -la "$OUT"

@@ -14,9 +14,10 @@ export TMPDIR=/tmp
 ARGS="--steps ${PROF_STEPS:-10} --warmup 2 --no-cpu-baseline --no-fused --no-filter-check --no-other-configs $*"
 run_pmc() {   # name counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.log"
+    # (a pass that hangs -- the TA_* counters did, for twenty minutes, in round 6 -- must not take the call with it)
+    timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.log"
 }
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.log"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.log"
 run_pmc fetch FETCH_SIZE
 run_pmc write WRITE_SIZE
 run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS
