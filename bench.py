@@ -330,11 +330,12 @@ def run(args):
 
 def run_sharded(args, env):
     """N > 1 (or the one-rank test hook): the RCCL exchange is tuned, TIMED and reported first;
-    the optional exchanges (peer writes, sparse peer writes) are tried afterwards, each under a
-    watchdog, and can only replace the RCCL result by a faster, bit-identical one.  Whatever
-    happens to an optional candidate -- an error on any rank, a rejected result, a hang -- the
-    line printed is at least the RCCL one and the exit status is 0; only a failure of the RCCL
-    path itself is an error."""
+    the other exchanges (grouped sends / receives; on request the ones over HIP IPC) are tried
+    afterwards, each under a watchdog, and can only replace the RCCL result by a faster,
+    bit-identical one.  An error or a rejected result of a candidate leaves the RCCL line and
+    status 0; a candidate that HANGS (a rank that never answers) leaves the valid RCCL line on
+    stdout and ends the process with status 3 -- the run is not reported as clean.  A failure of
+    the RCCL path itself is an error."""
     import threading
     solver, dev_comm, V0, rank, nat = (env[k] for k in ('solver', 'dev_comm', 'V0', 'rank', 'nat'))
     sync_all, timed_region = env['sync_all'], env['timed_region']
