@@ -81,8 +81,6 @@ WORKLOADS = {
     # certified filter on an array reduced over w (csrc/sdp_lead_kernel.h)
     'reservoirs': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float64', None,
                    'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations (two controlled state variables)'),
-    'reservoirs_f32': ('two_reservoirs', dict(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15)), 'float32', None,
-                       'two reservoirs 128x128x64 state x 16x16 controls x 16 perturbations, fp32 (the wide form of the reduced-array filter)'),
     # not a BASELINE config: ONE state variable (the reference's tutorial shape, x + u - w, at sizes worth a kernel): since
     # round 6 the filtered line kernel (csrc/sdp_line_kernel.h: the shifted lattice with the value array as its table);
     # round 5 ran the direct kernel (0.023 ms here, 6.6 ms on the fine grid below), rounds 2-4 the staged tiles (0.95 ms)
@@ -770,28 +768,6 @@ def finish_single(args, env, out):
                          'model_name', 'world', 'S', 'cells', 'U_max'))
     kernel_family = solver.backend_info.get('kernel')
     filtered = bool(solver.backend_info.get('certified_filter'))
-    if world == 1 and kernel_family == 'column' and args.fused and not solver.backend_info.get('row_window') \
-            and not solver.backend_info.get('table_per_control'):
-        # secondary figure (never the headline `value`): the opt-in fused-arithmetic
-        # variant of the same kernel (weight-scaled LDS table + FMAs; J within
-        # ~1e-15 relative of the exact kernel, see docs/NOTEBOOK.md 3.1)
-        try:
-            fs = clone_solver(DPSolver, sysd, solver, dtype, arithmetic='fused')
-            for k_ in [k_ for k_ in solver._cache if k_[0] == 'problem']:
-                solver._cache.pop(k_).close()               # free the exact problem's buffers first
-            fprob = fs._problem()
-            fprob.set_value(V0)
-            fprob.bench_sweeps(max(args.warmup, 1))
-            fprob.swap()
-            _, fk = fprob.bench_sweeps(args.steps)
-            out['fused_arithmetic'] = {'kernel_ms': fk / args.steps, 'sweeps_per_s': 1e3 * args.steps / fk,
-                                       'note': 'SECONDARY figure, never the headline `value`: opt-in '
-                                               'DPSolver.arithmetic="fused" (weight-scaled LDS table + 2 FMAs per '
-                                               'cell instead of the reference\'s 6 separately rounded operations; J '
-                                               'within ~1e-15 relative of the exact kernel, inside the 1e-10 parity '
-                                               'bar but not the reference rounding sequence); LDS-read bound'}
-        except Exception as e:
-            out['fused_arithmetic'] = {'error': repr(e)}
     if world == 1 and filtered and not args.no_filter_check:
         # The filter's claim, checked in this very run (outside the timed region): the same chain of
         # sweeps with every control evaluated the long way -- the reference's W x 6 operations per
@@ -953,10 +929,6 @@ def main():
     ap.add_argument('--no-filter', action='store_true',
                     help='column kernel: evaluate every control with the reference\'s W x 6 operations instead '
                          'of the certified expectation-first filter (same bits either way; A/B runs)')
-    ap.add_argument('--fused', action='store_true',
-                    help='also time the opt-in fused-arithmetic variant (secondary figure; off by default so '
-                         'that a profile of the default command holds ONE flavour of sdp_sweep_col)')
-    ap.add_argument('--no-fused', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the untimed steady-state runs of the other BASELINE configurations')
     ap.add_argument('--debug-define', action='append', default=[], metavar='NAME=VALUE',

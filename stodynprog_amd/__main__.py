@@ -20,8 +20,7 @@ def main():
     print('optimal stored power after 2 iterations: min {:.3f}, max {:.3f} MW'.format(
         u[..., 0].min(), u[..., 0].max()))
     info = dpsolv.backend_info
-    print('kernel: {} ({} arithmetic), {} controls at most'.format(
-        info.get('kernel'), info.get('arithmetic'), info.get('max_controls')))
+    print('kernel: {}, {} controls at most'.format(info.get('kernel'), info.get('max_controls')))
     return J, u
 
 

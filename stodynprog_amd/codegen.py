@@ -309,27 +309,26 @@ def lead_functions_source(model, m, order=None):
     return '\n\n'.join(out)
 
 
-def lead_filter_applies(model, dtype, min_axes=2, debug=None, wide=False):
+def lead_filter_applies(model, dtype, min_axes=2, debug=None):
     """Several controlled state variables next to an exogenous process (TracedModel.controlled_axes
     >= 2; one stock is the column kernel's case), a perturbation that does not reach them (the cost may see
-    it), 8-byte reals -- `wide`: 4-byte reals too (round 5, the wide form: correct, but on the benchmark's lattice of
-    256 controls its radius of ~1e-5 of the values keeps so many controls that the sweep is 3 x SLOWER than every
-    control the long way, 8.9 against 2.6 ms; only `kernel = 'lead'` asks for it) --: the node-order sweep with the certified filter on an array reduced over w
-    (csrc/sdp_lead_kernel.h).  Returns the number of controlled axes, or 0.  (`debug`: SDP_LEAD_FILTER = 0
-    switches it off, A/B runs.)"""
+    it), 8-byte reals (a form for 4-byte reals existed in round 5: its radius of ~1e-5 of the values kept so many
+    controls that the sweep was 3 x SLOWER than every control the long way, 8.9 against 2.6 ms; removed in round 6):
+    the node-order sweep with the certified filter on an array reduced over w (csrc/sdp_lead_kernel.h).  Returns the
+    number of controlled axes, or 0.  (`debug`: SDP_LEAD_FILTER = 0 switches it off, A/B runs.)"""
     if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0':
         return 0
-    if model.n_perturb != 1 or (np.dtype(dtype).itemsize != 8 and not wide):
+    if model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
         return 0
     m = model.controlled_axes()
     return int(m) if m is not None and m >= min_axes else 0
 
 
-def lead_order(model, dtype, debug=None, wide=False):
+def lead_order(model, dtype, debug=None):
     """(m, order) for the reduced-array sweep of a model whose stocks are NOT listed first (the order of the
     state variables is the user's: reference stodynprog.py:119-131), or None: TracedModel.controlled_order
-    with at least one exogenous variable, 8-byte reals (`wide`: see lead_filter_applies), one perturbation."""
-    if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0' or model.n_perturb != 1 or (np.dtype(dtype).itemsize != 8 and not wide):
+    with at least one exogenous variable, 8-byte reals, one perturbation."""
+    if _dbg(debug, 'SDP_LEAD_FILTER', '1') == '0' or model.n_perturb != 1 or np.dtype(dtype).itemsize != 8:
         return None
     co = model.controlled_order()
     if co is None or co[1] == tuple(range(model.n_state)) or co[0] >= model.n_state:
@@ -464,7 +463,7 @@ def _prologue_lines(model, real, lanes, debug):
     return lines
 
 
-def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug, wres=0):
+def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, utab, debug, wres=0):
     """the macros and model slices of a unit that includes csrc/sdp_column_kernel.h"""
     rs = np.dtype(dtype).itemsize
     wpair = use_wpair(model, dtype, debug) and window is None
@@ -474,7 +473,6 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
              '#define SDP_TRAIL_HAS_U {}'.format(1 if model.trail_depends_on_u else 0),
              '#define SDP_COL_N0 {}'.format(int(column[0])),
              '#define SDP_COL_W {}'.format(max(int(column[1]), 1)),
-             '#define SDP_COL_FUSED {}'.format(1 if fused else 0),
              '#define SDP_COL_THREADS {}'.format(col_cfg[0]),
              '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0)]
     if wres:
@@ -500,7 +498,7 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
             lines.append('#define SDP_COL_FILTER_SCALE {}'.format(float(_dbg(debug, 'SDP_COL_FILTER_SCALE'))))
     # how the table build deals its entries to the threads
     if per_control is None and not _dbg(debug, 'SDP_COL_A_ORDER'):
-        wide = column_wide_loads(column[0], dtype, fused, window, debug)
+        wide = column_wide_loads(column[0], dtype, window, debug)
         order = column_build_order(int(col_cfg[0]), column[1], int(window[2]) if window is not None else column[0],
                                    (16 // rs) if wide else 1)
         if order[0] == 2:
@@ -534,7 +532,7 @@ def _column_lines(model, dtype, column, col_cfg, fused, window, per_control, fil
                   control_table_source(model, utab[0]), '']
         # the short first passes: 8-byte reals in the resident-chunk kernel, 4-byte reals (wide form) in the full-table one
         short = None
-        if not shifted and not model.cost_depends_on_w and window is None and per_control is None and not fused \
+        if not shifted and not model.cost_depends_on_w and window is None and per_control is None \
                 and _dbg(debug, 'SDP_COL_LEAN2') != '0':
             if rs == 8 and wres and _dbg(debug, 'SDP_COL_LEAN') != '0':
                 short = short_pass_source(model, utab[0], 'SDP_COL_LEAN2')
@@ -604,7 +602,7 @@ def line_functions_source(model):
     return '\n\n'.join(out)
 
 
-def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None, window=None,
+def translation_unit(model, dtype, lanes, column=None, staged=None, window=None,
                      per_control=None, filtered=False, utab=None, lead_axes=0, col_cfg=None, debug=None, wres=0,
                      lead_perm=None, line=0):
     """column: None for the generic node-order kernels, or (N0, W[, controls, columns]) to also
@@ -642,7 +640,7 @@ def translation_unit(model, dtype, lanes, column=None, fused=False, staged=None,
                                     debug=debug)
         if col_cfg is None:
             raise ValueError('the column kernel does not fit this grid (its table exceeds the LDS of a CU)')
-        head += _column_lines(model, dtype, column, col_cfg, fused, window, per_control, filtered, utab, debug,
+        head += _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, utab, debug,
                               wres if (window is None and per_control is None) else 0)
     elif staged is not None:
         tile = tuple(staged['tile']) + (1,) * (4 - len(staged['tile']))
@@ -824,7 +822,7 @@ def column_shift_applies(model, dtype, table=None, debug=None):
     return ok
 
 
-def column_filter_applies(model, fused=False, window=None, per_control=None, dtype=None, table=None, debug=None):
+def column_filter_applies(model, window=None, per_control=None, dtype=None, table=None, debug=None):
     """Can phase B of the column kernel run the certified expectation-first filter
     (SDP_COL_FILTER of csrc/sdp_colfilter_kernel.h)?  It needs a perturbation that reaches
     neither x0' nor the cost -- then the expectation commutes with the lerp along axis 0 and
@@ -838,7 +836,7 @@ def column_filter_applies(model, fused=False, window=None, per_control=None, dty
     # expectation with the reference's own values, sdp_col_cost_expect; x0' must still not depend on it)
     # (and so is a perturbation that reaches x0' through a final sum, in 8-byte reals: column_shift_applies)
     return bool(model.n_perturb > 0 and (not model.lead_depends_on_w or column_shift_applies(model, dtype, table, debug))
-                and not model.trail_depends_on_u and not fused and window is None
+                and not model.trail_depends_on_u and window is None
                 and per_control is None)
 
 
@@ -944,7 +942,7 @@ def column_resident_points(model, n0, w, n_state, dtype, filtered, shift, wpair,
 RESIDENT_CHUNKS_DEFAULT = True
 
 
-def column_wide_loads(n0, dtype, fused, window, debug=None):
+def column_wide_loads(n0, dtype, window, debug=None):
     """16-byte vertex loads in the table build (SDP_COL_A_WIDE_LOADS of csrc/sdp_column_kernel.h): a lane
     takes 16 / sizeof(real) adjacent rows.  Needs whole groups of rows, no row window, exact arithmetic.
     (`debug`: SDP_COL_A_WIDE_LOADS = 0 switches it off, 1 forces it for 4-byte reals: A/B runs.)"""
@@ -955,7 +953,7 @@ def column_wide_loads(n0, dtype, fused, window, debug=None):
         # 4-byte reals: four rows per lane, but the pair layout of their table scatters the stores --
         # measured on 512^3 fp32: 11.5 ms against 11.2 without (not used)
         return False
-    return int(n0) % rpl == 0 and not fused and window is None
+    return int(n0) % rpl == 0 and window is None
 
 
 def column_build_order(threads, w, rows, rows_per_lane=1):

@@ -70,9 +70,6 @@
 #ifndef SDP_COL_UNROLL_W
 #define SDP_COL_UNROLL_W 4       // unroll factor of the perturbation loop (in batches)
 #endif
-#ifndef SDP_COL_FUSED
-#define SDP_COL_FUSED 0          // 1: opt-in fused arithmetic (not the reference's rounding sequence)
-#endif
 #ifndef SDP_COL_A_GROUP
 #define SDP_COL_A_GROUP 4        // table entries per thread whose vertex loads are issued together
 #endif
@@ -93,9 +90,6 @@
 #endif
 #ifndef SDP_COL_A_WIDE_LOADS
 #define SDP_COL_A_WIDE_LOADS 0   // table build, order 2: 16-byte vertex loads, two adjacent rows per lane (see there)
-#endif
-#if SDP_COL_A_WIDE_LOADS && SDP_COL_FUSED
-#error "SDP_COL_A_WIDE_LOADS: exact arithmetic only"
 #endif
 #ifndef SDP_COL_MIN_WAVES
 #define SDP_COL_MIN_WAVES 4      // waves per SIMD the register allocation must allow (2 workgroups per CU)
@@ -206,7 +200,7 @@
 // the same order: same bits.
 #define SDP_COL_WRES SDP_COL_W
 #endif
-#if SDP_COL_WRES < SDP_COL_W && (!SDP_COL_FILTER || SDP_COL_WPAIR || SDP_COST_HAS_W || SDP_COL_FUSED || \
+#if SDP_COL_WRES < SDP_COL_W && (!SDP_COL_FILTER || SDP_COL_WPAIR || SDP_COST_HAS_W || \
                                  SDP_COL_ROWS < SDP_COL_N0 || SDP_COL_THREADS < SDP_COL_N0 || 2 * SDP_COL_WRES < SDP_COL_W)
 #error "SDP_COL_WRES: lean filtered kernel, plain full-column table, one lane per node, at least half of the points resident"
 #endif
@@ -241,7 +235,7 @@ constexpr int sdp_bnb_block(int n) { int b = 8; while ((n + b - 1) / b > 64) b *
 // dependent chain, several times per unit.  0: as in round 3 (A/B runs)
 #define SDP_COL_HOIST 1
 #endif
-#if SDP_COL_FILTER && (!SDP_HAS_W || (SDP_LEAD_HAS_W && !SDP_COL_SHIFT) || SDP_TRAIL_HAS_U || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
+#if SDP_COL_FILTER && (!SDP_HAS_W || (SDP_LEAD_HAS_W && !SDP_COL_SHIFT) || SDP_TRAIL_HAS_U || SDP_COL_ROWS < SDP_COL_N0)
 #error "SDP_COL_FILTER needs a perturbation that reaches x0' through a final sum at most, and the plain full-column table"
 #endif
 #if SDP_COL_SHIFT && (!SDP_COL_FILTER || !SDP_LEAD_HAS_W || SDP_COL_WPAIR)
@@ -250,10 +244,10 @@ constexpr int sdp_bnb_block(int n) { int b = 8; while ((n + b - 1) / b > 64) b *
 #if SDP_COL_FILTER && SDP_COST_HAS_W && SDP_COL_UTAB
 #error "the control table holds sub-expressions without the perturbation: not with a cost that depends on it"
 #endif
-#if SDP_TRAIL_HAS_U && (SDP_COL_WPAIR || SDP_COL_FUSED || SDP_COL_ROWS < SDP_COL_N0)
+#if SDP_TRAIL_HAS_U && (SDP_COL_WPAIR || SDP_COL_ROWS < SDP_COL_N0)
 #error "control-dependent trailing dynamics: plain full table, exact arithmetic only"
 #endif
-#if SDP_COL_ROWS < SDP_COL_N0 && (SDP_COL_WPAIR || SDP_COL_FUSED)
+#if SDP_COL_ROWS < SDP_COL_N0 && SDP_COL_WPAIR
 #error "the row window is built for the plain table layout with exact arithmetic"
 #endif
 constexpr bool SDP_COL_WINDOW = SDP_COL_ROWS < SDP_COL_N0;
@@ -524,9 +518,6 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
             lam[k] = s.w_lam[w * SDP_DT + k];
             oml[k] = s.w_oml[w * SDP_DT + k];
         }
-#if SDP_COL_FUSED && SDP_HAS_W
-        const sdp_real pw_ = ((const sdp_real *)a.proba)[w];
-#endif
 #if SDP_COL_A_WIDE_LOADS
         // 16-byte vertex loads: a lane takes RPL = 16 / sizeof(real) ADJACENT rows (RPL rl .. RPL rl + RPL - 1),
         // then the rows RPL LW further on, ..: 1 / RPL of the vector-memory instructions for the same bytes
@@ -596,11 +587,7 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                 const int r = (j0 + j) * LW + rl;
                 if (r < N0) {
                     const sdp_real val = SdpColNest<0, SHIFT>::run(vals[j], lam, oml, tg.shift);
-#if SDP_COL_FUSED && SDP_HAS_W
-                    const sdp_real entry = val * pw_;
-#else
                     const sdp_real entry = val;
-#endif
 #if SDP_COL_WPAIR
                     s.T[((tw >> 1) * N0 + r) * 2 + (tw & 1)] = entry;
 #else
@@ -642,11 +629,7 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                         oml[k] = s.w_oml[w * SDP_DT + k];
                     }
                     const sdp_real val = SdpColNest<0, SHIFT>::run(vals[j], lam, oml, tg.shift);
-#if SDP_COL_FUSED && SDP_HAS_W
-                    const sdp_real entry = val * ((const sdp_real *)a.proba)[w];
-#else
                     const sdp_real entry = val;
-#endif
                     const int tw = w - w_begin;
 #if SDP_COL_WPAIR
                     s.T[((tw >> 1) * N0 + r) * 2 + (tw & 1)] = entry;
@@ -686,13 +669,7 @@ SDP_DEV void sdp_col_phase_a(const SdpSweepArgs &a, const SdpGrid<sdp_real, SDP_
                     oml[k] = s.w_oml[w * SDP_DT + k];
                 }
                 const sdp_real val = SdpColNest<0, SHIFT>::run(vals[j], lam, oml, tg.shift);
-#if SDP_COL_FUSED && SDP_HAS_W
-                // fused arithmetic: the table holds p_w * inner(r), so phase B is
-                // two fused multiply-adds per cell
-                const sdp_real entry = val * ((const sdp_real *)a.proba)[w];
-#else
                 const sdp_real entry = val;
-#endif
 #if SDP_COL_WPAIR
                 s.T[((tw >> 1) * N0 + r) * 2 + (tw & 1)] = entry;
 #else
@@ -759,7 +736,6 @@ struct SdpColWeights {
     sdp_real w[SDP_COL_W];
 #endif
 #endif
-    sdp_real psum;                         // sum of the weights (fused arithmetic only)
     const volatile sdp_cst_real *cp, *cw;  // mode 1 (volatile: stay inside the loop)
     const volatile sdp_lds_real *lp, *lw;  // mode 2
 };
@@ -785,10 +761,6 @@ SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k, sdp_r
     k.lp = (const volatile sdp_lds_real *)lds_p;
     k.lw = (const volatile sdp_lds_real *)lds_w;
     (void)gp; (void)gw;
-    k.psum = (sdp_real)0;
-#if SDP_HAS_W && SDP_COL_FUSED
-    for (int w = 0; w < SDP_COL_W; ++w) k.psum = k.psum + gp[w];
-#endif
 #if SDP_HAS_W
 #if SDP_COL_WMODE == 0
 #pragma unroll
@@ -820,7 +792,7 @@ SDP_DEV void sdp_col_load_weights(const SdpSweepArgs &a, SdpColWeights &k, sdp_r
 // reference's operation on the same operands (v_pk_mul_f32 / v_pk_add_f32 round
 // each half like the scalar instruction), and the expectation is accumulated
 // in w order (first .x, then .y), so the result is bit-identical to the plain
-// layout; the fused variant keeps two partial sums (even / odd points).
+// layout.
 typedef sdp_real sdp_v2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) sdp_v2 sdp_lds_v2;
 
@@ -851,12 +823,6 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &, const SdpGrid<sdp_real,
 #endif
     }
     constexpr int B = SDP_COL_BATCH;
-#if SDP_COL_FUSED
-    sdp_v2 acc2[K];
-    sdp_real gacc[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) { acc2[j] = (sdp_v2)(0); gacc[j] = (sdp_real)0; }
-#endif
 #pragma unroll SDP_COL_UNROLL_W
     for (int p0 = 0; p0 < WP; p0 += B) {
         sdp_v2 lo[B][K], hi[B][K];
@@ -873,17 +839,6 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &, const SdpGrid<sdp_real,
         for (int b = 0; b < B; ++b)
             if (p0 + b < WP) {
                 const int w = 2 * (p0 + b);
-#if SDP_COL_FUSED
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    acc2[j] = __builtin_elementwise_fma((sdp_v2)(lam0[j]), hi[b][j],
-                              __builtin_elementwise_fma((sdp_v2)(oml0[j]), lo[b][j], acc2[j]));
-#if SDP_COST_HAS_W
-                    gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t), SDP_COL_PW(k, w), gacc[j]);
-                    gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w + 1), t), SDP_COL_PW(k, w + 1), gacc[j]);
-#endif
-                }
-#else
                 sdp_v2 pw2;
                 pw2.x = SDP_COL_PW(k, w);
                 pw2.y = SDP_COL_PW(k, w + 1);
@@ -902,43 +857,25 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &, const SdpGrid<sdp_real,
                     acc[j] = acc[j] + tt.x;                           // stodynprog.py:681, w order
                     acc[j] = acc[j] + tt.y;
                 }
-#endif
             }
     }
-#if SDP_COL_FUSED
-#pragma unroll
-    for (int j = 0; j < K; ++j) acc[j] = acc2[j].x + acc2[j].y;
-#endif
     if (Wn & 1) {                                   // odd W: the last point sits alone in its pair
         constexpr int w = Wn - 1;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const sdp_real lo = row[j][WP * N0].x;
             const sdp_real hi = row[j][WP * N0 + 1].x;
-#if SDP_COL_FUSED
-            acc[j] = fma(lam0[j], hi, fma(oml0[j], lo, acc[j]));
-#if SDP_COST_HAS_W
-            gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t), SDP_COL_PW(k, w), gacc[j]);
-#endif
-#else
             const sdp_real val = oml0[j] * lo + lam0[j] * hi;
 #if SDP_COST_HAS_W
             g[j] = sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t);
 #endif
             const sdp_real jc = g[j] + val;
             acc[j] = acc[j] + jc * SDP_COL_PW(k, w);
-#endif
         }
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-#if SDP_COL_FUSED && SDP_COST_HAS_W
-        out[j] = gacc[j] + acc[j];
-#elif SDP_COL_FUSED
-        out[j] = fma(g[j], k.psum, acc[j]);
-#else
         out[j] = acc[j];
-#endif
     }
 }
 #else   // plain layout
@@ -1043,40 +980,7 @@ SDP_DEV void sdp_col_expected_cost(const SdpSweepArgs &a, const SdpGrid<sdp_real
         g[j] = sdp_model_cost(x, u[j], (sdp_real)0, t);
 #endif
     }
-#if SDP_HAS_W && SDP_COL_FUSED
-    // OPT-IN fused arithmetic (DPSolver.arithmetic = 'fused'): mathematically
-    //     sum_w p_w (g + val_w) = sum_w p_w g_w + sum_w [ (1-lam0) p_w inner_w(q0) + lam0 p_w inner_w(q0+1) ]
-    // with the table pre-scaled by p_w the cell costs two FMAs instead of the
-    // reference's six separately rounded operations.  NOT the reference's
-    // rounding sequence: J differs by a few ulp (tests bound it at 1e-12
-    // relative, the north-star tolerance is 1e-10).
-    sdp_real gacc[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) gacc[j] = (sdp_real)0;
-#pragma unroll SDP_COL_UNROLL_W
-    for (int w = 0; w < Wn; ++w) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-#if SDP_LEAD_HAS_W
-            SDP_COL_LOCATE(j, SDP_COL_GW(k, w))
-#endif
-            const sdp_real lo = row[j][w * N0];
-            const sdp_real hi = row[j][w * N0 + 1];
-            acc[j] = fma(lam0[j], hi, fma(oml0[j], lo, acc[j]));
-#if SDP_COST_HAS_W
-            gacc[j] = fma(sdp_model_cost(x, u[j], SDP_COL_GW(k, w), t), SDP_COL_PW(k, w), gacc[j]);
-#endif
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-#if SDP_COST_HAS_W
-        out[j] = gacc[j] + acc[j];
-#else
-        out[j] = fma(g[j], k.psum, acc[j]);
-#endif
-    }
-#elif SDP_HAS_W
+#if SDP_HAS_W
     // The LDS reads are issued in batches of SDP_COL_BATCH perturbation points
     // (volatile keeps their order); the expectation is accumulated strictly in
     // w order.

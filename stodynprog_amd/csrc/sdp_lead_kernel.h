@@ -37,25 +37,15 @@
 // reference, sdp_trunc_i32) makes Lp >= 2^30: all of them mark the node, which then evaluates every
 // control the long way.  Dabs carries 2 tiny / cu so that the radius never drops below the smallest
 // normal number.
-// 4-BYTE REALS (round 5): the wide form of sdp_col_wide_core.  The positions, the cells and g are the reference's
-// own 4-byte values (inputs of E); the reduced array accumulates the reference's 4-byte inner_w in 8-BYTE reals and F
-// is evaluated in 8-byte arithmetic, so |F - R| is what the inner_w carry, 3 (d - m) u per term, u = 2^-24, and the
-// radius has to cover |E - R| <= (W + 3d + 2) u S on top.  Two things change, both to keep a radius of ~1e-5 of the
-// values useful: S(u) = |g| Pcap + prod_k<m (|oml_k| + |lam_k|) Dabs with the reference's own oml_k = fl(1 - lam_k)
-// -- the weights of ITS nest (1 inside the grid), not the 1 + 2 |lam| of a fused lerp, which F no longer rounds in
-// 4-byte arithmetic -- and S_node takes the LARGEST |F| of the node, not the sum over its controls:
-//     S_node = ratio (max |F| (1 + 1e-6) + Lp Dabs) + Lp Dabs,   Lp = 1.001 max_u prod_k<m (|oml_k| + |lam_k|),
-//     radius = cu S_node,   cu = 4 (W + 3d + 4) 2^-24
-// (|h| <= prod (|1 - lam_k| + |lam_k|) max |A| (1 + tiny) in 8-byte arithmetic, and fl(1 - lam) is within u of 1 - lam:
-// the 1.001).  A node whose S_node reaches 2^100 takes the long way (the reference's own 4-byte intermediates are
-// bounded by a small multiple of S: none of them overflows below that).
+// 8-byte reals only: the form for 4-byte reals of round 5 (a radius of ~1e-5 of the values kept so many controls that the
+// sweep was 3 x slower than every control the long way) was removed in round 6; such problems run the staged tiles.
 #pragma once
 
 #if SDP_LEAD_AXES < 1 || SDP_LEAD_AXES > SDP_D || !SDP_HAS_W || SDP_LANES != 1
 #error "sdp_lead_kernel.h: 1 <= SDP_LEAD_AXES <= SDP_D, a perturbation, one lane per node"
 #endif
-typedef double sdp_lacc;             // the reduced array, F and the bound: 8-byte reals whatever sdp_real is
-constexpr bool SDP_LEAD_WIDE = sizeof(sdp_real) == 4;
+typedef double sdp_lacc;             // the reduced array, F and the bound
+static_assert(sizeof(sdp_real) == 8, "sdp_lead_kernel.h: 8-byte reals");
 #ifndef SDP_LEAD_COST_HAS_W
 #define SDP_LEAD_COST_HAS_W 0        // 1: the cost depends on the perturbation (see sdp_lead_first)
 #endif
@@ -277,8 +267,8 @@ SDP_DEV void sdp_lead_const(const SdpSweepArgs &a, SdpLeadConst &f)
     f.W = a.W;
     f.pcap = pa > (sdp_lacc)1 ? pa : (sdp_lacc)1;
     f.ratio = f.pcap / fabs(ps);                   // (psum = 0: infinite -> every node takes the long way)
-    f.cu = (sdp_lacc)SDP_LEAD_FILTER_SCALE * (sdp_lacc)(4 * (a.W + 3 * SDP_D + 4)) * (SDP_LEAD_WIDE ? (sdp_lacc)0x1p-24 : (sdp_lacc)0x1p-53);
-    f.floor = (sdp_lacc)2 * (SDP_LEAD_WIDE ? (sdp_lacc)1.17549435e-38 : (sdp_lacc)2.2250738585072014e-308) / f.cu;
+    f.cu = (sdp_lacc)SDP_LEAD_FILTER_SCALE * (sdp_lacc)(4 * (a.W + 3 * SDP_D + 4)) * (sdp_lacc)0x1p-53;
+    f.floor = (sdp_lacc)2 * (sdp_lacc)2.2250738585072014e-308 / f.cu;
     f.ok = pa <= (sdp_lacc)1024;                   // (false for a NaN)
 }
 
@@ -333,9 +323,7 @@ SDP_DEV sdp_lacc sdp_lead_first(const sdp_lacc *__restrict__ A, const SdpLeadGeo
         const int q = max(min((int)p, geo.ordm2[k]), 0);       // (saturating conversion; NaN -> 0)
         lam[k] = p - (sdp_real)q;
         off[k] = q * geo.pm[k];
-        // (8-byte reals: the fused lerp of F rounds too, 1 + 2 |lam|; 4-byte reals: the weights of the reference's nest)
-        prod = prod * (SDP_LEAD_WIDE ? (sdp_lacc)fabs((sdp_real)1 - lam[k]) + (sdp_lacc)fabs(lam[k])
-                                     : fma((sdp_lacc)2, (sdp_lacc)fabs(lam[k]), (sdp_lacc)1));
+        prod = prod * fma((sdp_lacc)2, (sdp_lacc)fabs(lam[k]), (sdp_lacc)1);      // (the fused lerp of F rounds too: 1 + 2 |lam|)
     }
     lp = sdp_lead_vmax(lp, prod);
     {
@@ -416,31 +404,29 @@ extern "C" __global__ void __launch_bounds__(256) sdp_sweep(SdpSweepArgs a)
         const sdp_lacc *__restrict__ A = Aall + trail * geo.ls;
         const sdp_lacc dabs = fc.pcap * ((sdp_lacc)E[trail] * vmax) + fc.floor;
         // pass 1
-        sdp_lacc f1 = INFINITY, f2 = INFINITY, fsum = (sdp_lacc)0, fbig = (sdp_lacc)0, lp = (sdp_lacc)0, gmax = (sdp_lacc)0;
+        sdp_lacc f1 = INFINITY, f2 = INFINITY, fsum = (sdp_lacc)0, lp = (sdp_lacc)0, gmax = (sdp_lacc)0;
         int i1 = INT_MAX, lmin = INT_MAX, lmax = INT_MIN;
         SdpLeadWalk walk;
         sdp_lead_walk_begin(box, walk);
 #pragma unroll SDP_LEAD_UNROLL
         for (int ci = 0; ci < box.total; ++ci) {
             const sdp_lacc F = sdp_lead_first(A, geo, fc, x, walk.u, t, lp, gmax, lmin, lmax);
-            fsum = fsum + fabs(F);                         // (a NaN sticks; 4-byte reals: only that is read of it)
-            if (SDP_LEAD_WIDE) fbig = sdp_lead_vmax_abs(fbig, F);
+            fsum = fsum + fabs(F);                         // (a NaN sticks)
             f2 = sdp_lead_vmin(f2, sdp_lead_vmax(f1, F));
             i1 = F < f1 ? ci : i1;
             f1 = sdp_lead_vmin(f1, F);
             sdp_lead_walk_next(box, walk);
         }
-        const sdp_lacc h_cap = (SDP_LEAD_WIDE ? lp * (sdp_lacc)1.001 : lp) * dabs;
+        const sdp_lacc h_cap = lp * dabs;
 #if SDP_LEAD_COST_HAS_W
         const sdp_lacc s_node = fsum == fsum ? gmax + h_cap : (sdp_lacc)NAN;     // (a NaN of any F sticks in the sum)
 #else
-        const sdp_lacc s_node = !SDP_LEAD_WIDE ? fma(fc.ratio, fsum + h_cap, h_cap)
-                                : (fsum == fsum ? fma(fc.ratio, fma(fbig, (sdp_lacc)1.000001, h_cap), h_cap) : (sdp_lacc)NAN);
+        const sdp_lacc s_node = fma(fc.ratio, fsum + h_cap, h_cap);
 #endif
         // the reduced array and the plane-major copy of V hold this rank's part of the grid: a control that reads
         // outside it saw stale values -- the node then takes every control the long way on V itself
         const bool outside = (int64_t)lmin < a.aux_begin || (int64_t)lmax >= a.aux_end;
-        const bool bad = outside || !fc.ok || !(s_node < (SDP_LEAD_WIDE ? (sdp_lacc)0x1p100 : (sdp_lacc)0x1p1000)) || !(lp < (sdp_lacc)1073741824.0);
+        const bool bad = outside || !fc.ok || !(s_node < (sdp_lacc)0x1p1000) || !(lp < (sdp_lacc)1073741824.0);
         const sdp_lacc radius = fc.cu * s_node;
         const sdp_lacc m_hi = f1 + radius;                 // >= the minimum of E over the node
         const bool single = !bad && i1 != INT_MAX && f2 - radius > m_hi;

@@ -270,11 +270,10 @@ class DPSolver(object):
         # in) -- for a contracting exogenous process a fraction of the array.  J is completed on every
         # rank when the host asks for it.  Full-table column kernels (all filter forms), stationary systems.
         self.comm_sparse = False
-        # 'exact': every floating-point operation of the reference, same order (default);
-        # 'fused': column kernel with a weight-scaled table and FMAs -- ~3x fewer
-        #          operations, J within ~1e-15 relative of 'exact' (opt-in)
-        self.arithmetic = 'exact'
-        # column kernel, 'exact' arithmetic: decide all but the near-minimal controls of a node on
+        # (every kernel performs the reference's floating-point operations in the reference's order; the opt-in
+        # 'fused' arithmetic of rounds 1-5 -- J within ~1e-15, 6.6 ms per benchmark sweep -- went in round 6, when the
+        # exact kernel with the certified filter ran the same sweep in 1.05 ms)
+        # column kernel: decide all but the near-minimal controls of a node on
         # a table reduced over the perturbation (rigorous error radius) and evaluate only the
         # survivors with the reference's operations -- same bits, ~W times less work per control
         # (csrc/sdp_colfilter_kernel.h, SdpColFilter).  False: every control the long way.
@@ -500,7 +499,7 @@ class DPSolver(object):
                  tuple(float(x) for x in self.control_steps), str(self.dtype), t_k,
                  id(self.comm), self.comm_phases, self.comm_taper, self.comm_exchange,
                  getattr(self, 'comm_sparse', False), self.kernel,
-                 self.arithmetic, getattr(self, 'certified_filter', True),
+                 getattr(self, 'certified_filter', True),
                  tuple(sorted((codegen.check_debug(self.debug_defines) or {}).items()))]
         for g in list(self.state_grid) + list(self.perturb_grid) + list(self.perturb_proba):
             parts.append(np.asarray(g, dtype=float).tobytes())
@@ -707,7 +706,7 @@ class DPSolver(object):
         # a CU run the column kernels, with per-node arrays stored axis-0-fastest
         if self.kernel not in ('auto', 'generic', 'column', 'staged', 'lead', 'line'):
             raise ValueError("kernel must be 'auto', 'column', 'lead', 'line', 'staged' or 'generic'")
-        may_filter = (getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'
+        may_filter = (getattr(self, 'certified_filter', True)
                       and codegen.column_filter_applies(model, dtype=dt, table=(shape[0], W, len(shape)), debug=debug))
         # The shape of the full-table column kernel is planned ONCE, with everything that sizes its LDS image
         # (the control table included), and handed to the code generator as it is.  A lattice that changes
@@ -737,25 +736,25 @@ class DPSolver(object):
         lead_axes = 0
         if (not column and self.kernel in ('auto', 'lead') and W > 0 and not self._cache.get('no_lead')
                 and (self.comm is None or self.comm.is_device)
-                and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
+                and getattr(self, 'certified_filter', True)):
             # (one stock whose table does not fit LDS too: measured 5.9 ms against 12.7 ms of the row-window
             # column kernel at 1024 x 128 x 128 x 64 x 32, tools/window_vs_lead.py)
             lead_axes = codegen.lead_filter_applies(
-                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2, debug, wide=self.kernel == 'lead')
+                model, dt, 1 if (self.kernel == 'lead' or model.storage_separable) else 2, debug)
         # the stocks need not be listed first (the order of the state variables is the user's, reference
         # stodynprog.py:119-131): the filter then works on a permuted view of the axes, the second pass keeps the
         # reference's own axis order
         lead_perm = None
         if (not column and not lead_axes and self.kernel in ('auto', 'lead') and W > 0 and not self._cache.get('no_lead')
                 and (self.comm is None or self.comm.is_device)
-                and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact'):
-            co = codegen.lead_order(model, dt, debug, wide=self.kernel == 'lead')
+                and getattr(self, 'certified_filter', True)):
+            co = codegen.lead_order(model, dt, debug)
             if co is not None:
                 lead_axes, lead_perm = co
         if self.kernel == 'lead' and not lead_axes:
             raise ValueError("kernel = 'lead' needs controlled state variables next to an exogenous process, "
-                             'a perturbation that reaches only that process, the certified '
-                             'filter and exact arithmetic (several GPUs: a device communicator)')
+                             'a perturbation that reaches only that process, 8-byte reals and the certified '
+                             'filter (several GPUs: a device communicator)')
         if lead_axes:
             lanes = 1                                     # one lane per node, the control loop in-lane
         # trailing next states that depend on the control but not on x0: the nodes of a
@@ -764,7 +763,7 @@ class DPSolver(object):
         # (on a grid of fewer than PERCONTROL_MIN_NODES nodes the direct kernel is faster than a table per control: 16^3
         # 0.160 / 0.036 ms, 24^3 0.224 / 0.101 ms, 32^3 0.242 / 0.251 ms, 48^3 0.46 / 0.95 ms -- round 5)
         per_control = (not column and not lead_axes and self.kernel in ('auto', 'column') and model.column_shareable
-                       and model.trail_depends_on_u and self.arithmetic == 'exact'
+                       and model.trail_depends_on_u
                        and (self.kernel == 'column' or int(np.prod(shape)) >= self.PERCONTROL_MIN_NODES)
                        and self._box_constant_along_axis0(bp, shape))
         per_control_cfg = None
@@ -773,7 +772,7 @@ class DPSolver(object):
             column = per_control = per_control_cfg is not None
         window = None
         if (not column and not per_control and not lead_axes and self.kernel in ('auto', 'column')
-                and model.storage_separable and self.arithmetic == 'exact'):
+                and model.storage_separable):
             # the W x N0 table exceeds the LDS of a CU: tabulate a window of rows per
             # segment of the column (csrc/sdp_column_kernel.h, SDP_COL_ROWS)
             window = codegen.column_window_config(shape[0], W, len(shape), dt,
@@ -790,8 +789,6 @@ class DPSolver(object):
         if self.kernel == 'column' and not column:
             raise ValueError('the column kernel needs a storage-separable model whose '
                              'table fits in LDS')
-        if self.arithmetic not in ('exact', 'fused'):
-            raise ValueError("arithmetic must be 'exact' or 'fused'")
         staged = None
         # The staged kernel gives a node to a thread, the direct one to `lanes` of them: below ~1e5 nodes the staged tiles
         # do not fill the chip and the value array sits in the caches anyway.  Measured in round 5 (staged / direct):
@@ -816,7 +813,7 @@ class DPSolver(object):
         # there is work to save: LINE_MIN_CELLS lattice cells per sweep (below that the direct kernel takes microseconds).
         line = 0
         if (len(shape) == 1 and self.kernel in ('auto', 'line') and self.comm is None and W > 0 and staged is None
-                and getattr(self, 'certified_filter', True) and self.arithmetic == 'exact' and box_t is None
+                and getattr(self, 'certified_filter', True) and box_t is None
                 and model.t_value is None and model.param_index is None
                 and (self.kernel == 'line' or S_nodes * int(bp['max_u']) * W >= self.LINE_MIN_CELLS)
                 and codegen.line_filter_applies(model, dt, W, debug)):
@@ -831,15 +828,15 @@ class DPSolver(object):
         if self.kernel == 'line' and not line:
             raise ValueError("kernel = 'line' needs one state variable whose perturbation enters x' through final sums "
                              "(x + u - w), a cost that does not see it, 8-byte reals, a stationary system, the certified "
-                             'filter and exact arithmetic, one GPU')
+                             'filter, one GPU')
         filtered = bool(column and getattr(self, 'certified_filter', True) and codegen.column_filter_applies(
-            model, self.arithmetic == 'fused', window, per_control_cfg if per_control else None, dtype=dt,
+            model, window, per_control_cfg if per_control else None, dtype=dt,
             table=(shape[0], W, len(shape)), debug=debug))
         if not filtered or window is not None or per_control:
             utab = None
         source = codegen.translation_unit(model, dt, lanes,
                                           column=(shape[0], W, n_controls, int(np.prod(shape[1:]))) if column else None,
-                                          fused=(self.arithmetic == 'fused'), staged=staged,
+                                          staged=staged,
                                           window=window, per_control=per_control_cfg if per_control else None,
                                           filtered=filtered, utab=utab, lead_axes=lead_axes,
                                           col_cfg=col_cfg, debug=debug, wres=wres if filtered else 0,
@@ -1076,7 +1073,6 @@ class DPSolver(object):
                          # x0' = a chain of sums in another nesting than ((a +- b) +- ..), x + (w - u): regrouped for the first pass
                          regrouped_sums=bool(plan.get('filtered') and '#define SDP_COL_SHIFT 1' in plan['source']
                                              and '#define SDP_COL_SHIFT_CHAIN 0' not in plan['source']),
-                         arithmetic=self.arithmetic if column else 'exact',
                          module=module, lanes_per_node=lanes,
                          max_controls=max_u, box_per_node=bool(per_node),
                          bit_exact_model=model.bit_exact,

@@ -261,16 +261,12 @@ def test_two_controls_on_one_lattice_go_through_the_control_table(gpu, dtype):
 
 
 def test_where_the_filter_does_not_apply(gpu):
-    """an x0' that sees the perturbation other than through a final sum (that form: test_gpu_shift.py), or fused arithmetic: every control the long way"""
+    """an x0' that sees the perturbation other than through a final sum (that form: test_gpu_shift.py), every control the long way"""
     sysd, s = _stock()
     sysd.dyn = lambda x, y, u, w: ((x + 0.7 * u) * (1.0 + 0.1 * w), 0.8 * y + w)
     s._cache.clear()
     s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
     assert s.backend_info['kernel'] == 'column' and not s.backend_info['certified_filter']
-    _, s = models.synthetic3d(N=16)
-    s.arithmetic = 'fused'
-    s.value_iteration(np.zeros(s._state_grid_shape), report_time=False)
-    assert not s.backend_info['certified_filter']
 
 
 # ---------------------------------------------------------------------------

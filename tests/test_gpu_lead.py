@@ -57,10 +57,11 @@ def test_the_plan(gpu):
     assert plan['lead_axes'] == 2 and plan['lanes'] == 1 and plan['filtered'] and not plan['column']
     src = plan['source']
     assert '#define SDP_LEAD_AXES 2' in src and 'sdp_model_leads' in src and 'sdp_model_trails' in src
-    s.dtype = np.dtype('float32')                 # 4-byte reals: not planned (the wide form exists since round 5, on request)
-    assert not s._kernel_plan()['lead_axes']
+    s.dtype = np.dtype('float32')                 # 4-byte reals: another kernel (round 5's form for them was 3 x slower than
+    assert not s._kernel_plan()['lead_axes']      # every control the long way and went in round 6)
     s.kernel = 'lead'
-    assert s._kernel_plan()['lead_axes'] == 2 and s._kernel_plan()['filtered']
+    with pytest.raises(ValueError):
+        s._kernel_plan()
 
 
 @pytest.mark.parametrize('box_on_state', [False, True])
@@ -270,98 +271,3 @@ def test_a_stock_that_is_not_listed_first(gpu, three, cost_w, recwarn):
         Jn, _ = a.value_iteration(V2, report_time=False)
         Jg, _ = b.value_iteration(V2, report_time=False)
     assert np.array_equal(Jn, Jg, equal_nan=True) and np.array_equal(a.last_policy_index, b.last_policy_index)
-
-
-# ---------------------------------------------------------------------------
-# Round 5: 4-byte reals.  The wide form: the reduced array and F in 8-byte reals on the reference's
-# 4-byte positions, cells, costs and inner values; the radius follows the reference's 4-byte roundings
-# (csrc/sdp_lead_kernel.h, tests/test_filter_bound_exact.py).  Same bits as the direct kernel in 4-byte reals, which
-# evaluates every control with the reference's float specialisation (multilinear_cython.pyx:13-15; golden G11).
-# `kernel = 'lead'` asks for it: the planner does not choose it (a radius of ~1e-5 of the values keeps too many controls on
-# a fine control lattice -- bench.py --config reservoirs_f32 --kernel lead: 8.9 ms against 2.6 ms every control the long way).
-# ---------------------------------------------------------------------------
-F32 = np.float32
-
-
-@pytest.mark.parametrize('box_on_state', [False, True])
-def test_4_byte_reals_same_bits_as_the_direct_kernel(gpu, box_on_state):
-    make = _small(box_on_state)
-    V = _smooth(make()[1])
-    lead, gen = _sweep(make, 'lead', V, dtype=F32), _sweep(make, 'generic', V, dtype=F32)
-    assert lead[0].dtype == F32 and lead[3].backend_info['kernel'] == 'lead' and lead[3].backend_info['filter_form'] == 'reduced array'
-    assert gen[3].backend_info['kernel'] == 'generic'
-    _same(lead, gen)
-    V = np.random.default_rng(3).standard_normal(V.shape)
-    _same(_sweep(make, 'lead', V, dtype=F32), _sweep(make, 'generic', V, dtype=F32))
-    _same(_sweep(make, 'lead', V, sweeps=3, dtype=F32), _sweep(make, 'generic', V, sweeps=3, dtype=F32))
-    # a cost-to-go that has grown (an undiscounted chain adds the stage cost every sweep): the radius grows with it
-    _same(_sweep(make, 'lead', V + 1000.0, dtype=F32), _sweep(make, 'generic', V + 1000.0, dtype=F32))
-    # and within the north star's 1e-5 of the 8-byte sweep of the same problem
-    J64 = _sweep(make, 'auto', _smooth(make()[1]))[0]
-    J32 = _sweep(make, 'lead', _smooth(make()[1]), dtype=F32)[0]
-    assert np.abs(J32 - J64).max() <= 1e-5 * np.abs(J64).max()
-
-
-@pytest.mark.parametrize('case', ['nan', 'inf', 'huge', 'subnormal', 'constant', 'tiny'])
-def test_4_byte_reals_special_values(gpu, case):
-    make = _small()
-    V = np.random.default_rng(5).standard_normal(make()[1]._state_grid_shape)
-    if case == 'nan':
-        V[3:5, 2:4, 1:3] = np.nan
-    elif case == 'inf':
-        V[:2] = np.inf
-    elif case == 'huge':
-        V *= 1e36                                   # (sums of a few of them overflow 4-byte reals)
-    elif case == 'subnormal':
-        V *= 1e-41
-    elif case == 'tiny':
-        V *= 1e-30
-    else:
-        V[:] = 2.5
-    with np.errstate(all='ignore'):
-        _same(_sweep(make, 'lead', V, dtype=F32), _sweep(make, 'generic', V, dtype=F32))
-
-
-@pytest.mark.parametrize('three,cost_w', [(False, False), (True, True)])
-def test_4_byte_reals_with_a_stock_that_is_not_listed_first(gpu, three, cost_w, recwarn):
-    make = lambda: _stock_not_first(three, cost_w)
-    V = np.random.default_rng(31).standard_normal(make()[1]._state_grid_shape)
-    lead, gen = _sweep(make, 'lead', V, dtype=F32), _sweep(make, 'generic', V, dtype=F32)
-    assert lead[3].backend_info['kernel'] == 'lead'
-    _same(lead, gen)
-
-
-@pytest.mark.parametrize('scale', ['1e2', '1e5'])
-def test_4_byte_reals_any_larger_radius_gives_the_same_bits(gpu, debug_defines, scale):
-    make = _small()
-    V = _smooth(make()[1])
-    ref = _sweep(make, 'generic', V, dtype=F32)
-    debug_defines.set(SDP_LEAD_FILTER_SCALE=scale)
-    _same(_sweep(make, 'lead', V, dtype=F32), ref)
-
-
-def test_4_byte_reals_a_radius_far_too_small_is_noticed(gpu, debug_defines):
-    """the flat objective of test_near_ties_and_a_radius_far_too_small in 4-byte reals: the reference's argmin hangs on
-    4-byte roundings that the 8-byte first pass does not make -- same bits at the proven radius and at a quarter of it
-    (the bound's own slack), mismatches with the radius cut by 1e6"""
-    def make():
-        sysd = SysDescription((3, 2, 1), name='flat')
-        sysd.dyn = lambda a, b, y, u, v, w: (a + 0.37 * u, b + 0.29 * v, 0.8 * y + w)
-        sysd.cost = lambda a, b, y, u, v, w: (-1.3 * 0.37) * u + (-0.7 * 0.29) * v
-        sysd.control_box = lambda a, b, y: ((-1., 1.), (-1., 1.))
-        sysd.perturb_laws = [NormalLaw(0, 0.2)]
-        s = DPSolver(sysd)
-        s.discretize_state(0, 3, 24, 0, 3, 20, -1, 1, 6)
-        s.discretize_perturb(-0.5, 0.5, 7)
-        s.control_steps = (2.0 / 11, 2.0 / 9)
-        return sysd, s
-    g = make()[1].state_grid
-    V = (1.3 * np.asarray(g[0])[:, None, None] + 0.7 * np.asarray(g[1])[None, :, None]
-         + np.cos(3 * np.asarray(g[2]))[None, None, :])
-    ref = _sweep(make, 'generic', V, dtype=F32)
-    assert len(np.unique(ref[2])) > 5
-    _same(_sweep(make, 'lead', V, dtype=F32), ref)
-    debug_defines.set(SDP_LEAD_FILTER_SCALE='0.25')
-    _same(_sweep(make, 'lead', V, dtype=F32), ref)
-    debug_defines.set(SDP_LEAD_FILTER_SCALE='1e-6')
-    assert (_sweep(make, 'lead', V, dtype=F32)[2] != ref[2]).sum() > 0

@@ -408,8 +408,6 @@ def test_certified_filter_planning_without_a_gpu():
     src = s._kernel_plan()['source']
     assert 'SDP_COL_FILTER' not in src and '#define SDP_COL_THREADS 512' in src
     s.certified_filter = True
-    s.arithmetic = 'fused'                               # not the reference's operations: no filter
-    assert not s._kernel_plan()['filtered']
     # 512 nodes per column: 512 lanes; beyond that the lanes of a wave share nodes as before
     _, s = models.synthetic3d(N=64)
     s.discretize_state(0, 1, 512, 0, 1, 16, 0, 1, 16)
@@ -522,7 +520,6 @@ def test_controlled_axes_and_the_reduced_array_plan_without_a_gpu():
     assert models.synthetic3d(N=8)[1]._traced().controlled_axes() == 1
     m = tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w))
     assert codegen.lead_filter_applies(m, np.float64) == 2 and codegen.lead_filter_applies(m, np.float32) == 0
-    assert codegen.lead_filter_applies(m, np.float32, wide=True) == 2     # (4-byte reals: the wide form, round 5, on request)
     mw = tr3(lambda a, b, y, u, v, w: (a + u - v, b + v, 0.8 * y + w), lambda a, b, y, u, v, w: u * w)
     assert codegen.lead_filter_applies(mw, np.float64) == 2          # a cost that sees the perturbation: its expectation per control
     _, s = models.two_reservoirs(n_a=12, n_b=10, n_y=6, n_w=5)
@@ -537,9 +534,7 @@ def test_controlled_axes_and_the_reduced_array_plan_without_a_gpu():
     s.kernel = 'column'                          # the table-per-control column kernel still takes the model when asked
     assert s._kernel_plan()['column'] and s._kernel_plan()['per_control']
     s.kernel = 'lead'
-    s.dtype = np.dtype('float32')
-    assert s._kernel_plan()['lead_axes'] == 2
-    s.arithmetic = 'fused'                       # (exact arithmetic only)
+    s.dtype = np.dtype('float32')                # (8-byte reals only since round 6)
     with pytest.raises(ValueError):
         s._kernel_plan()
 

@@ -7,7 +7,7 @@ DEFS=""; for kv in "$@"; do DEFS="$DEFS --debug-define $kv"; done
 OUT=$PWD/gpurun_out/pmcq_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-fused --no-filter-check --no-other-configs $DEFS"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-filter-check --no-other-configs $DEFS"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/l2" -- python3 bench.py $ARGS > "$OUT/b1.json" 2> "$OUT/l2.log"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $ARGS > "$OUT/b2.json" 2> "$OUT/fetch.log"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/sq" -- python3 bench.py $ARGS > "$OUT/b3.json" 2> "$OUT/sq.log"

@@ -15,7 +15,7 @@ for cfg in sys.argv[1:]:
         else:
             env[kv.split('=', 1)[0]] = kv.split('=', 1)[1]     # a hook of bench.py itself (SDP_COMM_PHASES, ..)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '10', '--warmup', '3',
-                        '--no-cpu-baseline', '--no-fused', '--no-other-configs'] + defs +
+                        '--no-cpu-baseline', '--no-other-configs'] + defs +
                        os.environ.get('TUNE_BENCH_ARGS', '').split(),
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     try:
