@@ -265,8 +265,9 @@ SDP_DEV void sdp_colres_partial_kept(const sdp_real *__restrict__ G, const SdpCo
 // with its own.  What is not finite: a or h (poisoned statistics: sdp_col_phase_u), K, the table (D), X (L) -- each
 // makes S_node or L fail its test and the node `bad`; and S_node < 2^1000 keeps every F' finite (|lam0 (A1 - A0)| <= 2 L D),
 // so the packing never meets an infinity.  tests/test_filter_bound_exact.py checks the inequality in exact arithmetic.
-static_assert(!SDP_COL_SHIFT && !SDP_COST_HAS_W && !SDP_COL_TOP2 && SDP_COL_UTAB && sizeof(sdp_real) == 8,
-              "short first pass: 8-byte reals, control table, a perturbation that reaches neither the stock nor the cost");
+static_assert(!SDP_COST_HAS_W && (SDP_COL_SHIFT ? !SDP_COL_SHIFT_CHAIN && !SDP_COL_BNB : !SDP_COL_TOP2) && SDP_COL_UTAB && sizeof(sdp_real) == 8,
+              "short first pass: 8-byte reals, control table, a perturbation that does not reach the cost and reaches the stock "
+              "through final sums at most (there without the branch and bound)");
 template <int AXIS>
 SDP_DEV sdp_real sdp_lean2_value(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
                                  sdp_real X, int ci)
@@ -323,6 +324,85 @@ SDP_DEV void sdp_lean2_pass1(const sdp_real *A, const sdp_real *utab, const SdpC
     }
     for (; ci < n; ++ci) insert(sdp_lean2_value<AXIS>(A, utab, f, l, X, ci), ci);
 }
+
+#if SDP_COL_SHIFT
+// The short first pass ON THE SHIFTED LATTICE (round 6): x0' = (X +- a) +- b_1(w) .. with final sums (docs/NOTEBOOK.md
+// section 3.1d), a and the control's part h of the cost from the column's control table.  The lattice's reduced table A'
+// takes the place of A, `l` is the lattice (koff = its first position, ordm2 = its rows - 2), and what the lerp between
+// whole positions leaves out is bounded by B' of the control's own cell.  What the short pass sheds is the same as above:
+//     F' = fma(+-h, psum, lerp(A', pa)),  the control's index in its low mantissa bits;
+//     S_node = Pcap (|K| + max |h|) + H D,   H = (1 + 2 (L + Lc)) (3 + Es),   L = max(1, |lam0| at the column's smallest and largest a)
+//     radius = (cu + 2^(bits+2) u) S_node + max B'[q0]
+// -- sdp_col_shift_reduce's bound with |g| Pcap <= Pcap (|K| + max |h|)(1 + u) in the place of ratio (sum |F| + H D), the
+// rounding of g = fl(K +- h) as in the short pass above, the packing as there (|F'| <= S_node).  The three smallest F'
+// are kept: ~1 % of the nodes of the benchmark problem hold two controls inside the radius (B' is of the order of
+// h^2 V'' / 16, not 1e-13), both are carried through the second pass.  tests/test_filter_bound_exact.py checks
+// |E - K P* - F'| <= radius in exact arithmetic.
+template <int AXIS>
+SDP_DEV void sdp_lean2s_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_real &lam0)
+{
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
+    const sdp_real pk = sn * l.nm1 - l.koff;                // (inside the lattice pk >= 0: the truncation is the floor)
+    q0 = (int)pk;                                           // (saturating conversion; NaN -> 0)
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));
+    lam0 = pk - (sdp_real)q0;
+}
+typedef sdp_real sdp_ab_pair __attribute__((ext_vector_type(2)));
+template <int AXIS>
+SDP_DEV sdp_real sdp_lean2s_value(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                                  sdp_real X, int ci, sdp_real &bmax)
+{
+    int q0;
+    sdp_real lam0;
+    sdp_lean2s_cell<AXIS>(l, SDP_LEAN2_LEAD(X, utab[ci * SDP_COL_UTAB + SDP_LEAN2_A_SLOT]), q0, lam0);
+    const sdp_ab_pair ab = *(const sdp_ab_pair *)(A + 2 * q0);
+    const sdp_real a1 = A[2 * q0 + 2];
+    bmax = sdp_vmax(bmax, ab.y);
+    const sdp_real h = fma(lam0, a1 - ab.x, ab.x);
+    if (SDP_LEAN2_H_SLOT < 0) return h;
+    const sdp_real hv = utab[ci * SDP_COL_UTAB + (SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT)];
+    return fma(SDP_LEAN2_HNEG ? -hv : hv, f.psum, h);
+}
+// the three smallest F' over the controls [0, n) of one node, the index of each in its low bits; the largest B' met
+template <int AXIS>
+SDP_DEV void sdp_lean2s_pass1(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
+                              sdp_real X, int n, int mask, sdp_real &f1, sdp_real &f2, sdp_real &f3, sdp_real &bmax)
+{
+    auto insert = [&](sdp_real F, int ci) {
+        const sdp_real Fp = __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci);
+        f3 = sdp_vmin(f3, sdp_vmax(f2, Fp));
+        f2 = sdp_vmin(f2, sdp_vmax(f1, Fp));
+        f1 = sdp_vmin(f1, Fp);
+    };
+    constexpr int K = SDP_LEAN2_GROUP;
+    constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
+    int ci = 0;
+    for (; ci + K <= n; ci += K) {
+        int q0[K];
+        sdp_real av[K], lam0[K], hv[K], a1[K];
+        sdp_ab_pair ab[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            av[j] = utab[(ci + j) * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
+            hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[(ci + j) * SDP_COL_UTAB + HS];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) sdp_lean2s_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            ab[j] = *(const sdp_ab_pair *)(A + 2 * q0[j]);
+            a1[j] = A[2 * q0[j] + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            bmax = sdp_vmax(bmax, ab[j].y);
+            const sdp_real h = fma(lam0[j], a1[j] - ab[j].x, ab[j].x);
+            insert(SDP_LEAN2_H_SLOT < 0 ? h : fma(SDP_LEAN2_HNEG ? -hv[j] : hv[j], f.psum, h), ci + j);
+        }
+    }
+    for (; ci < n; ++ci) insert(sdp_lean2s_value<AXIS>(A, utab, f, l, X, ci, bmax), ci);
+}
+#endif  // SDP_COL_SHIFT
 
 #endif  // SDP_COL_LEAN2
 
@@ -538,7 +618,40 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
         } else
         if (live) {
             x[0] = axis0[i];
-#if SDP_COL_LEAN2
+#if SDP_COL_LEAN2 && SDP_COL_SHIFT
+            // the short first pass on the shifted lattice (sdp_lean2s_pass1)
+            const sdp_real *utab = sdp_lds.utab[upar];
+            const sdp_real *ust = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;          // a_lo, a_hi, max |h| (or NaN)
+            const sdp_real X = sdp_model_lead_x(x, t), K = sdp_model_cost_x(x, t);
+            const int bits = 32 - __clz(max(box.total - 1, 1));
+            const int mask = (1 << bits) - 1;
+            struct { sdp_real f1, f2, f3; int i1, i2; } bd;
+            bd.f1 = bd.f2 = bd.f3 = INFINITY;
+            int q_e;
+            sdp_real lam_lo, lam_hi, b_max = (sdp_real)0;
+            if (axis_mode == 2) {
+                sdp_lean2s_cell<2>(lead1, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2s_cell<2>(lead1, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+                sdp_lean2s_pass1<2>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
+            } else if (axis_mode == 1) {
+                sdp_lean2s_cell<1>(lead1, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2s_cell<1>(lead1, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+                sdp_lean2s_pass1<1>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
+            } else {
+                sdp_lean2s_cell<0>(lead1, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
+                sdp_lean2s_cell<0>(lead1, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
+                sdp_lean2s_pass1<0>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
+            }
+            const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
+            const sdp_real h_cap = (((sdp_real)1 + (sdp_real)2 * (l_cap + shc.lc)) * ((sdp_real)3 + shc.es)) * dcol;
+            const sdp_real s_node = fma(filt.pcap, fabs(K) + ust[2], h_cap);
+            const bool bad = !filt.ok || !shc.ok || !(s_node < SDP_COL_FILTER_LIMIT) ||
+                             !(fabs(lam_lo) + fabs(lam_hi) + shc.lc < (sdp_real)1073741824.0) || bits > 24 || box.total > SDP_COL_UTAB_N;
+            const sdp_real radius = fma(filt.cu + (sdp_real)(SDP_COL_FILTER_SCALE) * ldexp(SDP_COL_FILTER_EPS, bits + 1), s_node,
+                                        (sdp_real)(SDP_COL_FILTER_SCALE) * b_max);
+            bd.i1 = bd.f1 < (sdp_real)INFINITY ? (__double2loint(bd.f1) & mask) : INT_MAX;
+            bd.i2 = bd.f2 < (sdp_real)INFINITY ? (__double2loint(bd.f2) & mask) : INT_MAX;
+#elif SDP_COL_LEAN2
             const sdp_real *utab = sdp_lds.utab[upar];
             const sdp_real *ust = utab + SDP_COL_UTAB * SDP_COL_UTAB_N;          // a_lo, a_hi, max |h| (or NaN)
             const sdp_real X = sdp_model_lead_x(x, t), K = sdp_model_cost_x(x, t);
@@ -619,7 +732,7 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             const sdp_real m_hi = bd.f1 + radius;              // >= the minimum of E over the node
             const bool single = !bad && bd.i1 != INT_MAX && bd.f2 - radius > m_hi;
             // exactly two survivors (the lattice points either side of the continuous optimum): both carried
-#if SDP_COL_LEAN2
+#if SDP_COL_LEAN2 && !SDP_COL_SHIFT
             const bool pair = false;
 #else
             const bool pair = SDP_COL_TOP2 && !bad && !single && bd.i2 != INT_MAX && bd.f3 - radius > m_hi;
@@ -647,7 +760,11 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
                     sdp_controls_at(box, ci, u);
                     bool cand = bad;
                     if (!cand) {
-#if SDP_COL_LEAN2
+#if SDP_COL_LEAN2 && SDP_COL_SHIFT
+                        sdp_real b_unused = (sdp_real)0;       // (the radius holds the largest B' of the node already)
+                        const sdp_real F = lead.pow2 ? sdp_lean2s_value<1>(sdp_lds.ad, utab, filt, lead1, X, ci, b_unused)
+                                                     : sdp_lean2s_value<0>(sdp_lds.ad, utab, filt, lead1, X, ci, b_unused);
+#elif SDP_COL_LEAN2
                         const sdp_real F = lead.pow2 ? sdp_lean2_value<1>(sdp_lds.ad, utab, filt, lead, X, ci)
                                                      : sdp_lean2_value<0>(sdp_lds.ad, utab, filt, lead, X, ci);
 #else

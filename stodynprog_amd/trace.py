@@ -596,8 +596,16 @@ class TracedModel(object):
         Returns None or a dict: lead = (X node, slot of a, form), cost = (K node or None, slot of h or None, form);
         form: 'add' (X + a), 'sub' (X - a) or 'rsub' (a - X)."""
         slot = {n.id: k for k, n in enumerate(frontier)}
-        if self.lead_depends_on_w or self.cost_depends_on_w:
+        if self.cost_depends_on_w:
             return None
+        lead_node = self.x_next[0]
+        if self.lead_depends_on_w:
+            # round 6: a perturbation that reaches x0' through FINAL sums, x0' = (X +- a) +- b_1(w) ..: the w-free part has the
+            # shape (the shifted lattice's short pass); a regrouped chain's a* is not a value the reference computes: not taken
+            sp = self.lead_split()
+            if sp is None or self.lead_split_chain() is not None:
+                return None
+            lead_node = sp[0]
 
         def split(node, need_control):
             if node.id in slot:
@@ -611,7 +619,7 @@ class TracedModel(object):
                 if part.id in slot and not (other.deps & (DEP_U | DEP_W)) and other.kind == 'r':
                     return (other, slot[part.id], form)
             return None
-        lead = split(self.x_next[0], True)
+        lead = split(lead_node, True)
         cost = split(self.cost, False)
         if lead is None or cost is None or lead[0] is None:
             return None

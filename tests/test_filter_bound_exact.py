@@ -776,6 +776,117 @@ def test_the_shifted_lattice_radius_covers_the_difference_exactly(regime, chain)
         assert model_part > 0.9, model_part                  # ... and it is what the radius is made of there
 
 
+# The SHORT first pass on the shifted lattice (round 6; SDP_COL_LEAN2 with SDP_COL_SHIFT of csrc/sdp_colres_kernel.h):
+# x0' = (X + a_u) - b_w with a_u and the control's part h_u of the cost = K + h_u from the column's control table.  The pass
+# orders F' = fma(+-h, psum, lerp(A', pa)) with the control's index in its low mantissa bits, bounds the cost by |K| + max |h|
+# and every |lam0| by the positions of the column's smallest and largest a:
+#     S = Pcap (|K| + max |h|) + (1 + 2 (L + Lc)) (3 + Es) D,    radius = (cu + 2^(bits+2) u) S + max B'[q0]
+def shifted_short_check(T, p, X, K, a, h, b, order, sign=1.0):
+    W, N0 = T.shape
+    nm1 = float(N0 - 1)
+    fc = filter_constants(p)
+    q_w, f_w, c_w, pbabs = [], [], [], 0
+    for w in range(W):
+        pb = (-b[w]) * nm1
+        fl = float(np.floor(pb))
+        q_w.append(int(fl))
+        f_w.append(pb - fl)
+        c_w.append(abs(p[w]) * (f_w[-1] * (1.0 - f_w[-1])))
+        pbabs = max(pbabs, int(abs(abs(b[w]) * nm1)) + 1)
+    flmax, nflmin = max(q_w), max(-q for q in q_w)
+    kmin, rows = -(flmax + 1), N0 + flmax + nflmin + 1
+    pbmax = float(max(abs(flmax), abs(nflmin), pbabs) + 1)
+    lc = float(rows) + float(abs(kmin)) + pbmax + 0.0 + float(N0 + 1)
+    es = float(1 + 2 * (flmax + nflmin + 2))
+    Ap, Bp, big = np.zeros(rows), np.zeros(rows), 0.0
+    for ki in range(rows):
+        k = kmin + ki
+        for w in order:
+            j = k + q_w[w]
+            q = max(min(j, N0 - 2), 0)
+            lam = float(j - q) + f_w[w]
+            t0, t1 = T[w][q], T[w][q + 1]
+            t2 = T[w][q + 2] if q + 2 < N0 else T[w][q + 1]
+            Ap[ki] = fma(p[w], fma(lam, t1 - t0, t0), Ap[ki])
+            d2 = (t2 - t1) - (t1 - t0)
+            Bp[ki] = fma(c_w[w], abs(d2) if 0 <= j <= N0 - 3 else 0.0, Bp[ki])
+            big = max(big, abs(t0), abs(t1))
+    dcol = fc['pcap'] * big + fc['floor']
+
+    def cell(xa):                                            # sdp_lean2_cell on the lattice
+        pk = xa * nm1 - float(kmin)
+        q0 = max(min(int(pk), rows - 2), 0)
+        return q0, pk - float(q0)
+    n = len(a)
+    bits = max((n - 1).bit_length(), 1)
+    mask = (1 << bits) - 1
+    L = max(1.0, abs(cell(X + min(a))[1]), abs(cell(X + max(a))[1]))
+    h_cap = ((1.0 + 2.0 * (L + lc)) * (3.0 + es)) * dcol
+    s_node = fma(fc['pcap'], abs(K) + max(abs(v) for v in h), h_cap)
+    p_exact = sum(Fraction(v) for v in p)
+    worst, bmax = Fraction(0), 0.0
+    for ci in range(n):
+        xa = X + a[ci]
+        q0, lam0 = cell(xa)
+        assert abs(lam0) <= L
+        bmax = max(bmax, Bp[q0])
+        F = fma(sign * h[ci], fc['psum'], fma(lam0, Ap[q0 + 1] - Ap[q0], Ap[q0]))
+        Fp = pack_index(F, ci, mask)
+        assert abs(Fraction(Fp) - Fraction(F)) <= Fraction(2.0 ** (bits + 1 - 53)) * Fraction(s_node) * (1 + Fraction(3, 2 ** 53))
+        g = K + sign * h[ci]                                 # the reference's cost, one rounding
+        acc = 0.0
+        for w in range(W):
+            sr = (xa - b[w]) * nm1
+            qr = max(min(int(sr), N0 - 2), 0)
+            lr = sr - float(qr)
+            val = (1.0 - lr) * T[w][qr] + lr * T[w][qr + 1]
+            acc = acc + (g + val) * p[w]
+        worst = max(worst, abs(Fraction(acc) - Fraction(K) * p_exact - Fraction(Fp)))
+    radius = fma(fc['cu'] + 2.0 ** (bits + 1 - 52), s_node, bmax)
+    return float(worst / Fraction(radius)), float(Fraction(bmax) / Fraction(radius))
+
+
+@pytest.mark.parametrize('regime', ['smooth', 'rough', 'cancel', 'weights', 'large'])
+def test_the_short_pass_on_the_shifted_lattice_covers_the_difference_exactly(regime):
+    rng = np.random.default_rng(450 + ['smooth', 'rough', 'cancel', 'weights', 'large'].index(regime))
+    worst, model_part = 0.0, 0.0
+    for trial in range(200):
+        W = int(rng.integers(1, 8))
+        N0 = int(rng.integers(4, 16))
+        r = np.arange(N0) / (N0 - 1.0)
+        if regime == 'smooth':
+            T = np.stack([(r - rng.uniform(0, 1)) ** 2 * rng.uniform(0.5, 3) + rng.uniform(-1, 1) * r for _ in range(W)])
+        elif regime == 'cancel':
+            T = 1e6 + 1e-6 * rng.standard_normal((W, N0))
+        else:
+            T = rng.standard_normal((W, N0))
+            if regime == 'large':
+                T *= 10.0 ** rng.uniform(100, 250)
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        if regime == 'weights':
+            p = rng.standard_normal(W) * 2.1
+            if abs(p.sum()) < 0.2:
+                p[0] += 1.0
+        scale = float(np.abs(T).max())
+        n = int(rng.integers(1, 70))
+        X = float(rng.uniform(0, 1))
+        spread = float(10.0 ** rng.uniform(-2, 0.5))
+        a = [float(v) for v in rng.uniform(-spread, spread, size=n)]
+        K = float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3)
+        h = [float(v) * scale * 10.0 ** rng.uniform(-3, 2) for v in rng.standard_normal(n)]
+        b = [float(v) for v in rng.uniform(-1, 1, size=W) * 10.0 ** rng.uniform(-2.5, 0.3)]
+        if trial % 4 == 0:
+            b[0] = float(rng.integers(-3, 4)) / (N0 - 1)
+        order = list(rng.permutation(W))
+        ratio, share = shifted_short_check(T, [float(v) for v in p], X, K, a, h, b, order, -1.0 if trial % 3 == 0 else 1.0)
+        assert ratio <= 1.0, (regime, trial, ratio)
+        worst, model_part = max(worst, ratio), max(model_part, share)
+    assert worst > 0.05, worst
+    if regime in ('smooth', 'rough'):
+        assert model_part > 0.9, model_part
+
+
 @pytest.mark.parametrize('chain', ['x+(w-u)', '(x-w)+u'])
 def test_a_regrouped_chain_needs_the_sum_of_its_leaves_in_the_bound(chain):
     """leaves that cancel far outside the grid (x = 1e3 .. 1e6, u = x - 1 .. x + 1 on a grid [0, 1]) and tables that are

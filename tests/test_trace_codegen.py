@@ -692,15 +692,25 @@ def test_the_short_first_pass_is_planned_where_the_model_has_its_shape():
         .additive_control_split(tm(lambda x, y, u: x + 0.5 * u, lambda x, y, u: (y - u) * (y - u)).control_uniform_frontier())['cost'][0] is None
     m = tm(lambda x, y, u: x * y + y * u, lambda x, y, u: x * x + y)
     assert m.additive_control_split(m.control_uniform_frontier())['cost'][1] is None     # no control in the cost
-    # not the shape: the control multiplies the stock; the cost couples them; the perturbation reaches the stock
+    # not the shape: the control multiplies the stock; the cost couples them; the stock is scaled after the control
     for dyn0, cost in ((lambda x, y, u: x * (1.0 + 0.1 * u) + u, lambda x, y, u: x + u * u),
                        (lambda x, y, u: x + u, lambda x, y, u: (x - u) * (x - u)),
                        (lambda x, y, u: (x + u) * 0.5, lambda x, y, u: x + u * u)):
         m = tm(dyn0, cost)
         fr = m.control_uniform_frontier()
         assert fr is None or m.additive_control_split(fr) is None
+    # a perturbation that reaches the stock through FINAL sums (round 6: the short pass on the shifted lattice): the w-free
+    # part has the shape; a chain of sums in another nesting is regrouped -- its a is not the reference's value: not taken
     m = trace_model(lambda x, y, u, w: ((x + 0.5 * u) - 0.1 * w, 0.5 * y + w), lambda x, y, u, w: x + u * u, 2, 1, 1)
-    assert m.additive_control_split(m.control_uniform_frontier(m.lead_split()[0])) is None
+    sp = m.additive_control_split(m.control_uniform_frontier(m.lead_split()[0]))
+    assert sp is not None and (sp['lead'][1], sp['lead'][2], sp['cost'][2]) == (0, 'add', 'add')
+    m = trace_model(lambda x, y, u, w: (x + (0.5 * u - 0.1 * w), 0.5 * y + w), lambda x, y, u, w: x + u * u, 2, 1, 1)
+    assert m.lead_split_chain() is not None and m.additive_control_split(m.control_uniform_frontier(m.lead_split()[0])) is None
+    _, sn = models.synthetic3d(N=256, stock_noise=0.07)
+    srcn = sn._kernel_plan()['source']
+    assert '#define SDP_COL_SHIFT 1' in srcn and '#define SDP_COL_LEAN2 1' in srcn and 'SDP_COL_BNB' not in srcn
+    sn.debug_defines = {'SDP_COL_LEAN2': '0'}
+    assert 'SDP_COL_LEAN2' not in sn._kernel_plan()['source']
 
 
 # ---------------------------------------------------------------------------
