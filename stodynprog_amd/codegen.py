@@ -534,10 +534,10 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
         short = None
         if not model.cost_depends_on_w and window is None and per_control is None \
                 and _dbg(debug, 'SDP_COL_LEAN2') != '0' and (not shifted or rs == 8):
-            # (round 6: on the shifted lattice too -- final sums only, additive_control_split -- without the branch and bound)
+            # (round 6: on the shifted lattice too -- final sums only, additive_control_split)
             if rs == 8 and wres and _dbg(debug, 'SDP_COL_LEAN') != '0':
                 short = short_pass_source(model, utab[0], 'SDP_COL_LEAN2')
-                if short and not shifted and _dbg(debug, 'SDP_COL_BNB') != '0':
+                if short and _dbg(debug, 'SDP_COL_BNB') != '0':
                     short += ('\n#define SDP_COL_BNB 1          // the short first pass as a certified branch and bound over '
                               'blocks of controls (sdp_lean2_bnb)')
             elif rs == 4 and not wres and _dbg(debug, 'SDP_COL_WIDE') != '0' and _dbg(debug, 'SDP_COL_LEAN') in (None, '0') \

@@ -945,6 +945,19 @@ SDP_DEV void sdp_lean2_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_rea
     asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));   // pyx:78
     lam0 = p - (sdp_real)q0;                                // pyx:81
 }
+#if SDP_COL_SHIFT
+// .. and on the shifted lattice (`l`: the lattice -- koff its first position, ordm2 its rows - 2), as sdp_col_lean_core
+// locates it: inside the lattice pk >= 0 and the truncation is the floor
+template <int AXIS>
+SDP_DEV void sdp_lean2s_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_real &lam0)
+{
+    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
+    const sdp_real pk = sn * l.nm1 - l.koff;
+    q0 = (int)pk;                                           // (saturating conversion; NaN -> 0)
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));
+    lam0 = pk - (sdp_real)q0;
+}
+#endif
 #endif
 #if SDP_COL_WIDE2
 // Short WIDE first pass (4-byte reals; the 8-byte one is in sdp_colres_kernel.h, where the reasoning is spelled out).
@@ -1055,16 +1068,33 @@ SDP_DEV void sdp_wide2_pass1(const sdp_real *ad, const sdp_real *utab, const Sdp
 template <int AXIS, bool WIDE, typename INSERT>
 SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
                            sdp_real X, sdp_real k_rows, int c_lo, int n, int mask, double slack, int guess, INSERT &insert,
-                           sdp_real &sdp_diag_cnt)
+                           sdp_real &sdp_diag_cnt, sdp_real *b_seen = nullptr)
 {
-    (void)sdp_diag_cnt; (void)c_lo;
+    // SDP_COL_SHIFT (round 6): `A` holds the (A', B') pairs of the shifted lattice, `l` is the lattice.  A control's F' is off
+    // from the real number it stands for by its OWN cell's chord bound B'[q0] on top of the rounding radius, so a block is
+    // ruled out against the guess g only when   LB - max B'[the rows the block's positions can fall in]  >  F'_g + B'[q0(g)] + slack
+    // (slack: twice the ROUNDING radius + the bound's own roundings): then E_c >= F'_c - rho_c > F'_g + rho_g >= E_g >= the
+    // node's minimum for every control c of the block.  The rows are those the bound reads anyway (q_b, q_b + 1, the rows
+    // between, q_b+1): B' rides along in the same 16-byte reads.  *b_seen: the largest B' among the controls evaluated.
+    (void)sdp_diag_cnt; (void)c_lo; (void)b_seen;
+    constexpr bool SHIFT = SDP_COL_SHIFT != 0;
+    static_assert(!(SHIFT && WIDE), "branch and bound on the shifted lattice: 8-byte reals");
+    constexpr double BSCALE = (double)(SDP_COL_FILTER_SCALE);
     constexpr int BS = SDP_BNB_BLOCK, NB = SDP_BNB_BLOCKS;
     constexpr int HS = SDP_LEAN2_H_SLOT < 0 ? 0 : SDP_LEAN2_H_SLOT;
     static_assert(NB <= 64, "branch and bound: at most 64 blocks");
     const sdp_real *rec = utab + SDP_COL_UTAB * SDP_COL_UTAB_N + 4;
     const double psum = WIDE ? f.psum64 : (double)f.psum;
     auto pack = [&](double F, int ci) { return __hiloint2double(__double2hiint(F), (__double2loint(F) & ~mask) | ci); };
-    auto row = [&](int q) -> double { return WIDE ? SDP_AD_A_CONST(A, q) : (double)A[q]; };
+    auto row = [&](int q) -> double { return WIDE ? SDP_AD_A_CONST(A, q) : (double)A[SHIFT ? 2 * q : q]; };
+    auto brow = [&](int q) -> double { return SHIFT ? (double)A[2 * q + 1] : 0.0; };
+    auto cell = [&](sdp_real xn0, int &q0, sdp_real &lam0) {
+#if SDP_COL_SHIFT
+        sdp_lean2s_cell<AXIS>(l, xn0, q0, lam0);
+#else
+        sdp_lean2_cell<AXIS>(l, xn0, q0, lam0);
+#endif
+    };
     auto start = [&](int b) -> sdp_real { return WIDE ? rec[4 * b] : rec[2 * b]; };
     auto least = [&](int b) -> double { return WIDE ? *(const double *)(rec + 4 * b + 2) : (double)rec[2 * b + 1]; };
     const int n_blocks = (n + BS - 1) / BS;
@@ -1074,18 +1104,18 @@ SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpCol
     // ---- stage 3: F' of the guess (an upper bound of the node's smallest F'), the bounds, the blocks to evaluate
     const sdp_real ga = utab[g * SDP_COL_UTAB + SDP_LEAN2_A_SLOT];
     const sdp_real gh = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[g * SDP_COL_UTAB + HS];
-    const sdp_real pX = SDP_LEAN2_FORM == 2 ? -((X + l.smin) * k_rows) : (X - l.smin) * k_rows;
+    const sdp_real pX = (SDP_LEAN2_FORM == 2 ? -((X + l.smin) * k_rows) : (X - l.smin) * k_rows) - (SHIFT ? l.koff : (sdp_real)0);
     const int extra = __builtin_amdgcn_readfirstlane(WIDE ? __float_as_int((float)rec[4 * n_blocks + 1]) : __double2loint((double)rec[2 * n_blocks + 1]));
     int gq;
     sdp_real glam;
-    sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, ga), gq, glam);
-    const double gA0 = row(gq), gA1 = row(gq + 1);
+    cell(SDP_LEAN2_LEAD(X, ga), gq, glam);
+    const double gA0 = row(gq), gA1 = row(gq + 1), gB = brow(gq);
     unsigned long long need = 0ull;
     double thresh = 0.0;
     constexpr int CB = NB < SDP_BNB_CHUNK ? NB : SDP_BNB_CHUNK;
     for (int b0 = 0; b0 < n_blocks; b0 += CB) {            // (uniform; one chunk on the benchmark lattice)
         int q[CB + 1];
-        double P[CB + 1], hp[CB], Aq[CB + 1], Aq1[CB + 1], m[CB];
+        double P[CB + 1], hp[CB], Aq[CB + 1], Aq1[CB + 1], m[CB], Bq[SHIFT ? CB + 1 : 1], bm[SHIFT ? CB : 1];
 #pragma unroll
         for (int j = 0; j <= CB; ++j) {
             const int b = min(b0 + j, n_blocks);           // end j of the chunk: where block b0 + j starts, or the lattice ends
@@ -1101,12 +1131,17 @@ SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpCol
         for (int j = 0; j <= CB; ++j) {
             Aq[j] = row(q[j]);
             Aq1[j] = row(q[j] + 1);
+            if (SHIFT) Bq[j] = brow(q[j]);
+        }
+        if (SHIFT) {
+#pragma unroll
+            for (int j = 0; j < CB; ++j) bm[j] = sdp_vmax(sdp_vmax(Bq[j], brow(q[j] + 1)), Bq[j + 1]);
         }
         if (b0 == 0) {
             // F' of the guess: its packed value is a first f1 (the block of the guess is evaluated like any other below)
             const double h = fma((double)glam, gA1 - gA0, gA0);
             const double Fg = pack(SDP_LEAN2_H_SLOT < 0 ? h : fma((double)(SDP_LEAN2_HNEG ? -gh : gh), psum, h), g);
-            thresh = Fg + slack;
+            thresh = (SHIFT ? fma(BSCALE, gB, Fg) : Fg) + slack;
         }
 #pragma unroll
         for (int j = 0; j <= CB; ++j) {
@@ -1121,11 +1156,15 @@ SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpCol
             for (int j = 0; j < CB; ++j) more[j] = row(max(min(q[j] + 2 + k, q[j + 1] - 1), 0));
 #pragma unroll
             for (int j = 0; j < CB; ++j) m[j] = sdp_vmin(m[j], more[j]);
+            if (SHIFT) {
+#pragma unroll
+                for (int j = 0; j < CB; ++j) bm[j] = sdp_vmax(bm[j], brow(max(min(q[j] + 2 + k, q[j + 1] - 1), 0)));
+            }
         }
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
             if (q[j + 1] - q[j] - 2 > extra) m[j] = -(double)INFINITY;      // (never seen; a count too small must not cost a row)
-            const double lbv = hp[j] + m[j];
+            const double lbv = SHIFT ? fma(-BSCALE, bm[j], hp[j] + m[j]) : hp[j] + m[j];
             // pruned only on a comparison that HOLDS (a NaN anywhere keeps the block); the guess's own block always stays
             if ((!(lbv > thresh) || b0 + j == g / BS) && b0 + j < n_blocks) need |= 1ull << (b0 + j);
         }
@@ -1144,7 +1183,7 @@ SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpCol
         for (int j0 = 0; j0 < BS; j0 += K) {
             int q0[K], ci[K];
             sdp_real av[K], lam0[K], hv[K];
-            double a0[K], a1[K];
+            double a0[K], a1[K], bq[SHIFT ? K : 1];
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 ci[j] = min(b * BS + j0 + j, n - 1);       // (past the end: the last control again, not inserted)
@@ -1152,11 +1191,17 @@ SDP_DEV void sdp_short_bnb(const sdp_real *A, const sdp_real *utab, const SdpCol
                 hv[j] = SDP_LEAN2_H_SLOT < 0 ? (sdp_real)0 : utab[ci[j] * SDP_COL_UTAB + HS];
             }
 #pragma unroll
-            for (int j = 0; j < K; ++j) sdp_lean2_cell<AXIS>(l, SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
+            for (int j = 0; j < K; ++j) cell(SDP_LEAN2_LEAD(X, av[j]), q0[j], lam0[j]);
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 a0[j] = row(q0[j]);
                 a1[j] = row(q0[j] + 1);
+                if (SHIFT) bq[j] = brow(q0[j]);
+            }
+            if (SHIFT) {
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    if (on && b * BS + j0 + j < n) *b_seen = sdp_vmax(*b_seen, (sdp_real)bq[j]);
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {

@@ -265,9 +265,9 @@ SDP_DEV void sdp_colres_partial_kept(const sdp_real *__restrict__ G, const SdpCo
 // with its own.  What is not finite: a or h (poisoned statistics: sdp_col_phase_u), K, the table (D), X (L) -- each
 // makes S_node or L fail its test and the node `bad`; and S_node < 2^1000 keeps every F' finite (|lam0 (A1 - A0)| <= 2 L D),
 // so the packing never meets an infinity.  tests/test_filter_bound_exact.py checks the inequality in exact arithmetic.
-static_assert(!SDP_COST_HAS_W && (SDP_COL_SHIFT ? !SDP_COL_SHIFT_CHAIN && !SDP_COL_BNB : !SDP_COL_TOP2) && SDP_COL_UTAB && sizeof(sdp_real) == 8,
+static_assert(!SDP_COST_HAS_W && (SDP_COL_SHIFT ? !SDP_COL_SHIFT_CHAIN : !SDP_COL_TOP2) && SDP_COL_UTAB && sizeof(sdp_real) == 8,
               "short first pass: 8-byte reals, control table, a perturbation that does not reach the cost and reaches the stock "
-              "through final sums at most (there without the branch and bound)");
+              "through final sums at most");
 template <int AXIS>
 SDP_DEV sdp_real sdp_lean2_value(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
                                  sdp_real X, int ci)
@@ -338,15 +338,6 @@ SDP_DEV void sdp_lean2_pass1(const sdp_real *A, const sdp_real *utab, const SdpC
 // are kept: ~1 % of the nodes of the benchmark problem hold two controls inside the radius (B' is of the order of
 // h^2 V'' / 16, not 1e-13), both are carried through the second pass.  tests/test_filter_bound_exact.py checks
 // |E - K P* - F'| <= radius in exact arithmetic.
-template <int AXIS>
-SDP_DEV void sdp_lean2s_cell(const SdpLeadAxis &l, sdp_real xn0, int &q0, sdp_real &lam0)
-{
-    const sdp_real sn = AXIS == 2 ? xn0 : (AXIS == 1 ? (xn0 - l.smin) * l.rspan : (xn0 - l.smin) / l.span);
-    const sdp_real pk = sn * l.nm1 - l.koff;                // (inside the lattice pk >= 0: the truncation is the floor)
-    q0 = (int)pk;                                           // (saturating conversion; NaN -> 0)
-    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(q0) : "s"(l.ordm2));
-    lam0 = pk - (sdp_real)q0;
-}
 typedef sdp_real sdp_ab_pair __attribute__((ext_vector_type(2)));
 template <int AXIS>
 SDP_DEV sdp_real sdp_lean2s_value(const sdp_real *A, const sdp_real *utab, const SdpColFilter &f, const SdpLeadAxis &l,
@@ -444,7 +435,8 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
     filt.psum = sdp_uniform(filt.psum); filt.pcap = sdp_uniform(filt.pcap); filt.cu = sdp_uniform(filt.cu);
     filt.floor = sdp_uniform(filt.floor); filt.ratio = sdp_uniform(filt.ratio);
     const sdp_real k_rows = sdp_uniform(lead.nm1 / lead.span);        // rows of axis 0 per unit of x0 (branch and bound: positions relative to the node)
-    const sdp_real x_cap = sdp_uniform((sdp_real)0x1p30 / k_rows - fabs(lead.smin));
+    // (on the shifted lattice the bounds' positions also lose the lattice's first position: half the range)
+    const sdp_real x_cap = sdp_uniform((sdp_real)(SDP_COL_SHIFT ? 0x1p29 : 0x1p30) / k_rows - fabs(lead.smin));
     (void)k_rows; (void)x_cap;
     if (threadIdx.x < 2) sdp_lds.dcol[threadIdx.x] = 0ull;
     int parity = 0;
@@ -629,26 +621,48 @@ extern "C" __global__ void __launch_bounds__(SDP_COL_THREADS, SDP_COL_MIN_WAVES)
             bd.f1 = bd.f2 = bd.f3 = INFINITY;
             int q_e;
             sdp_real lam_lo, lam_hi, b_max = (sdp_real)0;
+            // (the node's bound needs nothing of the pass itself: it comes first, the branch and bound uses it)
             if (axis_mode == 2) {
                 sdp_lean2s_cell<2>(lead1, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2s_cell<2>(lead1, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
-                sdp_lean2s_pass1<2>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
             } else if (axis_mode == 1) {
                 sdp_lean2s_cell<1>(lead1, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2s_cell<1>(lead1, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
-                sdp_lean2s_pass1<1>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
             } else {
                 sdp_lean2s_cell<0>(lead1, SDP_LEAN2_LEAD(X, ust[0]), q_e, lam_lo);
                 sdp_lean2s_cell<0>(lead1, SDP_LEAN2_LEAD(X, ust[1]), q_e, lam_hi);
-                sdp_lean2s_pass1<0>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
             }
             const sdp_real l_cap = sdp_vmax_abs(sdp_vmax_abs((sdp_real)1, lam_lo), lam_hi);
             const sdp_real h_cap = (((sdp_real)1 + (sdp_real)2 * (l_cap + shc.lc)) * ((sdp_real)3 + shc.es)) * dcol;
             const sdp_real s_node = fma(filt.pcap, fabs(K) + ust[2], h_cap);
             const bool bad = !filt.ok || !shc.ok || !(s_node < SDP_COL_FILTER_LIMIT) ||
                              !(fabs(lam_lo) + fabs(lam_hi) + shc.lc < (sdp_real)1073741824.0) || bits > 24 || box.total > SDP_COL_UTAB_N;
-            const sdp_real radius = fma(filt.cu + (sdp_real)(SDP_COL_FILTER_SCALE) * ldexp(SDP_COL_FILTER_EPS, bits + 1), s_node,
-                                        (sdp_real)(SDP_COL_FILTER_SCALE) * b_max);
+            const sdp_real radius0 = (filt.cu + (sdp_real)(SDP_COL_FILTER_SCALE) * ldexp(SDP_COL_FILTER_EPS, bits + 1)) * s_node;     // the roundings' part
+#if SDP_COL_BNB
+            // a block is skipped when its lower bound, less the largest B' of its rows, exceeds F' + B' of the guess by more
+            // than twice the rounding radius + 24 u S_node (sdp_short_bnb).  Only where the column's blocks are in order and
+            // |X| is small enough for the bounds' positions (ust[3]); a wave with a node that does not qualify, or a column
+            // whose lattice is not usable, takes the full pass.
+            const sdp_real slack = fma((sdp_real)2, radius0, ((sdp_real)12 * SDP_COL_FILTER_EPS) * s_node);
+            const bool bnb = fabs(X) < ust[3] && shc.ok;
+            if (__all(bnb)) {
+                auto ins = [&](double Fq) {
+                    bd.f3 = sdp_vmin(bd.f3, sdp_vmax(bd.f2, Fq));
+                    bd.f2 = sdp_vmin(bd.f2, sdp_vmax(bd.f1, Fq));
+                    bd.f1 = sdp_vmin(bd.f1, Fq);
+                };
+                if (axis_mode == 2) sdp_short_bnb<2, false>(sdp_lds.ad, utab, filt, lead1, X, k_rows, 0, box.total, mask, slack, guess, ins, diag_cnt, &b_max);
+                else if (axis_mode == 1) sdp_short_bnb<1, false>(sdp_lds.ad, utab, filt, lead1, X, k_rows, 0, box.total, mask, slack, guess, ins, diag_cnt, &b_max);
+                else sdp_short_bnb<0, false>(sdp_lds.ad, utab, filt, lead1, X, k_rows, 0, box.total, mask, slack, guess, ins, diag_cnt, &b_max);
+            } else
+#endif
+            {
+                if (axis_mode == 2) sdp_lean2s_pass1<2>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
+                else if (axis_mode == 1) sdp_lean2s_pass1<1>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
+                else sdp_lean2s_pass1<0>(sdp_lds.ad, utab, filt, lead1, X, box.total, mask, bd.f1, bd.f2, bd.f3, b_max);
+            }
+            // (b_max: the largest B' among the controls the pass evaluated -- the ones it skipped are ruled out with their own)
+            const sdp_real radius = fma((sdp_real)(SDP_COL_FILTER_SCALE), b_max, radius0);
             bd.i1 = bd.f1 < (sdp_real)INFINITY ? (__double2loint(bd.f1) & mask) : INT_MAX;
             bd.i2 = bd.f2 < (sdp_real)INFINITY ? (__double2loint(bd.f2) & mask) : INT_MAX;
 #elif SDP_COL_LEAN2

@@ -887,6 +887,142 @@ def test_the_short_pass_on_the_shifted_lattice_covers_the_difference_exactly(reg
         assert model_part > 0.9, model_part
 
 
+def _shift_lattice(T, p, b, order):
+    """sdp_col_phase_shift / sdp_col_shift_col / sdp_col_shift_reduce, as in shifted_check"""
+    W, N0 = T.shape
+    nm1 = float(N0 - 1)
+    fc = filter_constants(p)
+    q_w, f_w, c_w, pbabs = [], [], [], 0
+    for w in range(W):
+        pb = (-b[w]) * nm1
+        fl = float(np.floor(pb))
+        q_w.append(int(fl))
+        f_w.append(pb - fl)
+        c_w.append(abs(p[w]) * (f_w[-1] * (1.0 - f_w[-1])))
+        pbabs = max(pbabs, int(abs(abs(b[w]) * nm1)) + 1)
+    flmax, nflmin = max(q_w), max(-q for q in q_w)
+    kmin, rows = -(flmax + 1), N0 + flmax + nflmin + 1
+    pbmax = float(max(abs(flmax), abs(nflmin), pbabs) + 1)
+    lc = float(rows) + float(abs(kmin)) + pbmax + 0.0 + float(N0 + 1)
+    es = float(1 + 2 * (flmax + nflmin + 2))
+    Ap, Bp, big = np.zeros(rows), np.zeros(rows), 0.0
+    for ki in range(rows):
+        k = kmin + ki
+        for w in order:
+            j = k + q_w[w]
+            q = max(min(j, N0 - 2), 0)
+            lam = float(j - q) + f_w[w]
+            t0, t1 = T[w][q], T[w][q + 1]
+            t2 = T[w][q + 2] if q + 2 < N0 else T[w][q + 1]
+            Ap[ki] = fma(p[w], fma(lam, t1 - t0, t0), Ap[ki])
+            d2 = (t2 - t1) - (t1 - t0)
+            Bp[ki] = fma(c_w[w], abs(d2) if 0 <= j <= N0 - 3 else 0.0, Bp[ki])
+            big = max(big, abs(t0), abs(t1))
+    return dict(fc=fc, nm1=nm1, kmin=kmin, rows=rows, lc=lc, es=es, Ap=Ap, Bp=Bp, dcol=fc['pcap'] * big + fc['floor'])
+
+
+def shifted_block_bound_check(T, p, X, K, a, h, b, order, sign, block):
+    """The branch and bound of the short first pass ON THE SHIFTED LATTICE (sdp_short_bnb with SDP_COL_SHIFT, round 6).  As
+    block_bound_check, on the lattice's table A' -- and a control's F' is off from the real R - K P* by its OWN cell's
+    chord bound B'[q0] on top of the rounding radius, so a block is ruled out against the guess g only when
+        LB - max B'[cells of the block]  >  F'_g + B'[q0(g)] + 2 (cu + 2^(bits+2) u) S + 24 u S.
+    Checked here, exactly: LB - bm lies below F'_c - B'[q0(c)] of every control c of the block up to the 24 u S the test
+    allows for, and bm covers the control's cell.  Returns the largest ((LB - bm) - (F'_c - B'_c)) / (24 u S), or None
+    when the blocks are not in order."""
+    N0 = T.shape[1]
+    lat = _shift_lattice(T, p, b, order)
+    fc, nm1, kmin, rows, Ap, Bp = lat['fc'], lat['nm1'], lat['kmin'], lat['rows'], lat['Ap'], lat['Bp']
+
+    def cell(xa):
+        pk = xa * nm1 - float(kmin)
+        q0 = max(min(int(pk), rows - 2), 0)
+        return q0, pk - float(q0)
+    n = len(a)
+    bits = max((n - 1).bit_length(), 1)
+    mask = (1 << bits) - 1
+    L = max(1.0, abs(cell(X + min(a))[1]), abs(cell(X + max(a))[1]))
+    h_cap = ((1.0 + 2.0 * (L + lat['lc'])) * (3.0 + lat['es'])) * lat['dcol']
+    s_node = fma(fc['pcap'], abs(K) + max(abs(v) for v in h), h_cap)
+    blocks = [range(b0, min(b0 + block, n)) for b0 in range(0, n, block)]
+    pa = [v * nm1 for v in a]
+    lo = [min(pa[c] for c in m) for m in blocks]
+    hi = [max(pa[c] for c in m) for m in blocks]
+    if any(hi[k] + 2 * BNB_DELTA > lo[k + 1] for k in range(len(blocks) - 1)):
+        return None
+    starts = [v - BNB_DELTA for v in lo] + [hi[-1] + BNB_DELTA]
+    hp = [min((sign * h[c]) * fc['psum'] for c in m) for m in blocks]
+    pX = X * nm1 - float(kmin)                               # (the lattice's first position taken off the node's part)
+    assert (abs(X) + max(abs(v) for v in a)) < 2.0 ** 29 / nm1
+
+    def at(P):
+        q = max(min(int(P), rows - 2), 0)
+        return q, fma(P - float(q), Ap[q + 1] - Ap[q], Ap[q])
+    ends = [at(pX + v) for v in starts]
+    worst = Fraction(-10 ** 9)
+    for k, members in enumerate(blocks):
+        (qa, La), (qb, Lb) = ends[k], ends[k + 1]
+        m = min(La, Lb, Ap[qa + 1], Ap[qb])
+        bm = max(Bp[qa], Bp[min(qa + 1, rows - 1)], Bp[qb])
+        for r in range(qa + 2, qb):
+            m = min(m, Ap[r])
+            bm = max(bm, Bp[r])
+        lbv = (hp[k] + m) - bm
+        for ci in members:
+            q0, lam0 = cell(X + a[ci])
+            assert qa <= q0 <= qb                           # the block's rows cover the control's cell: bm >= B'[q0]
+            assert Bp[q0] <= bm
+            F = fma(sign * h[ci], fc['psum'], fma(lam0, Ap[q0 + 1] - Ap[q0], Ap[q0]))
+            Fp = pack_index(F, ci, mask)
+            worst = max(worst, (Fraction(lbv) - (Fraction(F) - Fraction(Bp[q0]))) / (24 * Fraction(U) * Fraction(s_node)))
+            assert abs(Fraction(Fp) - Fraction(F)) <= Fraction(2.0 ** (bits + 1 - 53)) * Fraction(s_node) * (1 + Fraction(3, 2 ** 53))
+    return float(worst)
+
+
+@pytest.mark.parametrize('regime', ['smooth', 'rough', 'cancel', 'weights', 'large'])
+def test_the_block_bound_on_the_shifted_lattice_lies_below_every_control_of_its_block(regime):
+    rng = np.random.default_rng(470 + ['smooth', 'rough', 'cancel', 'weights', 'large'].index(regime))
+    worst, checked = -1e9, 0
+    for trial in range(150):
+        W = int(rng.integers(1, 8))
+        N0 = int(rng.integers(4, 24))
+        r = np.arange(N0) / (N0 - 1.0)
+        if regime == 'smooth':
+            T = np.stack([(r - rng.uniform(0, 1)) ** 2 * rng.uniform(0.5, 3) + rng.uniform(-1, 1) * r for _ in range(W)])
+        elif regime == 'cancel':
+            T = 1e6 + 1e-6 * rng.standard_normal((W, N0))
+        else:
+            T = rng.standard_normal((W, N0))
+            if regime == 'large':
+                T *= 10.0 ** rng.uniform(100, 250)
+        p = np.abs(rng.standard_normal(W)) + 1e-3
+        p /= p.sum()
+        if regime == 'weights':
+            p = rng.standard_normal(W) * 2.1
+            if abs(p.sum()) < 0.2:
+                p[0] += 1.0
+        scale = float(np.abs(T).max())
+        n = int(rng.integers(1, 90))
+        X = float(rng.uniform(0, 1))
+        spread = float(10.0 ** rng.uniform(-2, 0.5))
+        a = [float(v) for v in -spread + np.cumsum(rng.uniform(0.1, 1.0, size=n)) * (2 * spread / n) + np.arange(n) * 4 * BNB_DELTA / (N0 - 1)]
+        if trial % 7 == 3:
+            a = [float(v) for v in rng.permutation(a)]
+        K = float(rng.standard_normal()) * scale * 10.0 ** rng.uniform(-3, 3)
+        h = [float(v) * scale * 10.0 ** rng.uniform(-3, 2) for v in rng.standard_normal(n)]
+        b = [float(v) for v in rng.uniform(-1, 1, size=W) * 10.0 ** rng.uniform(-2.5, 0.3)]
+        if trial % 4 == 0:
+            b[0] = float(rng.integers(-3, 4)) / (N0 - 1)
+        ratio = shifted_block_bound_check(T, [float(v) for v in p], X, K, a, h, b, list(rng.permutation(W)),
+                                          -1.0 if trial % 3 == 0 else 1.0, 8 if trial % 5 else 16)
+        if ratio is None:
+            assert trial % 7 == 3 and n > 8
+            continue
+        checked += 1
+        assert ratio <= 1.0, (regime, trial, ratio)
+        worst = max(worst, ratio)
+    assert checked >= 110 and worst < 0.5, (checked, worst)
+
+
 @pytest.mark.parametrize('chain', ['x+(w-u)', '(x-w)+u'])
 def test_a_regrouped_chain_needs_the_sum_of_its_leaves_in_the_bound(chain):
     """leaves that cancel far outside the grid (x = 1e3 .. 1e6, u = x - 1 .. x + 1 on a grid [0, 1]) and tables that are

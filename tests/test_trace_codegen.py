@@ -708,7 +708,9 @@ def test_the_short_first_pass_is_planned_where_the_model_has_its_shape():
     assert m.lead_split_chain() is not None and m.additive_control_split(m.control_uniform_frontier(m.lead_split()[0])) is None
     _, sn = models.synthetic3d(N=256, stock_noise=0.07)
     srcn = sn._kernel_plan()['source']
-    assert '#define SDP_COL_SHIFT 1' in srcn and '#define SDP_COL_LEAN2 1' in srcn and 'SDP_COL_BNB' not in srcn
+    assert '#define SDP_COL_SHIFT 1' in srcn and '#define SDP_COL_LEAN2 1' in srcn and '#define SDP_COL_BNB 1' in srcn
+    sn.debug_defines = {'SDP_COL_BNB': '0'}
+    assert '#define SDP_COL_LEAN2 1' in sn._kernel_plan()['source'] and 'SDP_COL_BNB' not in sn._kernel_plan()['source']
     sn.debug_defines = {'SDP_COL_LEAN2': '0'}
     assert 'SDP_COL_LEAN2' not in sn._kernel_plan()['source']
 

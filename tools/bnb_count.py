@@ -1,10 +1,19 @@
-import sys
-sys.path.insert(0, '/root/repo')
+"""Blocks of controls a node asks its branch and bound for (diagnostic build SDP_DIAG_BNB_COUNT: J := the count + 100 x the
+guess's block).  usage: python tools/bnb_count.py [stock_noise [sweeps]]      (through gpurun)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from stodynprog_amd import models, DPSolver
 DPSolver.debug_defines = {'SDP_EXTRA_DEFINES': 'SDP_DIAG_BNB_COUNT=1'}
-_, s = models.synthetic3d(N=256)
+noise = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
+sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_, s = models.synthetic3d(N=256, stock_noise=noise) if noise else models.synthetic3d(N=256)
 V0 = models.synthetic3d_V0(s.state_grid)
+if sweeps > 1:                                            # (the chain's earlier sweeps with the product kernel)
+    DPSolver.debug_defines = None
+    _, s0 = models.synthetic3d(N=256, stock_noise=noise) if noise else models.synthetic3d(N=256)
+    V0, _ = s0.value_iterations(V0, sweeps - 1, report_time=False)
+    DPSolver.debug_defines = {'SDP_EXTRA_DEFINES': 'SDP_DIAG_BNB_COUNT=1'}
 J, pol = s.value_iterations(V0, 1, report_time=False)
 idx = s.last_policy_index
 cnt = np.round(J).astype(int)
