@@ -477,6 +477,13 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
              '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0)]
     if wres:
         lines.append('#define SDP_COL_WRES {}         // resident-chunk form: perturbation points the table holds at a time'.format(int(wres)))
+        if rs == 8 and not _dbg(debug, 'SDP_COL_UNROLL_W'):
+            # the second pass of the resident-chunk kernel one batch of perturbation points at a time: unrolled four times it
+            # kept 16 points' table entries in flight, in registers the kernel does not have at four (three) waves per SIMD --
+            # round 6, same box: the benchmark 1.096 -> 1.044 ms, the shifted lattice 2.45 -> 2.23 ms (boxes 9-12 of
+            # profiles/r06_column_ab.txt); 4-byte reals (the full-table kernel) keep the default, 7.51 against 7.72 ms
+            # (batches of 2, 8 or 16 points instead of 4, two batches per trip: within the noise of the boxes, boxes 14 and 16)
+            lines.append('#define SDP_COL_UNROLL_W 1')
     if filtered and int(col_cfg[0]) <= 256 and not _dbg(debug, 'SDP_COL_MIN_WAVES'):
         if wres:
             # (at most 4: 128 registers per lane.  Round 4 asked for up to 8 for small tables -- 64 registers, which these
@@ -510,7 +517,9 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
                 # resident chunks: the tail is built once, its entries wait in the registers of the threads that made
                 # them (SDP_COL_TAIL_HOLD of csrc/sdp_colres_kernel.h; round 6: 1.235 -> 1.048 ms on the benchmark, same
                 # bits) -- where they are whole rounds of points and rows and at most 32 registers per thread
-                if (wres and rs == 8 and not shifted and not wpair and window is None and _dbg(debug, 'SDP_COL_TAIL_HOLD') is None
+                # (on the shifted lattice too since the second pass is no longer unrolled there: 2.23 -> 2.12 ms, box 11 of
+                # profiles/r06_column_ab.txt; with the unrolled pass it had lost, 2.96 against 2.71 ms)
+                if (wres and rs == 8 and not wpair and window is None and _dbg(debug, 'SDP_COL_TAIL_HOLD') is None
                         and not _dbg(debug, 'SDP_COL_TAIL_KEEP')):
                     tail, groups = int(column[1]) - int(wres), int(col_cfg[0]) // lw
                     if (tail > 0 and tail % groups == 0 and int(column[0]) % (2 * lw) == 0
@@ -540,6 +549,7 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
                 if short and _dbg(debug, 'SDP_COL_BNB') != '0':
                     short += ('\n#define SDP_COL_BNB 1          // the short first pass as a certified branch and bound over '
                               'blocks of controls (sdp_lean2_bnb)')
+
             elif rs == 4 and not wres and _dbg(debug, 'SDP_COL_WIDE') != '0' and _dbg(debug, 'SDP_COL_LEAN') in (None, '0') \
                     and _dbg(debug, 'SDP_COL_FILTER_TOP2') in (None, '1'):
                 short = short_pass_source(model, utab[0], 'SDP_COL_WIDE2')
