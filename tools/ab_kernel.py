@@ -3,7 +3,7 @@
 kernels (codegen.DEBUG_NAMES); the variants are timed in interleaved rounds in ONE process (devices differ by a few per
 cent, and a chip warms up), and every variant's J and policy index after the chain of sweeps are compared with the
 first variant's over all nodes.
-usage: python tools/ab_kernel.py [--config synth256|synth512f32|noisy256] [--rounds R] [--sweeps K] -- [K=V ..] -- [K=V ..] ...
+usage: python tools/ab_kernel.py [--config synth256|synth512f32|noisy256|searev|ar1|ar1_ref] [--rounds R] [--sweeps K] -- [K=V ..] -- [K=V ..] ...
        (an empty group is the default kernel)                                          (through gpurun)"""
 import os
 import sys
@@ -24,6 +24,15 @@ def build(config, defs):
         _, s = models.synthetic3d(N=512)
         s.dtype = np.dtype('float32')
         V0 = models.synthetic3d_V0(s.state_grid, np.float32)
+    elif config == 'searev':                               # BASELINE configs[2] as bench.py --config searev
+        _, s = models.searev(n_E=128, n_S=128, n_A=128, step=2.2 / 31)
+        V0 = np.random.default_rng(0).standard_normal(s._state_grid_shape)
+    elif config == 'ar1':                                  # BASELINE configs[1]
+        _, s = models.storage_ar1(n_E=200, n_P=200, steps=(8. / 49, 0.1))
+        V0 = np.random.default_rng(0).standard_normal(s._state_grid_shape)
+    elif config == 'ar1_ref':                              # the reference's published case
+        _, s = models.storage_ar1()
+        V0 = np.random.default_rng(0).standard_normal(s._state_grid_shape)
     else:
         raise SystemExit('unknown config ' + config)
     s.debug_defines = dict(defs) or None
