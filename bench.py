@@ -792,6 +792,23 @@ def finish_single(args, env, out):
             del lprob, J_f, idx_f, idx_l
         except Exception as e:
             out['every_control_the_long_way'] = {'error': repr(e)}
+    if world == 1 and not args.no_other_configs:
+        # The timed region is sweeps W+1 .. W+K of a chain from a closed-form start: with the driver's W = 5, K = 20 it lies in
+        # the part where the cost-to-go is still rough (more blocks survive the branch and bound) and the clock still ramps
+        # (profiles/r06_final40_summary.txt: 1.14, 1.27, 1.39 ms .. 1.05 ms from dispatch 27 on).  A value iteration runs for
+        # hundreds of sweeps; what the later ones cost stands beside, outside the timed region and never in `value`.
+        try:
+            prob.swap()
+            prob.bench_sweeps(30)
+            prob.swap()
+            _, sk = prob.bench_sweeps(50)
+            out['later_sweeps_of_the_chain'] = {
+                'kernel_ms': sk / 50, 'sweeps_per_s': 1e3 * 50 / sk,
+                'note': 'sweeps {} .. {} of the same chain, kernel time by HIP events, outside the timed region (`value` is sweeps '
+                        '{} .. {})'.format(args.warmup + args.steps + 31, args.warmup + args.steps + 80, args.warmup + 1,
+                                           args.warmup + args.steps)}
+        except Exception as e:
+            out['later_sweeps_of_the_chain'] = {'error': repr(e)}
     if world == 1 and args.config == 'synth256' and not args.grid and not args.no_other_configs:
         # The other GPU configurations of BASELINE.json (configs[1], [2], [4]) in the same run, outside
         # the timed region: steady-state kernel time per sweep (sweeps 6..25 of a chain, HIP events),

@@ -477,12 +477,13 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
              '#define SDP_COL_WPAIR {}'.format(1 if wpair else 0)]
     if wres:
         lines.append('#define SDP_COL_WRES {}         // resident-chunk form: perturbation points the table holds at a time'.format(int(wres)))
-        if rs == 8 and not _dbg(debug, 'SDP_COL_UNROLL_W'):
-            # the second pass of the resident-chunk kernel one batch of perturbation points at a time: unrolled four times it
-            # kept 16 points' table entries in flight, in registers the kernel does not have at four (three) waves per SIMD --
-            # round 6, same box: the benchmark 1.096 -> 1.044 ms, the shifted lattice 2.45 -> 2.23 ms (boxes 9-12 of
-            # profiles/r06_column_ab.txt); 4-byte reals (the full-table kernel) keep the default, 7.51 against 7.72 ms
-            # (batches of 2, 8 or 16 points instead of 4, two batches per trip: within the noise of the boxes, boxes 14 and 16)
+        if rs == 8 and shifted and not _dbg(debug, 'SDP_COL_UNROLL_W'):
+            # the second pass of the shifted lattice's resident-chunk kernel one batch of perturbation points at a time: unrolled
+            # four times it kept 8 points' cells, table entries and weights per survivor in flight (two survivors in half of the
+            # waves), in registers the kernel does not have at three waves per SIMD -- round 6, same box: 2.45 -> 2.23 ms, and
+            # with the tail held on top 2.12 ms (boxes 9-11 of profiles/r06_column_ab.txt: 48 -> 22 spilled registers).  The
+            # benchmark's kernel (no cell per point, one survivor) does not care: 948.8 against 954.3 sweeps/s over 50 steps
+            # (box 20; the 5 % of box 12 were the A/B tool's first-position penalty); 4-byte reals: 7.51 against 7.72 ms.
             lines.append('#define SDP_COL_UNROLL_W 1')
     if filtered and int(col_cfg[0]) <= 256 and not _dbg(debug, 'SDP_COL_MIN_WAVES'):
         if wres:
