@@ -3,7 +3,7 @@
 kernels (codegen.DEBUG_NAMES); the variants are timed in interleaved rounds in ONE process (devices differ by a few per
 cent, and a chip warms up), and every variant's J and policy index after the chain of sweeps are compared with the
 first variant's over all nodes.
-usage: python tools/ab_kernel.py [--config synth256|synth512f32|noisy256|searev|ar1|ar1_ref] [--rounds R] [--sweeps K] -- [K=V ..] -- [K=V ..] ...
+usage: python tools/ab_kernel.py [--config synth256|synth512f32|noisy256|searev|ar1|ar1_ref|coupled256|reservoirs] [--rounds R] [--sweeps K] -- [K=V ..] -- [K=V ..] ...
        (an empty group is the default kernel)                                          (through gpurun)"""
 import os
 import sys
@@ -24,6 +24,12 @@ def build(config, defs):
         _, s = models.synthetic3d(N=512)
         s.dtype = np.dtype('float32')
         V0 = models.synthetic3d_V0(s.state_grid, np.float32)
+    elif config == 'coupled256':                           # trailing axes that see the control: a table per control
+        _, s = models.synthetic3d_coupled(N=256)
+        V0 = models.synthetic3d_V0(s.state_grid)
+    elif config == 'reservoirs':                           # two controlled stocks: the reduced-array sweep
+        _, s = models.two_reservoirs(n_a=128, n_b=128, n_y=64, n_w=16, steps=(1. / 15, 1. / 15))
+        V0 = np.random.default_rng(0).standard_normal(s._state_grid_shape)
     elif config == 'searev':                               # BASELINE configs[2] as bench.py --config searev
         _, s = models.searev(n_E=128, n_S=128, n_A=128, step=2.2 / 31)
         V0 = np.random.default_rng(0).standard_normal(s._state_grid_shape)
