@@ -7,7 +7,8 @@ set -u
 TAG=${1:-r04}
 OUT=$PWD/gpurun_out/final_$TAG
 mkdir -p "$OUT"
-bash tools/profile_bench.sh ${TAG}_final synth256_f64_column_filter > "$OUT/profile_default.log" 2>&1
+# (the driver's own command line: --steps 20 --warmup 5)
+PROF_STEPS=20 PROF_WARMUP=5 bash tools/profile_bench.sh ${TAG}_final synth256_f64_column_filter > "$OUT/profile_default.log" 2>&1
 cp gpurun_out/prof_${TAG}_final/summary.txt "$OUT/${TAG}_final_summary.txt"
 cp gpurun_out/prof_${TAG}_final/kernel_stats.csv "$OUT/${TAG}_final_kernel_stats.csv"
 cp gpurun_out/prof_${TAG}_final/pmc_synth256_f64_column_filter.json "$OUT/"

@@ -11,7 +11,7 @@ KEY=${1:-synth256_f64_column}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps ${PROF_STEPS:-10} --warmup 2 --no-cpu-baseline --no-filter-check --no-other-configs $*"
+ARGS="--steps ${PROF_STEPS:-10} --warmup ${PROF_WARMUP:-2} --no-cpu-baseline --no-filter-check --no-other-configs $*"
 run_pmc() {   # name counters...
     local name=$1; shift
     # (a pass that hangs -- the TA_* counters did, for twenty minutes, in round 6 -- must not take the call with it)
