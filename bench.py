@@ -318,10 +318,21 @@ def run(args):
     if dev_comm is None:
         prob = solver._problem()
         assert solver.backend_info['max_controls'] == U_max
+        # The procedure -- W untimed + K timed sweeps from V0 between barriers and synchronisations -- runs TWICE, back to back.
+        # The first run finds a chip that has been idle while the host set the problem up: its clock ramps for ~25 ms of load
+        # (tools/ramp_probe.py, profiles/r06_ramp_probe.txt: the same chain from the same V0 costs 1.27, 1.15, 1.12, 1.09,
+        # 1.07 ms per sweep in its first five chunks of five sweeps the first time and 1.04, 1.05, 1.03, 1.02, 1.02 ms the
+        # second time -- it is not the content).  `value` is the second run; the first stands beside it (`first_run_from_idle`).
+        cold = timed_region(prob) if not args.single_run else None
         elapsed, kernel_ms = timed_region(prob)
         if rank != 0:
             return None
         out = report(args, locals())
+        if cold is not None:
+            out['first_run_from_idle'] = {
+                'value': args.steps / cold[0], 'ms_per_step': 1e3 * cold[0] / args.steps, 'kernel_ms': cold[1] / args.steps,
+                'note': 'the same W + K sweeps from the same V0, run first: the chip had been idle and its clock ramps '
+                        '(tools/ramp_probe.py); `value` is the run that follows it (bench.py --single-run: this one only)'}
         return finish_single(args, locals(), out)
     return run_sharded(args, locals())
 
@@ -941,6 +952,9 @@ def main():
     ap.add_argument('--exchanges', default=None, metavar='LIST',
                     help="N > 1: the exchanges of J to time, comma-separated (default rccl,sendrecv: the collective library "
                          "alone; direct / sparse / peer write into buffers mapped through HIP IPC: opt-in)")
+    ap.add_argument('--single-run', action='store_true',
+                    help='one GPU: run the W + K sweeps once, from an idle chip (default: twice back to back, `value` is the '
+                         'second run, the first is reported as first_run_from_idle)')
     ap.add_argument('--no-filter-check', action='store_true',
                     help='skip the untimed re-run of the chain with every control the long way and its comparison')
     ap.add_argument('--no-filter', action='store_true',
