@@ -513,8 +513,13 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
             lw = int(_dbg(debug, 'SDP_COL_A_LW') or order[1])
             lines += ['#define SDP_COL_A_ORDER 2',
                       '#define SDP_COL_A_LW {}'.format(lw)]
+            if rs == 4 and int(column[0]) >= 512 and not wres and window is None and not _dbg(debug, 'SDP_COL_A_GROUP'):
+                # (config 5, 512^3 in 4-byte reals, same box: 7.50 -> 7.36 ms, with four blocks' bounds per stage of
+                # the branch and bound 7.24 ms -- boxes 25-26 of profiles/r06_column_ab.txt; 8-byte reals: worse)
+                lines.append('#define SDP_COL_A_GROUP 8      // table entries per thread whose vertex loads are issued together')
             if wide and not _dbg(debug, 'SDP_COL_A_WIDE_LOADS'):
                 lines.append('#define SDP_COL_A_WIDE_LOADS 1')
+
                 # resident chunks: the tail is built once, its entries wait in the registers of the threads that made
                 # them (SDP_COL_TAIL_HOLD of csrc/sdp_colres_kernel.h; round 6: 1.235 -> 1.048 ms on the benchmark, same
                 # bits) -- where they are whole rounds of points and rows and at most 32 registers per thread
@@ -557,6 +562,8 @@ def _column_lines(model, dtype, column, col_cfg, window, per_control, filtered, 
                 if short and _dbg(debug, 'SDP_COL_BNB') != '0':
                     short += ('\n#define SDP_COL_BNB 1          // the short wide first pass as a certified branch and bound over '
                               'blocks of controls (sdp_short_bnb)')
+                    if int(column[0]) >= 512 and not _dbg(debug, 'SDP_BNB_CHUNK'):
+                        short += '\n#define SDP_BNB_CHUNK 4        // blocks whose bounds are evaluated together (see SDP_COL_A_GROUP above)'
         if short:
             lines += [short, '']
     lines += ['#include "sdp_column_kernel.h"    // also brings in sdp_sweep_kernel.h', '']
