@@ -400,3 +400,33 @@ def test_resident_chunks_carry_two_survivors(gpu, debug_defines, scale):
             if scale:
                 debug_defines.unset('SDP_COL_FILTER_SCALE')
         _same(res, off)
+
+
+@pytest.mark.parametrize('controls', [41, 251])
+def test_the_branch_and_bound_on_the_shifted_lattice_is_what_runs_and_keeps_the_bits(gpu, debug_defines, controls):
+    """round 6: with final sums and the additive shape the resident-chunk kernel's first pass on the shifted lattice is the
+    short one, as a branch and bound over blocks of controls (6 blocks of 8, 32 blocks of 8) -- the same bits as that pass
+    without the pruning, as the lean pass of round 3, and as every control the long way; smooth and rough cost-to-go"""
+    make = lambda: _shop(order_step=10.0 / (controls - 1))
+    s0 = make()[1]
+
+    def run(V, **knobs):
+        debug_defines.set(SDP_COL_WRES='4', **knobs)
+        try:
+            out = _sweep(make, True, V, sweeps=2)
+            return out, out[3]._kernel_plan()['source']
+        finally:
+            debug_defines.unset('SDP_COL_WRES', *knobs)
+    for V in (_smooth(s0), np.random.default_rng(11).standard_normal(s0._state_grid_shape)):
+        off = _sweep(make, False, V, sweeps=2)
+        res, src = run(V)
+        assert '#define SDP_COL_SHIFT 1' in src and '#define SDP_COL_WRES 4' in src
+        assert '#define SDP_COL_LEAN2 1' in src and '#define SDP_COL_BNB 1' in src and '#define SDP_COL_UNROLL_W 1' in src
+        assert res[3].backend_info['max_controls'] == controls
+        _same(res, off)
+        res, src = run(V, SDP_COL_BNB='0')
+        assert '#define SDP_COL_LEAN2 1' in src and 'SDP_COL_BNB' not in src
+        _same(res, off)
+        res, src = run(V, SDP_COL_LEAN2='0')
+        assert 'SDP_COL_LEAN2' not in src
+        _same(res, off)
